@@ -1,0 +1,200 @@
+"""Quantized wrappers of the hot-path blocks; mirror of the hot-path classes of
+``opencood/quant/quant_block.py``: ``BaseQuantBlock :45-65``, ``QuantBaseBEVBackbone :243-335``,
+``QuantDoubleConv / QuantDownsampleConv :552-586``, ``QuantPFNLayer :589-629`` (extra activation
+quantizer after the ReLU, before the max), ``QuantPillarVFE :632-715``, ``QuantPointPillar :718-741``,
+``QuantNaiveCompressor :1543-1570``; registries ``opencood_specials :1581-1591``,
+``specials_unquantized_names :1599-1615``.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..models.heter_encoders import PointPillar
+from ..models.sub_modules.base_bev_backbone import BaseBEVBackbone
+from ..models.sub_modules.downsample_conv import DoubleConv, DownsampleConv
+from ..models.sub_modules.naive_compress import NaiveCompressor
+from ..models.sub_modules.pillar_vfe import PFNLayer, PillarVFE
+from .quant_layer import QuantModule, StraightThrough, UniformAffineQuantizer
+
+
+class BaseQuantBlock(nn.Module):
+    """A block whose inner ``QuantModule``s are switched together."""
+
+    def __init__(self):
+        super().__init__()
+        self.use_weight_quant = False
+        self.use_act_quant = False
+        self.ignore_reconstruction = False
+        self.trained = False
+
+    def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
+        self.use_weight_quant = weight_quant
+        self.use_act_quant = act_quant
+        for m in self.modules():
+            if isinstance(m, QuantModule):
+                m.set_quant_state(weight_quant, act_quant)
+
+
+def _wrap(conv, norm, act, wq, aq):
+    q = QuantModule(conv, wq, aq)
+    if norm is not None:
+        q.norm_function = norm
+    if act is not None:
+        q.activation_function = act
+    return q
+
+
+class QuantBaseBEVBackbone(BaseQuantBlock):
+    """``blocks.{i}`` = Sequential[ZeroPad2d, QuantModule, QuantModule, ...]; ``deblocks.{i}`` = Sequential[QuantModule]."""
+
+    def __init__(self, basebevbackbone: BaseBEVBackbone, weight_quant_params={}, act_quant_params={}):
+        super().__init__()
+        wq, aq = weight_quant_params, act_quant_params
+        self.num_levels = basebevbackbone.num_levels
+        self.blocks = nn.ModuleList()
+        self.deblocks = nn.ModuleList()
+        for blk in basebevbackbone.blocks:
+            seq = nn.Sequential(blk[0])                       # ZeroPad2d kept in place
+            for at in range(1, len(blk), 3):                  # (conv, norm, relu) triplets
+                seq.add_module(str(len(seq)), _wrap(blk[at], blk[at + 1], blk[at + 2], wq, aq))
+            self.blocks.append(seq)
+        for de in basebevbackbone.deblocks:
+            self.deblocks.append(nn.Sequential(_wrap(de[0], de[1], de[2], wq, aq)))
+        self.num_bev_features = basebevbackbone.num_bev_features
+
+    def _merge(self, ups):
+        x = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
+        if len(self.deblocks) > self.num_levels:
+            x = self.deblocks[-1](x)
+        return x
+
+    def forward(self, x):
+        ups = []
+        for lvl in range(len(self.blocks)):
+            x = self.blocks[lvl](x)
+            ups.append(self.deblocks[lvl](x) if len(self.deblocks) > 0 else x)
+        return self._merge(ups)
+
+    def get_multiscale_feature(self, spatial_features):
+        feats, x = [], spatial_features
+        for blk in self.blocks:
+            x = blk(x)
+            feats.append(x)
+        return feats
+
+    def decode_multiscale_feature(self, x):
+        return self._merge([self.deblocks[l](x[l]) if len(self.deblocks) > 0 else x[l]
+                            for l in range(self.num_levels)])
+
+
+class QuantDoubleConv(BaseQuantBlock):
+    def __init__(self, double_conv: DoubleConv, weight_quant_params={}, act_quant_params={}):
+        super().__init__()
+        dc = double_conv.double_conv
+        self.double_conv = nn.Sequential(
+            _wrap(dc[0], None, dc[1], weight_quant_params, act_quant_params),
+            _wrap(dc[2], None, dc[3], weight_quant_params, act_quant_params))
+
+    def forward(self, x):
+        return self.double_conv[1](self.double_conv[0](x))
+
+
+class QuantDownsampleConv(BaseQuantBlock):
+    def __init__(self, downsample_conv: DownsampleConv, weight_quant_params={}, act_quant_params={}):
+        super().__init__()
+        self.layers = nn.ModuleList(QuantDoubleConv(l, weight_quant_params, act_quant_params)
+                                    for l in downsample_conv.layers)
+
+    def forward(self, x):
+        for layer in self.layers:
+            x = layer(x)
+        return x
+
+
+class QuantPFNLayer(BaseQuantBlock):
+    """Quantized pillar Linear; the ReLU is applied *outside* the QuantModule and is followed by a
+    second activation quantizer (``self.act_quantizer``) before the max over points."""
+
+    def __init__(self, pfn_layer: PFNLayer, weight_quant_params={}, act_quant_params={}):
+        super().__init__()
+        self.last_vfe = pfn_layer.last_vfe
+        self.use_norm = pfn_layer.use_norm
+        self.part = pfn_layer.part
+        self.linear = QuantModule(pfn_layer.linear, weight_quant_params, act_quant_params)
+        if self.use_norm:
+            self.linear.norm_function = pfn_layer.norm
+        self.act_quantizer = UniformAffineQuantizer(**act_quant_params)
+
+    def forward(self, inputs):
+        m = inputs.shape[0]
+        if m > self.part:
+            x = torch.cat([self.linear(inputs[s:s + self.part])
+                           for s in range(0, (m // self.part + 1) * self.part, self.part)], dim=0)
+        else:
+            x = self.linear(inputs)
+        x = F.relu(x)
+        if self.use_act_quant:
+            x = self.act_quantizer(x)
+        pooled = x.max(dim=1, keepdim=True)[0]
+        if self.last_vfe:
+            return pooled
+        return torch.cat([x, pooled.repeat(1, inputs.shape[1], 1)], dim=2)
+
+
+class QuantPillarVFE(nn.Module):
+    def __init__(self, pillar_vfe: PillarVFE, weight_quant_params={}, act_quant_params={}):
+        super().__init__()
+        for attr in ('with_distance', 'use_absolute_xyz', 'voxel_x', 'voxel_y', 'voxel_z',
+                     'x_offset', 'y_offset', 'z_offset'):
+            setattr(self, attr, getattr(pillar_vfe, attr))
+        self.pfn_layers = nn.ModuleList(QuantPFNLayer(l, weight_quant_params, act_quant_params)
+                                        for l in pillar_vfe.pfn_layers)
+
+    get_paddings_indicator = staticmethod(PillarVFE.get_paddings_indicator)
+    augment = PillarVFE.augment
+
+    def forward(self, batch_dict):
+        feats = self.augment(batch_dict['voxel_features'], batch_dict['voxel_num_points'],
+                             batch_dict['voxel_coords'])
+        for pfn in self.pfn_layers:
+            feats = pfn(feats)
+        batch_dict['pillar_features'] = feats.squeeze()
+        return batch_dict
+
+
+class QuantPointPillar(nn.Module):
+    def __init__(self, point_pillar: PointPillar, weight_quant_params={}, act_quant_params={}):
+        super().__init__()
+        self.pillar_vfe = QuantPillarVFE(point_pillar.pillar_vfe, weight_quant_params, act_quant_params)
+        self.scatter = point_pillar.scatter
+
+    def forward(self, data_dict, modality_name):
+        src = data_dict[f'inputs_{modality_name}']
+        batch = {k: src[k] for k in ('voxel_features', 'voxel_coords', 'voxel_num_points')}
+        return self.scatter(self.pillar_vfe(batch))['spatial_features']
+
+
+class QuantNaiveCompressor(BaseQuantBlock):
+    def __init__(self, naive_compressor: NaiveCompressor, weight_quant_params={}, act_quant_params={}):
+        super().__init__()
+        e, d, wq, aq = naive_compressor.encoder, naive_compressor.decoder, weight_quant_params, act_quant_params
+        self.encoder = nn.Sequential(_wrap(e[0], e[1], e[2], wq, aq))
+        self.decoder = nn.Sequential(_wrap(d[0], d[1], d[2], wq, aq), _wrap(d[3], d[4], d[5], wq, aq))
+
+    def forward(self, x):
+        return self.decoder(self.encoder(x))
+
+
+specials = {}
+
+opencood_specials = {
+    BaseBEVBackbone: QuantBaseBEVBackbone,
+    DownsampleConv: QuantDownsampleConv,
+    PointPillar: QuantPointPillar,
+    NaiveCompressor: QuantNaiveCompressor,
+}
+
+specials_unquantized = []
+
+# children with these *names* are neither folded nor quantized (the codebook stays fp32)
+specials_unquantized_names = ['aligner_m1', 'aligner_m2', 'codebook']
