@@ -1,0 +1,349 @@
+"""Generate the golden vectors under ``tests/golden/`` by importing the reference on CPU.
+
+Runs ONLY in the build container (needs ``/root/reference``):
+
+    python tests/golden/make_golden.py
+
+What is produced (all inputs and weights are regenerated from seeds by ``quantv2x_amd.synth``,
+only expected outputs are stored):
+
+  tiny_fp32.npz    per-stage fp32 outputs of the reference model (tiny shape, N = 2 agents), hard
+                   codebook path (``codebook.encode`` -> ``decode``) and the reference's own soft
+                   ``forward`` under ``torch.manual_seed(0)``; preds for N = 1 and N = 3; state-dict keys
+  tiny_w8a8.npz    the same model under the reference ``QuantModel`` (W8A8, min-max, one EMA pass,
+                   then frozen): every (delta, zero_point), integer weight codes, per-module output codes
+  uaq_units.npz    ``UniformAffineQuantizer`` unit vectors (minmax / mse, EMA sequence, channel-wise
+                   conv / deconv / linear), ``fold_bn`` vectors, AdaRound hard rounding
+  geometry.npz     ``normalize_pairwise_tfm`` + ``warp_affine_simple`` + ``AttFusion`` vectors
+  codebook.npz     ``UMGMQuantizer.encode`` codes, top-2 distance gaps, ``decode`` output
+"""
+import copy
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, HERE)
+import _refimport  # noqa: E402
+
+_refimport.install()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from quantv2x_amd import synth  # noqa: E402
+
+from opencood.tools import train_utils as ref_tu  # noqa: E402
+from opencood.quant import QuantModel, set_weight_quantize_params  # noqa: E402
+from opencood.quant.quant_layer import QuantModule, UniformAffineQuantizer  # noqa: E402
+from opencood.quant.fold_bn import fold_bn_into_conv  # noqa: E402
+from opencood.quant.adaptive_rounding import AdaRoundQuantizer  # noqa: E402
+from opencood.utils.transformation_utils import normalize_pairwise_tfm  # noqa: E402
+from opencood.models.sub_modules.torch_transformation_utils import warp_affine_simple  # noqa: E402
+from opencood.models.fuse_modules.fusion_in_one import AttFusion  # noqa: E402
+
+torch.set_num_threads(1)   # single thread: bit-reproducible reductions
+SEED_W, SEED_SCENE = 1, 3
+N_POINTS = 3000
+
+
+def build_ref(shape="tiny", **kw):
+    hy = synth.make_hypes(shape, **kw)
+    model = ref_tu.create_model(copy.deepcopy(hy)).eval()
+    synth.load_state_dict_numpy(model, synth.make_state_dict(model.state_dict(), seed=SEED_W))
+    return model
+
+
+def scene(n_agents, shape="tiny"):
+    return synth.scene_to_torch(synth.make_scene(shape, n_agents=n_agents, seed=SEED_SCENE, n_points=N_POINTS))
+
+
+def hard_forward(model, dd, taps=None):
+    """The reference's forward with the deterministic codebook pair, assembled from the reference's own modules."""
+    taps = {} if taps is None else taps
+    affine = normalize_pairwise_tfm(dd['pairwise_t_matrix'].clone(), model.H, model.W, model.fake_voxel_size)
+    f = model.encoder_m1(dd, 'm1'); taps['spatial_features'] = f
+    f = model.backbone_m1(f); taps['backbone'] = f
+    f = model.shrinker_m1(f); taps['shrinker'] = f
+    n, c, h, w = f.shape
+    rows = f.permute(0, 2, 3, 1).contiguous().view(-1, c)
+    codes = model.codebook.encode(rows)
+    dec = model.codebook.decode(codes)
+    taps['codes'] = torch.stack([cd[:, 0] for cd in codes]).view(3, n, h, w)
+    taps['decoded'] = dec.view(n, h, w, c).permute(0, 3, 1, 2).contiguous()
+    fused = model.fusion_net(taps['decoded'], dd['record_len'], affine); taps['fused'] = fused
+    preds = torch.cat([model.cls_head(fused), model.reg_head(fused), model.dir_head(fused)], dim=1)
+    taps['preds_tensor'] = preds
+    taps['affine'] = affine
+    return preds
+
+
+def np32(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def sub8(t):
+    """Channel-subsampled copy (every 8th channel) -- keeps the fixtures small."""
+    return np32(t)[:, ::8].copy()
+
+
+def weight_checksums(code):
+    """Order-sensitive checksums of an integer weight-code tensor: [sum, sum(code * (1 + idx % 251))]."""
+    c = code.reshape(-1).astype(np.int64)
+    return np.array([c.sum(), (c * (1 + np.arange(c.size) % 251)).sum()], dtype=np.int64)
+
+
+def gen_fp32():
+    out = {}
+    model = build_ref()
+    out['state_dict_keys'] = np.array(list(model.state_dict().keys()))
+    dd = scene(2)
+    out['in_checksum'] = np.array([float(dd['inputs_m1']['voxel_features'].double().sum()),
+                                   float(dd['inputs_m1']['voxel_coords'].double().sum()),
+                                   float(dd['inputs_m1']['voxel_num_points'].double().sum())])
+    with torch.no_grad():
+        bd = {k: dd['inputs_m1'][k] for k in dd['inputs_m1']}
+        out['pillar_features'] = np32(model.encoder_m1.pillar_vfe(dict(bd))['pillar_features'])
+        x = model.encoder_m1(dd, 'm1')
+        for lvl in range(3):
+            x = model.backbone_m1.blocks[lvl](x)
+            out[f'block{lvl}'] = sub8(x)
+            out[f'up{lvl}'] = sub8(model.backbone_m1.deblocks[lvl](x))
+        taps = {}
+        hard_forward(model, dd, taps)
+        for k in ('backbone', 'shrinker', 'decoded', 'fused'):
+            out[k] = sub8(taps[k])
+        for k in ('preds_tensor', 'affine'):
+            out[k] = np32(taps[k])
+        out['codes'] = np32(taps['codes']).astype(np.uint8)
+        torch.manual_seed(0)
+        soft = model(dd)
+        out['soft_preds_tensor_seed0'] = np32(soft['preds_tensor'])
+        out['soft_codebook_loss_seed0'] = np32(soft['codebook_loss'])
+        out['cls_preds_single_soft_seed0'] = np32(soft['cls_preds_single'])
+        for n in (1, 3):
+            out[f'preds_tensor_n{n}'] = np32(hard_forward(model, scene(n)))
+        # no-codebook single-class model: plain forward is deterministic
+        plain = build_ref(multiclass=False, codebook=False)
+        out['plain_sc_preds_tensor'] = np32(plain(scene(2))['preds_tensor'])
+    np.savez_compressed(os.path.join(HERE, "tiny_fp32.npz"), **out)
+    print("tiny_fp32.npz", {k: v.shape for k, v in out.items() if k != 'state_dict_keys'})
+
+
+def quant_wrap(model, method="minmax"):
+    wq = dict(n_bits=8, channel_wise=True, scale_method=method)
+    aq = dict(n_bits=8, channel_wise=False, scale_method=method, leaf_param=True, prob=0.5)
+    qt = QuantModel(model, wq, aq).eval()
+    set_weight_quantize_params(qt)
+    return qt
+
+
+def act_quantizers(qt):
+    return [m for m in qt.modules() if isinstance(m, UniformAffineQuantizer) and m.leaf_param]
+
+
+def gen_w8a8():
+    out = {}
+    qt = quant_wrap(build_ref())
+    for a in act_quantizers(qt):
+        a.set_inited(False)
+    qt.set_quant_state(True, True)
+    dd = scene(2)
+    with torch.no_grad():
+        torch.manual_seed(0)
+        qt(dd)                       # one EMA-initialising pass (inference_quant.py:58-64 path)
+    for a in act_quantizers(qt):
+        a.set_inited(True)           # freeze
+    model = qt.model
+    names = []
+    hooks, outs = [], {}
+    for name, m in model.named_modules():
+        if isinstance(m, QuantModule):
+            names.append(name)
+            hooks.append(m.register_forward_hook(lambda mod, i, o, name=name: outs.__setitem__(name, o)))
+    with torch.no_grad():
+        taps = {}
+        hard_forward(model, dd, taps)
+    for h in hooks:
+        h.remove()
+    out['module_names'] = np.array(names)
+    for name, m in model.named_modules():
+        if not isinstance(m, QuantModule):
+            continue
+        wqz, aqz = m.weight_quantizer, m.act_quantizer
+        key = name.replace('.', '/')
+        out[key + '/w_delta'] = np32(wqz.delta).reshape(-1)
+        out[key + '/w_zp'] = np32(wqz.zero_point).reshape(-1)
+        wcode = np32(torch.clamp(torch.round(m.weight / wqz.delta) + wqz.zero_point, 0, 255)).astype(np.uint8)
+        out[key + '/w_code_checksum'] = weight_checksums(wcode)
+        if wcode.size <= 40000:
+            out[key + '/w_code'] = wcode
+        out[key + '/bias'] = np32(m.bias) if m.bias is not None else np.zeros(0, np.float32)
+        out[key + '/a_delta'] = np.float32(aqz.delta)
+        out[key + '/a_zp'] = np.float32(aqz.zero_point)
+        if name in outs:
+            o = outs[name]
+            code = torch.round(o / aqz.delta + aqz.zero_point)
+            assert float((((code - aqz.zero_point) * aqz.delta) - o).abs().max()) < 1e-4 * max(1.0, float(o.abs().max()))
+            if 'pfn_layers' in name:
+                out[key + '/out_checksum'] = np.float64(code.double().sum().item())
+            else:
+                out[key + '/out_code'] = np32(code).astype(np.uint8)
+    pfn = model.encoder_m1.pillar_vfe.pfn_layers[0]
+    out['pfn/a2_delta'] = np.float32(pfn.act_quantizer.delta)
+    out['pfn/a2_zp'] = np.float32(pfn.act_quantizer.zero_point)
+    with torch.no_grad():
+        bd = {k: dd['inputs_m1'][k] for k in dd['inputs_m1']}
+        pf = model.encoder_m1.pillar_vfe(dict(bd))['pillar_features']
+        out['pfn/pillar_code'] = np32(torch.round(pf / pfn.act_quantizer.delta + pfn.act_quantizer.zero_point)).astype(np.uint8)
+    for k in ('shrinker', 'decoded', 'fused'):
+        out['hard/' + k] = sub8(taps[k])
+    out['hard/preds_tensor'] = np32(taps['preds_tensor'])
+    out['hard/codes'] = np32(taps['codes']).astype(np.uint8)
+    with torch.no_grad():
+        for n in (1, 3):
+            out[f'hard/preds_tensor_n{n}'] = np32(hard_forward(model, scene(n)))
+    np.savez_compressed(os.path.join(HERE, "tiny_w8a8.npz"), **out)
+    print("tiny_w8a8.npz: %d arrays, %d modules" % (len(out), len(names)))
+
+
+def gen_uaq_units():
+    out = {}
+    g = np.random.Generator(np.random.PCG64(7))
+    tensors = {
+        'conv': g.normal(0, 0.1, (8, 4, 3, 3)).astype(np.float32),
+        'deconv': g.normal(0, 0.2, (6, 5, 2, 2)).astype(np.float32),
+        'linear': g.normal(0, 0.3, (16, 10)).astype(np.float32),
+        'act_pos': np.abs(g.normal(0, 1.0, (2, 8, 6, 6))).astype(np.float32),
+        'act_signed': g.normal(0.3, 1.0, (2, 8, 6, 6)).astype(np.float32),
+    }
+    for tname, arr in tensors.items():
+        out['in/' + tname] = arr
+        for method in ('minmax', 'mse'):
+            cw = tname in ('conv', 'deconv', 'linear')
+            if method == 'mse' and tname == 'act_signed':
+                n_bits = 4   # 2-D search is 100 x 2^n quantize calls; keep it short
+            else:
+                n_bits = 8
+            q = UniformAffineQuantizer(n_bits=n_bits, channel_wise=cw, scale_method=method, leaf_param=not cw)
+            q.set_inited(False)
+            y = q(torch.from_numpy(arr))
+            k = f'{tname}/{method}'
+            out[k + '/delta'] = np32(torch.as_tensor(q.delta)).reshape(-1)
+            out[k + '/zp'] = np32(torch.as_tensor(q.zero_point)).reshape(-1)
+            out[k + '/out'] = np32(y)
+            out[k + '/n_bits'] = np.int64(n_bits)
+    # EMA sequence: three observations with inited False throughout
+    q = UniformAffineQuantizer(n_bits=8, channel_wise=False, scale_method='minmax', leaf_param=True)
+    q.set_inited(False)
+    seq = [np.abs(g.normal(0, s, (4, 16))).astype(np.float32) for s in (1.0, 2.0, 0.5)]
+    for i, arr in enumerate(seq):
+        out[f'ema/in{i}'] = arr
+        out[f'ema/out{i}'] = np32(q(torch.from_numpy(arr)))
+        out[f'ema/delta{i}'] = np.float32(q.delta)
+        out[f'ema/zp{i}'] = np.float32(q.zero_point)
+    # 'entropy': the reference's perform_entropy_search (quant_layer.py:276-321) raises on its second
+    # candidate (reshape of i bins into 256 x (i // 256)) for any input, so there is nothing to pin.
+    # fold_bn: conv / deconv / linear (with and without a layer bias)
+    def bn_fill(bn):
+        c = bn.num_features
+        bn.weight.data = torch.from_numpy(g.uniform(0.5, 1.5, c).astype(np.float32))
+        bn.bias.data = torch.from_numpy(g.normal(0, 0.2, c).astype(np.float32))
+        bn.running_mean = torch.from_numpy(g.normal(0, 0.3, c).astype(np.float32))
+        bn.running_var = torch.from_numpy(g.uniform(0.3, 2.0, c).astype(np.float32))
+    cases = {
+        'conv': (torch.nn.Conv2d(4, 6, 3, bias=False), torch.nn.BatchNorm2d(6, eps=1e-3)),
+        'conv_bias': (torch.nn.Conv2d(4, 6, 3, bias=True), torch.nn.BatchNorm2d(6, eps=1e-3)),
+        'deconv': (torch.nn.ConvTranspose2d(4, 6, 2, stride=2, bias=False), torch.nn.BatchNorm2d(6, eps=1e-3)),
+        'linear': (torch.nn.Linear(10, 8, bias=False), torch.nn.BatchNorm1d(8, eps=1e-3)),
+    }
+    for cname, (layer, bn) in cases.items():
+        layer.weight.data = torch.from_numpy(g.normal(0, 0.2, tuple(layer.weight.shape)).astype(np.float32))
+        if layer.bias is not None:
+            layer.bias.data = torch.from_numpy(g.normal(0, 0.2, tuple(layer.bias.shape)).astype(np.float32))
+        bn_fill(bn)
+        k = 'fold/' + cname
+        out[k + '/w'] = np32(layer.weight); out[k + '/b'] = np32(layer.bias) if layer.bias is not None else np.zeros(0, np.float32)
+        out[k + '/gamma'] = np32(bn.weight); out[k + '/beta'] = np32(bn.bias)
+        out[k + '/mean'] = np32(bn.running_mean); out[k + '/var'] = np32(bn.running_var)
+        fold_bn_into_conv(layer, bn)
+        out[k + '/w_folded'] = np32(layer.weight); out[k + '/b_folded'] = np32(layer.bias)
+    # AdaRound: init alpha, then a synthetic "as-if-calibrated" perturbation and the hard mask
+    w = torch.from_numpy(tensors['conv'])
+    uaq = UniformAffineQuantizer(n_bits=8, channel_wise=True, scale_method='minmax')
+    uaq.set_inited(False); uaq(w); uaq.set_inited(True)
+    ada = AdaRoundQuantizer(uaq, w, round_mode='learned_hard_sigmoid')
+    out['ada/alpha0'] = np32(ada.alpha)
+    ada.alpha.data += torch.from_numpy(g.normal(0, 2.0, tuple(w.shape)).astype(np.float32))
+    out['ada/alpha1'] = np32(ada.alpha)
+    out['ada/hard'] = np32(ada(w))
+    ada.soft_targets = True
+    out['ada/soft'] = np32(ada(w))
+    np.savez_compressed(os.path.join(HERE, "uaq_units.npz"), **out)
+    print("uaq_units.npz: %d arrays" % len(out))
+
+
+def gen_geometry():
+    out = {}
+    g = np.random.Generator(np.random.PCG64(11))
+    poses = [synth.pose_matrix(0, 0, 0), synth.pose_matrix(4.0, -1.5, 0.2), synth.pose_matrix(-30.0, 3.0, -1.1),
+             synth.pose_matrix(1.0, 9.0, 3.0)]
+    T = synth.pairwise_t_matrix(poses, 5)[None]
+    out['pairwise'] = T
+    H, W = 12.8, 25.6
+    aff64 = normalize_pairwise_tfm(torch.from_numpy(T.copy()), H, W, 1)
+    aff32 = normalize_pairwise_tfm(torch.from_numpy(T.copy()).float(), H, W, 1)
+    out['affine_f64'] = np32(aff64); out['affine_f32'] = np32(aff32)
+    src = g.normal(0, 1, (4, 8, 16, 32)).astype(np.float32)
+    out['src'] = src
+    with torch.no_grad():
+        m = aff64[0, 0, :4]
+        warped = warp_affine_simple(torch.from_numpy(src), m, (16, 32))
+        out['warped'] = np32(warped)
+        att = AttFusion(8)
+        out['att_fused'] = np32(att(torch.from_numpy(src), torch.tensor([4]), aff64))
+        out['att_fused_n1'] = np32(att(torch.from_numpy(src[:1]), torch.tensor([1]), aff64))
+        out['att_fused_b2'] = np32(att(torch.from_numpy(src), torch.tensor([1, 3]), torch.cat([aff64, aff64])))
+    np.savez_compressed(os.path.join(HERE, "geometry.npz"), **out)
+    print("geometry.npz", {k: v.shape for k, v in out.items()})
+
+
+def gen_codebook():
+    out = {}
+    model = build_ref()
+    cb = model.codebook
+    g = np.random.Generator(np.random.PCG64(13))
+    x = np.abs(g.normal(0, 0.6, (512, 256))).astype(np.float32)   # post-ReLU-like rows
+    x[g.uniform(size=x.shape) < 0.4] = 0
+    out['x'] = x
+    with torch.no_grad():
+        xt = torch.from_numpy(x)
+        codes = cb.encode(xt)
+        out['codes'] = np.stack([np32(c[:, 0]) for c in codes]).astype(np.uint8)
+        out['decoded'] = np32(cb.decode(codes))
+        # top-2 distance gaps per level (classifies rows whose argmin is fragile to summation order)
+        cur, gaps = xt, []
+        for enc in cb._encoders:
+            z = enc._latentStageEncoder(cur)
+            d = enc._quantizer._distance(enc._quantizationHead(z))[:, 0]
+            top2 = torch.topk(d, 2, dim=-1, largest=False)[0]
+            gaps.append(np32(top2[:, 1] - top2[:, 0]))
+            cur, _ = enc.encode(cur)
+        out['gaps'] = np.stack(gaps)
+        torch.manual_seed(0)
+        soft, scodes, _, loss = cb(xt)
+        out['soft_seed0'] = np32(soft); out['soft_loss_seed0'] = np32(loss)
+        out['soft_codes_seed0'] = np.stack([np32(c[:, 0]) for c in scodes]).astype(np.uint8)
+    np.savez_compressed(os.path.join(HERE, "codebook.npz"), **out)
+    print("codebook.npz", {k: v.shape for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["fp32", "w8a8", "uaq", "geometry", "codebook"]
+    with torch.no_grad():
+        pass
+    if "fp32" in which: gen_fp32()
+    if "w8a8" in which: gen_w8a8()
+    if "uaq" in which: gen_uaq_units()
+    if "geometry" in which: gen_geometry()
+    if "codebook" in which: gen_codebook()
