@@ -108,12 +108,12 @@ class UniformAffineQuantizer(nn.Module):
 
     def _observed_range(self, x, include_zero):
         if self.channel_wise:
-            lo, hi = torch._aminmax(torch.flatten(x, 1), 1)
+            lo, hi = torch.aminmax(torch.flatten(x, 1), dim=1)
             if include_zero:
                 hi = torch.max(hi, torch.zeros_like(hi))
                 lo = torch.min(lo, torch.zeros_like(lo))
             return lo, hi
-        return torch._aminmax(x)
+        return tuple(torch.aminmax(x))
 
     def perform_2D_search(self, x):
         """Search (range width, zero point) minimising the L2.4 error (reference ``:202-234``)."""

@@ -1,0 +1,118 @@
+"""Frozen W8A8 state of a calibrated ``QuantModel`` as plain numpy arrays.
+
+The reference never persists PTQ state -- calibration reruns on every ``inference_quant.py`` launch
+(SURVEY.md §5 "Checkpoint / resume").  ``export_ptq_state`` walks a calibrated ``QuantModel`` -- the
+reference's own (``opencood/quant/quant_model.py``) or this build's mirror; only attribute names are
+used -- and collects exactly what the deployed integer path needs:
+
+  <module>/w_code   uint8   clamp(round(w / delta_w) + zp_w, 0, 255)      (quant_layer.py:132-133)
+                            or floor(w / delta_w) + (alpha >= 0) for AdaRound (adaptive_rounding.py:46-58)
+  <module>/w_delta  f32 [dim0], <module>/w_zp f32 [dim0]   per dim-0 (C_out; C_in for ConvTranspose2d)
+  <module>/bias     f32 [C_out]  (BN already folded, fold_bn.py)
+  <module>/a_delta, <module>/a_zp   f32 scalars of the output activation quantizer
+  pfn/a2_delta, pfn/a2_zp           the extra quantizer of QuantPFNLayer (quant_block.py:619-621)
+  codebook/...                      fp32 heads + codebooks (the codebook is left unquantized)
+  meta/...                          geometry of the BEV grid
+
+``save_ptq_state`` / ``load_ptq_state`` store it as one ``.npz``.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import numpy as np
+import torch
+
+_HEADS = ("cls_head", "reg_head", "dir_head")
+
+
+def _np(t) -> np.ndarray:
+    if isinstance(t, torch.Tensor):
+        return t.detach().cpu().numpy().copy()
+    return np.asarray(t)
+
+
+def _is_quant_module(m) -> bool:
+    return all(hasattr(m, a) for a in ("weight_quantizer", "act_quantizer", "org_weight", "fwd_func"))
+
+
+def weight_codes(qm) -> np.ndarray:
+    """Integer weight codes of one ``QuantModule`` (uint8)."""
+    wq = qm.weight_quantizer
+    w = qm.weight.detach()
+    delta, zp = torch.as_tensor(wq.delta), torch.as_tensor(wq.zero_point)
+    if hasattr(wq, "alpha") and getattr(wq, "round_mode", "") == "learned_hard_sigmoid":
+        code = torch.floor(w / delta) + (wq.alpha >= 0).float()
+    else:
+        code = torch.round(w / delta)
+    return _np(torch.clamp(code + zp, 0, wq.n_levels - 1)).astype(np.uint8)
+
+
+def export_ptq_state(qt_model) -> Dict[str, np.ndarray]:
+    model = qt_model.model if hasattr(qt_model, "model") and not _is_quant_module(qt_model) else qt_model
+    out: Dict[str, np.ndarray] = {}
+    names = []
+    for name, m in model.named_modules():
+        if not _is_quant_module(m):
+            continue
+        if m.weight_quantizer.n_bits != 8 or m.act_quantizer.n_bits != 8:
+            raise ValueError(f"{name}: the deployed path is W8A8 only")
+        if not (m.weight_quantizer.inited and m.act_quantizer.inited):
+            raise ValueError(f"{name}: quantizers must be frozen (set_inited(True)) before export")
+        names.append(name)
+        wq, aq = m.weight_quantizer, m.act_quantizer
+        out[name + "/w_code"] = weight_codes(m)
+        out[name + "/w_delta"] = _np(torch.as_tensor(wq.delta)).reshape(-1).astype(np.float32)
+        out[name + "/w_zp"] = _np(torch.as_tensor(wq.zero_point)).reshape(-1).astype(np.float32)
+        out[name + "/bias"] = _np(m.bias).astype(np.float32) if m.bias is not None \
+            else np.zeros(0, np.float32)
+        out[name + "/a_delta"] = np.float32(_np(torch.as_tensor(aq.delta)).reshape(-1)[0])
+        out[name + "/a_zp"] = np.float32(_np(torch.as_tensor(aq.zero_point)).reshape(-1)[0])
+        out[name + "/a_off"] = np.bool_(bool(m.disable_act_quant))
+    out["meta/module_names"] = np.array(names)
+
+    enc = model.encoder_m1
+    vfe = enc.pillar_vfe
+    if len(vfe.pfn_layers) != 1 or vfe.with_distance or not vfe.use_absolute_xyz:
+        raise NotImplementedError("deployed PFN: one layer, use_absolute_xyz, no distance feature (the V2X-Real / OPV2V yaml)")
+    pfn = vfe.pfn_layers[0]
+    out["pfn/a2_delta"] = np.float32(_np(torch.as_tensor(pfn.act_quantizer.delta)).reshape(-1)[0])
+    out["pfn/a2_zp"] = np.float32(_np(torch.as_tensor(pfn.act_quantizer.zero_point)).reshape(-1)[0])
+    out["meta/voxel"] = np.array([vfe.voxel_x, vfe.voxel_y, vfe.voxel_z], dtype=np.float64)
+    out["meta/offset"] = np.array([vfe.x_offset, vfe.y_offset, vfe.z_offset], dtype=np.float64)
+    sc = enc.scatter
+    out["meta/grid"] = np.array([sc.nx, sc.ny, sc.nz], dtype=np.int64)
+    out["meta/HW_metres"] = np.array([model.H, model.W], dtype=np.float64)
+    out["meta/discrete_ratio"] = np.float64(model.fake_voxel_size)
+
+    bb = model.backbone_m1
+    out["meta/layer_nums"] = np.array([len(b) - 2 for b in bb.blocks], dtype=np.int64)
+    out["meta/layer_strides"] = np.array([int(b[1].fwd_kwargs["stride"][0]) for b in bb.blocks], dtype=np.int64)
+    out["meta/upsample_strides"] = np.array([int(d[0].fwd_kwargs["stride"][0]) for d in bb.deblocks], dtype=np.int64)
+    out["meta/supervise_single"] = np.bool_(bool(getattr(model, "supervise_single", False)))
+
+    cb = getattr(model, "codebook", None)
+    out["meta/has_codebook"] = np.bool_(cb is not None)
+    if cb is not None:
+        if cb._m != 1:
+            raise NotImplementedError("deployed codebook path: seg_num (m) == 1")
+        for lvl, (e, d) in enumerate(zip(cb._encoders, cb._decoders)):
+            p = f"codebook/{lvl}/"
+            out[p + "codebook"] = _np(e._quantizer._codebook)[0].astype(np.float32)          # [k, d]
+            for tag, lin in (("stage", e._latentStageEncoder), ("qhead", e._quantizationHead),
+                             ("lhead", e._latentHead), ("dqhead", d._dequantizationHead),
+                             ("side", d._sideHead), ("restore", d._restoreHead)):
+                if lin is not None:
+                    out[p + tag + "_w"] = _np(lin.weight).astype(np.float32)
+                    out[p + tag + "_b"] = _np(lin.bias).astype(np.float32)
+        out["meta/codebook_levels"] = np.int64(len(cb._encoders))
+    return out
+
+
+def save_ptq_state(path: str, state: Dict[str, np.ndarray]) -> None:
+    np.savez_compressed(path, **state)
+
+
+def load_ptq_state(path: str) -> Dict[str, np.ndarray]:
+    with np.load(path, allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
