@@ -1,0 +1,153 @@
+/*
+ * qv2x.h -- C ABI of libqv2x.so: the MI355X (gfx950) implementation of QuantV2X's quantized
+ * per-agent encode + intermediate-fusion hot path.
+ *
+ * The reference has no FFI on this path -- it is Python on torch ops.  Each entry
+ * point below replaces the torch call sequence of one reference function; the Python host
+ * (quantv2x_amd/engine.py) binds them with ctypes.  Conventions:
+ *   - plain device pointers + sizes; no allocation inside; the caller owns every buffer
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); calls only enqueue work
+ *   - return 0 on success, a negative QV2X_E* code on an argument error, or -1000 - hipError_t;
+ *     qv2x_last_error() returns a message for the calling thread's last failure
+ *   - reentrant per stream, no global mutable state
+ *
+ * Data layout in HBM (the "i8 BEV" format used between kernels):
+ *   activation tensor = signed int8, value = uint8 code - 128, NHWC with a one-pixel border:
+ *       [N][H + 2][W + 2][C],  element (n, y, x, c) at ((n*(H+2) + y+1)*(W+2) + x+1)*C + c
+ *   the border holds (zero_point - 128), i.e. the code of 0.0, so 3x3 windows need no bounds checks.
+ */
+#ifndef QV2X_H
+#define QV2X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QV2X_OK 0
+#define QV2X_EINVAL (-1)     /* bad argument (shape not supported, null pointer ...) */
+#define QV2X_EALIGN (-2)     /* pointer / channel count not aligned as required */
+#define QV2X_MAX_GROUPS 4
+
+const char* qv2x_last_error(void);
+int qv2x_version(void);
+
+/* Fill a padded i8 BEV tensor (border AND interior) with one byte value: the per-frame canvas clear and the
+ * one-time border initialisation.  Replaces torch.zeros(...) in PointPillarScatter.forward
+ * (opencood/models/sub_modules/point_pillar_scatter.py:45-49). */
+int qv2x_fill_i8(int8_t* buf, int64_t bytes, int value, void* stream);
+
+/* a1 + a2.  QuantPillarVFE/QuantPFNLayer + PointPillarScatter in one pass
+ * (opencood/quant/quant_block.py:589-715, opencood/models/sub_modules/pillar_vfe.py:105-155,
+ *  point_pillar_scatter.py:19-75).
+ *   voxel_features f32 [M][32][4], voxel_coords i32 [M][4] = (agent, z, y, x), voxel_num_points i32 [M]
+ *   w f32 [64][10] fake-quantized folded weight, b f32 [64]; (d1, z1) Linear output quantizer,
+ *   (d2, z2) the second quantizer after the ReLU; vox/off = voxel size and (voxel/2 + range_min), xyz.
+ *   canvas: padded i8 BEV [N][ny+2][nx+2][64], already filled with (z2 - 128). */
+typedef struct {
+    float w[64 * 10];
+    float b[64];
+    float d1, z1, d2, z2;
+    float vox[3], off[3];
+} qv2x_pfn_params;
+int qv2x_pfn_scatter_i8(const float* voxel_features, const int32_t* voxel_coords, const int32_t* voxel_num_points,
+                        int M, int max_points, const qv2x_pfn_params* params /* host */,
+                        int8_t* canvas, int N, int ny, int nx, void* stream);
+
+/* a3 / a4 / a5.  One QuantModule 3x3 convolution (zero padding 1, stride 1 or 2) + folded BN bias + ReLU +
+ * output activation quantizer (opencood/quant/quant_layer.py:391-410 on F.conv2d; blocks of
+ * QuantBaseBEVBackbone quant_block.py:243-303 and QuantDoubleConv :552-572), on integer codes:
+ *     T_g  = sum_{kh,kw,ci in group g} (x - zx_g) * (w - zw[co])                  exact int32 (MFMA i8)
+ *     y    = bias[co] + sum_g float(T_g) * scale[g][co]                           fp32 mul, add
+ *     out  = clamp(rint(max(y, 0) / out_delta) + out_zp, 0, 255) - 128
+ *   in   : padded i8 BEV [N][H+2][W+2][cin_total]; input channel groups (the concat of the three deblocks
+ *          carries three activation scales) described by group_c0/group_c/group_zx
+ *   w    : i8 (code - 128), [Cout][G][3][3][C_g]  (K contiguous per output channel)
+ *   scale: f32 [G][Cout] = delta_x[g] * delta_w[co];  corr: i32 [G][Cout] = ax_g * sum_k ws + K_g * ax_g * aw[co]
+ *          with ax_g = 128 - zx_g, aw[co] = 128 - zw[co], ws = w code - 128;  aw: i32 [Cout]; bias f32 [Cout]
+ *   out  : padded i8 BEV [N][Ho+2][Wo+2][out_ctotal], written at channel offset out_c0 (interior only). */
+typedef struct {
+    int32_t n, h, w, cin_total, stride, cout;
+    int32_t ngroups;
+    int32_t group_c0[QV2X_MAX_GROUPS], group_c[QV2X_MAX_GROUPS], group_zx[QV2X_MAX_GROUPS];
+    int32_t out_ctotal, out_c0;
+    int32_t relu;
+    float out_delta, out_zp;
+} qv2x_conv_desc;
+int qv2x_conv3x3_i8(const qv2x_conv_desc* desc /* host */, const int8_t* in, const int8_t* w,
+                    const float* scale, const int32_t* corr, const int32_t* aw, const float* bias,
+                    int8_t* out, void* stream);
+
+/* a3 deblocks.  QuantModule over ConvTranspose2d with kernel == stride == s, + bias + ReLU + output quantizer.
+ * The reference's per-dim-0 weight scales are per C_in here (quant_layer.py:192-195 on a [Cin,Cout,s,s]
+ * weight), i.e. on the reduction axis, so the sum runs in fp32 on the f32 MFMA as an ascending-ci fmaf chain:
+ *     acc = 0; acc = fma(float(x - zx) * dx, wdeq[ci][co][i][j], acc);  y = acc + bias[co]
+ *   w: f32, [Cin/4][s*s*Cout][4] (column = (i*s + j)*Cout + co; four consecutive ci innermost). */
+typedef struct {
+    int32_t n, h, w, cin, cout, s;
+    int32_t in_zx;
+    float in_delta;
+    int32_t out_ctotal, out_c0, relu;
+    float out_delta, out_zp;
+} qv2x_deconv_desc;
+int qv2x_deconv_i8(const qv2x_deconv_desc* desc /* host */, const int8_t* in, const float* w, const float* bias,
+                   int8_t* out, void* stream);
+
+/* a6.  UMGMQuantizer.encode (opencood/models/sub_modules/codebook.py:330-337 -> :231-239 -> :106-131), m = 1,
+ * D = 256, up to 3 residual levels, Kc <= 128 codes per level, on the dequantized shrinker output.
+ *   in: padded i8 BEV [N][H+2][W+2][256] with (in_delta, in_zx)
+ *   weights: one f32 blob per level, laid out by the host as
+ *       stage [64][256][4] | stage_b [256] | qhead [64][256][4] | qhead_b [256] | lhead [64][256][4] | lhead_b [256]
+ *       | cb_packed [64][Kc][4] | cb [Kc][256] | c2 [Kc]
+ *     ([K/4][cols][4] = four consecutive k innermost); lhead* unused on the last level
+ *   codes: u8 [levels][N*H*W]. */
+typedef struct {
+    int32_t n, h, w;
+    int32_t levels, kc;
+    int32_t in_zx;
+    float in_delta;
+} qv2x_encode_desc;
+int64_t qv2x_codebook_level_floats(int kc);
+/* |C_k|^2 of a [kc][256] codebook with the summation order the encode kernel assumes (four 64-wide ascending
+ * fma chains, (s0 + s1) + (s2 + s3)); fills the c2 slot of a level blob at engine-build time. */
+int qv2x_codebook_c2_f32(const float* codebook, int kc, float* c2, void* stream);
+int qv2x_codebook_encode_f32(const qv2x_encode_desc* desc /* host */, const int8_t* in,
+                             const float* const* level_weights /* host array of device pointers */,
+                             uint8_t* codes, void* stream);
+
+/* a7 + a8 + a9 + a10.  UMGMQuantizer.decode as three table look-ups (codebook.py:339-343; all heads affine),
+ * warp_affine_simple (torch_transformation_utils.py:323-332: affine_grid + bilinear grid_sample, zeros,
+ * align_corners=False) of every agent into the ego frame and AttFusion's per-cell scaled-dot-product
+ * attention, ego row (fusion_in_one.py:126-151).
+ *   codes   : u8 code planes; plane (agent, level) starts at agent*code_agent_stride + level*code_level_stride
+ *             ([levels][A][H*W] out of qv2x_codebook_encode_f32, [A][levels][H*W] after an all-gather)
+ *   lut     : f32 [levels][kc][256], lut_bias f32 [256]
+ *   feats   : optional f32 [A][H*W][256] instead of codes (models without the codebook); pass codes = NULL
+ *   pairwise: DEVICE f64 [max_cav][max_cav][4][4], T[i][j] = T_j^-1 T_i; row `ego` is normalised in-kernel exactly as
+ *             normalize_pairwise_tfm(T, H, W, discrete_ratio) does (transformation_utils.py:68-92)
+ *   fused   : f32 [H*W][256] */
+typedef struct {
+    int32_t agents, h, w, levels, kc;
+    int32_t max_cav, ego;
+    int64_t code_agent_stride, code_level_stride;
+    double h_metres, w_metres, discrete_ratio;
+} qv2x_fuse_desc;
+int qv2x_fuse_att_f32(const qv2x_fuse_desc* desc /* host */, const uint8_t* codes, const float* lut, const float* lut_bias,
+                      const float* feats, const double* pairwise, float* fused, void* stream);
+
+/* codes -> fp32 rows (decode only), used for the *_single heads: out f32 [R][256] */
+int qv2x_decode_lut_f32(const uint8_t* codes, int R, int levels, int kc, const float* lut, const float* lut_bias,
+                        float* out, void* stream);
+
+/* a11.  1x1 QuantModule heads (heter_model_baseline.py:128-133,242-260) on fp32 rows:
+ *     y = fma chain over ci (acc0 = bias[co]);  out = (clamp(rint(y / da[co]) + za[co], 0, 255) - za[co]) * da[co]
+ *   x f32 [R][256]; w f32 [64][cout_pad][4] (cout_pad = cout rounded up to 32, zero filled); bias/da/za f32 [cout_pad]
+ *   (da[co] <= 0 disables the output quantizer for that channel); out f32 NCHW [B][cout][hw] with R = B * hw. */
+int qv2x_heads_f32(const float* x, int R, int hw, int cout, int cout_pad, const float* w, const float* bias,
+                   const float* da, const float* za, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QV2X_H */

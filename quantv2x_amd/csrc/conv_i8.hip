@@ -1,0 +1,239 @@
+// a3 / a4 / a5: 3x3 W8A8 convolution as an implicit GEMM on v_mfma_i32_32x32x32_i8 (gfx950).
+//
+//   M = N*Ho*Wo output pixels, N = Cout, K = G * 9 * C_g walked as (group, kh, kw, 64-channel chunk).
+//   A (activations): padded i8 BEV, so a K-chunk of a pixel is 64 contiguous bytes, no bounds checks.
+//   B (weights): [Cout][K] i8, K contiguous and in loop order, so the K-chunk offset is linear in the step.
+//   Both are staged through LDS in 64-byte rows (16-byte chunks XOR-swizzled by (row >> 2) & 3 so that the
+//   ds_read_b128 fragment reads of a 16-lane group hit 16 distinct slots), double buffered: the next chunk's
+//   global loads are in flight while the MFMAs of the current one issue.
+//
+// Unsigned x unsigned codes on a signed MFMA (SURVEY.md §7 "hard parts"): with xs = x - 128, ws = w - 128,
+// ax = 128 - zx, aw = 128 - zw,
+//     sum (x - zx)(w - zw) = sum xs*ws + aw * sum xs + ax * sum ws + K*ax*aw
+// sum xs (per pixel window) comes from v_dot4_i32_i8 on the A fragments already in registers; the last two
+// terms are the per-(group, co) constant `corr`.  The border of the padded tensor stores zx - 128 = -ax, i.e.
+// (x - zx) = 0 there, which is exactly zero padding in the dequantized domain.
+//
+// Epilogue (spec shared with oracle/qv2x_oracle.c:orc_conv3x3): y = bias + sum_g float(T_g) * scale[g][co]
+// (separate mul and add), ReLU, requantize with IEEE division + rint, store code - 128.
+#include "common.h"
+
+namespace qv2x {
+
+struct ConvArgs {
+    const int8_t* in; const int8_t* w; const float* scale; const int* corr; const int* aw; const float* bias; int8_t* out;
+    int n, hp, wp, cin_total, stride, cout, ngroups;
+    int gc0[QV2X_MAX_GROUPS], gc[QV2X_MAX_GROUPS];
+    int ho, wo, M, ktot;
+    int out_ctotal, out_c0, relu;
+    float out_delta, out_zp;
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv3x3_i8_kernel(const ConvArgs a) {
+    constexpr int TM = BM / WM, TN = BN / WN;      // wave tile
+    constexpr int MT = TM / 32, NT = TN / 32;      // 32x32 MFMA tiles per wave
+    constexpr int LA = BM / 64, LB = BN / 64;      // 16-byte global loads per thread per K-chunk
+    static_assert(WM * WN == 4 && MT >= 1 && NT >= 1 && LA >= 1 && LB >= 1, "tile shape");
+
+    __shared__ __attribute__((aligned(16))) int8_t lds[2 * (BM + BN) * 64 + 4 * TM * 4];
+    int8_t* ldsA = lds;
+    int8_t* ldsB = lds + 2 * BM * 64;
+    int* xbuf = (int*)(lds + 2 * (BM + BN) * 64);  // [4 waves][TM] window sums
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+    // ---- per-thread global source addresses --------------------------------------------------------
+    const int8_t* srcA[LA];
+    int dstA[LA];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int id = tid + i * 256, row = id >> 2, ch = id & 3;
+        int m = m0 + row;
+        m = m < a.M ? m : a.M - 1;
+        const int img = m / (a.ho * a.wo), rem = m - img * (a.ho * a.wo);
+        const int yo = rem / a.wo, xo = rem - yo * a.wo;
+        srcA[i] = a.in + ((size_t)(img * a.hp + yo * a.stride) * a.wp + xo * a.stride) * a.cin_total + ch * 16;
+        dstA[i] = swz(row, ch);
+    }
+    const int8_t* srcB[LB];
+    int dstB[LB];
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        const int id = tid + i * 256, row = id >> 2, ch = id & 3;
+        srcB[i] = a.w + (size_t)(n0 + row) * a.ktot + ch * 16;
+        dstB[i] = swz(row, ch);
+    }
+
+    v16i acc[MT][NT];
+    float facc[MT][NT][16];
+    int xs[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        xs[i] = 0;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0; }
+            const float b = a.bias[n0 + wn * TN + j * 32 + (lane & 31)];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) facc[i][j][r] = b;
+        }
+    }
+
+    v4i ra[LA], rb[LB];
+    int kofs = 0;      // byte offset into a weight row == 64 * (chunks consumed so far)
+    int cur = 0;
+
+    for (int g = 0; g < a.ngroups; ++g) {
+        const int chunks = a.gc[g] >> 6;
+        const int steps = 9 * chunks;
+        // step s -> (tap = s / chunks, cc = s % chunks); source offset of the A chunk
+        auto a_off = [&](int s) {
+            const int tap = s / chunks, cc = s - tap * chunks;
+            const int kh = tap / 3, kw = tap - kh * 3;
+            return (kh * a.wp + kw) * a.cin_total + a.gc0[g] + cc * 64;
+        };
+        {   // prologue: chunk 0 of this group
+            const int ao = a_off(0);
+#pragma unroll
+            for (int i = 0; i < LA; ++i) ra[i] = *(const v4i*)(srcA[i] + ao);
+#pragma unroll
+            for (int i = 0; i < LB; ++i) rb[i] = *(const v4i*)(srcB[i] + kofs);
+#pragma unroll
+            for (int i = 0; i < LA; ++i) *(v4i*)(ldsA + cur * BM * 64 + dstA[i]) = ra[i];
+#pragma unroll
+            for (int i = 0; i < LB; ++i) *(v4i*)(ldsB + cur * BN * 64 + dstB[i]) = rb[i];
+            __syncthreads();
+        }
+        for (int s = 0; s < steps; ++s) {
+            const bool more = (s + 1) < steps;
+            if (more) {
+                const int ao = a_off(s + 1);
+#pragma unroll
+                for (int i = 0; i < LA; ++i) ra[i] = *(const v4i*)(srcA[i] + ao);
+#pragma unroll
+                for (int i = 0; i < LB; ++i) rb[i] = *(const v4i*)(srcB[i] + kofs + 64);
+            }
+            const int8_t* bufA = ldsA + cur * BM * 64;
+            const int8_t* bufB = ldsB + cur * BN * 64;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                v4i fa[MT], fb[NT];
+                const int ch = ks * 2 + (lane >> 5);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) fa[i] = *(const v4i*)(bufA + swz(wm * TM + i * 32 + (lane & 31), ch));
+#pragma unroll
+                for (int j = 0; j < NT; ++j) fb[j] = *(const v4i*)(bufB + swz(wn * TN + j * 32 + (lane & 31), ch));
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xs[i] = __builtin_amdgcn_sdot4(fa[i][q], 0x01010101, xs[i], false);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                }
+            }
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < LA; ++i) *(v4i*)(ldsA + (cur ^ 1) * BM * 64 + dstA[i]) = ra[i];
+#pragma unroll
+                for (int i = 0; i < LB; ++i) *(v4i*)(ldsB + (cur ^ 1) * BN * 64 + dstB[i]) = rb[i];
+            }
+            __syncthreads();
+            cur ^= more ? 1 : 0;
+            kofs += 64;
+        }
+        // ---- fold this group into the fp32 accumulator ---------------------------------------------
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int tot = xs[i] + __shfl_xor(xs[i], 32);
+            if (lane < 32) xbuf[wave * TM + i * 32 + lane] = tot;
+            xs[i] = 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int co = n0 + wn * TN + j * 32 + (lane & 31);
+            const int awv = a.aw[co];
+            const int cr = a.corr[g * a.cout + co];
+            const float sc = a.scale[g * a.cout + co];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int T = acc[i][j][r] + awv * xbuf[wave * TM + i * 32 + mfma32_row(r, lane)] + cr;
+                    facc[i][j][r] = facc[i][j][r] + (float)T * sc;
+                    acc[i][j][r] = 0;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: ReLU, requantize, store code - 128 --------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * TM + i * 32 + mfma32_row(r, lane);
+            if (m >= a.M) continue;
+            const int img = m / (a.ho * a.wo), rem = m - img * (a.ho * a.wo);
+            const int yo = rem / a.wo, xo = rem - yo * a.wo;
+            int8_t* o = a.out + ((size_t)(img * (a.ho + 2) + yo + 1) * (a.wo + 2) + xo + 1) * a.out_ctotal + a.out_c0;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                float y = facc[i][j][r];
+                if (a.relu) y = fmaxf(y, 0.0f);
+                o[n0 + wn * TN + j * 32 + (lane & 31)] = (int8_t)((int)q_code(y, a.out_delta, a.out_zp) - 128);
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch(const ConvArgs& a, hipStream_t st) {
+    dim3 grid((a.M + BM - 1) / BM, a.cout / BN);
+    conv3x3_i8_kernel<BM, BN, WM, WN><<<grid, 256, 0, st>>>(a);
+    return hip_check(hipGetLastError(), "qv2x_conv3x3_i8 launch");
+}
+
+}  // namespace qv2x
+
+extern "C" int qv2x_conv3x3_i8(const qv2x_conv_desc* d, const int8_t* in, const int8_t* w, const float* scale,
+                               const int32_t* corr, const int32_t* aw, const float* bias, int8_t* out, void* stream) {
+    using namespace qv2x;
+    if (!d || !in || !w || !scale || !corr || !aw || !bias || !out) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8: null pointer");
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || (d->stride != 1 && d->stride != 2))
+        return fail(QV2X_EINVAL, "qv2x_conv3x3_i8: bad shape n=%d h=%d w=%d stride=%d", d->n, d->h, d->w, d->stride);
+    if (d->ngroups < 1 || d->ngroups > QV2X_MAX_GROUPS) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8: 1..%d input groups", QV2X_MAX_GROUPS);
+    if (d->cout % 64 || d->cin_total % 16 || d->out_ctotal < d->out_c0 + d->cout)
+        return fail(QV2X_EALIGN, "qv2x_conv3x3_i8: cout %% 64, cin_total %% 16, out channel window");
+    if (((uintptr_t)in & 15) || ((uintptr_t)w & 15)) return fail(QV2X_EALIGN, "qv2x_conv3x3_i8: in / w must be 16-byte aligned");
+    ConvArgs a;
+    a.in = in; a.w = w; a.scale = scale; a.corr = corr; a.aw = aw; a.bias = bias; a.out = out;
+    a.n = d->n; a.hp = d->h + 2; a.wp = d->w + 2; a.cin_total = d->cin_total; a.stride = d->stride; a.cout = d->cout;
+    a.ngroups = d->ngroups;
+    a.ktot = 0;
+    for (int g = 0; g < QV2X_MAX_GROUPS; ++g) {
+        a.gc0[g] = g < d->ngroups ? d->group_c0[g] : 0;
+        a.gc[g] = g < d->ngroups ? d->group_c[g] : 0;
+        if (g < d->ngroups) {
+            if (a.gc[g] <= 0 || a.gc[g] % 64 || a.gc0[g] % 16 || a.gc0[g] + a.gc[g] > d->cin_total)
+                return fail(QV2X_EALIGN, "qv2x_conv3x3_i8: group %d (c0=%d, c=%d): channels must come in multiples of 64", g, a.gc0[g], a.gc[g]);
+            a.ktot += 9 * a.gc[g];
+        }
+    }
+    a.ho = (d->h + 2 - 3) / d->stride + 1;
+    a.wo = (d->w + 2 - 3) / d->stride + 1;
+    a.M = d->n * a.ho * a.wo;
+    a.out_ctotal = d->out_ctotal; a.out_c0 = d->out_c0; a.relu = d->relu;
+    a.out_delta = d->out_delta; a.out_zp = d->out_zp;
+    if (!(a.out_delta > 0.0f)) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8: out_delta must be positive");
+    hipStream_t st = (hipStream_t)stream;
+    if (d->cout % 128 == 0) return launch<128, 128, 2, 2>(a, st);
+    return launch<128, 64, 4, 1>(a, st);
+}

@@ -1,0 +1,101 @@
+// a3 deblocks: ConvTranspose2d(kernel == stride == s) under QuantModel, on v_mfma_f32_32x32x2_f32.
+//
+// The reference's per-dim-0 weight scale lands on C_in for a [Cin, Cout, s, s] weight (quant_layer.py:192-195),
+// i.e. on the reduction axis, so no integer accumulation can be factored; the sum is an ascending-ci fp32 fma
+// chain, which is exactly what the f32 MFMA computes (k ascending, C-in first; verified bit-exact against fmaf
+// on hardware, tools/probes/mfma_probe.hip).  GEMM view: rows = input pixels, cols = (i*s + j)*Cout + co, K = Cin.
+// One wave = 32 pixels x 64 columns; A converted on the fly from the i8 BEV, B = [Cin/4][cols][4] fp32 from L2.
+#include "common.h"
+
+namespace qv2x {
+
+struct DeconvArgs {
+    const int8_t* in; const float* w; const float* bias; int8_t* out;
+    int n, h, wd, cin, cout, s, ax, ncols, M, relu, out_ctotal, out_c0;
+    float dx, out_delta, out_zp;
+};
+
+__global__ __launch_bounds__(256) void deconv_f32_kernel(const DeconvArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int tiles_n = a.ncols >> 6;
+    int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    tile = __builtin_amdgcn_readfirstlane(tile);
+    const int tiles_m = (a.M + 31) >> 5;
+    if (tile >= tiles_m * tiles_n) return;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int par = lane >> 5;
+
+    int m = tm * 32 + (lane & 31);
+    m = m < a.M ? m : a.M - 1;
+    const int img = m / (a.h * a.wd), rem = m - img * (a.h * a.wd);
+    const int y = rem / a.wd, x = rem - y * a.wd;
+    const int8_t* src = a.in + ((size_t)(img * (a.h + 2) + y + 1) * (a.wd + 2) + x + 1) * a.cin;
+    const int col0 = tn * 64 + (lane & 31);
+    const float4* wq = (const float4*)a.w;
+
+    v16f acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    const int sh = par * 8;
+    for (int k0 = 0; k0 < a.cin; k0 += 16) {
+        const v4i raw = *(const v4i*)(src + k0);
+        float4 b[2][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) b[t][q] = wq[(size_t)((k0 >> 2) + q) * a.ncols + col0 + t * 32];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {              // MFMA k-step: k = k0 + 2j + par
+            const int word = raw[j >> 1];
+            const int xs = (word << (24 - ((j & 1) * 16 + sh))) >> 24;       // sign-extended byte 2*(j&1) + par
+            const float av = (float)(xs + a.ax) * a.dx;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float4 bq = b[t][j >> 1];
+                const float bv = (j & 1) ? (par ? bq.w : bq.z) : (par ? bq.y : bq.x);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int col = col0 + t * 32;
+        const int ij = col / a.cout, co = col - ij * a.cout;
+        const int di = ij / a.s, dj = ij - di * a.s;
+        const float bias = a.bias[co];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mm = tm * 32 + mfma32_row(r, lane);
+            if (mm >= a.M) continue;
+            const int im = mm / (a.h * a.wd), rm = mm - im * (a.h * a.wd);
+            const int yy = rm / a.wd, xx = rm - yy * a.wd;
+            float yv = acc[t][r] + bias;
+            if (a.relu) yv = fmaxf(yv, 0.0f);
+            const size_t pix = (size_t)(im * (a.h * a.s + 2) + yy * a.s + di + 1) * (a.wd * a.s + 2) + xx * a.s + dj + 1;
+            a.out[pix * a.out_ctotal + a.out_c0 + co] = (int8_t)((int)q_code(yv, a.out_delta, a.out_zp) - 128);
+        }
+    }
+}
+
+}  // namespace qv2x
+
+extern "C" int qv2x_deconv_i8(const qv2x_deconv_desc* d, const int8_t* in, const float* w, const float* bias, int8_t* out, void* stream) {
+    using namespace qv2x;
+    if (!d || !in || !w || !bias || !out) return fail(QV2X_EINVAL, "qv2x_deconv_i8: null pointer");
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->s < 1 || d->s > 8) return fail(QV2X_EINVAL, "qv2x_deconv_i8: bad shape");
+    if (d->cin % 16 || (d->s * d->s * d->cout) % 64 || d->cout % 32) return fail(QV2X_EALIGN, "qv2x_deconv_i8: cin %% 16, cout %% 32, s*s*cout %% 64");
+    if (((uintptr_t)in & 15) || ((uintptr_t)w & 15)) return fail(QV2X_EALIGN, "qv2x_deconv_i8: in / w must be 16-byte aligned");
+    if (!(d->out_delta > 0.0f)) return fail(QV2X_EINVAL, "qv2x_deconv_i8: out_delta must be positive");
+    DeconvArgs a;
+    a.in = in; a.w = w; a.bias = bias; a.out = out;
+    a.n = d->n; a.h = d->h; a.wd = d->w; a.cin = d->cin; a.cout = d->cout; a.s = d->s; a.ax = 128 - d->in_zx;
+    a.ncols = d->s * d->s * d->cout; a.M = d->n * d->h * d->w; a.relu = d->relu;
+    a.out_ctotal = d->out_ctotal; a.out_c0 = d->out_c0; a.dx = d->in_delta; a.out_delta = d->out_delta; a.out_zp = d->out_zp;
+    const int tiles = ((a.M + 31) / 32) * (a.ncols / 64);
+    deconv_f32_kernel<<<(tiles + 3) / 4, 256, 0, (hipStream_t)stream>>>(a);
+    return hip_check(hipGetLastError(), "qv2x_deconv_i8 launch");
+}

@@ -1,0 +1,74 @@
+// a1 + a2: pillar feature net (W8A8 semantics) fused with the scatter into the padded i8 BEV canvas.
+// One wavefront per pillar, lane = output channel (64).  HBM-bound: reads M * (512 + 16 + 4) B, writes 64 B
+// per pillar.  Every quantization step is monotone non-decreasing, so max over points commutes with it: the
+// kernel takes the max of the pre-quantization value and quantizes once (bit-identical to the per-point form
+// in oracle/qv2x_oracle.c:orc_pfn, verified by tests/test_hip_parity.py).
+#include "common.h"
+
+namespace qv2x {
+
+__global__ __launch_bounds__(256) void pfn_scatter_kernel(const float4* __restrict__ vf, const int4* __restrict__ coords,
+                                                          const int* __restrict__ npts, int M, int P,
+                                                          const qv2x_pfn_params prm, int8_t* __restrict__ canvas,
+                                                          int N, int ny, int nx) {
+    const int lane = threadIdx.x & 63;
+    int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    m = __builtin_amdgcn_readfirstlane(m);
+    if (m >= M) return;
+    const float4* pts = vf + (size_t)m * P;
+    const int4 c = coords[m];                 // (agent, z, y, x)
+    const int np = npts[m];
+
+    float sx = 0.f, sy = 0.f, sz = 0.f;       // ascending-slot sums over all P slots (padded slots hold zeros)
+    for (int p = 0; p < P; ++p) {
+        const float4 q = pts[p];
+        sx += q.x; sy += q.y; sz += q.z;
+    }
+    const float n = (float)np;
+    const float mx = sx / n, my = sy / n, mz = sz / n;
+    const float cx = (float)c.w * prm.vox[0] + prm.off[0];
+    const float cy = (float)c.z * prm.vox[1] + prm.off[1];
+    const float cz = (float)c.y * prm.vox[2] + prm.off[2];
+
+    float w[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) w[k] = prm.w[lane * 10 + k];
+    const float b = prm.b[lane];
+
+    float ymax = -INFINITY;
+    const int real = np < P ? np : P;
+    for (int p = 0; p < real; ++p) {
+        const float4 q = pts[p];
+        float f[10] = {q.x, q.y, q.z, q.w, q.x - mx, q.y - my, q.z - mz, q.x - cx, q.y - cy, q.z - cz};
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) acc = fmaf(f[k], w[k], acc);
+        ymax = fmaxf(ymax, acc + b);
+    }
+    if (real < P) ymax = fmaxf(ymax, b);       // zero-masked slots contribute the bias alone
+
+    const float q1 = q_code(ymax, prm.d1, prm.z1);
+    float y1 = (q1 - prm.z1) * prm.d1;
+    y1 = fmaxf(y1, 0.0f);
+    const int code = (int)q_code(y1, prm.d2, prm.z2);
+
+    if (c.x < 0 || c.x >= N || c.z < 0 || c.z >= ny || (c.y + c.w) < 0 || (c.y + c.w) >= nx) return;
+    const size_t cell = ((size_t)c.x * (ny + 2) + (c.z + 1)) * (nx + 2) + (size_t)(c.y + c.w + 1);
+    canvas[cell * 64 + lane] = (int8_t)(code - 128);
+}
+
+}  // namespace qv2x
+
+extern "C" int qv2x_pfn_scatter_i8(const float* voxel_features, const int32_t* voxel_coords, const int32_t* voxel_num_points,
+                                   int M, int max_points, const qv2x_pfn_params* params, int8_t* canvas, int N, int ny, int nx,
+                                   void* stream) {
+    using namespace qv2x;
+    if (M == 0) return QV2X_OK;
+    if (!voxel_features || !voxel_coords || !voxel_num_points || !params || !canvas)
+        return fail(QV2X_EINVAL, "qv2x_pfn_scatter_i8: null pointer");
+    if (M < 0 || max_points <= 0 || N <= 0 || ny <= 0 || nx <= 0) return fail(QV2X_EINVAL, "qv2x_pfn_scatter_i8: bad sizes");
+    if (((uintptr_t)voxel_features & 15) || ((uintptr_t)voxel_coords & 15)) return fail(QV2X_EALIGN, "qv2x_pfn_scatter_i8: inputs must be 16-byte aligned");
+    pfn_scatter_kernel<<<(M + 3) / 4, 256, 0, (hipStream_t)stream>>>((const float4*)voxel_features, (const int4*)voxel_coords,
+                                                                     voxel_num_points, M, max_points, *params, canvas, N, ny, nx);
+    return hip_check(hipGetLastError(), "qv2x_pfn_scatter_i8 launch");
+}

@@ -1,0 +1,417 @@
+"""Deployed W8A8 hot path on MI355X: host side of ``libqv2x.so``.
+
+``deploy(qt_model)`` takes a calibrated ``QuantModel`` (the reference's ``opencood.quant.QuantModel`` or this
+build's mirror -- only attribute names are read), freezes its PTQ state (``ptq_state.export_ptq_state``) and
+returns a ``DeployedModel``: an ``nn.Module`` with the reference's model contract
+
+    out = model(data_dict)      # data_dict = batch['ego'];  out: cls_preds / reg_preds / dir_preds / preds_tensor
+
+whose forward is the chain of HIP kernels declared in ``include/qv2x.h`` (PyTorch only provides device memory
+and the stream).  The codebook runs the deterministic ``encode -> decode`` pair (the wire format); see
+DESIGN.md for why the reference's Gumbel ``forward`` is not used at inference.
+
+There is no CPU / eager fallback here: if ``libqv2x.so`` is missing, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import lib as L
+from .ptq_state import export_ptq_state, load_ptq_state
+
+_HEADS = ("cls_head", "reg_head", "dir_head")
+
+
+def _pack_k4(w: np.ndarray) -> np.ndarray:
+    """[J, K] row-major (out = W x) -> [K/4][J][4] float32: four consecutive k innermost, J coalesced per wave."""
+    j, k = w.shape
+    assert k % 4 == 0
+    return np.ascontiguousarray(w.T.reshape(k // 4, 4, j).transpose(0, 2, 1), dtype=np.float32)
+
+
+def decode_tables(state: Dict[str, np.ndarray], levels: int):
+    """UMGMQuantizer.decode (codebook.py:339-343, 263-269) collapsed: every head is affine, so
+    decode(c_0..c_{L-1}) = bias + sum_l T_l[c_l].  float64 algebra, fp32 tables ``[L][kc][256]``."""
+    g = lambda l, n: state[f"codebook/{l}/{n}"].astype(np.float64)
+    tables, const, chain = [], np.zeros(256), np.eye(256)
+    for l in range(levels):
+        front = chain @ g(l, "restore_w")
+        tables.append((front @ g(l, "dqhead_w") @ g(l, "codebook").T).T)
+        const = const + front @ g(l, "dqhead_b") + chain @ g(l, "restore_b")
+        if l < levels - 1:
+            const = const + front @ g(l, "side_b")
+            chain = front @ g(l, "side_w")
+    return np.stack(tables).astype(np.float32), const.astype(np.float32)
+
+
+class _ConvLayer:
+    """Device-side constants of one 3x3 QuantModule convolution."""
+
+    def __init__(self, state, name, in_groups, stride, dev):
+        code = state[name + "/w_code"]                              # [Cout, Cin, 3, 3] uint8
+        dw = state[name + "/w_delta"].astype(np.float32)
+        zw = state[name + "/w_zp"].astype(np.int64)
+        cout = code.shape[0]
+        ws = code.astype(np.int64) - 128
+        aw = 128 - zw
+        parts, corr, scale = [], [], []
+        for (c0, c, dx, zx) in in_groups:
+            blk = ws[:, c0:c0 + c].transpose(0, 2, 3, 1).reshape(cout, -1)      # [Cout][3][3][c]
+            parts.append(blk)
+            ax = 128 - int(zx)
+            corr.append(ax * blk.sum(axis=1) + blk.shape[1] * ax * aw)
+            scale.append(np.float32(dx) * dw)
+        self.name, self.stride, self.cout = name, stride, cout
+        self.groups = [(int(c0), int(c), int(zx)) for (c0, c, _, zx) in in_groups]
+        self.w = torch.from_numpy(np.concatenate(parts, axis=1).astype(np.int8)).to(dev)
+        self.scale = torch.from_numpy(np.stack(scale).astype(np.float32)).to(dev)
+        self.corr = torch.from_numpy(np.stack(corr).astype(np.int32)).to(dev)
+        self.aw = torch.from_numpy(aw.astype(np.int32)).to(dev)
+        self.bias = torch.from_numpy(state[name + "/bias"].astype(np.float32)).to(dev)
+        self.out_q = (float(np.float32(state[name + "/a_delta"])), int(state[name + "/a_zp"]))
+        assert np.abs(np.stack(corr)).max() < 2 ** 31
+
+
+class _DeconvLayer:
+    def __init__(self, state, name, in_q, dev):
+        code = state[name + "/w_code"].astype(np.float32)            # [Cin, Cout, s, s]; scales per C_in (dim 0)
+        dw = state[name + "/w_delta"].astype(np.float32).reshape(-1, 1, 1, 1)
+        zw = state[name + "/w_zp"].astype(np.float32).reshape(-1, 1, 1, 1)
+        wdeq = ((code - zw) * dw).astype(np.float32)
+        cin, cout, s, _ = wdeq.shape
+        cols = wdeq.transpose(0, 2, 3, 1).reshape(cin, s * s * cout)              # col = (i*s + j)*Cout + co
+        self.w = torch.from_numpy(_pack_k4(cols.T)).to(dev)
+        self.bias = torch.from_numpy(state[name + "/bias"].astype(np.float32)).to(dev)
+        self.name, self.cin, self.cout, self.s, self.in_q = name, cin, cout, s, in_q
+        self.out_q = (float(np.float32(state[name + "/a_delta"])), int(state[name + "/a_zp"]))
+
+
+class _Heads:
+    """cls | reg | dir stacked on the channel axis, each with its own output quantizer."""
+
+    def __init__(self, state, suffix, dev):
+        ws, bs, das, zas = [], [], [], []
+        for h in _HEADS:
+            n = h + suffix
+            code = state[n + "/w_code"].astype(np.float32).reshape(state[n + "/w_code"].shape[0], -1)
+            w = ((code - state[n + "/w_zp"].astype(np.float32)[:, None]) * state[n + "/w_delta"].astype(np.float32)[:, None])
+            ws.append(w.astype(np.float32))
+            bs.append(state[n + "/bias"].astype(np.float32))
+            off = bool(state[n + "/a_off"])
+            das.append(np.full(w.shape[0], -1.0 if off else float(np.float32(state[n + "/a_delta"])), np.float32))
+            zas.append(np.full(w.shape[0], float(state[n + "/a_zp"]), np.float32))
+        self.splits = [w.shape[0] for w in ws]
+        self.cout = sum(self.splits)
+        self.cout_pad = (self.cout + 31) // 32 * 32
+        if self.cout_pad > 96:
+            raise NotImplementedError("heads: at most 96 stacked output channels")
+        pad = self.cout_pad - self.cout
+        w = np.concatenate(ws + [np.zeros((pad, 256), np.float32)])
+        self.w = torch.from_numpy(_pack_k4(w)).to(dev)
+        self.bias = torch.from_numpy(np.concatenate(bs + [np.zeros(pad, np.float32)])).to(dev)
+        self.da = torch.from_numpy(np.concatenate(das + [np.full(pad, -1.0, np.float32)])).to(dev)
+        self.za = torch.from_numpy(np.concatenate(zas + [np.zeros(pad, np.float32)])).to(dev)
+
+
+class DeployedModel(nn.Module):
+    """The hot path as HIP kernels.  Same call contract as the reference's model."""
+
+    def __init__(self, state: Dict[str, np.ndarray], device="cuda", emit_single_preds: Optional[bool] = None):
+        super().__init__()
+        self.lib = L.load()                      # raises if libqv2x.so is absent: no fallback
+        if not torch.cuda.is_available():
+            raise L.Qv2xError("DeployedModel needs an MI355X (torch.cuda.is_available() is False)")
+        self.state = state
+        self.dev = torch.device(device)
+        s = state
+        self.nx, self.ny, _ = (int(v) for v in s["meta/grid"])
+        self.hm, self.wm = (float(v) for v in s["meta/HW_metres"])
+        self.ratio = float(s["meta/discrete_ratio"])
+        self.layer_nums = [int(v) for v in s["meta/layer_nums"]]
+        self.strides = [int(v) for v in s["meta/layer_strides"]]
+        self.ups = [int(v) for v in s["meta/upsample_strides"]]
+        self.has_codebook = bool(s["meta/has_codebook"])
+        self.emit_single = bool(s["meta/supervise_single"]) if emit_single_preds is None else bool(emit_single_preds)
+        dev = self.dev
+
+        # ---- a1: PFN parameters (host struct, passed by value to the kernel) ------------------------------
+        n = "encoder_m1.pillar_vfe.pfn_layers.0.linear"
+        wq = ((s[n + "/w_code"].astype(np.float32) - s[n + "/w_zp"].astype(np.float32)[:, None])
+              * s[n + "/w_delta"].astype(np.float32)[:, None]).astype(np.float32)
+        if wq.shape != (64, 10):
+            raise NotImplementedError("deployed PFN expects Linear(10 -> 64)")
+        p = L.PfnParams()
+        p.w[:] = wq.reshape(-1).tolist()
+        p.b[:] = s[n + "/bias"].astype(np.float32).tolist()
+        p.d1, p.z1 = float(np.float32(s[n + "/a_delta"])), float(s[n + "/a_zp"])
+        p.d2, p.z2 = float(np.float32(s["pfn/a2_delta"])), float(s["pfn/a2_zp"])
+        p.vox[:] = [float(np.float32(v)) for v in s["meta/voxel"]]
+        p.off[:] = [float(np.float32(v)) for v in s["meta/offset"]]
+        self.pfn = p
+        q = (p.d2, int(p.z2))                                    # quantizer of the canvas
+
+        # ---- a3: backbone ----------------------------------------------------------------------------------
+        self.blocks: List[List[_ConvLayer]] = []
+        self.deblocks: List[_DeconvLayer] = []
+        cat_groups, c0 = [], 0
+        cin = 64
+        for lvl in range(len(self.layer_nums)):
+            convs = []
+            for i in range(self.layer_nums[lvl] + 1):
+                layer = _ConvLayer(s, f"backbone_m1.blocks.{lvl}.{i + 1}", [(0, cin, q[0], q[1])],
+                                   self.strides[lvl] if i == 0 else 1, dev)
+                convs.append(layer)
+                q, cin = layer.out_q, layer.cout
+            self.blocks.append(convs)
+            de = _DeconvLayer(s, f"backbone_m1.deblocks.{lvl}.0", q, dev)
+            self.deblocks.append(de)
+            cat_groups.append((c0, de.cout, de.out_q[0], de.out_q[1]))
+            c0 += de.cout
+        self.cat_channels = c0
+        # ---- a4: shrinker ----------------------------------------------------------------------------------
+        self.shrink0 = _ConvLayer(s, "shrinker_m1.layers.0.double_conv.0", cat_groups, 1, dev)
+        self.shrink1 = _ConvLayer(s, "shrinker_m1.layers.0.double_conv.1",
+                                  [(0, self.shrink0.cout, *self.shrink0.out_q)], 1, dev)
+        if self.shrink1.cout != 256:
+            raise NotImplementedError("deployed path expects a 256-channel shared feature")
+        # ---- a6 / a7: codebook -----------------------------------------------------------------------------
+        if self.has_codebook:
+            self.levels = int(s["meta/codebook_levels"])
+            self.kc = int(s["codebook/0/codebook"].shape[0])
+            lut, lut_bias = decode_tables(s, self.levels)
+            self.lut = torch.from_numpy(lut).to(dev)
+            self.lut_bias = torch.from_numpy(lut_bias).to(dev)
+            self.level_blobs = [self._level_blob(l) for l in range(self.levels)]
+            self.level_ptrs = (C.c_void_p * self.levels)(*[b.data_ptr() for b in self.level_blobs])
+        # ---- a11: heads ------------------------------------------------------------------------------------
+        self.heads = _Heads(s, "", dev)
+        self.heads_single = _Heads(s, "_single", dev) if (self.emit_single and "cls_head_single/w_code" in s) else None
+        self._bufs: Dict[int, dict] = {}
+        self._graphs: Dict[tuple, tuple] = {}
+
+    # ------------------------------------------------------------------------------------------------------
+    def _level_blob(self, l: int) -> torch.Tensor:
+        s, kc = self.state, self.kc
+        g = lambda n: s[f"codebook/{l}/{n}"].astype(np.float32)
+        zeros_w, zeros_b = np.zeros((64, 256, 4), np.float32), np.zeros(256, np.float32)
+        last = f"codebook/{l}/lhead_w" not in s
+        cb = g("codebook")
+        parts = [_pack_k4(g("stage_w")), g("stage_b"), _pack_k4(g("qhead_w")), g("qhead_b"),
+                 zeros_w if last else _pack_k4(g("lhead_w")), zeros_b if last else g("lhead_b"),
+                 _pack_k4(cb), cb, np.zeros(kc, np.float32)]
+        flat = np.concatenate([p.reshape(-1) for p in parts])
+        assert flat.size == self.lib.qv2x_codebook_level_floats(kc)
+        blob = torch.from_numpy(flat).to(self.dev)
+        cb_off = flat.size - kc - kc * 256
+        L.check(self.lib.qv2x_codebook_c2_f32(C.c_void_p(blob.data_ptr() + 4 * cb_off), kc,
+                                              C.c_void_p(blob.data_ptr() + 4 * (flat.size - kc)), L.current_stream()),
+                "qv2x_codebook_c2_f32")
+        return blob
+
+    def _padded(self, n, h, w, c, q):
+        """Padded i8 BEV tensor with the border (and interior) preset to the code of 0.0."""
+        t = torch.empty((n, h + 2, w + 2, c), dtype=torch.int8, device=self.dev)
+        t.fill_(int(q[1]) - 128)
+        return t
+
+    def _buffers(self, n: int) -> dict:
+        if n in self._bufs:
+            return self._bufs[n]
+        b = {}
+        h, w = self.ny, self.nx
+        b["canvas"] = self._padded(n, h, w, 64, (self.pfn.d2, int(self.pfn.z2)))
+        b["lvl"] = []
+        for lvl, convs in enumerate(self.blocks):
+            h, w = (h + 2 - 3) // self.strides[lvl] + 1, (w + 2 - 3) // self.strides[lvl] + 1
+            # ping-pong pair per level.  The border stores the consumer's input zero point; post-ReLU quantizers all
+            # have zero point 0, and a shared buffer needs them equal.
+            zps = {c.out_q[1] for c in convs}
+            if len(zps) != 1:
+                raise NotImplementedError("conv outputs of one backbone level must share a zero point (post-ReLU: 0)")
+            pair = [self._padded(n, h, w, convs[0].cout, convs[0].out_q) for _ in range(2)]
+            b["lvl"].append((pair, h, w))
+        (_, h0, w0) = b["lvl"][0]
+        self.fh, self.fw = h0 * self.ups[0], w0 * self.ups[0]
+        cat = torch.empty((n, self.fh + 2, self.fw + 2, self.cat_channels), dtype=torch.int8, device=self.dev)
+        c0 = 0
+        for de in self.deblocks:
+            cat[..., c0:c0 + de.cout] = int(de.out_q[1]) - 128
+            c0 += de.cout
+        b["cat"] = cat
+        b["s0"] = self._padded(n, self.fh, self.fw, self.shrink0.cout, self.shrink0.out_q)
+        b["s1"] = self._padded(n, self.fh, self.fw, self.shrink1.cout, self.shrink1.out_q)
+        hw = self.fh * self.fw
+        if self.has_codebook:
+            b["codes"] = torch.empty((self.levels, n, hw), dtype=torch.uint8, device=self.dev)
+        if not self.has_codebook or self.heads_single is not None:
+            b["feats"] = torch.empty((n, hw, 256), dtype=torch.float32, device=self.dev)
+        self._bufs[n] = b
+        return b
+
+    # ---- kernel launch helpers -----------------------------------------------------------------------------
+    def _conv(self, layer: _ConvLayer, x, n, h, w, out, out_ctotal=None, out_c0=0):
+        d = L.ConvDesc()
+        d.n, d.h, d.w, d.cin_total, d.stride, d.cout = n, h, w, x.shape[-1], layer.stride, layer.cout
+        d.ngroups = len(layer.groups)
+        for i, (c0, c, zx) in enumerate(layer.groups):
+            d.group_c0[i], d.group_c[i], d.group_zx[i] = c0, c, zx
+        d.out_ctotal = out.shape[-1] if out_ctotal is None else out_ctotal
+        d.out_c0, d.relu = out_c0, 1
+        d.out_delta, d.out_zp = layer.out_q[0], float(layer.out_q[1])
+        L.check(self.lib.qv2x_conv3x3_i8(C.byref(d), L.ptr(x), L.ptr(layer.w), L.ptr(layer.scale), L.ptr(layer.corr),
+                                         L.ptr(layer.aw), L.ptr(layer.bias), L.ptr(out), L.current_stream()), layer.name)
+
+    def _deconv(self, de: _DeconvLayer, x, n, h, w, out, out_c0):
+        d = L.DeconvDesc()
+        d.n, d.h, d.w, d.cin, d.cout, d.s = n, h, w, de.cin, de.cout, de.s
+        d.in_zx, d.in_delta = int(de.in_q[1]), float(de.in_q[0])
+        d.out_ctotal, d.out_c0, d.relu = out.shape[-1], out_c0, 1
+        d.out_delta, d.out_zp = de.out_q[0], float(de.out_q[1])
+        L.check(self.lib.qv2x_deconv_i8(C.byref(d), L.ptr(x), L.ptr(de.w), L.ptr(de.bias), L.ptr(out), L.current_stream()), de.name)
+
+    def _run_heads(self, hd: _Heads, rows, nb, hw):
+        out = torch.empty((nb, hd.cout, self.fh, self.fw), dtype=torch.float32, device=self.dev)
+        L.check(self.lib.qv2x_heads_f32(L.ptr(rows), nb * hw, hw, hd.cout, hd.cout_pad, L.ptr(hd.w), L.ptr(hd.bias),
+                                        L.ptr(hd.da), L.ptr(hd.za), L.ptr(out), L.current_stream()), "qv2x_heads_f32")
+        return out
+
+    # ---- stages (also used one by one by the parity tests and the multi-GPU driver) --------------------------
+    def encode_agents(self, inputs: dict, n_agents: int, taps: Optional[dict] = None):
+        """a1-a6 for ``n_agents`` agents.  Returns codes u8 [levels, n, H*W] (or the i8 shrinker output without a codebook)."""
+        b = self._buffers(n_agents)
+        st = L.current_stream()
+        vf = inputs["voxel_features"].contiguous()
+        co = inputs["voxel_coords"].to(torch.int32).contiguous()
+        npnt = inputs["voxel_num_points"].to(torch.int32).contiguous()
+        if vf.dtype != torch.float32 or vf.shape[1:] != (32, 4):
+            raise ValueError("voxel_features must be float32 [M, 32, 4]")
+        canvas = b["canvas"]
+        L.check(self.lib.qv2x_fill_i8(L.ptr(canvas), canvas.numel(), int(self.pfn.z2) - 128, st), "qv2x_fill_i8")
+        L.check(self.lib.qv2x_pfn_scatter_i8(L.ptr(vf), L.ptr(co), L.ptr(npnt), vf.shape[0], 32, C.byref(self.pfn),
+                                             L.ptr(canvas), n_agents, self.ny, self.nx, st), "qv2x_pfn_scatter_i8")
+        x, h, w = canvas, self.ny, self.nx
+        if taps is not None:
+            taps["canvas"] = canvas
+        c0 = 0
+        for lvl, convs in enumerate(self.blocks):
+            pair, ho, wo = b["lvl"][lvl]
+            for i, layer in enumerate(convs):
+                out = pair[i % 2]
+                self._conv(layer, x, n_agents, h, w, out)
+                x, h, w = out, ho, wo
+                if taps is not None:
+                    taps[layer.name] = out.clone()
+            de = self.deblocks[lvl]
+            self._deconv(de, x, n_agents, h, w, b["cat"], c0)
+            c0 += de.cout
+        if taps is not None:
+            taps["cat"] = b["cat"]
+        self._conv(self.shrink0, b["cat"], n_agents, self.fh, self.fw, b["s0"])
+        self._conv(self.shrink1, b["s0"], n_agents, self.fh, self.fw, b["s1"])
+        if taps is not None:
+            taps[self.shrink0.name], taps[self.shrink1.name] = b["s0"], b["s1"]
+        if not self.has_codebook:
+            return b["s1"]
+        d = L.EncodeDesc()
+        d.n, d.h, d.w, d.levels, d.kc = n_agents, self.fh, self.fw, self.levels, self.kc
+        d.in_zx, d.in_delta = int(self.shrink1.out_q[1]), float(self.shrink1.out_q[0])
+        L.check(self.lib.qv2x_codebook_encode_f32(C.byref(d), L.ptr(b["s1"]), self.level_ptrs, L.ptr(b["codes"]), st),
+                "qv2x_codebook_encode_f32")
+        return b["codes"]
+
+    def decode_rows(self, codes, n_rows_total):
+        """codes u8 [levels, R] -> fp32 [R, 256] (only needed for the *_single heads)."""
+        out = torch.empty((n_rows_total, 256), dtype=torch.float32, device=self.dev)
+        L.check(self.lib.qv2x_decode_lut_f32(L.ptr(codes), n_rows_total, self.levels, self.kc, L.ptr(self.lut),
+                                             L.ptr(self.lut_bias), L.ptr(out), L.current_stream()), "qv2x_decode_lut_f32")
+        return out
+
+    def fuse(self, codes_ptr, agent_stride, level_stride, feats, pairwise_b, n, out, ego=0):
+        d = L.FuseDesc()
+        d.agents, d.h, d.w = n, self.fh, self.fw
+        d.levels, d.kc = (self.levels, self.kc) if self.has_codebook else (1, 1)
+        d.max_cav, d.ego = pairwise_b.shape[0], ego
+        d.code_agent_stride, d.code_level_stride = agent_stride, level_stride
+        d.h_metres, d.w_metres, d.discrete_ratio = self.hm, self.wm, self.ratio
+        lut = L.ptr(self.lut) if self.has_codebook else None
+        lb = L.ptr(self.lut_bias) if self.has_codebook else None
+        L.check(self.lib.qv2x_fuse_att_f32(C.byref(d), codes_ptr, lut, lb, L.ptr(feats) if feats is not None else None,
+                                           L.ptr(pairwise_b), L.ptr(out), L.current_stream()), "qv2x_fuse_att_f32")
+
+    # ---- the reference's model contract ----------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, data_dict: dict, taps: Optional[dict] = None) -> dict:
+        agents = data_dict["agent_modality_list"]
+        n_total = len(agents)
+        if any(a != "m1" for a in agents):
+            raise NotImplementedError("deployed path: every agent is the LiDAR modality 'm1'")
+        pairwise = data_dict["pairwise_t_matrix"]
+        if pairwise.dtype != torch.float64 or not pairwise.is_contiguous():
+            pairwise = pairwise.to(torch.float64).contiguous()
+        nb = pairwise.shape[0]
+        lens = [n_total] if nb == 1 else [int(v) for v in data_dict["record_len"].tolist()]
+        enc = self.encode_agents(data_dict["inputs_m1"], n_total, taps)
+        hw = self.fh * self.fw
+        bufs = self._buffers(n_total)
+        feats = None
+        if not self.has_codebook:
+            # no codebook: the fp32 shared feature is the dequantized shrinker output
+            q = self.shrink1.out_q
+            feats = bufs["feats"]
+            feats.copy_(((enc[:, 1:-1, 1:-1, :].to(torch.float32) + (128.0 - q[1])) * q[0]).reshape(n_total, hw, 256))
+        elif self.heads_single is not None:
+            feats = self.decode_rows(enc, n_total * hw).view(n_total, hw, 256)
+        fused = torch.empty((nb, hw, 256), dtype=torch.float32, device=self.dev)
+        start = 0
+        for bi, n in enumerate(lens):
+            if self.has_codebook:
+                base = C.c_void_p(enc.data_ptr() + start * hw)
+                self.fuse(base, hw, n_total * hw, None, pairwise[bi], n, fused[bi])
+            else:
+                self.fuse(None, 0, 0, feats[start:start + n], pairwise[bi], n, fused[bi])
+            start += n
+        preds = self._run_heads(self.heads, fused, nb, hw)
+        c, r, _ = self.heads.splits
+        out = {"cls_preds": preds[:, :c], "reg_preds": preds[:, c:c + r], "dir_preds": preds[:, c + r:], "preds_tensor": preds}
+        if self.heads_single is not None:
+            sp = self._run_heads(self.heads_single, feats, n_total, hw)
+            c, r, _ = self.heads_single.splits
+            out.update({"cls_preds_single": sp[:, :c], "reg_preds_single": sp[:, c:c + r], "dir_preds_single": sp[:, c + r:]})
+        if taps is not None:
+            taps["codes"] = enc if self.has_codebook else None
+            taps["fused"] = fused
+            taps["features"] = feats
+        return out
+
+    # ---- HIP-graph replay of a fixed-shape frame ---------------------------------------------------------------
+    def capture(self, data_dict: dict):
+        """Capture one frame into a HIP graph (torch.cuda.CUDAGraph on ROCm).  The returned callable replays it on
+        the same input tensors (refresh their contents in place between replays) and returns the same output dict."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self.forward(data_dict)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self.forward(data_dict)
+
+        def replay():
+            graph.replay()
+            return out
+        replay.graph = graph
+        return replay
+
+
+def deploy(qt_model=None, state: Optional[Dict[str, np.ndarray]] = None, path: Optional[str] = None,
+           device="cuda", **kw) -> DeployedModel:
+    """Freeze a calibrated ``QuantModel`` (or load a saved PTQ state) into the HIP int8 path."""
+    if state is None:
+        state = load_ptq_state(path) if path is not None else export_ptq_state(qt_model)
+    return DeployedModel(state, device=device, **kw)

@@ -1,0 +1,112 @@
+"""ctypes binding of ``libqv2x.so`` (C ABI in ``include/qv2x.h``).
+
+The library is the product: there is no fallback.  ``load()`` raises if the shared object is missing or
+does not export every symbol the header declares.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqv2x.so")
+MAX_GROUPS = 4
+
+SYMBOLS = [
+    "qv2x_last_error", "qv2x_version", "qv2x_fill_i8", "qv2x_pfn_scatter_i8", "qv2x_conv3x3_i8",
+    "qv2x_deconv_i8", "qv2x_codebook_level_floats", "qv2x_codebook_c2_f32", "qv2x_codebook_encode_f32", "qv2x_fuse_att_f32",
+    "qv2x_decode_lut_f32", "qv2x_heads_f32",
+]
+
+
+class PfnParams(C.Structure):
+    _fields_ = [("w", C.c_float * 640), ("b", C.c_float * 64),
+                ("d1", C.c_float), ("z1", C.c_float), ("d2", C.c_float), ("z2", C.c_float),
+                ("vox", C.c_float * 3), ("off", C.c_float * 3)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cin_total", C.c_int32),
+                ("stride", C.c_int32), ("cout", C.c_int32), ("ngroups", C.c_int32),
+                ("group_c0", C.c_int32 * MAX_GROUPS), ("group_c", C.c_int32 * MAX_GROUPS),
+                ("group_zx", C.c_int32 * MAX_GROUPS),
+                ("out_ctotal", C.c_int32), ("out_c0", C.c_int32), ("relu", C.c_int32),
+                ("out_delta", C.c_float), ("out_zp", C.c_float)]
+
+
+class DeconvDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32),
+                ("s", C.c_int32), ("in_zx", C.c_int32), ("in_delta", C.c_float),
+                ("out_ctotal", C.c_int32), ("out_c0", C.c_int32), ("relu", C.c_int32),
+                ("out_delta", C.c_float), ("out_zp", C.c_float)]
+
+
+class EncodeDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("levels", C.c_int32), ("kc", C.c_int32),
+                ("in_zx", C.c_int32), ("in_delta", C.c_float)]
+
+
+class FuseDesc(C.Structure):
+    _fields_ = [("agents", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("levels", C.c_int32), ("kc", C.c_int32),
+                ("max_cav", C.c_int32), ("ego", C.c_int32),
+                ("code_agent_stride", C.c_int64), ("code_level_stride", C.c_int64),
+                ("h_metres", C.c_double), ("w_metres", C.c_double), ("discrete_ratio", C.c_double)]
+
+
+class Qv2xError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Qv2xError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the deployed path.")
+    lib = C.CDLL(LIB_PATH)
+    missing = [s for s in SYMBOLS if not hasattr(lib, s)]
+    if missing:
+        raise Qv2xError(f"libqv2x.so does not export {missing}")
+    vp = C.c_void_p
+    lib.qv2x_last_error.restype = C.c_char_p
+    lib.qv2x_version.restype = C.c_int
+    lib.qv2x_fill_i8.argtypes = [vp, C.c_int64, C.c_int, vp]
+    lib.qv2x_pfn_scatter_i8.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(PfnParams), vp, C.c_int, C.c_int, C.c_int, vp]
+    lib.qv2x_conv3x3_i8.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.qv2x_deconv_i8.argtypes = [C.POINTER(DeconvDesc), vp, vp, vp, vp, vp]
+    lib.qv2x_codebook_level_floats.argtypes = [C.c_int]
+    lib.qv2x_codebook_level_floats.restype = C.c_int64
+    lib.qv2x_codebook_c2_f32.argtypes = [vp, C.c_int, vp, vp]
+    lib.qv2x_codebook_encode_f32.argtypes = [C.POINTER(EncodeDesc), vp, C.POINTER(vp), vp, vp]
+    lib.qv2x_fuse_att_f32.argtypes = [C.POINTER(FuseDesc), vp, vp, vp, vp, vp, vp, vp]
+    lib.qv2x_decode_lut_f32.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
+    lib.qv2x_heads_f32.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
+    for s in SYMBOLS:
+        if s not in ("qv2x_last_error", "qv2x_codebook_level_floats"):
+            getattr(lib, s).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().qv2x_last_error().decode(errors="replace")
+        raise Qv2xError(f"{what or 'libqv2x'} failed with {rc}: {msg}")
+
+
+def ptr(t) -> C.c_void_p:
+    """Device (or host) address of a torch tensor / numpy array; None -> NULL."""
+    if t is None:
+        return C.c_void_p(0)
+    if hasattr(t, "data_ptr"):
+        return C.c_void_p(t.data_ptr())
+    return C.c_void_p(t.ctypes.data)
+
+
+def current_stream() -> C.c_void_p:
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
