@@ -27,6 +27,11 @@ from .ptq_state import export_ptq_state, load_ptq_state
 _HEADS = ("cls_head", "reg_head", "dir_head")
 
 
+def _dev(a: np.ndarray, dev) -> torch.Tensor:
+    """numpy -> device tensor, always C-contiguous (the kernels take raw pointers)."""
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev).contiguous()
+
+
 def _pack_k4(w: np.ndarray) -> np.ndarray:
     """[J, K] row-major (out = W x) -> [K/4][J][4] float32: four consecutive k innermost, J coalesced per wave."""
     j, k = w.shape
@@ -46,7 +51,7 @@ def decode_tables(state: Dict[str, np.ndarray], levels: int):
         if l < levels - 1:
             const = const + front @ g(l, "side_b")
             chain = front @ g(l, "side_w")
-    return np.stack(tables).astype(np.float32), const.astype(np.float32)
+    return np.ascontiguousarray(np.stack(tables), dtype=np.float32), np.ascontiguousarray(const, dtype=np.float32)
 
 
 class _ConvLayer:
@@ -68,11 +73,11 @@ class _ConvLayer:
             scale.append(np.float32(dx) * dw)
         self.name, self.stride, self.cout = name, stride, cout
         self.groups = [(int(c0), int(c), int(zx)) for (c0, c, _, zx) in in_groups]
-        self.w = torch.from_numpy(np.concatenate(parts, axis=1).astype(np.int8)).to(dev)
-        self.scale = torch.from_numpy(np.stack(scale).astype(np.float32)).to(dev)
-        self.corr = torch.from_numpy(np.stack(corr).astype(np.int32)).to(dev)
-        self.aw = torch.from_numpy(aw.astype(np.int32)).to(dev)
-        self.bias = torch.from_numpy(state[name + "/bias"].astype(np.float32)).to(dev)
+        self.w = _dev(np.concatenate(parts, axis=1).astype(np.int8), dev)
+        self.scale = _dev(np.stack(scale).astype(np.float32), dev)
+        self.corr = _dev(np.stack(corr).astype(np.int32), dev)
+        self.aw = _dev(aw.astype(np.int32), dev)
+        self.bias = _dev(state[name + "/bias"].astype(np.float32), dev)
         self.out_q = (float(np.float32(state[name + "/a_delta"])), int(state[name + "/a_zp"]))
         assert np.abs(np.stack(corr)).max() < 2 ** 31
 
@@ -85,8 +90,8 @@ class _DeconvLayer:
         wdeq = ((code - zw) * dw).astype(np.float32)
         cin, cout, s, _ = wdeq.shape
         cols = wdeq.transpose(0, 2, 3, 1).reshape(cin, s * s * cout)              # col = (i*s + j)*Cout + co
-        self.w = torch.from_numpy(_pack_k4(cols.T)).to(dev)
-        self.bias = torch.from_numpy(state[name + "/bias"].astype(np.float32)).to(dev)
+        self.w = _dev(_pack_k4(cols.T), dev)
+        self.bias = _dev(state[name + "/bias"].astype(np.float32), dev)
         self.name, self.cin, self.cout, self.s, self.in_q = name, cin, cout, s, in_q
         self.out_q = (float(np.float32(state[name + "/a_delta"])), int(state[name + "/a_zp"]))
 
@@ -112,10 +117,10 @@ class _Heads:
             raise NotImplementedError("heads: at most 96 stacked output channels")
         pad = self.cout_pad - self.cout
         w = np.concatenate(ws + [np.zeros((pad, 256), np.float32)])
-        self.w = torch.from_numpy(_pack_k4(w)).to(dev)
-        self.bias = torch.from_numpy(np.concatenate(bs + [np.zeros(pad, np.float32)])).to(dev)
-        self.da = torch.from_numpy(np.concatenate(das + [np.full(pad, -1.0, np.float32)])).to(dev)
-        self.za = torch.from_numpy(np.concatenate(zas + [np.zeros(pad, np.float32)])).to(dev)
+        self.w = _dev(_pack_k4(w), dev)
+        self.bias = _dev(np.concatenate(bs + [np.zeros(pad, np.float32)]), dev)
+        self.da = _dev(np.concatenate(das + [np.full(pad, -1.0, np.float32)]), dev)
+        self.za = _dev(np.concatenate(zas + [np.zeros(pad, np.float32)]), dev)
 
 
 class DeployedModel(nn.Module):
@@ -184,8 +189,8 @@ class DeployedModel(nn.Module):
             self.levels = int(s["meta/codebook_levels"])
             self.kc = int(s["codebook/0/codebook"].shape[0])
             lut, lut_bias = decode_tables(s, self.levels)
-            self.lut = torch.from_numpy(lut).to(dev)
-            self.lut_bias = torch.from_numpy(lut_bias).to(dev)
+            self.lut = _dev(lut, dev)
+            self.lut_bias = _dev(lut_bias, dev)
             self.level_blobs = [self._level_blob(l) for l in range(self.levels)]
             self.level_ptrs = (C.c_void_p * self.levels)(*[b.data_ptr() for b in self.level_blobs])
         # ---- a11: heads ------------------------------------------------------------------------------------
@@ -206,7 +211,7 @@ class DeployedModel(nn.Module):
                  _pack_k4(cb), cb, np.zeros(kc, np.float32)]
         flat = np.concatenate([p.reshape(-1) for p in parts])
         assert flat.size == self.lib.qv2x_codebook_level_floats(kc)
-        blob = torch.from_numpy(flat).to(self.dev)
+        blob = _dev(flat, self.dev)
         cb_off = flat.size - kc - kc * 256
         L.check(self.lib.qv2x_codebook_c2_f32(C.c_void_p(blob.data_ptr() + 4 * cb_off), kc,
                                               C.c_void_p(blob.data_ptr() + 4 * (flat.size - kc)), L.current_stream()),
@@ -219,7 +224,7 @@ class DeployedModel(nn.Module):
         t.fill_(int(q[1]) - 128)
         return t
 
-    def _buffers(self, n: int) -> dict:
+    def _workspace(self, n: int) -> dict:
         if n in self._bufs:
             return self._bufs[n]
         b = {}
@@ -283,7 +288,7 @@ class DeployedModel(nn.Module):
     # ---- stages (also used one by one by the parity tests and the multi-GPU driver) --------------------------
     def encode_agents(self, inputs: dict, n_agents: int, taps: Optional[dict] = None):
         """a1-a6 for ``n_agents`` agents.  Returns codes u8 [levels, n, H*W] (or the i8 shrinker output without a codebook)."""
-        b = self._buffers(n_agents)
+        b = self._workspace(n_agents)
         st = L.current_stream()
         vf = inputs["voxel_features"].contiguous()
         co = inputs["voxel_coords"].to(torch.int32).contiguous()
@@ -357,7 +362,7 @@ class DeployedModel(nn.Module):
         lens = [n_total] if nb == 1 else [int(v) for v in data_dict["record_len"].tolist()]
         enc = self.encode_agents(data_dict["inputs_m1"], n_total, taps)
         hw = self.fh * self.fw
-        bufs = self._buffers(n_total)
+        bufs = self._workspace(n_total)
         feats = None
         if not self.has_codebook:
             # no codebook: the fp32 shared feature is the dequantized shrinker output
