@@ -286,48 +286,73 @@ class DeployedModel(nn.Module):
         return out
 
     # ---- stages (also used one by one by the parity tests and the multi-GPU driver) --------------------------
-    def encode_agents(self, inputs: dict, n_agents: int, taps: Optional[dict] = None):
-        """a1-a6 for ``n_agents`` agents.  Returns codes u8 [levels, n, H*W] (or the i8 shrinker output without a codebook)."""
+    def conv_plan(self, n_agents: int):
+        """Static launch list of a3 + a4 for ``n_agents`` agents: ``(kind, layer, x, h, w, out, out_c0, macs)``."""
+        b = self._workspace(n_agents)
+        if "plan" in b:
+            return b["plan"]
+        plan = []
+        x, h, w, c0 = b["canvas"], self.ny, self.nx, 0
+        for lvl, convs in enumerate(self.blocks):
+            pair, ho, wo = b["lvl"][lvl]
+            for i, layer in enumerate(convs):
+                out = pair[i % 2]
+                plan.append(("conv", layer, x, h, w, out, 0, n_agents * ho * wo * layer.cout * layer.w.shape[1]))
+                x, h, w = out, ho, wo
+            de = self.deblocks[lvl]
+            plan.append(("deconv", de, x, h, w, b["cat"], c0, n_agents * h * w * de.cin * de.cout * de.s * de.s))
+            c0 += de.cout
+        hw = n_agents * self.fh * self.fw
+        plan.append(("conv", self.shrink0, b["cat"], self.fh, self.fw, b["s0"], 0, hw * self.shrink0.cout * self.shrink0.w.shape[1]))
+        plan.append(("conv", self.shrink1, b["s0"], self.fh, self.fw, b["s1"], 0, hw * self.shrink1.cout * self.shrink1.w.shape[1]))
+        b["plan"] = plan
+        return plan
+
+    def run_plan(self, n_agents: int, only=None, taps: Optional[dict] = None):
+        for (kind, layer, x, h, w, out, c0, _) in self.conv_plan(n_agents):
+            if only is not None and not only(kind, layer):
+                continue
+            if kind == "conv":
+                self._conv(layer, x, n_agents, h, w, out)
+                if taps is not None:
+                    taps[layer.name] = out.clone()
+            else:
+                self._deconv(layer, x, n_agents, h, w, out, c0)
+
+    def pillars_to_canvas(self, inputs: dict, n_agents: int):
+        """a1 + a2: clear the canvas, run the PFN and scatter."""
         b = self._workspace(n_agents)
         st = L.current_stream()
         vf = inputs["voxel_features"].contiguous()
         co = inputs["voxel_coords"].to(torch.int32).contiguous()
         npnt = inputs["voxel_num_points"].to(torch.int32).contiguous()
-        if vf.dtype != torch.float32 or vf.shape[1:] != (32, 4):
+        if vf.dtype != torch.float32 or vf.dim() != 3 or tuple(vf.shape[1:]) != (32, 4):
             raise ValueError("voxel_features must be float32 [M, 32, 4]")
         canvas = b["canvas"]
         L.check(self.lib.qv2x_fill_i8(L.ptr(canvas), canvas.numel(), int(self.pfn.z2) - 128, st), "qv2x_fill_i8")
         L.check(self.lib.qv2x_pfn_scatter_i8(L.ptr(vf), L.ptr(co), L.ptr(npnt), vf.shape[0], 32, C.byref(self.pfn),
                                              L.ptr(canvas), n_agents, self.ny, self.nx, st), "qv2x_pfn_scatter_i8")
-        x, h, w = canvas, self.ny, self.nx
-        if taps is not None:
-            taps["canvas"] = canvas
-        c0 = 0
-        for lvl, convs in enumerate(self.blocks):
-            pair, ho, wo = b["lvl"][lvl]
-            for i, layer in enumerate(convs):
-                out = pair[i % 2]
-                self._conv(layer, x, n_agents, h, w, out)
-                x, h, w = out, ho, wo
-                if taps is not None:
-                    taps[layer.name] = out.clone()
-            de = self.deblocks[lvl]
-            self._deconv(de, x, n_agents, h, w, b["cat"], c0)
-            c0 += de.cout
-        if taps is not None:
-            taps["cat"] = b["cat"]
-        self._conv(self.shrink0, b["cat"], n_agents, self.fh, self.fw, b["s0"])
-        self._conv(self.shrink1, b["s0"], n_agents, self.fh, self.fw, b["s1"])
-        if taps is not None:
-            taps[self.shrink0.name], taps[self.shrink1.name] = b["s0"], b["s1"]
-        if not self.has_codebook:
-            return b["s1"]
+        return canvas
+
+    def encode_codes(self, n_agents: int):
+        """a6 on the shrinker output already in the workspace."""
+        b = self._workspace(n_agents)
         d = L.EncodeDesc()
         d.n, d.h, d.w, d.levels, d.kc = n_agents, self.fh, self.fw, self.levels, self.kc
         d.in_zx, d.in_delta = int(self.shrink1.out_q[1]), float(self.shrink1.out_q[0])
-        L.check(self.lib.qv2x_codebook_encode_f32(C.byref(d), L.ptr(b["s1"]), self.level_ptrs, L.ptr(b["codes"]), st),
-                "qv2x_codebook_encode_f32")
+        L.check(self.lib.qv2x_codebook_encode_f32(C.byref(d), L.ptr(b["s1"]), self.level_ptrs, L.ptr(b["codes"]),
+                                                  L.current_stream()), "qv2x_codebook_encode_f32")
         return b["codes"]
+
+    def encode_agents(self, inputs: dict, n_agents: int, taps: Optional[dict] = None):
+        """a1-a6 for ``n_agents`` agents.  Returns codes u8 [levels, n, H*W] (or the i8 shrinker output without a codebook)."""
+        b = self._workspace(n_agents)
+        canvas = self.pillars_to_canvas(inputs, n_agents)
+        self.run_plan(n_agents, taps=taps)
+        if taps is not None:
+            taps["canvas"], taps["cat"] = canvas, b["cat"]
+            taps[self.shrink0.name], taps[self.shrink1.name] = b["s0"], b["s1"]
+        return self.encode_codes(n_agents) if self.has_codebook else b["s1"]
 
     def decode_rows(self, codes, n_rows_total):
         """codes u8 [levels, R] -> fp32 [R, 256] (only needed for the *_single heads)."""
@@ -347,6 +372,17 @@ class DeployedModel(nn.Module):
         lb = L.ptr(self.lut_bias) if self.has_codebook else None
         L.check(self.lib.qv2x_fuse_att_f32(C.byref(d), codes_ptr, lut, lb, L.ptr(feats) if feats is not None else None,
                                            L.ptr(pairwise_b), L.ptr(out), L.current_stream()), "qv2x_fuse_att_f32")
+
+    def fuse_and_heads(self, codes, agent_stride, level_stride, pairwise_b, n_agents, ego=0) -> dict:
+        """a7-a11 on an (all-gathered) code tensor for one scene; ``pairwise_b`` f64 [L, L, 4, 4] on the device."""
+        hw = self.fh * self.fw
+        if pairwise_b.dtype != torch.float64 or not pairwise_b.is_contiguous():
+            pairwise_b = pairwise_b.to(torch.float64).contiguous()
+        fused = torch.empty((1, hw, 256), dtype=torch.float32, device=self.dev)
+        self.fuse(L.ptr(codes), agent_stride, level_stride, None, pairwise_b, n_agents, fused[0], ego)
+        preds = self._run_heads(self.heads, fused, 1, hw)
+        c, r, _ = self.heads.splits
+        return {"cls_preds": preds[:, :c], "reg_preds": preds[:, c:c + r], "dir_preds": preds[:, c + r:], "preds_tensor": preds}
 
     # ---- the reference's model contract ----------------------------------------------------------------------
     @torch.no_grad()

@@ -26,31 +26,19 @@ def scene(n_agents, shape="tiny", device="cpu", **kw):
 
 
 def quant_wrap(model, method="minmax"):
-    from quantv2x_amd.plugin.quant import QuantModel, set_weight_quantize_params
-    wq = dict(n_bits=8, channel_wise=True, scale_method=method)
-    aq = dict(n_bits=8, channel_wise=False, scale_method=method, leaf_param=True, prob=0.5)
-    qt = QuantModel(model, wq, aq).eval()
-    set_weight_quantize_params(qt)
-    return qt
+    from quantv2x_amd.plugin.tools.inference_quant import wrap
+    return wrap(model, method)
 
 
 def act_quantizers(qt):
-    from quantv2x_amd.plugin.quant import UniformAffineQuantizer
-    return [m for m in qt.modules() if isinstance(m, UniformAffineQuantizer) and m.leaf_param]
+    from quantv2x_amd.plugin.tools.inference_quant import activation_quantizers
+    return activation_quantizers(qt)
 
 
-def calibrated_plugin(shape="tiny", n_agents=2, **kw):
+def calibrated_plugin(shape="tiny", n_agents=2, n_points=N_POINTS, **kw):
     """W8A8 min-max ``QuantModel`` frozen after one EMA pass -- the golden ``tiny_w8a8`` recipe."""
-    qt = quant_wrap(build_plugin(shape, **kw))
-    for a in act_quantizers(qt):
-        a.set_inited(False)
-    qt.set_quant_state(True, True)
-    with torch.no_grad():
-        torch.manual_seed(0)
-        qt(scene(n_agents, shape))
-    for a in act_quantizers(qt):
-        a.set_inited(True)
-    return qt
+    from quantv2x_amd.plugin.tools.inference_quant import calibrate_minmax
+    return calibrate_minmax(quant_wrap(build_plugin(shape, **kw)), [scene(n_agents, shape, n_points=n_points)])
 
 
 def hard_forward(model, dd, taps=None):
