@@ -28,7 +28,7 @@ def exchange_codes(codes: torch.Tensor, group=None, out: Optional[torch.Tensor] 
     if world == 1:
         out[0].copy_(codes)
     else:
-        dist.all_gather_into_tensor(out, codes, group=group)
+        dist.all_gather_into_tensor(out, codes.unsqueeze(0), group=group)   # concat-along-dim-0 form (gloo and RCCL)
     return out
 
 
