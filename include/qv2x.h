@@ -100,7 +100,7 @@ int qv2x_deconv_i8(const qv2x_deconv_desc* desc /* host */, const int8_t* in, co
  *   weights: one f32 blob per level, laid out by the host as
  *       stage [64][256][4] | stage_b [256] | qhead [64][256][4] | qhead_b [256] | lhead [64][256][4] | lhead_b [256]
  *       | cb_packed [64][Kc][4] | cb [Kc][256] | c2 [Kc]
- *     ([K/4][cols][4] = four consecutive k innermost); lhead* unused on the last level
+ *     ([K/4][cols][4] = four consecutive k innermost, stored in the order k0, k2, k1, k3); lhead* unused on the last level
  *   codes: u8 [levels][N*H*W]. */
 typedef struct {
     int32_t n, h, w;

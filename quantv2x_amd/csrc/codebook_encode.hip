@@ -5,18 +5,23 @@
 //             x <- lhead(z) - C[code]          (reference op order; every dot product is an ascending-k fp32
 //             fma chain with acc0 = bias, which is what the f32 MFMA evaluates -- bit-exact against
 //             oracle/qv2x_oracle.c:orc_codebook_encode).
-// A workgroup owns 64 BEV cells: x / z / q live in two LDS buffers (row stride 260 floats: ds_read_b128 of a
-// 16-lane group lands on 16 distinct 16-byte slots), the 256 x 256 weight matrices stream from L2 as
-// [K/4][col][4] float4 (coalesced per wave), register double buffered.  Wave w owns output columns
-// [64w, 64w + 64) for all 64 rows (2 x 2 MFMA tiles); for the distance GEMM codes [32w, 32w + 32).
+// A workgroup (8 waves) owns 64 BEV cells: x / z / q live in two LDS buffers (row stride 260 floats: ds_read_b128 of
+// a 16-lane group lands on 16 distinct 16-byte slots), the 256 x 256 weight matrices stream from L2 as
+// [K/4][col][k0,k2,k1,k3] (coalesced float2 per half-wave), prefetched four k-quads ahead.  Wave w owns output columns
+// [32w, 32w + 32) for all 64 rows; for the distance GEMM one 32 x 32 (rows x codes) tile.
 // The argmin runs on the accumulator registers: half-wave butterfly on (distance, index) with ties to the lower
 // index, then a 4-way combine across waves through LDS.
 #include "common.h"
 
 namespace qv2x {
 
-constexpr int ER = 64;              // rows per workgroup
-constexpr int LDF = 260;            // LDS row stride in floats
+constexpr int ER = 32;              // rows per workgroup (two workgroups share a CU: 4 waves per SIMD)
+constexpr int ERT = ER / 32;        // 32-row MFMA tiles per workgroup
+constexpr int LDF = 258;            // LDS row stride in floats: 32 rows x ds_read_b64 land on 32 distinct bank pairs
+// Within every group of four consecutive k the LDS tiles and the packed weights are stored in the order (k0, k2, k1, k3):
+// the half-wave that feeds MFMA k-parity p reads ONE float2 = (k_p, k_{p+2}) -- no per-MFMA select instructions, so the
+// dependent MFMAs issue back to back (an extra VALU between two MFMAs on one accumulator costs ~45 cycles on gfx950).
+__device__ __forceinline__ int kpos(int c) { return (c & ~3) | ((c & 1) << 1) | ((c >> 1) & 1); }
 constexpr int D = 256;
 
 struct EncArgs {
@@ -29,56 +34,79 @@ struct EncArgs {
 __device__ __forceinline__ size_t off_stage_w() { return 0; }
 __device__ __host__ __forceinline__ int64_t level_floats(int kc) { return 3LL * (D * D + D) + (int64_t)D * kc + (int64_t)kc * D + kc; }
 
-// out[64 rows][cols 64*wave .. +64) = in[64][256] . W^T, acc0 = bias.  W packed [64][256][4].
-__device__ __forceinline__ void gemm_64x64(const float* __restrict__ src, const float4* __restrict__ wp, const float* __restrict__ bias,
-                                           int wave, int lane, v16f (&acc)[2][2]) {
-    const int par = lane >> 5, col = wave * 64 + (lane & 31);
+// out[64 rows][cols 32*wave .. +32) = in[64][256] . W^T, acc0 = bias.  W packed [64][256][4].  Eight waves split
+// the 256 output columns, so every weight element is fetched by exactly one wave of the workgroup; two waves share
+// a SIMD and cover each other's LDS / L2 latency (one f32 MFMA occupies the pipe for 64 cycles).
+// First four k-quads of a weight matrix + the bias of this lane's output column, requested ahead of the barrier that
+// precedes the GEMM so that its L2 latency overlaps the previous phase.
+// out[rows][cols 32*wave .. +32) = in[rows][256] . W^T, acc0 = bias.  Eight waves split the 256 output columns, so
+// every weight element is fetched by exactly one wave of the workgroup.  The weights of the next four k-quads (one
+// float2 per lane each) are requested from L2 while the 8 MFMAs of the current four run; two static register sets,
+// so the in-order vmcnt wait at a set's first use leaves the other set's loads in flight (sched_barrier pins the
+// request block ahead of the MFMA block: hipcc otherwise sinks every load to its first use).  Reads past the last
+// k-quad hit the next section of the weight blob.
+__device__ __forceinline__ void gemm_rows_x32(const float* __restrict__ src, const float2* __restrict__ wp, const float* __restrict__ bias,
+                                              int wave, int lane, v16f (&acc)[ERT]) {
+    const int par = lane >> 5, col = wave * 32 + (lane & 31);
+    const float b = bias[col];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const float b = bias[col + j * 32];
+    for (int i = 0; i < ERT; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int r = 0; r < 16; ++r) acc[i][r] = b;
+    const float2* wl = wp + (size_t)col * 2 + par;
+    const float* al = src + (lane & 31) * LDF + 2 * par;
+    auto loadB = [&](float2 (&dst)[4], int q0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = b;
-    }
-    float4 bn[2];
+        for (int t = 0; t < 4; ++t) dst[t] = wl[(size_t)(q0 + t) * D * 2];
+    };
+    auto compute4 = [&](const float2 (&bset)[4], int q0) {
+        float2 av[4][ERT];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) bn[j] = wp[col + j * 32];
-    for (int q = 0; q < 64; ++q) {
-        float4 bc[2] = {bn[0], bn[1]};
-        if (q + 1 < 64) {
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bn[j] = wp[(size_t)(q + 1) * D + col + j * 32];
+            for (int i = 0; i < ERT; ++i) av[t][i] = *(const float2*)(al + i * 32 * LDF + (q0 + t) * 4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int i = 0; i < ERT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][i].x, bset[t].x, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < ERT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][i].y, bset[t].y, acc[i], 0, 0, 0);
         }
-        float4 av[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) av[i] = *(const float4*)(src + (i * 32 + (lane & 31)) * LDF + q * 4);
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const float a = half ? (par ? av[i].w : av[i].z) : (par ? av[i].y : av[i].x);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const float b = half ? (par ? bc[j].w : bc[j].z) : (par ? bc[j].y : bc[j].x);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
-                }
-            }
-        }
+    };
+    float2 s0[4], s1[4];
+    loadB(s0, 0);
+    for (int q0 = 0; q0 < 64; q0 += 8) {
+        loadB(s1, q0 + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        compute4(s0, q0);
+        __builtin_amdgcn_sched_barrier(0);
+        loadB(s0, q0 + 8);
+        __builtin_amdgcn_sched_barrier(0);
+        compute4(s1, q0 + 4);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-__device__ __forceinline__ void store_tile(float* __restrict__ dst, int wave, int lane, const v16f (&acc)[2][2]) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                dst[(i * 32 + mfma32_row(r, lane)) * LDF + wave * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+// one step of the (value, index) argmin reduction: combine with the lane `shift` positions up inside the 16-lane row
+template <int CTRL>
+__device__ __forceinline__ void argmin_dpp(float& v, int& i) {
+    const int vb = __builtin_bit_cast(int, v);
+    const float ov = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(vb, vb, CTRL, 0xf, 0xf, false));
+    const int oi = __builtin_amdgcn_update_dpp(i, i, CTRL, 0xf, 0xf, false);
+    const bool take = (ov < v) || (ov == v && oi < i);
+    v = take ? ov : v;
+    i = take ? oi : i;
 }
 
-__global__ __launch_bounds__(256) void codebook_encode_kernel(const EncArgs a) {
+__device__ __forceinline__ void store_tile(float* __restrict__ dst, int wave, int lane, const v16f (&acc)[ERT]) {
+#pragma unroll
+    for (int i = 0; i < ERT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            dst[(i * 32 + mfma32_row(r, lane)) * LDF + kpos(wave * 32 + (lane & 31))] = acc[i][r];
+}
+
+__global__ __launch_bounds__(512, 4) void codebook_encode_kernel(const EncArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* bufA = smem;                       // x, then q, then next x
     float* bufB = smem + ER * LDF;            // z
@@ -90,26 +118,28 @@ __global__ __launch_bounds__(256) void codebook_encode_kernel(const EncArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * ER;
 
-    {   // ---- load 64 rows x 256 channels from the i8 BEV, dequantize ---------------------------------
-        const int row = tid >> 2, part = tid & 3;
+    {   // ---- load ER rows x 256 channels from the i8 BEV, dequantize ---------------------------------
+        constexpr int TPR = 512 / ER;                 // threads per row
+        constexpr int CPT = D / TPR;                  // channels per thread (16 for ER = 32)
+        const int row = tid / TPR, part = tid % TPR;
         int m = m0 + row;
         m = m < a.M ? m : a.M - 1;
         const int img = m / (a.h * a.w), rem = m - img * (a.h * a.w);
         const int y = rem / a.w, x = rem - y * a.w;
-        const int8_t* src = a.in + ((size_t)(img * (a.h + 2) + y + 1) * (a.w + 2) + x + 1) * D + part * 64;
+        const int8_t* src = a.in + ((size_t)(img * (a.h + 2) + y + 1) * (a.w + 2) + x + 1) * D + part * CPT;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < CPT / 16; ++c) {
             const v4i raw = *(const v4i*)(src + c * 16);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int xs = (raw[e >> 2] << (24 - (e & 3) * 8)) >> 24;
-                bufA[row * LDF + part * 64 + c * 16 + e] = (float)(xs + a.ax) * a.dx;
+                bufA[row * LDF + kpos(part * CPT + c * 16 + e)] = (float)(xs + a.ax) * a.dx;
             }
         }
     }
     __syncthreads();
 
-    v16f acc[2][2];
+    v16f acc[ERT];
     for (int l = 0; l < a.levels; ++l) {
         const float* W = a.lvl[l];
         const float* stage_w = W;
@@ -122,77 +152,91 @@ __global__ __launch_bounds__(256) void codebook_encode_kernel(const EncArgs a) {
         const float* cb = cbp + (size_t)D * a.kc;             // [kc][256]
         const float* c2 = cb + (size_t)a.kc * D;              // [kc]
 
-        gemm_64x64(bufA, (const float4*)stage_w, stage_b, wave, lane, acc);      // z = stage(x)
+        gemm_rows_x32(bufA, (const float2*)stage_w, stage_b, wave, lane, acc);      // z = stage(x)
         store_tile(bufB, wave, lane, acc);
         __syncthreads();
-        gemm_64x64(bufB, (const float4*)qhead_w, qhead_b, wave, lane, acc);      // q = qhead(z)
-        __syncthreads();                                                          // all reads of x (bufA) done in GEMM 1; safe to overwrite
-        store_tile(bufA, wave, lane, acc);
+        gemm_rows_x32(bufB, (const float2*)qhead_w, qhead_b, wave, lane, acc);      // q = qhead(z)
+        store_tile(bufA, wave, lane, acc);                                        // x is dead since the barrier above
         __syncthreads();
 
-        {   // |q|^2: four 64-wide ascending fma chains per row, combined (s0 + s1) + (s2 + s3)
-            const int row = tid >> 2, part = tid & 3;
-            const float* qr = bufA + row * LDF + part * 64;
+        if (tid < ER * 4) {   // |q|^2: four 64-wide ascending fma chains per row; thread = (chain = tid / ER, row = tid % ER)
+            const int row = tid % ER, part = tid / ER;
+            const float2* qr = (const float2*)(bufA + row * LDF + part * 64);
             float s = 0.0f;
-#pragma unroll 8
-            for (int i = 0; i < 64; ++i) s = fmaf(qr[i], qr[i], s);
-            const float s01 = s + __shfl_xor(s, 1);
-            const float tot = s01 + __shfl_xor(s01, 2);
-            if (part == 0) x2[row] = tot;
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) {             // one k-quad per step, stored (k0, k2, k1, k3)
+                const float2 e = qr[2 * j], o = qr[2 * j + 1];
+                s = fmaf(e.x, e.x, s); s = fmaf(o.x, o.x, s); s = fmaf(e.y, e.y, s); s = fmaf(o.y, o.y, s);
+            }
+            pval[part * ER + row] = s;
         }
         __syncthreads();
+        if (tid < ER) x2[tid] = (pval[tid] + pval[ER + tid]) + (pval[2 * ER + tid] + pval[3 * ER + tid]);
+        __syncthreads();
 
-        // ---- distances for codes [32*wave, +32) and the per-wave argmin ---------------------------------
-        if (wave * 32 < a.kc) {
-            const int par = lane >> 5, code = wave * 32 + (lane & 31);
-            v16f dacc[2];
+        // ---- distances: wave -> (row tile = wave >> 2, codes [32*(wave & 3), +32)), then the argmin ------------
+        const int ct = wave & 3, rt = wave >> 2;
+        if (rt < ERT && ct * 32 < a.kc) {
+            const int par = lane >> 5, code = ct * 32 + (lane & 31);
+            v16f dacc;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int r = 0; r < 16; ++r) dacc[r] = 0.0f;
+            const float2* cl = (const float2*)cbp + (size_t)code * 2 + par;
+            const float* al = bufA + (rt * 32 + (lane & 31)) * LDF + 2 * par;
+            auto loadC = [&](float2 (&dst)[4], int q0) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dacc[i][r] = 0.0f;
-            const float4* cp = (const float4*)cbp;
-            float4 bn = cp[code];
-            for (int q = 0; q < 64; ++q) {
-                const float4 bc = bn;
-                if (q + 1 < 64) bn = cp[(size_t)(q + 1) * a.kc + code];
-                float4 av[2];
+                for (int t = 0; t < 4; ++t) dst[t] = cl[(size_t)(q0 + t) * a.kc * 2];   // past the end: the [kc][256] copy
+            };
+            auto dist4 = [&](const float2 (&bset)[4], int q0) {
+                float2 av[4];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) av[i] = *(const float4*)(bufA + (i * 32 + (lane & 31)) * LDF + q * 4);
+                for (int t = 0; t < 4; ++t) av[t] = *(const float2*)(al + (q0 + t) * 4);
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const float b = half ? (par ? bc.w : bc.z) : (par ? bc.y : bc.x);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const float av_ = half ? (par ? av[i].w : av[i].z) : (par ? av[i].y : av[i].x);
-                        dacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_, b, dacc[i], 0, 0, 0);
-                    }
+                for (int t = 0; t < 4; ++t) {
+                    dacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].x, bset[t].x, dacc, 0, 0, 0);
+                    dacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].y, bset[t].y, dacc, 0, 0, 0);
                 }
+            };
+            float2 s0[4], s1[4];
+            loadC(s0, 0);
+            for (int q0 = 0; q0 < 64; q0 += 8) {
+                loadC(s1, q0 + 4);
+                __builtin_amdgcn_sched_barrier(0);
+                dist4(s0, q0);
+                __builtin_amdgcn_sched_barrier(0);
+                loadC(s0, q0 + 8);
+                __builtin_amdgcn_sched_barrier(0);
+                dist4(s1, q0 + 4);
+                __builtin_amdgcn_sched_barrier(0);
             }
             const float c2v = c2[code];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = i * 32 + mfma32_row(r, lane);
-                    float dv = (x2[row] + c2v) - 2.0f * dacc[i][r];
-                    int di = code;
-#pragma unroll
-                    for (int off = 16; off >= 1; off >>= 1) {      // butterfly inside each 32-lane half
-                        const float ov = __shfl_xor(dv, off);
-                        const int oi = __shfl_xor(di, off);
-                        const bool take = (ov < dv) || (ov == dv && oi < di);
-                        dv = take ? ov : dv;
-                        di = take ? oi : di;
-                    }
-                    if ((lane & 31) == 0) { pval[wave * ER + row] = dv; pidx[wave * ER + row] = di; }
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int row = rt * 32 + mfma32_row(r, lane);
+                float dv = (x2[row] + c2v) - 2.0f * dacc[r];
+                int di = code;
+                // (distance, index) minimum with ties to the lower index, reduced towards lane 0 of each 16-lane row with
+                // DPP row shifts (full-rate VALU; the ds_bpermute butterfly this replaces cost ~20 us per workgroup)
+                argmin_dpp<0x108>(dv, di); argmin_dpp<0x104>(dv, di); argmin_dpp<0x102>(dv, di); argmin_dpp<0x101>(dv, di);
+                // rows 0|1 (lanes 0, 16) and 2|3 (lanes 32, 48) of the wave
+                const float v16 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dv), 16));
+                const int i16 = __builtin_amdgcn_readlane(di, 16);
+                const float v48 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dv), 48));
+                const int i48 = __builtin_amdgcn_readlane(di, 48);
+                const float ov = lane < 32 ? v16 : v48;
+                const int oi = lane < 32 ? i16 : i48;
+                const bool take = (ov < dv) || (ov == dv && oi < di);
+                dv = take ? ov : dv;
+                di = take ? oi : di;
+                if ((lane & 31) == 0) { pval[ct * ER + row] = dv; pidx[ct * ER + row] = di; }
+            }
         }
         __syncthreads();
         if (tid < ER) {
             float bv = pval[tid]; int bi = pidx[tid];
             for (int wv = 1; wv * 32 < a.kc; ++wv) {
                 const float ov = pval[wv * ER + tid]; const int oi = pidx[wv * ER + tid];
-                if (ov < bv) { bv = ov; bi = oi; }                 // strict: earlier wave = lower indices wins ties
+                if (ov < bv) { bv = ov; bi = oi; }                 // strict: lower code tile wins ties
             }
             code_s[tid] = bi;
             if (m0 + tid < a.M) a.codes[(size_t)l * a.M + m0 + tid] = (uint8_t)bi;
@@ -200,16 +244,19 @@ __global__ __launch_bounds__(256) void codebook_encode_kernel(const EncArgs a) {
         __syncthreads();
 
         if (l + 1 < a.levels) {      // x <- lhead(z) - C[code]
-            gemm_64x64(bufB, (const float4*)lhead_w, lhead_b, wave, lane, acc);
+            gemm_rows_x32(bufB, (const float2*)lhead_w, lhead_b, wave, lane, acc);
+            const int col = wave * 32 + (lane & 31);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < ERT; ++i) {
+                int cd[16];
+                float cv[16];
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int r = 0; r < 16; ++r) cd[r] = code_s[i * 32 + mfma32_row(r, lane)];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = i * 32 + mfma32_row(r, lane), col = wave * 64 + j * 32 + (lane & 31);
-                        bufA[row * LDF + col] = acc[i][j][r] - cb[(size_t)code_s[row] * D + col];
-                    }
+                for (int r = 0; r < 16; ++r) cv[r] = cb[(size_t)cd[r] * D + col];       // 16 gathers in flight
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bufA[(i * 32 + mfma32_row(r, lane)) * LDF + kpos(col)] = acc[i][r] - cv[r];
+            }
             __syncthreads();
         }
     }
@@ -260,6 +307,6 @@ extern "C" int qv2x_codebook_encode_f32(const qv2x_encode_desc* d, const int8_t*
         if (rc) return rc;
         attr_set = true;
     }
-    codebook_encode_kernel<<<(a.M + ER - 1) / ER, 256, smem, (hipStream_t)stream>>>(a);
+    codebook_encode_kernel<<<(a.M + ER - 1) / ER, 512, smem, (hipStream_t)stream>>>(a);
     return hip_check(hipGetLastError(), "qv2x_codebook_encode_f32 launch");
 }

@@ -16,6 +16,8 @@
 //
 // Epilogue (spec shared with oracle/qv2x_oracle.c:orc_conv3x3): y = bias + sum_g float(T_g) * scale[g][co]
 // (separate mul and add), ReLU, requantize with IEEE division + rint, store code - 128.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace qv2x {
@@ -29,19 +31,28 @@ struct ConvArgs {
     float out_delta, out_zp;
 };
 
-__device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+// LDS rows are BK bytes = CH 16-byte chunks; chunk c of row r is stored at c ^ f(r) so that the 16 lanes of a
+// ds_read_b128 group (rows {0-3,12-15,20-27}, ... of a 32-row fragment, same chunk) hit 16 distinct 16-byte slots.
+template <int BK>
+__device__ __forceinline__ int swz(int row, int chunk) {
+    constexpr int CH = BK / 16;
+    return row * BK + ((chunk ^ ((row >> (CH == 4 ? 2 : 1)) & (CH - 1))) << 4);
+}
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv3x3_i8_kernel(const ConvArgs a) {
+template <int BM, int BN, int WM, int WN, int BK, bool MULTI, int MINW>
+__global__ __launch_bounds__(256, MINW) void conv3x3_i8_kernel(const ConvArgs a) {
     constexpr int TM = BM / WM, TN = BN / WN;      // wave tile
     constexpr int MT = TM / 32, NT = TN / 32;      // 32x32 MFMA tiles per wave
-    constexpr int LA = BM / 64, LB = BN / 64;      // 16-byte global loads per thread per K-chunk
+    constexpr int CH = BK / 16;
+    constexpr int LA = BM * CH / 256, LB = BN * CH / 256;      // 16-byte global loads per thread per K-chunk
+    constexpr int NF = MULTI ? 16 : 1;
     static_assert(WM * WN == 4 && MT >= 1 && NT >= 1 && LA >= 1 && LB >= 1, "tile shape");
 
-    __shared__ __attribute__((aligned(16))) int8_t lds[2 * (BM + BN) * 64 + 4 * TM * 4];
+    __shared__ __attribute__((aligned(16))) int8_t lds[2 * (BM + BN) * BK + 4 * TM * 4 + BM * 4];
     int8_t* ldsA = lds;
-    int8_t* ldsB = lds + 2 * BM * 64;
-    int* xbuf = (int*)(lds + 2 * (BM + BN) * 64);  // [4 waves][TM] window sums
+    int8_t* ldsB = lds + 2 * BM * BK;
+    int* xbuf = (int*)(lds + 2 * (BM + BN) * BK);  // [4 waves][TM] window sums
+    int* rowoff = xbuf + 4 * TM;                    // [BM] output pixel offset (in pixels), -1 = past the end
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -52,25 +63,35 @@ __global__ __launch_bounds__(256) void conv3x3_i8_kernel(const ConvArgs a) {
     int dstA[LA];
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-        const int id = tid + i * 256, row = id >> 2, ch = id & 3;
+        const int id = tid + i * 256, row = id / CH, ch = id % CH;
         int m = m0 + row;
         m = m < a.M ? m : a.M - 1;
         const int img = m / (a.ho * a.wo), rem = m - img * (a.ho * a.wo);
         const int yo = rem / a.wo, xo = rem - yo * a.wo;
         srcA[i] = a.in + ((size_t)(img * a.hp + yo * a.stride) * a.wp + xo * a.stride) * a.cin_total + ch * 16;
-        dstA[i] = swz(row, ch);
+        dstA[i] = swz<BK>(row, ch);
+    }
+    if (tid < BM) {
+        const int m = m0 + tid;
+        int off = -1;
+        if (m < a.M) {
+            const int img = m / (a.ho * a.wo), rem = m - img * (a.ho * a.wo);
+            const int yo = rem / a.wo, xo = rem - yo * a.wo;
+            off = (img * (a.ho + 2) + yo + 1) * (a.wo + 2) + xo + 1;
+        }
+        rowoff[tid] = off;
     }
     const int8_t* srcB[LB];
     int dstB[LB];
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
-        const int id = tid + i * 256, row = id >> 2, ch = id & 3;
+        const int id = tid + i * 256, row = id / CH, ch = id % CH;
         srcB[i] = a.w + (size_t)(n0 + row) * a.ktot + ch * 16;
-        dstB[i] = swz(row, ch);
+        dstB[i] = swz<BK>(row, ch);
     }
 
     v16i acc[MT][NT];
-    float facc[MT][NT][16];
+    float facc[MT][NT][NF];
     int xs[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -78,57 +99,61 @@ __global__ __launch_bounds__(256) void conv3x3_i8_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0; }
-            const float b = a.bias[n0 + wn * TN + j * 32 + (lane & 31)];
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+            if (MULTI) {
+                const float b = a.bias[n0 + wn * TN + j * 32 + (lane & 31)];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) facc[i][j][r] = b;
+                for (int r = 0; r < NF; ++r) facc[i][j][r] = b;
+            }
         }
     }
 
     v4i ra[LA], rb[LB];
-    int kofs = 0;      // byte offset into a weight row == 64 * (chunks consumed so far)
+    int kofs = 0;      // byte offset into a weight row == BK * (chunks consumed so far)
     int cur = 0;
 
-    for (int g = 0; g < a.ngroups; ++g) {
-        const int chunks = a.gc[g] >> 6;
+    for (int g = 0; g < (MULTI ? a.ngroups : 1); ++g) {
+        const int chunks = a.gc[g] / BK;
         const int steps = 9 * chunks;
-        // step s -> (tap = s / chunks, cc = s % chunks); source offset of the A chunk
-        auto a_off = [&](int s) {
-            const int tap = s / chunks, cc = s - tap * chunks;
-            const int kh = tap / 3, kw = tap - kh * 3;
-            return (kh * a.wp + kw) * a.cin_total + a.gc0[g] + cc * 64;
+        // (tap, cc) of the chunk being PREFETCHED; advanced without divisions
+        int p_tap = 0, p_cc = 0;
+        auto next_off = [&]() {
+            const int kh = p_tap >= 6 ? 2 : (p_tap >= 3 ? 1 : 0), kw = p_tap - kh * 3;
+            const int off = (kh * a.wp + kw) * a.cin_total + a.gc0[g] + p_cc * BK;
+            if (++p_cc == chunks) { p_cc = 0; ++p_tap; }
+            return off;
         };
         {   // prologue: chunk 0 of this group
-            const int ao = a_off(0);
+            const int ao = next_off();
 #pragma unroll
             for (int i = 0; i < LA; ++i) ra[i] = *(const v4i*)(srcA[i] + ao);
 #pragma unroll
             for (int i = 0; i < LB; ++i) rb[i] = *(const v4i*)(srcB[i] + kofs);
 #pragma unroll
-            for (int i = 0; i < LA; ++i) *(v4i*)(ldsA + cur * BM * 64 + dstA[i]) = ra[i];
+            for (int i = 0; i < LA; ++i) *(v4i*)(ldsA + cur * BM * BK + dstA[i]) = ra[i];
 #pragma unroll
-            for (int i = 0; i < LB; ++i) *(v4i*)(ldsB + cur * BN * 64 + dstB[i]) = rb[i];
+            for (int i = 0; i < LB; ++i) *(v4i*)(ldsB + cur * BN * BK + dstB[i]) = rb[i];
             __syncthreads();
         }
         for (int s = 0; s < steps; ++s) {
             const bool more = (s + 1) < steps;
             if (more) {
-                const int ao = a_off(s + 1);
+                const int ao = next_off();
 #pragma unroll
                 for (int i = 0; i < LA; ++i) ra[i] = *(const v4i*)(srcA[i] + ao);
 #pragma unroll
-                for (int i = 0; i < LB; ++i) rb[i] = *(const v4i*)(srcB[i] + kofs + 64);
+                for (int i = 0; i < LB; ++i) rb[i] = *(const v4i*)(srcB[i] + kofs + BK);
             }
-            const int8_t* bufA = ldsA + cur * BM * 64;
-            const int8_t* bufB = ldsB + cur * BN * 64;
+            const int8_t* bufA = ldsA + cur * BM * BK;
+            const int8_t* bufB = ldsB + cur * BN * BK;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < BK / 32; ++ks) {
                 v4i fa[MT], fb[NT];
                 const int ch = ks * 2 + (lane >> 5);
 #pragma unroll
-                for (int i = 0; i < MT; ++i) fa[i] = *(const v4i*)(bufA + swz(wm * TM + i * 32 + (lane & 31), ch));
+                for (int i = 0; i < MT; ++i) fa[i] = *(const v4i*)(bufA + swz<BK>(wm * TM + i * 32 + (lane & 31), ch));
 #pragma unroll
-                for (int j = 0; j < NT; ++j) fb[j] = *(const v4i*)(bufB + swz(wn * TN + j * 32 + (lane & 31), ch));
+                for (int j = 0; j < NT; ++j) fb[j] = *(const v4i*)(bufB + swz<BK>(wn * TN + j * 32 + (lane & 31), ch));
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -139,15 +164,15 @@ __global__ __launch_bounds__(256) void conv3x3_i8_kernel(const ConvArgs a) {
             }
             if (more) {
 #pragma unroll
-                for (int i = 0; i < LA; ++i) *(v4i*)(ldsA + (cur ^ 1) * BM * 64 + dstA[i]) = ra[i];
+                for (int i = 0; i < LA; ++i) *(v4i*)(ldsA + (cur ^ 1) * BM * BK + dstA[i]) = ra[i];
 #pragma unroll
-                for (int i = 0; i < LB; ++i) *(v4i*)(ldsB + (cur ^ 1) * BN * 64 + dstB[i]) = rb[i];
+                for (int i = 0; i < LB; ++i) *(v4i*)(ldsB + (cur ^ 1) * BN * BK + dstB[i]) = rb[i];
             }
             __syncthreads();
             cur ^= more ? 1 : 0;
-            kofs += 64;
+            kofs += BK;
         }
-        // ---- fold this group into the fp32 accumulator ---------------------------------------------
+        // ---- window sums of this group to LDS (C-fragment rows differ from A-fragment rows) -----------
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int tot = xs[i] + __shfl_xor(xs[i], 32);
@@ -155,49 +180,73 @@ __global__ __launch_bounds__(256) void conv3x3_i8_kernel(const ConvArgs a) {
             xs[i] = 0;
         }
         __syncthreads();
+        if (MULTI) {       // fold this group into the fp32 accumulator with its own activation scale
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int co = n0 + wn * TN + j * 32 + (lane & 31);
-            const int awv = a.aw[co];
-            const int cr = a.corr[g * a.cout + co];
-            const float sc = a.scale[g * a.cout + co];
+            for (int j = 0; j < NT; ++j) {
+                const int co = n0 + wn * TN + j * 32 + (lane & 31);
+                const int awv = a.aw[co];
+                const int cr = a.corr[g * a.cout + co];
+                const float sc = a.scale[g * a.cout + co];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
+                for (int i = 0; i < MT; ++i) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int T = acc[i][j][r] + awv * xbuf[wave * TM + i * 32 + mfma32_row(r, lane)] + cr;
-                    facc[i][j][r] = facc[i][j][r] + (float)T * sc;
-                    acc[i][j][r] = 0;
+                    for (int r = 0; r < NF; ++r) {
+                        const int T = acc[i][j][r] + awv * xbuf[wave * TM + i * 32 + mfma32_row(r, lane)] + cr;
+                        facc[i][j][r] = facc[i][j][r] + (float)T * sc;
+                        acc[i][j][r] = 0;
+                    }
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
 
-    // ---- epilogue: ReLU, requantize, store code - 128 --------------------------------------------------
+    // ---- epilogue: (single group: bias + T * scale), ReLU, requantize; the 32 x TN byte tile of each MFMA row block
+    // is transposed through LDS (the K-loop buffers are free now) so that every lane stores 16 contiguous channels.
+    int8_t* stage = lds + wave * (32 * TN);            // per-wave [32 rows][TN] bytes, inside the (dead) A/B buffers
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * TM + i * 32 + mfma32_row(r, lane);
-            if (m >= a.M) continue;
-            const int img = m / (a.ho * a.wo), rem = m - img * (a.ho * a.wo);
-            const int yo = rem / a.wo, xo = rem - yo * a.wo;
-            int8_t* o = a.out + ((size_t)(img * (a.ho + 2) + yo + 1) * (a.wo + 2) + xo + 1) * a.out_ctotal + a.out_c0;
+        for (int j = 0; j < NT; ++j) {
+            const int co = n0 + wn * TN + j * 32 + (lane & 31);
+            int awv = 0, cr = 0;
+            float sc = 0.f, bs = 0.f;
+            if (!MULTI) { awv = a.aw[co]; cr = a.corr[co]; sc = a.scale[co]; bs = a.bias[co]; }
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                float y = facc[i][j][r];
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma32_row(r, lane);
+                float y;
+                if (MULTI) {
+                    y = facc[i][j][r % NF];
+                } else {
+                    const int T = acc[i][j][r] + awv * xbuf[wave * TM + i * 32 + row] + cr;
+                    y = bs + (float)T * sc;
+                }
                 if (a.relu) y = fmaxf(y, 0.0f);
-                o[n0 + wn * TN + j * 32 + (lane & 31)] = (int8_t)((int)q_code(y, a.out_delta, a.out_zp) - 128);
+                stage[row * TN + j * 32 + (lane & 31)] = (int8_t)((int)q_code(y, a.out_delta, a.out_zp) - 128);
             }
         }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        constexpr int CPR = TN / 16;                     // 16-byte chunks per row
+#pragma unroll
+        for (int t = 0; t < (32 * CPR + 63) / 64; ++t) {
+            const int id = lane + t * 64, row = id / CPR, chn = id % CPR;
+            if (id < 32 * CPR) {
+                const int off = rowoff[wm * TM + i * 32 + row];
+                if (off >= 0)
+                    *(v4i*)(a.out + (size_t)off * a.out_ctotal + a.out_c0 + n0 + wn * TN + chn * 16) = *(const v4i*)(stage + row * TN + chn * 16);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK, bool MULTI, int MINW>
 static int launch(const ConvArgs& a, hipStream_t st) {
     dim3 grid((a.M + BM - 1) / BM, a.cout / BN);
-    conv3x3_i8_kernel<BM, BN, WM, WN><<<grid, 256, 0, st>>>(a);
+    conv3x3_i8_kernel<BM, BN, WM, WN, BK, MULTI, MINW><<<grid, 256, 0, st>>>(a);
     return hip_check(hipGetLastError(), "qv2x_conv3x3_i8 launch");
 }
 
@@ -212,7 +261,8 @@ extern "C" int qv2x_conv3x3_i8(const qv2x_conv_desc* d, const int8_t* in, const 
     if (d->ngroups < 1 || d->ngroups > QV2X_MAX_GROUPS) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8: 1..%d input groups", QV2X_MAX_GROUPS);
     if (d->cout % 64 || d->cin_total % 16 || d->out_ctotal < d->out_c0 + d->cout)
         return fail(QV2X_EALIGN, "qv2x_conv3x3_i8: cout %% 64, cin_total %% 16, out channel window");
-    if (((uintptr_t)in & 15) || ((uintptr_t)w & 15)) return fail(QV2X_EALIGN, "qv2x_conv3x3_i8: in / w must be 16-byte aligned");
+    if (((uintptr_t)in & 15) || ((uintptr_t)w & 15) || ((uintptr_t)out & 15)) return fail(QV2X_EALIGN, "qv2x_conv3x3_i8: in / w / out must be 16-byte aligned");
+    if (d->out_ctotal % 16 || d->out_c0 % 16) return fail(QV2X_EALIGN, "qv2x_conv3x3_i8: out_ctotal and out_c0 must be multiples of 16");
     ConvArgs a;
     a.in = in; a.w = w; a.scale = scale; a.corr = corr; a.aw = aw; a.bias = bias; a.out = out;
     a.n = d->n; a.hp = d->h + 2; a.wp = d->w + 2; a.cin_total = d->cin_total; a.stride = d->stride; a.cout = d->cout;
@@ -234,6 +284,16 @@ extern "C" int qv2x_conv3x3_i8(const qv2x_conv_desc* d, const int8_t* in, const 
     a.out_delta = d->out_delta; a.out_zp = d->out_zp;
     if (!(a.out_delta > 0.0f)) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8: out_delta must be positive");
     hipStream_t st = (hipStream_t)stream;
-    if (d->cout % 128 == 0) return launch<128, 128, 2, 2>(a, st);
-    return launch<128, 64, 4, 1>(a, st);
+    bool k128 = true;
+    for (int g = 0; g < a.ngroups; ++g) k128 = k128 && (a.gc[g] % 128 == 0);
+    const bool multi = a.ngroups > 1;
+    static const char* force = getenv("QV2X_CONV_TILE");      // dev knob: "large" | "small"
+    const bool large = force ? (force[0] == 'l') : (a.cout % 128 == 0 && a.M >= 16384);
+    if (multi) {
+        if (a.cout % 128) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8: multi-group input needs cout %% 128 == 0");
+        return launch<128, 128, 2, 2, 64, true, 2>(a, st);
+    }
+    if (large && a.cout % 128 == 0)
+        return k128 ? launch<128, 128, 2, 2, 128, false, 2>(a, st) : launch<128, 128, 2, 2, 64, false, 3>(a, st);
+    return k128 ? launch<64, 64, 2, 2, 128, false, 4>(a, st) : launch<64, 64, 2, 2, 64, false, 4>(a, st);
 }

@@ -54,6 +54,12 @@ def decode_tables(state: Dict[str, np.ndarray], levels: int):
     return np.ascontiguousarray(np.stack(tables), dtype=np.float32), np.ascontiguousarray(const, dtype=np.float32)
 
 
+def _pack_k4p(w: np.ndarray) -> np.ndarray:
+    """As ``_pack_k4`` but the four k of a group are stored (k0, k2, k1, k3): the half-wave feeding MFMA k-parity p
+    reads one contiguous float2 = (k_p, k_{p+2}) (codebook_encode.hip)."""
+    return np.ascontiguousarray(_pack_k4(w)[:, :, [0, 2, 1, 3]])
+
+
 class _ConvLayer:
     """Device-side constants of one 3x3 QuantModule convolution."""
 
@@ -206,9 +212,9 @@ class DeployedModel(nn.Module):
         zeros_w, zeros_b = np.zeros((64, 256, 4), np.float32), np.zeros(256, np.float32)
         last = f"codebook/{l}/lhead_w" not in s
         cb = g("codebook")
-        parts = [_pack_k4(g("stage_w")), g("stage_b"), _pack_k4(g("qhead_w")), g("qhead_b"),
-                 zeros_w if last else _pack_k4(g("lhead_w")), zeros_b if last else g("lhead_b"),
-                 _pack_k4(cb), cb, np.zeros(kc, np.float32)]
+        parts = [_pack_k4p(g("stage_w")), g("stage_b"), _pack_k4p(g("qhead_w")), g("qhead_b"),
+                 zeros_w if last else _pack_k4p(g("lhead_w")), zeros_b if last else g("lhead_b"),
+                 _pack_k4p(cb), cb, np.zeros(kc, np.float32)]
         flat = np.concatenate([p.reshape(-1) for p in parts])
         assert flat.size == self.lib.qv2x_codebook_level_floats(kc)
         blob = _dev(flat, self.dev)
