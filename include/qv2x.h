@@ -83,7 +83,7 @@ int qv2x_conv3x3_i8(const qv2x_conv_desc* desc /* host */, const int8_t* in, con
  * The reference's per-dim-0 weight scales are per C_in here (quant_layer.py:192-195 on a [Cin,Cout,s,s]
  * weight), i.e. on the reduction axis, so the sum runs in fp32 on the f32 MFMA as an ascending-ci fmaf chain:
  *     acc = 0; acc = fma(float(x - zx) * dx, wdeq[ci][co][i][j], acc);  y = acc + bias[co]
- *   w: f32, [Cin/4][s*s*Cout][4] (column = (i*s + j)*Cout + co; four consecutive ci innermost). */
+ *   w: f32, [Cin/4][s*s*Cout][4] (column = (i*s + j)*Cout + co; four consecutive ci innermost, stored k0, k2, k1, k3). */
 typedef struct {
     int32_t n, h, w, cin, cout, s;
     int32_t in_zx;
@@ -142,7 +142,7 @@ int qv2x_decode_lut_f32(const uint8_t* codes, int R, int levels, int kc, const f
 
 /* a11.  1x1 QuantModule heads (heter_model_baseline.py:128-133,242-260) on fp32 rows:
  *     y = fma chain over ci (acc0 = bias[co]);  out = (clamp(rint(y / da[co]) + za[co], 0, 255) - za[co]) * da[co]
- *   x f32 [R][256]; w f32 [64][cout_pad][4] (cout_pad = cout rounded up to 32, zero filled); bias/da/za f32 [cout_pad]
+ *   x f32 [R][256]; w f32 [64][cout_pad][4] (k0, k2, k1, k3 order; cout_pad = cout rounded up to 32, zero filled); bias/da/za f32 [cout_pad]
  *   (da[co] <= 0 disables the output quantizer for that channel); out f32 NCHW [B][cout][hw] with R = B * hw. */
 int qv2x_heads_f32(const float* x, int R, int hw, int cout, int cout_pad, const float* w, const float* bias,
                    const float* da, const float* za, float* out, void* stream);

@@ -11,6 +11,8 @@
 // [32w, 32w + 32) for all 64 rows; for the distance GEMM one 32 x 32 (rows x codes) tile.
 // The argmin runs on the accumulator registers: half-wave butterfly on (distance, index) with ties to the lower
 // index, then a 4-way combine across waves through LDS.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace qv2x {
@@ -27,7 +29,7 @@ constexpr int D = 256;
 struct EncArgs {
     const int8_t* in; uint8_t* codes;
     const float* lvl[4];
-    int n, h, w, levels, kc, ax, M;
+    int n, h, w, levels, kc, ax, M, stagger;
     float dx;
 };
 
@@ -117,6 +119,12 @@ __global__ __launch_bounds__(512, 4) void codebook_encode_kernel(const EncArgs a
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * ER;
+    // Two workgroups share a CU and run identical phase sequences; started together they hit their MFMA-free phases
+    // (|q|^2, argmin, residual gather, barriers) at the same time and the matrix pipe idles.  Delaying every other
+    // dispatch wave of workgroups by ~half a level de-phases the pair (speed only; results do not depend on it).
+    if ((blockIdx.x >> 8) & 1) {
+        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 
     {   // ---- load ER rows x 256 channels from the i8 BEV, dequantize ---------------------------------
         constexpr int TPR = 512 / ER;                 // threads per row
@@ -283,6 +291,15 @@ extern "C" int qv2x_codebook_c2_f32(const float* codebook, int kc, float* c2, vo
     return hip_check(hipGetLastError(), "qv2x_codebook_c2_f32 launch");
 }
 
+extern "C" int qv2x_debug_encode_occupancy(void) {
+    using namespace qv2x;
+    const size_t smem = (size_t)(2 * ER * LDF + ER + 4 * ER + 4 * ER + ER) * sizeof(float);
+    hipFuncSetAttribute((const void*)codebook_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    int n = -1;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, codebook_encode_kernel, 512, smem);
+    return n * 1000 + (int)(smem / 1024);
+}
+
 extern "C" int64_t qv2x_codebook_level_floats(int kc) { return qv2x::level_floats(kc); }
 
 extern "C" int qv2x_codebook_encode_f32(const qv2x_encode_desc* d, const int8_t* in, const float* const* level_weights,
@@ -295,11 +312,14 @@ extern "C" int qv2x_codebook_encode_f32(const qv2x_encode_desc* d, const int8_t*
     EncArgs a;
     a.in = in; a.codes = codes; a.n = d->n; a.h = d->h; a.w = d->w; a.levels = d->levels; a.kc = d->kc;
     a.ax = 128 - d->in_zx; a.dx = d->in_delta; a.M = d->n * d->h * d->w;
+    static const char* stg = getenv("QV2X_ENC_STAGGER");
+    a.stagger = stg ? atoi(stg) : 6;
     for (int l = 0; l < 4; ++l) {
         a.lvl[l] = l < d->levels ? level_weights[l] : nullptr;
         if (l < d->levels && (!a.lvl[l] || ((uintptr_t)a.lvl[l] & 15))) return fail(QV2X_EALIGN, "qv2x_codebook_encode_f32: level %d weights null or unaligned", l);
     }
-    const size_t smem = (size_t)(2 * ER * LDF + ER + 4 * ER + 4 * ER + ER) * sizeof(float);
+    static const char* padenv = getenv("QV2X_ENC_SMEM_PAD");
+    const size_t smem = (size_t)(2 * ER * LDF + ER + 4 * ER + 4 * ER + ER) * sizeof(float) + (padenv ? atoi(padenv) * 1024 : 0);
     static bool attr_set = false;
     if (!attr_set) {
         int rc = hip_check(hipFuncSetAttribute((const void*)codebook_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem),

@@ -16,6 +16,7 @@ struct DeconvArgs {
 };
 
 __global__ __launch_bounds__(256) void deconv_f32_kernel(const DeconvArgs a) {
+    __shared__ int rowbase[4][32];            // per wave: output pixel index of (row, i = 0, j = 0), -1 past the end
     const int lane = threadIdx.x & 63;
     const int tiles_n = a.ncols >> 6;
     int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -30,8 +31,13 @@ __global__ __launch_bounds__(256) void deconv_f32_kernel(const DeconvArgs a) {
     const int img = m / (a.h * a.wd), rem = m - img * (a.h * a.wd);
     const int y = rem / a.wd, x = rem - y * a.wd;
     const int8_t* src = a.in + ((size_t)(img * (a.h + 2) + y + 1) * (a.wd + 2) + x + 1) * a.cin;
+    if (lane < 32) {
+        const int mm = tm * 32 + lane;
+        rowbase[threadIdx.x >> 6][lane] = mm < a.M ? (img * (a.h * a.s + 2) + y * a.s + 1) * (a.wd * a.s + 2) + x * a.s + 1 : -1;
+    }
     const int col0 = tn * 64 + (lane & 31);
-    const float4* wq = (const float4*)a.w;
+    // weights: [Cin/4][cols][k0, k2, k1, k3]; the half-wave of MFMA k-parity `par` reads one float2 = (k_par, k_par+2)
+    const float2* wq = (const float2*)a.w + (size_t)col0 * 2 + par;
 
     v16f acc[2];
 #pragma unroll
@@ -39,45 +45,70 @@ __global__ __launch_bounds__(256) void deconv_f32_kernel(const DeconvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-    const int sh = par * 8;
-    for (int k0 = 0; k0 < a.cin; k0 += 16) {
-        const v4i raw = *(const v4i*)(src + k0);
-        float4 b[2][4];
+    // one step = 16 input channels = 8 MFMA k-steps x 2 column tiles; the next step's operands are requested before the
+    // MFMA block of the current one (register double buffer, pinned with sched_barrier: hipcc sinks loads otherwise)
+    auto loadA = [&](int k0) { return *(const v4i*)(src + k0); };
+    auto loadB = [&](float2 (&dst)[4][2], int k0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) b[t][q] = wq[(size_t)((k0 >> 2) + q) * a.ncols + col0 + t * 32];
+            for (int t = 0; t < 2; ++t) dst[q][t] = wq[((size_t)((k0 >> 2) + q) * a.ncols + t * 32) * 2];
+    };
+    const int sh = par * 8;
+    auto step = [&](const v4i raw, const float2 (&b)[4][2]) {
+        float av[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {              // MFMA k-step: k = k0 + 2j + par
-            const int word = raw[j >> 1];
-            const int xs = (word << (24 - ((j & 1) * 16 + sh))) >> 24;       // sign-extended byte 2*(j&1) + par
-            const float av = (float)(xs + a.ax) * a.dx;
+        for (int j = 0; j < 8; ++j) {              // MFMA k-step j: k = k0 + 2j + par  ->  byte 2*(j&1) + par of word j>>1
+            const int xs = (raw[j >> 1] << (24 - ((j & 1) * 16 + sh))) >> 24;
+            av[j] = (float)(xs + a.ax) * a.dx;
+        }
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const float4 bq = b[t][j >> 1];
-                const float bv = (j & 1) ? (par ? bq.w : bq.z) : (par ? bq.y : bq.x);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-            }
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], (j & 1) ? b[j >> 1][t].y : b[j >> 1][t].x, acc[t], 0, 0, 0);
+    };
+    v4i r0 = loadA(0), r1;
+    float2 b0[4][2], b1[4][2];
+    loadB(b0, 0);
+    for (int k0 = 0; k0 < a.cin; k0 += 32) {
+        const bool two = k0 + 16 < a.cin;
+        if (two) { r1 = loadA(k0 + 16); loadB(b1, k0 + 16); }
+        __builtin_amdgcn_sched_barrier(0);
+        step(r0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (two) {
+            if (k0 + 32 < a.cin) { r0 = loadA(k0 + 32); loadB(b0, k0 + 32); }
+            __builtin_amdgcn_sched_barrier(0);
+            step(r1, b1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const int* rb = rowbase[threadIdx.x >> 6];
+    const int orow = a.wd * a.s + 2;             // output pixels per padded row
+    int pix[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pix[r] = rb[mfma32_row(r, lane)];      // all 16 LDS reads in flight, no per-element branch
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int col = col0 + t * 32;
         const int ij = col / a.cout, co = col - ij * a.cout;
         const int di = ij / a.s, dj = ij - di * a.s;
         const float bias = a.bias[co];
+        const int obase = (di * orow + dj) * a.out_ctotal + a.out_c0 + co;   // byte offsets fit 32 bits (tensor < 2 GiB)
+        int8_t q[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int mm = tm * 32 + mfma32_row(r, lane);
-            if (mm >= a.M) continue;
-            const int im = mm / (a.h * a.wd), rm = mm - im * (a.h * a.wd);
-            const int yy = rm / a.wd, xx = rm - yy * a.wd;
             float yv = acc[t][r] + bias;
             if (a.relu) yv = fmaxf(yv, 0.0f);
-            const size_t pix = (size_t)(im * (a.h * a.s + 2) + yy * a.s + di + 1) * (a.wd * a.s + 2) + xx * a.s + dj + 1;
-            a.out[pix * a.out_ctotal + a.out_c0 + co] = (int8_t)((int)q_code(yv, a.out_delta, a.out_zp) - 128);
+            q[r] = (int8_t)((int)q_code(yv, a.out_delta, a.out_zp) - 128);
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (pix[r] >= 0) a.out[(unsigned)(obase + pix[r] * a.out_ctotal)] = q[r];
     }
 }
 

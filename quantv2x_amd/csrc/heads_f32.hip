@@ -5,65 +5,85 @@
 
 namespace qv2x {
 
-template <int NT>
+// wave = (32-row tile, 32-column tile): with <= 96 stacked output channels that is up to three waves per row tile, which
+// keeps all 1024 SIMDs of the chip busy at 35 200 rows (a 96-column wave tile left the second round almost empty).
 __global__ __launch_bounds__(256) void heads_f32_kernel(const float* __restrict__ x, int R, int hw, int cout, int cout_pad,
-                                                        const float4* __restrict__ w, const float* __restrict__ bias,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
                                                         const float* __restrict__ da, const float* __restrict__ za,
                                                         float* __restrict__ out) {
     __shared__ float tr[4][32][33];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int tm = blockIdx.x * 4 + wave;
-    tm = __builtin_amdgcn_readfirstlane(tm);
+    const int nct = cout_pad >> 5;
+    int tile = blockIdx.x * 4 + wave;
+    tile = __builtin_amdgcn_readfirstlane(tile);
+    const int tm = tile / nct, ct = tile - tm * nct;
     if (tm * 32 >= R) return;
     const int par = lane >> 5;
     int m = tm * 32 + (lane & 31);
     m = m < R ? m : R - 1;
     const float4* xr = (const float4*)(x + (size_t)m * 256);
 
-    v16f acc[NT];
+    v16f acc;
+    {
+        const float b = bias[ct * 32 + (lane & 31)];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const float b = bias[t * 32 + (lane & 31)];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = b;
+        for (int r = 0; r < 16; ++r) acc[r] = b;
     }
-#pragma unroll 4
-    for (int q = 0; q < 64; ++q) {                 // k = 4q .. 4q+3
-        const float4 av = xr[q];
-        float4 bv[NT];
+    // weights: [64][cout_pad][k0, k2, k1, k3] -> one float2 per lane per k-quad; activations: the lane's row, float4 per
+    // k-quad (both half-waves read the same 16 B and keep their parity's pair).  Eight k-quads are requested ahead of
+    // each MFMA block (register double buffer pinned with sched_barrier).
+    const float2* wl = (const float2*)w + (size_t)(ct * 32 + (lane & 31)) * 2 + par;
+    auto loadA = [&](float4 (&dst)[8], int q0) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) bv[t] = w[(size_t)q * cout_pad + t * 32 + (lane & 31)];
-        const float a0 = par ? av.y : av.x, a1 = par ? av.w : av.z;
+        for (int t = 0; t < 8; ++t) dst[t] = xr[q0 + t];
+    };
+    auto loadB = [&](float2 (&dst)[8], int q0) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, par ? bv[t].y : bv[t].x, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, par ? bv[t].w : bv[t].z, acc[t], 0, 0, 0);
+        for (int t = 0; t < 8; ++t) dst[t] = wl[(size_t)(q0 + t) * cout_pad * 2];
+    };
+    auto block = [&](const float4 (&av)[8], const float2 (&bv)[8]) {
+        float a0[8], a1[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { a0[t] = par ? av[t].y : av[t].x; a1[t] = par ? av[t].w : av[t].z; }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], bv[t].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], bv[t].y, acc, 0, 0, 0);
         }
+    };
+    float4 xa[8], xb[8];
+    float2 wa[8], wb[8];
+    loadA(xa, 0); loadB(wa, 0);
+    for (int q0 = 0; q0 < 64; q0 += 16) {
+        loadA(xb, q0 + 8); loadB(wb, q0 + 8);
+        __builtin_amdgcn_sched_barrier(0);
+        block(xa, wa);
+        __builtin_amdgcn_sched_barrier(0);
+        if (q0 + 16 < 64) { loadA(xa, q0 + 16); loadB(wa, q0 + 16); }
+        __builtin_amdgcn_sched_barrier(0);
+        block(xb, wb);
+        __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int co = t * 32 + (lane & 31);
+    {
+        const int co = ct * 32 + (lane & 31);
         const float d = da[co], z = za[co];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float y = acc[t][r];
+            float y = acc[r];
             if (d > 0.0f) y = (q_code(y, d, z) - z) * d;
             tr[wave][mfma32_row(r, lane)][lane & 31] = y;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): this wave's LDS writes have landed
         __builtin_amdgcn_wave_barrier();
-        // lane -> row (cell) lane&31, channels (lane>>5) + 2*c
+        // lane -> cell lane&31 (128 B contiguous per channel in the NCHW output), channels (lane>>5) + 2*c
+        const int mm = tm * 32 + (lane & 31);
+        const int bi = mm / hw, cell = mm - bi * hw;
+        float* ob = out + (size_t)bi * cout * hw + cell;
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-            const int ch = t * 32 + par + 2 * c;
-            const int mm = tm * 32 + (lane & 31);
-            if (ch < cout && mm < R) {
-                const int bi = mm / hw, cell = mm - bi * hw;
-                out[((size_t)bi * cout + ch) * hw + cell] = tr[wave][lane & 31][par + 2 * c];
-            }
+            const int ch = ct * 32 + par + 2 * c;
+            if (ch < cout && mm < R) ob[(size_t)ch * hw] = tr[wave][lane & 31][par + 2 * c];
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -91,12 +111,8 @@ extern "C" int qv2x_heads_f32(const float* x, int R, int hw, int cout, int cout_
     if (R <= 0 || hw <= 0 || R % hw || cout <= 0 || cout > cout_pad || cout_pad % 32 || cout_pad > 96)
         return fail(QV2X_EINVAL, "qv2x_heads_f32: R=%d hw=%d cout=%d cout_pad=%d (cout_pad in {32, 64, 96})", R, hw, cout, cout_pad);
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return fail(QV2X_EALIGN, "qv2x_heads_f32: x / w must be 16-byte aligned");
-    const int blocks = ((R + 31) / 32 + 3) / 4;
-    hipStream_t st = (hipStream_t)stream;
-    const float4* w4 = (const float4*)w;
-    if (cout_pad == 32) heads_f32_kernel<1><<<blocks, 256, 0, st>>>(x, R, hw, cout, cout_pad, w4, bias, da, za, out);
-    else if (cout_pad == 64) heads_f32_kernel<2><<<blocks, 256, 0, st>>>(x, R, hw, cout, cout_pad, w4, bias, da, za, out);
-    else heads_f32_kernel<3><<<blocks, 256, 0, st>>>(x, R, hw, cout, cout_pad, w4, bias, da, za, out);
+    const int tiles = ((R + 31) / 32) * (cout_pad / 32);
+    heads_f32_kernel<<<(tiles + 3) / 4, 256, 0, (hipStream_t)stream>>>(x, R, hw, cout, cout_pad, w, bias, da, za, out);
     return hip_check(hipGetLastError(), "qv2x_heads_f32 launch");
 }
 

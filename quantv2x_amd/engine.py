@@ -96,7 +96,7 @@ class _DeconvLayer:
         wdeq = ((code - zw) * dw).astype(np.float32)
         cin, cout, s, _ = wdeq.shape
         cols = wdeq.transpose(0, 2, 3, 1).reshape(cin, s * s * cout)              # col = (i*s + j)*Cout + co
-        self.w = _dev(_pack_k4(cols.T), dev)
+        self.w = _dev(_pack_k4p(cols.T), dev)
         self.bias = _dev(state[name + "/bias"].astype(np.float32), dev)
         self.name, self.cin, self.cout, self.s, self.in_q = name, cin, cout, s, in_q
         self.out_q = (float(np.float32(state[name + "/a_delta"])), int(state[name + "/a_zp"]))
@@ -123,7 +123,7 @@ class _Heads:
             raise NotImplementedError("heads: at most 96 stacked output channels")
         pad = self.cout_pad - self.cout
         w = np.concatenate(ws + [np.zeros((pad, 256), np.float32)])
-        self.w = _dev(_pack_k4(w), dev)
+        self.w = _dev(_pack_k4p(w), dev)
         self.bias = _dev(np.concatenate(bs + [np.zeros(pad, np.float32)]), dev)
         self.da = _dev(np.concatenate(das + [np.full(pad, -1.0, np.float32)]), dev)
         self.za = _dev(np.concatenate(zas + [np.zeros(pad, np.float32)]), dev)
