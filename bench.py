@@ -132,6 +132,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the N>1 code path (eager launches + all_gather of the code planes) even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -143,8 +145,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or args.force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
 
     cores = os.cpu_count() or 8
@@ -152,7 +157,7 @@ def main():
     sc_np, full, mine = my_scene(world, rank, device)
     pairwise = full["pairwise_t_matrix"][0].contiguous()
 
-    if world == 1:
+    if world == 1 and not args.force_sharded:
         step = eng.capture(full)            # HIP graph of the whole frame
         launch = "hipGraph replay of the whole frame"
     else:
@@ -162,7 +167,7 @@ def main():
         launch = "eager launches + RCCL all_gather_into_tensor of the code planes"
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -212,10 +217,14 @@ def main():
                 from quantv2x_amd import synth
                 one = synth.make_scene(SHAPE, n_agents=1, seed=3, n_points=N_POINTS)
             line["cpu_baseline"] = cpu_baseline(state, one)
-        print(json.dumps(line), flush=True)
-    if world > 1:
+    else:
+        line = None
+    if dist.is_initialized():
         dist.barrier()
-        dist.destroy_process_group()
+        dist.destroy_process_group()     # RCCL prints its version banner around here: keep the JSON line last
+    if line is not None:
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

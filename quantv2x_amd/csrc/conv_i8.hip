@@ -243,6 +243,234 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_i8_kernel(const ConvArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Same implicit GEMM with the operand tiles streamed by LDS-DMA (global_load_lds_dwordx4: HBM/L2 -> LDS without a
+// VGPR round trip) through an S-stage ring, so several K-chunks are in flight per workgroup and the per-chunk
+// latency (the limiter of the register-staged variant above: one chunk of prefetch, ~1 us per chunk exposed on the
+// small layers) is covered.  One s_barrier per chunk:
+//     wait vmcnt((S-2)*LPS)  ->  s_barrier  ->  issue chunk s+S-1 into the stage freed by chunk s-1  ->  MFMAs of chunk s
+// The DMA writes LDS lane-linearly (wave-uniform base + lane*16), so the XOR swizzle is applied to the per-lane SOURCE
+// address and again on the fragment reads (cdna guide rule 21).  All LDS is one array (a second __shared__ object makes
+// hipcc drain vmcnt before every ds_read).
+template <int BM, int BN, int WM, int WN, int BK, bool MULTI, int S, int MINW>
+__global__ __launch_bounds__(256, MINW) void conv3x3_i8_dma_kernel(const ConvArgs a) {
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int MT = TM / 32, NT = TN / 32;
+    constexpr int CH = BK / 16;
+    constexpr int IA = BM * BK / 1024, IB = BN * BK / 1024;     // 1 KiB DMA instructions per tile
+    constexpr int LPS = (IA + IB) / 4;                          // per wave per chunk
+    constexpr int STAGE = (BM + BN) * BK;
+    constexpr int NF = MULTI ? 16 : 1;
+    static_assert(WM * WN == 4 && (IA + IB) % 4 == 0 && IA % LPS == 0 && S >= 3, "tile shape");
+
+    __shared__ __attribute__((aligned(16))) int8_t lds[S * STAGE + 4 * TM * 4 + BM * 4];
+    int* xbuf = (int*)(lds + S * STAGE);
+    int* rowoff = xbuf + 4 * TM;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+    // ---- this wave's DMA instructions: ids [wave*LPS, +LPS) over [A blocks | B blocks] ---------------------------
+    const bool loads_a = wave * LPS < IA;                        // wave-uniform
+    const int8_t* src[LPS];
+    int dst[LPS];                                                // LDS byte offset inside a stage (wave-uniform)
+#pragma unroll
+    for (int j = 0; j < LPS; ++j) {
+        const int id = wave * LPS + j;
+        const int blk = loads_a ? id : id - IA;
+        const int p = blk * 64 + lane, row = p / CH, c = (p % CH) ^ ((row >> (CH == 4 ? 2 : 1)) & (CH - 1));
+        if (loads_a) {
+            int m = m0 + row;
+            m = m < a.M ? m : a.M - 1;
+            const int img = m / (a.ho * a.wo), rem = m - img * (a.ho * a.wo);
+            const int yo = rem / a.wo, xo = rem - yo * a.wo;
+            src[j] = a.in + ((size_t)(img * a.hp + yo * a.stride) * a.wp + xo * a.stride) * a.cin_total + c * 16;
+            dst[j] = blk * 1024;
+        } else {
+            src[j] = a.w + (size_t)(n0 + row) * a.ktot + c * 16;
+            dst[j] = BM * BK + blk * 1024;
+        }
+    }
+    if (tid < BM) {
+        const int m = m0 + tid;
+        int off = -1;
+        if (m < a.M) {
+            const int img = m / (a.ho * a.wo), rem = m - img * (a.ho * a.wo);
+            const int yo = rem / a.wo, xo = rem - yo * a.wo;
+            off = (img * (a.ho + 2) + yo + 1) * (a.wo + 2) + xo + 1;
+        }
+        rowoff[tid] = off;
+    }
+
+    v16i acc[MT][NT];
+    float facc[MT][NT][NF];
+    int xs[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        xs[i] = 0;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+            if (MULTI) {
+                const float b = a.bias[n0 + wn * TN + j * 32 + (lane & 31)];
+#pragma unroll
+                for (int r = 0; r < NF; ++r) facc[i][j][r] = b;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // nothing of ours may sit in the VM queue before the ring starts
+
+    // ---- chunk enumeration over (group, tap, 64/128-channel chunk) for the ISSUE side ---------------------------------
+    int total = 0;
+#pragma unroll
+    for (int g = 0; g < QV2X_MAX_GROUPS; ++g) total += (g < (MULTI ? a.ngroups : 1)) ? 9 * (a.gc[g] / BK) : 0;
+    int i_g = 0, i_tap = 0, i_cc = 0, i_chunks = a.gc[0] / BK, i_step = 0;
+    auto issue = [&]() {                                        // DMA of chunk i_step into stage i_step % S
+        const int kh = i_tap >= 6 ? 2 : (i_tap >= 3 ? 1 : 0), kw = i_tap - kh * 3;
+        const int off = loads_a ? (kh * a.wp + kw) * a.cin_total + a.gc0[i_g] + i_cc * BK : i_step * BK;
+        int8_t* stage = lds + (i_step % S) * STAGE;
+#pragma unroll
+        for (int j = 0; j < LPS; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + off),
+                                             (__attribute__((address_space(3))) void*)(stage + dst[j]), 16, 0, 0);
+        ++i_step;
+        if (++i_cc == i_chunks) { i_cc = 0; if (++i_tap == 9) { i_tap = 0; ++i_g; i_chunks = a.gc[i_g < QV2X_MAX_GROUPS ? i_g : 0] / BK; } }
+    };
+#pragma unroll
+    for (int p = 0; p < S - 1; ++p)
+        if (p < total) issue();
+
+    // per-lane fragment read offsets inside a stage (loop invariant; the stage base is an immediate after unrolling by S)
+    constexpr int KS = BK / 32;
+    int offA[MT][KS], offB[NT][KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int ch = ks * 2 + (lane >> 5);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) offA[i][ks] = swz<BK>(wm * TM + i * 32 + (lane & 31), ch);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) offB[j][ks] = BM * BK + swz<BK>(wn * TN + j * 32 + (lane & 31), ch);
+    }
+
+    int g = 0, g_end = 9 * (a.gc[0] / BK);
+    auto fold_group = [&]() {
+        // window sums of this group to LDS (C-fragment rows differ from A-fragment rows)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int tot = xs[i] + __shfl_xor(xs[i], 32);
+            if (lane < 32) xbuf[wave * TM + i * 32 + lane] = tot;
+            xs[i] = 0;
+        }
+        __syncthreads();
+        if (MULTI) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int co = n0 + wn * TN + j * 32 + (lane & 31);
+                const int awv = a.aw[co];
+                const int cr = a.corr[g * a.cout + co];
+                const float sc = a.scale[g * a.cout + co];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                    for (int r = 0; r < NF; ++r) {
+                        const int T = acc[i][j][r] + awv * xbuf[wave * TM + i * 32 + mfma32_row(r, lane)] + cr;
+                        facc[i][j][r] = facc[i][j][r] + (float)T * sc;
+                        acc[i][j][r] = 0;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    };
+
+    for (int base = 0; base < total; base += S) {
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+            const int step = base + u;
+            if (step < total) {
+                // chunk `step` has landed once at most (chunks issued after it) * LPS of this wave's DMAs are outstanding
+                const int later = total - 1 - step;
+                if (later >= S - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((S - 2) * LPS) : "memory");
+                else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                   // every wave's part of chunk `step` is in LDS; stage (step-1)%S is free
+                if (i_step < total) issue();
+                const int8_t* stg = lds + u * STAGE;            // base % S == 0, so stage == u: a compile-time offset
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    v4i fa[MT], fb[NT];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) fa[i] = *(const v4i*)(stg + offA[i][ks]);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) fb[j] = *(const v4i*)(stg + offB[j][ks]);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) xs[i] = __builtin_amdgcn_sdot4(fa[i][q], 0x01010101, xs[i], false);
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+                if (step + 1 == g_end) {
+                    fold_group();
+                    ++g;
+                    g_end += 9 * (a.gc[g < QV2X_MAX_GROUPS ? g : 0] / BK);
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                            // ring is idle: its first bytes become the epilogue staging tile
+
+    int8_t* stage = lds + wave * (32 * TN);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int co = n0 + wn * TN + j * 32 + (lane & 31);
+            int awv = 0, cr = 0;
+            float sc = 0.f, bs = 0.f;
+            if (!MULTI) { awv = a.aw[co]; cr = a.corr[co]; sc = a.scale[co]; bs = a.bias[co]; }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma32_row(r, lane);
+                float y;
+                if (MULTI) {
+                    y = facc[i][j][r % NF];
+                } else {
+                    const int T = acc[i][j][r] + awv * xbuf[wave * TM + i * 32 + row] + cr;
+                    y = bs + (float)T * sc;
+                }
+                if (a.relu) y = fmaxf(y, 0.0f);
+                stage[row * TN + j * 32 + (lane & 31)] = (int8_t)((int)q_code(y, a.out_delta, a.out_zp) - 128);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        constexpr int CPR = TN / 16;
+#pragma unroll
+        for (int t = 0; t < (32 * CPR + 63) / 64; ++t) {
+            const int id = lane + t * 64, row = id / CPR, chn = id % CPR;
+            if (id < 32 * CPR) {
+                const int off = rowoff[wm * TM + i * 32 + row];
+                if (off >= 0)
+                    *(v4i*)(a.out + (size_t)off * a.out_ctotal + a.out_c0 + n0 + wn * TN + chn * 16) = *(const v4i*)(stage + row * TN + chn * 16);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int BK, bool MULTI, int S, int MINW>
+static int launch_dma(const ConvArgs& a, hipStream_t st) {
+    dim3 grid((a.M + BM - 1) / BM, a.cout / BN);
+    conv3x3_i8_dma_kernel<BM, BN, WM, WN, BK, MULTI, S, MINW><<<grid, 256, 0, st>>>(a);
+    return hip_check(hipGetLastError(), "qv2x_conv3x3_i8 launch");
+}
+
 template <int BM, int BN, int WM, int WN, int BK, bool MULTI, int MINW>
 static int launch(const ConvArgs& a, hipStream_t st) {
     dim3 grid((a.M + BM - 1) / BM, a.cout / BN);
@@ -289,6 +517,16 @@ extern "C" int qv2x_conv3x3_i8(const qv2x_conv_desc* d, const int8_t* in, const 
     const bool multi = a.ngroups > 1;
     static const char* force = getenv("QV2X_CONV_TILE");      // dev knob: "large" | "small"
     const bool large = force ? (force[0] == 'l') : (a.cout % 128 == 0 && a.M >= 16384);
+    static const char* dmaenv = getenv("QV2X_CONV_DMA");     // dev knob: "0" selects the register-staged kernels
+    const bool use_dma = !(dmaenv && dmaenv[0] == '0');
+    if (use_dma) {
+        if (multi) {
+            if (a.cout % 128) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8: multi-group input needs cout %% 128 == 0");
+            return launch_dma<128, 128, 2, 2, 64, true, 4, 2>(a, st);
+        }
+        if (large && a.cout % 128 == 0) return launch_dma<128, 128, 2, 2, 64, false, 3, 3>(a, st);
+        return k128 ? launch_dma<64, 64, 2, 2, 128, false, 4, 2>(a, st) : launch_dma<64, 64, 2, 2, 64, false, 4, 4>(a, st);
+    }
     if (multi) {
         if (a.cout % 128) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8: multi-group input needs cout %% 128 == 0");
         return launch<128, 128, 2, 2, 64, true, 2>(a, st);
