@@ -113,6 +113,34 @@ def stage_times(eng, dd, iters=20):
     return stages
 
 
+def frames_in_flight(state, dd, steps, n_flight=2):
+    """Throughput with ``n_flight`` independent frames in flight (one engine + HIP graph + stream each): the small backbone
+    layers leave most CUs idle, a second frame fills them.  Reported next to ``value`` (one frame at a time), SURVEY.md
+    §8(d) "throughput also at the best frame-batch"."""
+    import torch
+    from quantv2x_amd.engine import deploy
+    engs = [deploy(state=state) for _ in range(n_flight)]
+    streams = [torch.cuda.Stream() for _ in range(n_flight)]
+    reps = []
+    for e, st in zip(engs, streams):
+        with torch.cuda.stream(st):
+            reps.append(e.capture(dd))
+    torch.cuda.synchronize()
+
+    def round_():
+        for r, st in zip(reps, streams):
+            with torch.cuda.stream(st):
+                r()
+    for _ in range(10):
+        round_()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        round_()
+    torch.cuda.synchronize()
+    return round(n_flight * steps / (time.perf_counter() - t0), 2)
+
+
 def cpu_baseline(state, sc_np, budget_s=12.0, max_frames=6):
     """The CPU oracle (checker) on the same workload, on the host cores of this box."""
     from oracle.spec import Oracle
@@ -134,6 +162,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-inflight", action="store_true", help="skip the extra 2-frames-in-flight throughput measurement")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N>1 code path (eager launches + all_gather of the code planes) even with one rank")
     args = ap.parse_args()
@@ -213,6 +242,8 @@ def main():
         solo = full if world == 1 else None
         if solo is not None:
             line["stage_ms"] = stage_times(eng, solo)
+            if not args.no_inflight:
+                line["throughput_2_frames_in_flight"] = frames_in_flight(state, solo, max(20, args.steps // 2))
         if not args.no_cpu_baseline:
             one = sc_np if world == 1 else None
             if one is None:
