@@ -550,7 +550,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_i8_big_kernel(const ConvAr
     const int total = a.nsteps;
     int i_step = 0;
     auto issue = [&]() {
-        const int aoff = a.aoff[i_step], boff = i_step * BK;
+        const int chunk = i_step < total ? i_step : total - 1;
+        const int aoff = a.aoff[chunk], boff = chunk * BK;
         int8_t* stage = lds + (i_step % S) * STAGE;
 #pragma unroll
         for (int j = 0; j < LPS; ++j)
@@ -572,6 +573,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_i8_big_kernel(const ConvAr
         offB[ks] = BM * BK + swz<BK>(wave * 32 + (lane & 31), ch);
     }
 
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);     // provably wave-uniform copy for scalar branches
     int g = 0;
     auto fold_group = [&]() {
 #pragma unroll
@@ -604,43 +606,43 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_i8_big_kernel(const ConvAr
         }
     };
 
-    for (int base = 0; base < total; base += S) {
+    // Steady state without per-chunk conditionals: every iteration issues exactly one chunk (past the end: the last chunk
+    // again, into a stage that has already been consumed), so "chunk `step` has landed" is always vmcnt((S-2)*LPS).
+    auto one_step = [&](int step, const int8_t* stg) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((S - 2) * LPS) : "memory");
+        __builtin_amdgcn_s_barrier();
+        issue();
+        v4i fa[2][MT], fb[2];
 #pragma unroll
-        for (int u = 0; u < S; ++u) {
-            const int step = base + u;
-            if (step < total) {
-                {   // chunk `step` has landed once at most min(chunks issued after it, S-2) * LPS DMAs are outstanding
-                    const int later = total - 1 - step;
-                    if (later >= S - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((S - 2) * LPS) : "memory");
-                    else if (S > 4 && later == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * LPS) : "memory");
-                    else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPS) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int i = 0; i < MT; ++i) fa[0][i] = *(const v4i*)(stg + offA[i][0]);
+        fb[0] = *(const v4i*)(stg + offB[0]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[1][i] = *(const v4i*)(stg + offA[i][1]);
+        fb[1] = *(const v4i*)(stg + offB[1]);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (NW == 4 || ks == (wave_u >> 2)) {
+                switch (wave_u & 3) {
+                    case 0: _Pragma("unroll") for (int i = 0; i < MT; ++i) xs[i] = __builtin_amdgcn_sdot4(fa[ks][i][0], 0x01010101, xs[i], false); break;
+                    case 1: _Pragma("unroll") for (int i = 0; i < MT; ++i) xs[i] = __builtin_amdgcn_sdot4(fa[ks][i][1], 0x01010101, xs[i], false); break;
+                    case 2: _Pragma("unroll") for (int i = 0; i < MT; ++i) xs[i] = __builtin_amdgcn_sdot4(fa[ks][i][2], 0x01010101, xs[i], false); break;
+                    default: _Pragma("unroll") for (int i = 0; i < MT; ++i) xs[i] = __builtin_amdgcn_sdot4(fa[ks][i][3], 0x01010101, xs[i], false); break;
                 }
-                __builtin_amdgcn_s_barrier();
-                if (i_step < total) issue();
-                const int8_t* stg = lds + u * STAGE;
-                v4i fa[2][MT], fb[2];
-#pragma unroll
-                for (int i = 0; i < MT; ++i) fa[0][i] = *(const v4i*)(stg + offA[i][0]);
-                fb[0] = *(const v4i*)(stg + offB[0]);
-#pragma unroll
-                for (int i = 0; i < MT; ++i) fa[1][i] = *(const v4i*)(stg + offA[i][1]);
-                fb[1] = *(const v4i*)(stg + offB[1]);
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    if (((step * 2 + ks) & (NW - 1)) == wave) {  // this wave's share of the window sums (wave-uniform branch)
-#pragma unroll
-                        for (int i = 0; i < MT; ++i)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) xs[i] = __builtin_amdgcn_sdot4(fa[ks][i][q], 0x01010101, xs[i], false);
-                    }
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ks][i], fb[ks], acc[i], 0, 0, 0);
-                }
-                if (step + 1 == a.gend[g]) { fold_group(); ++g; }
             }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ks][i], fb[ks], acc[i], 0, 0, 0);
         }
+        if (MULTI && step + 1 == a.gend[g]) { fold_group(); ++g; }
+    };
+    int base = 0;
+    for (; base + S <= total; base += S) {
+#pragma unroll
+        for (int u = 0; u < S; ++u) one_step(base + u, lds + u * STAGE);
     }
+#pragma unroll
+    for (int u = 0; u < S; ++u)
+        if (base + u < total) one_step(base + u, lds + u * STAGE);
+    if (!MULTI) fold_group();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 

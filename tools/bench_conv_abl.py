@@ -1,0 +1,27 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from quantv2x_amd import lib as L
+v = sys.argv[1]
+L.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cache", "abl", f"libqv2x_abl{v}.so")
+from quantv2x_amd import synth
+from quantv2x_amd.engine import deploy
+eng = deploy(path=os.path.join(os.path.dirname(os.path.abspath(__file__)), "cache", "v2xreal_state.npz"))
+dd = synth.scene_to_torch(synth.make_scene("v2xreal", n_agents=1, seed=3, n_points=60000), "cuda")
+eng(dd); torch.cuda.synchronize()
+def timeit(fn, iters=30):
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3): fn()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters): fn()
+    g.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+out = []
+for (kind, layer, x, h, w, o, c0, macs) in eng.conv_plan(1):
+    if kind == "conv" and layer.name.startswith("shrinker"): out.append(f"{timeit(lambda: eng._conv(layer, x, 1, h, w, o)):.1f}")
+print("variant", v, "shrinker us:", out)
