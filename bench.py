@@ -244,12 +244,8 @@ def main():
             line["stage_ms"] = stage_times(eng, solo)
             if not args.no_inflight:
                 line["throughput_2_frames_in_flight"] = frames_in_flight(state, solo, max(20, args.steps // 2))
-        if not args.no_cpu_baseline:
-            one = sc_np if world == 1 else None
-            if one is None:
-                from quantv2x_amd import synth
-                one = synth.make_scene(SHAPE, n_agents=1, seed=3, n_points=N_POINTS)
-            line["cpu_baseline"] = cpu_baseline(state, one)
+        if not args.no_cpu_baseline and world == 1:       # reported on rank 0 at N = 1 only
+            line["cpu_baseline"] = cpu_baseline(state, sc_np)
     else:
         line = None
     if dist.is_initialized():

@@ -390,6 +390,16 @@ class DeployedModel(nn.Module):
         c, r, _ = self.heads.splits
         return {"cls_preds": preds[:, :c], "reg_preds": preds[:, c:c + r], "dir_preds": preds[:, c + r:], "preds_tensor": preds}
 
+    def single_preds(self, codes, n_agents: int) -> dict:
+        """``*_preds_single`` (heter_model_baseline.py:224-230): the per-agent heads on each agent's own decoded feature."""
+        if self.heads_single is None:
+            return {}
+        hw = self.fh * self.fw
+        feats = self.decode_rows(codes, n_agents * hw)
+        sp = self._run_heads(self.heads_single, feats, n_agents, hw)
+        c, r, _ = self.heads_single.splits
+        return {"cls_preds_single": sp[:, :c], "reg_preds_single": sp[:, c:c + r], "dir_preds_single": sp[:, c + r:]}
+
     # ---- the reference's model contract ----------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, data_dict: dict, taps: Optional[dict] = None) -> dict:

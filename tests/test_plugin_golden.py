@@ -159,3 +159,32 @@ def test_codebook_is_left_unquantized():
     qt = quant_wrap(build_plugin())
     assert not any(isinstance(m, QuantModule) for m in qt.model.codebook.modules())
     assert isinstance(qt.model.codebook._encoders[0]._latentStageEncoder, torch.nn.Linear)
+
+
+def test_inference_wrappers_contract():
+    """inference_intermediate_fusion(batch, model, dataset) -> {pred_box_tensor, pred_score, gt_box_tensor}; to_device recursion."""
+    from quantv2x_amd.plugin.tools import inference_utils, train_utils
+
+    class _Post:
+        def generate_gt_bbx(self, batch):
+            return "gt"
+
+    class _Dataset:
+        post_processor = _Post()
+
+        def __init__(self, three):
+            self.three = three
+
+        def post_process(self, batch, out):
+            assert set(out['ego']) >= {'cls_preds', 'reg_preds', 'dir_preds', 'preds_tensor'}
+            return ("box", "score", "gt3") if self.three else ("box", "score")
+
+    model = build_plugin()
+    model.hard_eval = True
+    batch = train_utils.to_device({'ego': scene(2), 'meta': [1, 'x', 2.0]}, 'cpu')
+    assert batch['meta'] == [1, 'x', 2.0]
+    with torch.no_grad():
+        a = inference_utils.inference_intermediate_fusion(batch, model, _Dataset(True))
+        b = inference_utils.inference_early_fusion(batch, model, _Dataset(False))
+    assert a == {"pred_box_tensor": "box", "pred_score": "score", "gt_box_tensor": "gt3"}
+    assert b["gt_box_tensor"] == "gt"
