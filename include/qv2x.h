@@ -38,6 +38,19 @@ int qv2x_version(void);
  * (opencood/models/sub_modules/point_pillar_scatter.py:45-49). */
 int qv2x_fill_i8(int8_t* buf, int64_t bytes, int value, void* stream);
 
+/* SURVEY.md §8(f) rank 1 ("next" row).  Points -> pillars, the pre-step the reference runs on the CPU with the un-vendored
+ * spconv.utils.Point2VoxelCPU3d (opencood/data_utils/pre_processor/sp_voxel_preprocessor.py:54-85).  Contract (not a parity
+ * claim): voxels in order of first point appearance, first-come <= max_points points per voxel, <= max_voxels voxels,
+ * coords (agent, z, y, x), zero padded; deterministic.
+ *   points f32 [n_points][4] (x, y, z, intensity), n_points < 2^20; lidar_range [6], voxel_size [3] HOST floats
+ *   outputs sized for max_voxels: voxel_features f32 [max_voxels][max_points][4] (zero filled), voxel_coords i32 [..][4],
+ *   voxel_num_points i32 [..]; n_voxels: DEVICE int32 = number of voxels written
+ *   workspace: qv2x_voxelize_workspace_bytes(n_points) bytes of device memory */
+int64_t qv2x_voxelize_workspace_bytes(int n_points);
+int qv2x_voxelize_f32(const float* points, int n_points, const float* lidar_range, const float* voxel_size, int agent,
+                      int max_points, int max_voxels, void* workspace, int64_t workspace_bytes,
+                      float* voxel_features, int32_t* voxel_coords, int32_t* voxel_num_points, int32_t* n_voxels, void* stream);
+
 /* a1 + a2.  QuantPillarVFE/QuantPFNLayer + PointPillarScatter in one pass
  * (opencood/quant/quant_block.py:589-715, opencood/models/sub_modules/pillar_vfe.py:105-155,
  *  point_pillar_scatter.py:19-75).

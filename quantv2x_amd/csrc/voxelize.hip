@@ -1,0 +1,140 @@
+// Points -> pillars on the GPU: the pre-step the reference runs on the CPU with
+// spconv.utils.Point2VoxelCPU3d (opencood/data_utils/pre_processor/sp_voxel_preprocessor.py:54-85).  spconv is not
+// vendored by the reference, so this implements the *contract* stated in quantv2x_amd/synth.py / oracle/voxelize.py:
+//   voxels in order of first point appearance, first-come <= max_points points per voxel, <= max_voxels voxels,
+//   coords (z, y, x), zero padded -- deterministically (no atomics decide an order):
+//   1. cell id per point (float32 arithmetic identical to the numpy statement), key = cell << 20 | point index
+//   2. one device radix sort of the keys  (hipCUB; points of a cell become contiguous, in index order)
+//   3. segment heads -> rank of each point inside its cell; flag the first point of every cell
+//   4. exclusive scan of the flags in point order = voxel number in order of first appearance
+//   5. scatter points / coords / counts
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+
+namespace qv2x {
+
+constexpr unsigned long long INVALID_KEY = ~0ull;
+
+struct VoxGrid {
+    float lo[3], vs[3];
+    int nx, ny, nz;
+};
+
+__global__ void vox_keys_kernel(const float4* __restrict__ pts, int P, VoxGrid g, unsigned long long* __restrict__ keys) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float4 p = pts[i];
+    const float fx = floorf((p.x - g.lo[0]) / g.vs[0]), fy = floorf((p.y - g.lo[1]) / g.vs[1]), fz = floorf((p.z - g.lo[2]) / g.vs[2]);
+    const bool ok = fx >= 0.f && fx < (float)g.nx && fy >= 0.f && fy < (float)g.ny && fz >= 0.f && fz < (float)g.nz;
+    const unsigned long long cell = ((unsigned long long)fz * g.ny + (unsigned long long)fy) * g.nx + (unsigned long long)fx;
+    keys[i] = ok ? ((cell << 20) | (unsigned)i) : INVALID_KEY;
+}
+
+// sorted position j: head[j] = j if the cell changes here else 0; first_flag[point index] = 1 for the head point of a cell
+__global__ void vox_heads_kernel(const unsigned long long* __restrict__ keys, int P, int* __restrict__ head, int* __restrict__ first_flag) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P) return;
+    const unsigned long long k = keys[j];
+    const bool valid = k != INVALID_KEY;
+    const bool is_head = valid && (j == 0 || (keys[j - 1] >> 20) != (k >> 20));
+    head[j] = is_head ? j : 0;
+    if (is_head) first_flag[(int)(k & 0xFFFFF)] = 1;
+}
+
+__global__ void vox_scatter_kernel(const float4* __restrict__ pts, const unsigned long long* __restrict__ keys,
+                                   const int* __restrict__ head, const int* __restrict__ vox_of_first, int P, VoxGrid g,
+                                   int agent, int max_points, int max_voxels, float4* __restrict__ feats,
+                                   int4* __restrict__ coords, int* __restrict__ nump, int* __restrict__ count) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P) return;
+    const unsigned long long k = keys[j];
+    if (k == INVALID_KEY) return;
+    const int h = head[j];                                   // sorted position of this cell's first point (after the max-scan)
+    const int v = vox_of_first[(int)(keys[h] & 0xFFFFF)];    // voxel number = cells whose first point comes earlier
+    if (v >= max_voxels) return;
+    const int rank = j - h, idx = (int)(k & 0xFFFFF);
+    if (rank < max_points) feats[(size_t)v * max_points + rank] = pts[idx];
+    const bool last = (j + 1 == P) || (keys[j + 1] == INVALID_KEY) || ((keys[j + 1] >> 20) != (k >> 20));
+    if (last) {
+        const unsigned long long cell = k >> 20;
+        const int cx = (int)(cell % g.nx), cy = (int)((cell / g.nx) % g.ny), cz = (int)(cell / ((unsigned long long)g.nx * g.ny));
+        coords[v] = make_int4(agent, cz, cy, cx);
+        nump[v] = rank + 1 < max_points ? rank + 1 : max_points;
+        atomicMax(count, v + 1);                              // number of voxels = highest voxel number + 1 (order independent)
+    }
+}
+
+struct VoxWorkspace {
+    unsigned long long *keys_in, *keys_out;
+    int *head, *first_flag, *vox_of_first, *count;
+    void* cub;
+    size_t cub_bytes;
+};
+
+static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static size_t cub_bytes_for(int P) {
+    size_t a = 0, b = 0, c = 0;
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, a, (unsigned long long*)nullptr, (unsigned long long*)nullptr, P, 0, 64);
+    (void)hipcub::DeviceScan::InclusiveScan(nullptr, b, (int*)nullptr, (int*)nullptr, hipcub::Max(), P);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, c, (int*)nullptr, (int*)nullptr, P);
+    return a > b ? (a > c ? a : c) : (b > c ? b : c);
+}
+
+}  // namespace qv2x
+
+extern "C" int64_t qv2x_voxelize_workspace_bytes(int n_points) {
+    using namespace qv2x;
+    if (n_points <= 0) return 0;
+    const size_t P = (size_t)n_points;
+    return (int64_t)(2 * align_up(P * 8) + 3 * align_up(P * 4) + 256 + align_up(cub_bytes_for(n_points)));
+}
+
+extern "C" int qv2x_voxelize_f32(const float* points, int n_points, const float* lidar_range, const float* voxel_size, int agent,
+                                 int max_points, int max_voxels, void* workspace, int64_t workspace_bytes,
+                                 float* voxel_features, int32_t* voxel_coords, int32_t* voxel_num_points, int32_t* n_voxels,
+                                 void* stream) {
+    using namespace qv2x;
+    if (!points || !lidar_range || !voxel_size || !workspace || !voxel_features || !voxel_coords || !voxel_num_points || !n_voxels)
+        return fail(QV2X_EINVAL, "qv2x_voxelize_f32: null pointer");
+    if (n_points <= 0 || n_points >= (1 << 20) || max_points <= 0 || max_voxels <= 0)
+        return fail(QV2X_EINVAL, "qv2x_voxelize_f32: 0 < n_points < 2^20, max_points > 0, max_voxels > 0");
+    if (workspace_bytes < qv2x_voxelize_workspace_bytes(n_points)) return fail(QV2X_EINVAL, "qv2x_voxelize_f32: workspace too small");
+    if ((uintptr_t)points & 15 || (uintptr_t)voxel_features & 15 || (uintptr_t)voxel_coords & 15) return fail(QV2X_EALIGN, "qv2x_voxelize_f32: 16-byte alignment");
+    VoxGrid g;
+    for (int d = 0; d < 3; ++d) { g.lo[d] = lidar_range[d]; g.vs[d] = voxel_size[d]; }
+    g.nx = (int)lrintf((lidar_range[3] - lidar_range[0]) / voxel_size[0]);
+    g.ny = (int)lrintf((lidar_range[4] - lidar_range[1]) / voxel_size[1]);
+    g.nz = (int)lrintf((lidar_range[5] - lidar_range[2]) / voxel_size[2]);
+    if (g.nx <= 0 || g.ny <= 0 || g.nz <= 0 || (long long)g.nx * g.ny * g.nz >= (1ll << 43)) return fail(QV2X_EINVAL, "qv2x_voxelize_f32: bad grid");
+    const int P = n_points;
+    hipStream_t st = (hipStream_t)stream;
+    char* w = (char*)workspace;
+    VoxWorkspace ws;
+    ws.keys_in = (unsigned long long*)w; w += align_up((size_t)P * 8);
+    ws.keys_out = (unsigned long long*)w; w += align_up((size_t)P * 8);
+    ws.head = (int*)w; w += align_up((size_t)P * 4);
+    ws.first_flag = (int*)w; w += align_up((size_t)P * 4);
+    ws.vox_of_first = (int*)w; w += align_up((size_t)P * 4);
+    ws.count = (int*)w; w += 256;
+    ws.cub = w; ws.cub_bytes = (size_t)workspace_bytes - (size_t)(w - (char*)workspace);
+
+    int rc;
+    if ((rc = hip_check(hipMemsetAsync(ws.first_flag, 0, (size_t)P * 4, st), "voxelize memset"))) return rc;
+    if ((rc = hip_check(hipMemsetAsync(ws.count, 0, 4, st), "voxelize memset"))) return rc;
+    if ((rc = hip_check(hipMemsetAsync(voxel_features, 0, (size_t)max_voxels * max_points * 16, st), "voxelize memset"))) return rc;
+    const int B = 256, G = (P + B - 1) / B;
+    vox_keys_kernel<<<G, B, 0, st>>>((const float4*)points, P, g, ws.keys_in);
+    size_t tb = ws.cub_bytes;
+    if ((rc = hip_check(hipcub::DeviceRadixSort::SortKeys(ws.cub, tb, ws.keys_in, ws.keys_out, P, 0, 64, st), "voxelize sort"))) return rc;
+    vox_heads_kernel<<<G, B, 0, st>>>(ws.keys_out, P, ws.head, ws.first_flag);
+    tb = ws.cub_bytes;
+    if ((rc = hip_check(hipcub::DeviceScan::InclusiveScan(ws.cub, tb, ws.head, ws.head, hipcub::Max(), P, st), "voxelize scan"))) return rc;
+    tb = ws.cub_bytes;
+    if ((rc = hip_check(hipcub::DeviceScan::ExclusiveSum(ws.cub, tb, ws.first_flag, ws.vox_of_first, P, st), "voxelize scan"))) return rc;
+    vox_scatter_kernel<<<G, B, 0, st>>>((const float4*)points, ws.keys_out, ws.head, ws.vox_of_first, P, g, agent, max_points, max_voxels,
+                                        (float4*)voxel_features, (int4*)voxel_coords, voxel_num_points, ws.count);
+    if ((rc = hip_check(hipMemcpyAsync(n_voxels, ws.count, 4, hipMemcpyDeviceToDevice, st), "voxelize count"))) return rc;
+    return hip_check(hipGetLastError(), "qv2x_voxelize_f32 launch");
+}
