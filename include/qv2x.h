@@ -153,6 +153,10 @@ int qv2x_fuse_att_f32(const qv2x_fuse_desc* desc /* host */, const uint8_t* code
 int qv2x_decode_lut_f32(const uint8_t* codes, int R, int levels, int kc, const float* lut, const float* lut_bias,
                         float* out, void* stream);
 
+/* Interior of a padded i8 BEV tensor -> fp32 rows [N*H*W][C], x = (code - zp) * delta: the shared feature of models
+ * WITHOUT the codebook (HeterModelBaseline), i.e. the dequantized output activation of the shrinker's last QuantModule. */
+int qv2x_dequant_i8_f32(const int8_t* in, int n, int h, int w, int c, int zp, float delta, float* out, void* stream);
+
 /* a11.  1x1 QuantModule heads (heter_model_baseline.py:128-133,242-260) on fp32 rows:
  *     y = fma chain over ci (acc0 = bias[co]);  out = (clamp(rint(y / da[co]) + za[co], 0, 255) - za[co]) * da[co]
  *   x f32 [R][256]; w f32 [64][cout_pad][4] (k0, k2, k1, k3 order; cout_pad = cout rounded up to 32, zero filled); bias/da/za f32 [cout_pad]

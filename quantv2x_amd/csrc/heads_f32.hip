@@ -102,7 +102,31 @@ __global__ __launch_bounds__(256) void decode_lut_kernel(const uint8_t* __restri
     out[(size_t)r * 64 + lane] = v;
 }
 
+// interior of a padded i8 BEV tensor -> fp32 rows [N*H*W][C]: x = (code - zp) * delta  (models without the codebook)
+__global__ __launch_bounds__(256) void dequant_i8_kernel(const int8_t* __restrict__ in, int n, int h, int w, int c, int ax, float delta,
+                                                         float* __restrict__ out) {
+    const size_t total = (size_t)n * h * w * (c / 4);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % (c / 4));
+        const size_t pix = i / (c / 4);
+        const int x = (int)(pix % w), y = (int)((pix / w) % h), img = (int)(pix / ((size_t)w * h));
+        const char4 v = *(const char4*)(in + (((size_t)img * (h + 2) + y + 1) * (w + 2) + x + 1) * c + c4 * 4);
+        *(float4*)(out + pix * c + c4 * 4) = make_float4((float)((int)v.x + ax) * delta, (float)((int)v.y + ax) * delta,
+                                                         (float)((int)v.z + ax) * delta, (float)((int)v.w + ax) * delta);
+    }
+}
+
 }  // namespace qv2x
+
+extern "C" int qv2x_dequant_i8_f32(const int8_t* in, int n, int h, int w, int c, int zp, float delta, float* out, void* stream) {
+    using namespace qv2x;
+    if (!in || !out) return fail(QV2X_EINVAL, "qv2x_dequant_i8_f32: null pointer");
+    if (n <= 0 || h <= 0 || w <= 0 || c <= 0 || c % 4) return fail(QV2X_EINVAL, "qv2x_dequant_i8_f32: bad shape (c %% 4 == 0)");
+    const size_t total = (size_t)n * h * w * (c / 4);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    dequant_i8_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(in, n, h, w, c, 128 - zp, delta, out);
+    return hip_check(hipGetLastError(), "qv2x_dequant_i8_f32 launch");
+}
 
 extern "C" int qv2x_heads_f32(const float* x, int R, int hw, int cout, int cout_pad, const float* w, const float* bias,
                               const float* da, const float* za, float* out, void* stream) {

@@ -420,7 +420,8 @@ class DeployedModel(nn.Module):
             # no codebook: the fp32 shared feature is the dequantized shrinker output
             q = self.shrink1.out_q
             feats = bufs["feats"]
-            feats.copy_(((enc[:, 1:-1, 1:-1, :].to(torch.float32) + (128.0 - q[1])) * q[0]).reshape(n_total, hw, 256))
+            L.check(self.lib.qv2x_dequant_i8_f32(L.ptr(enc), n_total, self.fh, self.fw, 256, int(q[1]), float(q[0]), L.ptr(feats),
+                                                 L.current_stream()), "qv2x_dequant_i8_f32")
         elif self.heads_single is not None:
             feats = self.decode_rows(enc, n_total * hw).view(n_total, hw, 256)
         fused = torch.empty((nb, hw, 256), dtype=torch.float32, device=self.dev)

@@ -203,6 +203,14 @@ def gen_w8a8():
     with torch.no_grad():
         for n in (1, 3):
             out[f'hard/preds_tensor_n{n}'] = np32(hard_forward(model, scene(n)))
+    # the deployed path's freeze step applied to the REFERENCE's own QuantModel object (drop-in level 1 of INTEGRATION.md):
+    # per-key checksums of quantv2x_amd.ptq_state.export_ptq_state(reference_qt_model)
+    from quantv2x_amd.ptq_state import export_ptq_state
+    st = export_ptq_state(qt)
+    keys = sorted(k for k in st if not k.startswith("meta/module_names"))
+    out['ptq_export/keys'] = np.array(keys)
+    out['ptq_export/checksum'] = np.array([float(np.asarray(st[k], dtype=np.float64).sum()) for k in keys])
+    out['ptq_export/absum'] = np.array([float(np.abs(np.asarray(st[k], dtype=np.float64)).sum()) for k in keys])
     np.savez_compressed(os.path.join(HERE, "tiny_w8a8.npz"), **out)
     print("tiny_w8a8.npz: %d arrays, %d modules" % (len(out), len(names)))
 

@@ -104,3 +104,52 @@ def test_error_paths(tiny):
         dd = scene(2, device="cuda")
         dd["agent_modality_list"] = ["m1", "m2"]
         eng(dd)
+
+
+def test_model_without_codebook_single_class():
+    """HeterModelBaseline (no codebook, single-class heads): the shared feature is the dequantized shrinker output."""
+    from oracle.spec import Oracle
+    from quantv2x_amd.engine import deploy
+    from quantv2x_amd.ptq_state import export_ptq_state
+    state = export_ptq_state(calibrated_plugin(multiclass=False, codebook=False))
+    assert not bool(state["meta/has_codebook"])
+    eng = deploy(state=state)
+    sc = scene_np(3)
+    from quantv2x_amd import synth
+    ot, gt = {}, {}
+    want = Oracle(state).forward(sc, ot)
+    got = eng(synth.scene_to_torch(sc, "cuda"), gt)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(_interior(gt["shrinker_m1.layers.0.double_conv.1"]), ot["shrinker_m1.layers.0.double_conv.1"])
+    np.testing.assert_array_equal(gt["features"].cpu().numpy().reshape(ot["features"].shape), ot["features"])   # exact dequantization
+    np.testing.assert_allclose(gt["fused"].cpu().numpy().reshape(ot["fused"].shape), ot["fused"], **FUSE_TOL)
+    assert got["preds_tensor"].shape == (1, 20, 16, 32)
+    lsb = max(float(state[k + "/a_delta"]) for k in ("cls_head", "reg_head", "dir_head"))
+    d = np.abs(got["preds_tensor"].cpu().numpy() - want["preds_tensor"])
+    assert d.max() <= lsb * 1.001 and (d > 1e-5).mean() < 2e-3
+
+
+def test_empty_agent_and_agent_count_limits(tiny):
+    """an agent with no pillar at all (canvas = code of 0.0 everywhere), 8 agents (the kernel's maximum), 9 -> error"""
+    from quantv2x_amd import lib as L, synth
+    state, orc, eng = tiny
+    sc = scene_np(2)
+    keep = sc["inputs_m1"]["voxel_coords"][:, 0] == 0          # drop every pillar of agent 1
+    sc["inputs_m1"] = {k: v[keep] for k, v in sc["inputs_m1"].items()}
+    ot, gt = {}, {}
+    orc.forward(sc, ot)
+    # the oracle sizes its canvas from the agent list, the engine too
+    got = eng(synth.scene_to_torch(sc, "cuda"), gt)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(_interior(gt["canvas"]), ot["canvas"])
+    np.testing.assert_array_equal(gt["codes"].cpu().numpy().reshape(ot["codes"].shape), ot["codes"])
+    sc8 = synth.make_scene("tiny", n_agents=8, seed=11, n_points=1500, layout="ring", max_cav=8)
+    o8, g8 = {}, {}
+    want = orc.forward(sc8, o8)
+    got = eng(synth.scene_to_torch(sc8, "cuda"), g8)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(g8["codes"].cpu().numpy().reshape(o8["codes"].shape), o8["codes"])
+    np.testing.assert_allclose(g8["fused"].cpu().numpy().reshape(o8["fused"].shape), o8["fused"], **FUSE_TOL)
+    sc9 = synth.make_scene("tiny", n_agents=9, seed=11, n_points=500, max_cav=9)
+    with pytest.raises(L.Qv2xError):
+        eng(synth.scene_to_torch(sc9, "cuda"))

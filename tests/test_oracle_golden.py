@@ -135,3 +135,15 @@ def test_other_agent_counts_shapes(state, n):
     out = Oracle(state).forward(scene_np(n))
     assert out["preds_tensor"].shape == (1, 72, 16, 32) and np.isfinite(out["preds_tensor"]).all()
     assert out["cls_preds_single"].shape[0] == n
+
+
+def test_freeze_step_gives_the_same_state_on_the_reference_objects(golden, state):
+    """``export_ptq_state`` was run on the reference's own ``QuantModel`` when the goldens were made (it only reads
+    attribute names): same keys, same contents as on the mirror -- ``quantv2x_amd.deploy`` accepts the reference's objects."""
+    g = golden["tiny_w8a8"]
+    keys = [str(k) for k in g["ptq_export/keys"]]
+    assert keys == sorted(k for k in state if not k.startswith("meta/module_names"))
+    got_sum = np.array([float(np.asarray(state[k], dtype=np.float64).sum()) for k in keys])
+    got_abs = np.array([float(np.abs(np.asarray(state[k], dtype=np.float64)).sum()) for k in keys])
+    np.testing.assert_allclose(got_sum, g["ptq_export/checksum"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(got_abs, g["ptq_export/absum"], rtol=1e-6, atol=1e-9)
