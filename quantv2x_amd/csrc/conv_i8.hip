@@ -38,8 +38,8 @@ struct ConvArgs {
 // ds_read_b128 group (rows {0-3,12-15,20-27}, ... of a 32-row fragment, same chunk) hit 16 distinct 16-byte slots.
 template <int BK>
 __device__ __forceinline__ int swz(int row, int chunk) {
-    constexpr int CH = BK / 16;
-    return row * BK + ((chunk ^ ((row >> (CH == 4 ? 2 : 1)) & (CH - 1))) << 4);
+    constexpr int CH = BK / 16;       // 4, 8 or 16 chunks per row
+    return row * BK + ((chunk ^ ((row >> (CH == 4 ? 2 : (CH == 8 ? 1 : 0))) & (CH - 1))) << 4);
 }
 
 template <int BM, int BN, int WM, int WN, int BK, bool MULTI, int MINW>
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_i8_dma_kernel(const ConvArg
     for (int j = 0; j < LPS; ++j) {
         const int id = wave * LPS + j;
         const int blk = loads_a ? id : id - IA;
-        const int p = blk * 64 + lane, row = p / CH, c = (p % CH) ^ ((row >> (CH == 4 ? 2 : 1)) & (CH - 1));
+        const int p = blk * 64 + lane, row = p / CH, c = (p % CH) ^ ((row >> (CH == 4 ? 2 : (CH == 8 ? 1 : 0))) & (CH - 1));
         if (loads_a) {
             int m = m0 + row;
             m = m < a.M ? m : a.M - 1;
@@ -757,6 +757,8 @@ extern "C" int qv2x_conv3x3_i8(const qv2x_conv_desc* d, const int8_t* in, const 
             return launch_dma<128, 128, 2, 2, 64, true, 4, 2>(a, st);
         }
         if (large && a.cout % 128 == 0) return launch_dma<128, 128, 2, 2, 64, false, 3, 3>(a, st);
+        static const char* k256env = getenv("QV2X_CONV_BK256");  // dev knob
+        if (a.gc[0] % 256 == 0 && !(k256env && k256env[0] == '0')) return launch_dma<64, 64, 2, 2, 256, false, 3, 1>(a, st);
         return k128 ? launch_dma<64, 64, 2, 2, 128, false, 4, 2>(a, st) : launch_dma<64, 64, 2, 2, 64, false, 4, 4>(a, st);
     }
     if (multi) {
