@@ -92,6 +92,18 @@ int qv2x_conv3x3_i8(const qv2x_conv_desc* desc /* host */, const int8_t* in, con
                     const float* scale, const int32_t* corr, const int32_t* aw, const float* bias,
                     int8_t* out, void* stream);
 
+/* The same convolution for wide layers (stride 1, cout % 256 == 0: the DoubleConv shrinker,
+ * opencood/models/sub_modules/downsample_conv.py:17-31 under quant_block.py:552-572) with the weights pre-tiled:
+ *   w_wide : i8 [Cout/256][chunk][tap][256][64], chunk = the 64-channel chunks of group 0, then of group 1, ...
+ *            (16 KB contiguous per K-step; made from the row-major layout by qv2x_conv3x3_i8_pack_wide, once).
+ * Results are bit-identical to qv2x_conv3x3_i8.  qv2x_conv3x3_i8_wide_ok returns 1 when the layer qualifies
+ * (and is large enough for the wide kernel to pay: N*H*W >= 16384), else 0. */
+int qv2x_conv3x3_i8_wide_ok(const qv2x_conv_desc* desc /* host */);
+int qv2x_conv3x3_i8_pack_wide(const qv2x_conv_desc* desc /* host */, const int8_t* w, int8_t* w_wide, void* stream);
+int qv2x_conv3x3_i8_wide(const qv2x_conv_desc* desc /* host */, const int8_t* in, const int8_t* w_wide,
+                         const float* scale, const int32_t* corr, const int32_t* aw, const float* bias,
+                         int8_t* out, void* stream);
+
 /* a3 deblocks.  QuantModule over ConvTranspose2d with kernel == stride == s, + bias + ReLU + output quantizer.
  * The reference's per-dim-0 weight scales are per C_in here (quant_layer.py:192-195 on a [Cin,Cout,s,s]
  * weight), i.e. on the reduction axis, so the sum runs in fp32 on the f32 MFMA as an ascending-ci fmaf chain:

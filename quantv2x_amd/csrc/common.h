@@ -15,12 +15,20 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-// UniformAffineQuantizer.forward on one value (quant_layer.py:132-133): code in [0, 255] as a float.
-// IEEE division and round-half-even, so it matches the CPU oracle bit for bit.
+// UniformAffineQuantizer.forward on one value (quant_layer.py:132-133): code in [0, 255] as a float, equal bit for
+// bit to clamp(rintf(y / delta) + zp, 0, 255) with IEEE division (what the CPU oracle computes) -- without paying for
+// the division on every element.  t = y * fl(1/delta) is within |y/delta| * 1.8e-7 of fl(y/delta); below 1100 that is
+// < 2.0e-4, so both round to the same integer unless t sits within 3e-4 of a half-integer; above 1100 either value
+// clamps to 0 or 255 (0 <= zp <= 255).  The rare wave with a lane in the doubtful band redoes the division.
 __device__ __forceinline__ float q_code(float y, float delta, float zp) {
-    float t = rintf(y / delta) + zp;
-    t = fmaxf(t, 0.0f);
-    return fminf(t, 255.0f);
+    const float rdelta = 1.0f / delta;                  // uniform: hoisted out of every loop
+    const float t = y * rdelta;
+    float k = rintf(t);
+    const bool doubtful = (fabsf(t - k) > 0.4997f) & (fabsf(t) < 1100.0f);
+    if (__builtin_amdgcn_ballot_w64(doubtful) != 0) k = rintf(y / delta);
+    float c = k + zp;
+    c = fmaxf(c, 0.0f);
+    return fminf(c, 255.0f);
 }
 
 // C/D fragment row of register r for the 32x32 MFMA forms (cdna guide §3): row = (r&3) + 8*(r>>2) + 4*(lane>>5)

@@ -749,6 +749,7 @@ extern "C" int qv2x_conv3x3_i8(const qv2x_conv_desc* d, const int8_t* in, const 
     static const char* bigenv = getenv("QV2X_CONV_BIG");     // dev knob: "0" disables the 8-wave wide-layer kernel
     if (!(bigenv && bigenv[0] == '0') && a.cout == 256 && a.M >= 16384) {
         if (bigenv && bigenv[0] == '4') return multi ? launch_big<5, 4, 4, true>(a, st) : launch_big<5, 4, 4, false>(a, st);
+        if (bigenv && bigenv[0] == 'm') return multi ? launch_big<4, 8, 5, true>(a, st) : launch_big<4, 8, 5, false>(a, st);
         return multi ? launch_big<5, 8, 5, true>(a, st) : launch_big<5, 8, 5, false>(a, st);
     }
     if (use_dma) {

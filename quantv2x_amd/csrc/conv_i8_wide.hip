@@ -1,0 +1,398 @@
+// Wide 3x3 QuantModule convolution (cout % 256 == 0, stride 1): the two shrinker layers of the V2X-Real model
+// (opencood/quant/quant_block.py:552-572 over DoubleConv, downsample_conv.py:17-31), i.e. 52 of the 75 GMAC of the
+// integer backbone.  Same arithmetic as conv_i8.hip (exact i32 sums on the i8 MFMA, per-group fp32 fold), different
+// data movement -- what bounds this layer on gfx950 is the L2 -> LDS fetch rate, not the MFMA pipe:
+//   * one workgroup = a 5 x 32 patch of output pixels (160 GEMM rows) x 256 output channels, 4 waves (one per
+//     SIMD), each wave a 160 x 64 register tile = 5 x 2 accumulators of v_mfma_i32_32x32x32_i8: 14 LDS fragment
+//     reads per 20 MFMAs (the 8-wave 160 x 32 layout needs 12 per 10 and is LDS-read bound);
+//   * the input is staged as a 7 x 34 pixel HALO tile per 64-channel chunk and the nine taps read it at shifted
+//     pixel offsets: 15.2 KB fetched per nine K-steps instead of 9 x 10 KB;
+//   * the weights are pre-tiled (qv2x_conv3x3_i8_pack_wide) so that the [256][64] tile of one K-step is 16 KB
+//     contiguous: every LDS-DMA instruction reads 1 KiB of whole cache lines (64-byte row gathers run the same
+//     stream at half the rate);
+//   * fragments of K-step s+1 are read from LDS while step s is multiplied (two register sets).
+#include "common.h"
+
+#include <cstdlib>
+
+namespace qv2x {
+
+namespace {
+
+constexpr int TH = 5, TW = 32, HWD = TW + 2, HPIX = (TH + 2) * HWD;    // 238 halo pixels
+constexpr int HBLK = (HPIX * 64 + 1023) / 1024;                       // 15 DMA instructions of 1 KiB
+constexpr int HBUF = HBLK * 1024;
+constexpr int BM = TH * TW, BN = 256, BSTAGE = BN * 64;
+constexpr int MT = 5;
+constexpr int MAX_CHUNKS = 24;
+#ifndef QV2X_ABL
+#define QV2X_ABL 0
+#endif
+constexpr int ABL = QV2X_ABL;
+
+struct WideArgs {
+    const int8_t* in; const int8_t* wt; const float* scale; const int* corr; const int* aw; const float* bias; int8_t* out;
+    int n, hp, wp, cin_total, cout, ho, wo, tiles_x, tiles_y;
+    int out_ctotal, out_c0, relu;
+    float out_delta, out_zp;
+    int nchunks, ngroups;
+    int cend[QV2X_MAX_GROUPS];        // first chunk index past group g
+    int coff[MAX_CHUNKS];             // channel byte offset of each 64-channel chunk inside a pixel
+};
+
+template <int V> struct IC { static constexpr int value = V; };
+
+// The multi-group kernel carries 160 i32 MFMA accumulators AND 160 fp32 fold accumulators per lane.  Both fit the
+// 512-register file of a lone wave only if 96 of the fp32 values rest in AGPRs next to the MFMA accumulators; the
+// register allocator does not split the array that way by itself, so those are pinned with an "a" constraint.
+constexpr int PIN_MT = 0;
+__device__ __forceinline__ void fput(float& slot, float v, bool pinned) {
+    if (pinned) asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(slot) : "v"(v));
+    else slot = v;
+}
+__device__ __forceinline__ float fget(const float& slot, bool pinned) {
+    if (!pinned) return slot;
+    float v;
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(slot));
+    return v;
+}
+
+// NW waves, each a 160 x (NT*32) register tile, NW * NT * 32 == 256:  <4, 2> one wave per SIMD, 0.7 fragment reads per
+// MFMA, two fragment register sets (single-group layers);  <8, 1> two waves per SIMD, 1.2 reads per MFMA, one set --
+// the multi-group layer also carries an fp32 fold accumulator per output, 2 x 160 registers do not fit next to two sets.
+template <int S, bool MULTI, int NW, int NT>
+__global__ __launch_bounds__(NW * 64, 1) void conv3x3_i8_wide_kernel(const WideArgs a) {
+    static_assert(NW * NT * 32 == BN, "wave layout");
+    constexpr int LH = (HBLK + NW - 1) / NW, LB = BSTAGE / 1024 / NW;  // DMA instructions per wave: halo tile, weight tile
+    constexpr int NF = MULTI ? 16 : 1;
+    __shared__ __attribute__((aligned(16))) int8_t lds[2 * HBUF + S * BSTAGE + NW * BM * 4];
+    int8_t* hbuf = lds;
+    int8_t* bst = lds + 2 * HBUF;
+    int* xbuf = (int*)(bst + S * BSTAGE);                              // [NW][BM] partial window sums
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int txi = blockIdx.x % a.tiles_x, tyi = (blockIdx.x / a.tiles_x) % a.tiles_y, img = blockIdx.x / (a.tiles_x * a.tiles_y);
+    const int y0 = tyi * TH, x0 = txi * TW, n0 = blockIdx.y * BN;
+    const int total = a.nchunks * 9;
+
+    // ---- DMA sources (the LDS side of global_load_lds is lane-linear, so the XOR swizzle lives in the source address)
+    unsigned srcH[LH];                                                 // byte offsets from a.in (the tensor is < 4 GiB)
+    int dstH[LH];
+#pragma unroll
+    for (int j = 0; j < LH; ++j) {
+        int blk = wave + NW * j;
+        blk = blk < HBLK ? blk : blk - HBLK;                          // surplus slots re-load a block: same bytes
+        const int p = blk * 64 + lane;
+        int hpx = p >> 2;
+        const int c = (p & 3) ^ ((hpx >> 2) & 3);
+        hpx = hpx < HPIX ? hpx : HPIX - 1;
+        const int hy = hpx / HWD, hx = hpx - hy * HWD;
+        const int yy = min(y0 + hy, a.hp - 1), xx = min(x0 + hx, a.wp - 1);
+        srcH[j] = (unsigned)(((img * a.hp + yy) * a.wp + xx) * a.cin_total + c * 16);
+        dstH[j] = blk * 1024;
+    }
+    const int8_t* srcB;
+    {
+        const int p = wave * LB * 64 + lane, row = p >> 2, c = (p & 3) ^ ((row >> 2) & 3);
+        srcB = a.wt + (size_t)blockIdx.y * total * BSTAGE + row * 64 + c * 16;   // + j KiB per instruction: rows advance by 16
+    }
+
+    v16i acc[MT][NT];
+    float facc[MT][NT][NF];
+    int xs[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        xs[i] = 0;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+            if (MULTI) {
+                const float b = a.bias[n0 + (wave * NT + j) * 32 + (lane & 31)];
+#pragma unroll
+                for (int r = 0; r < NF; ++r) fput(facc[i][j][r], b, i < PIN_MT);
+            }
+        }
+    }
+
+    int b_step = 0;
+    auto issue_b = [&]() __attribute__((always_inline)) {
+        const int st = b_step < total ? b_step : total - 1;
+        int8_t* stage = bst + (b_step % S) * BSTAGE + wave * LB * 1024;
+        const int8_t* s0 = srcB + (size_t)st * BSTAGE;
+#pragma unroll
+        for (int j = 0; j < LB; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s0 + j * 1024),
+                                             (__attribute__((address_space(3))) void*)(stage + j * 1024), 16, 0, 0);
+        ++b_step;
+    };
+    auto issue_halo = [&](int chunk) __attribute__((always_inline)) {
+        const int cc = chunk < a.nchunks ? chunk : a.nchunks - 1;
+        const int off = a.coff[cc];
+        int8_t* buf = hbuf + (chunk & 1) * HBUF;
+#pragma unroll
+        for (int j = 0; j < LH; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.in + (size_t)(srcH[j] + (unsigned)off)),
+                                             (__attribute__((address_space(3))) void*)(buf + dstH[j]), 16, 0, 0);
+    };
+
+    // fragment addresses: A row r of m-tile i is output pixel (i, r) of the patch; tap (dy, dx) reads halo pixel
+    // hp = r + 34 (i + dy) + dx, its 16-byte chunk ch stored at ch ^ ((hp >> 2) & 3).  The 32 lanes of a half-wave read 32
+    // CONSECUTIVE halo pixels, so every 16-lane service group of ds_read_b128 ({0-3,12-15,20-27}, ...) covers 16
+    // distinct hp mod 16 = 16 distinct 16-byte slots of the 256-byte bank row, whatever the tap shift.
+    const int half = lane >> 5;
+    const int hp0 = lane & 31;
+    int offB[NT][2];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int row = (wave * NT + j) * 32 + (lane & 31);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) offB[j][ks] = row * 64 + (((ks * 2 + half) ^ ((row >> 2) & 3)) << 4);
+    }
+
+    constexpr int NSET = NT == 2 ? 2 : 1;
+    v4i fa[NSET][2][MT], fb[NSET][2][NT];
+    auto read_frags = [&](auto set_c, int chunk, int tap, int step) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_c)::value;
+        const int8_t* hb = hbuf + (chunk & 1) * HBUF;
+        const int8_t* bs = bst + (step % S) * BSTAGE;
+        const int d = (tap / 3) * HWD + (tap % 3);
+        int hpl = hp0;
+        if (MULTI) asm volatile("" : "+v"(hpl));                        // keep the 45 tap addresses from being hoisted (and spilled)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int hp = hpl + HWD * i + d;
+            const int t = (hp >> 2) & 3;
+            const int a0 = hp * 64 + ((half ^ t) << 4);
+            fa[SET][0][i] = *(const v4i*)(hb + a0);
+            fa[SET][1][i] = *(const v4i*)(hb + (a0 ^ 32));
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            fb[SET][0][j] = *(const v4i*)(bs + offB[j][0]);
+            fb[SET][1][j] = *(const v4i*)(bs + offB[j][1]);
+        }
+    };
+
+    int g = 0;
+    auto fold_group = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int tot = xs[i] + __shfl_xor(xs[i], 32);
+            if (lane < 32) xbuf[wave * BM + i * 32 + lane] = tot;
+            xs[i] = 0;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid < BM) {
+            int v = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += xbuf[w * BM + tid];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            xbuf[tid] = v;                                             // only thread tid touches column tid of row 0
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (MULTI) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int co = n0 + (wave * NT + j) * 32 + (lane & 31);
+                const int awv = a.aw[co];
+                const int cr = a.corr[g * a.cout + co];
+                const float sc = a.scale[g * a.cout + co];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int r = 0; r < NF; ++r) {
+                        const int T = acc[i][j][r] + __mul24(awv, xbuf[i * 32 + mfma32_row(r, lane)]) + cr;
+                        fput(facc[i][j][r], fget(facc[i][j][r], i < PIN_MT) + (float)T * sc, i < PIN_MT);
+                        acc[i][j][r] = 0;
+                    }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                              // xbuf is rewritten by the next fold
+        }
+    };
+
+    // ---- prologue: halo of chunk 0, weight tiles of steps 0 .. S-2 ------------------------------------------------
+    issue_halo(0);
+#pragma unroll
+    for (int p = 0; p < S - 1; ++p) issue_b();
+
+    // One K-step = (chunk, tap).  At its barrier: weight tile step+1 and (from tap S-1 on) the next halo have landed for
+    // every wave, and every wave is done reading tile step-1 -- the stage the new DMA overwrites.  Taps 0..7 read the
+    // fragments of the next tap while they multiply; tap 0 reads its own first (one exposed LDS latency per chunk keeps
+    // the register-set parity the same in every chunk: 9 taps, sets 0 1 0 1 0 1 0 1 0).
+    auto one_step = [&](auto tap_c, int chunk) __attribute__((always_inline)) {
+        constexpr int TAP = decltype(tap_c)::value, SET = (NSET == 2) ? (TAP & 1) : 0;
+        constexpr int INFLIGHT = (S - 3) * LB + ((TAP >= 1 && TAP <= S - 2) ? LH : 0);
+        const int step = chunk * 9 + TAP;
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(INFLIGHT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        if (ABL != 3) issue_b();
+        if (TAP == 0 && ABL != 2) issue_halo(chunk + 1);
+        if (TAP == 0 || NSET == 1) read_frags(IC<0>{}, chunk, TAP, step);
+        if (TAP < 8 && NSET == 2) read_frags(IC<(SET ^ 1) % NSET>{}, chunk, TAP + 1, step + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ABL != 1 && ((chunk + TAP) & (NW - 1)) == wave_u) {        // window sums: the waves take turns, one step each
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xs[i] = __builtin_amdgcn_sdot4(fa[SET][ks][i][q], 0x01010101, xs[i], false);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    if (ABL != 4) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[SET][ks][i], fb[SET][ks][j], acc[i][j], 0, 0, 0);
+                    else acc[i][j][0] += fa[SET][ks][i][0] + fb[SET][ks][j][1];
+    };
+    for (int chunk = 0; chunk < (ABL == 6 ? 1 : a.nchunks); ++chunk) {
+        one_step(IC<0>{}, chunk); one_step(IC<1>{}, chunk); one_step(IC<2>{}, chunk);
+        one_step(IC<3>{}, chunk); one_step(IC<4>{}, chunk); one_step(IC<5>{}, chunk);
+        one_step(IC<6>{}, chunk); one_step(IC<7>{}, chunk); one_step(IC<8>{}, chunk);
+        if (MULTI && chunk + 1 == a.cend[g]) { fold_group(); ++g; }
+    }
+    if (!MULTI) fold_group();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- epilogue: requantize, transpose through LDS, 16-byte stores -----------------------------------------------
+    int8_t* stagebuf = lds + wave * (NT * 1024);                       // per wave [32 rows][NT * 32 channels]
+    int awv[NT], cr[NT];
+    float sc[NT], bsv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int co = n0 + (wave * NT + j) * 32 + (lane & 31);
+        awv[j] = 0; cr[j] = 0; sc[j] = 0.f; bsv[j] = 0.f;
+        if (!MULTI) { awv[j] = a.aw[co]; cr[j] = a.corr[co]; sc[j] = a.scale[co]; bsv[j] = a.bias[co]; }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma32_row(r, lane);
+                float y;
+                if (MULTI) {
+                    y = fget(facc[i][j][r % NF], i < PIN_MT);
+                } else {
+                    const int T = acc[i][j][r] + __mul24(awv[j], xbuf[i * 32 + row]) + cr[j];
+                    y = bsv[j] + (float)T * sc[j];
+                }
+                if (a.relu) y = fmaxf(y, 0.0f);
+                if (ABL == 5) stagebuf[row * (NT * 32) + j * 32 + (lane & 31)] = (int8_t)(int)y; else
+                stagebuf[row * (NT * 32) + j * 32 + (lane & 31)] = (int8_t)((int)q_code(y, a.out_delta, a.out_zp) - 128);
+            }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            const int u = q * 64 + lane, row = u / (2 * NT), chn = u % (2 * NT);
+            const int yo = y0 + i, xo = x0 + row;
+            if (yo < a.ho && xo < a.wo)
+                *(v4i*)(a.out + ((size_t)(img * (a.ho + 2) + yo + 1) * (a.wo + 2) + xo + 1) * a.out_ctotal + a.out_c0 + n0 + wave * (NT * 32) + chn * 16) =
+                    *(const v4i*)(stagebuf + row * (NT * 32) + chn * 16);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// [Cout][G][3][3][C_g] -> [Cout/256][chunk = (g, cc)][tap][256][64]
+__global__ void pack_wide_kernel(const int8_t* __restrict__ w, int8_t* __restrict__ wt, int cout, int ktot, int nchunks,
+                                 WideArgs a) {
+    const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one 16-byte unit each
+    const long long units = (long long)cout * ktot / 16;
+    if (u >= units) return;
+    const int c16 = u & 3;
+    const int row = (u >> 2) & 255;
+    const long long tile = u >> 10;
+    const int step = tile % (nchunks * 9);
+    const int nb = tile / (nchunks * 9);
+    const int chunk = step / 9, tap = step % 9;
+    // group of this chunk and its K offset in the row-major layout
+    int g = 0, k0 = 0, cfirst = 0;
+    while (chunk >= a.cend[g]) { const int gc = (a.cend[g] - cfirst) * 64; k0 += 9 * gc; cfirst = a.cend[g]; ++g; }
+    const int gc = (a.cend[g] - cfirst) * 64;
+    const int k = k0 + tap * gc + (chunk - cfirst) * 64 + c16 * 16;
+    *(v4i*)(wt + u * 16) = *(const v4i*)(w + (size_t)(nb * 256 + row) * ktot + k);
+}
+
+int fill_args(const qv2x_conv_desc* d, WideArgs& a) {
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_wide: bad shape n=%d h=%d w=%d", d->n, d->h, d->w);
+    if (d->stride != 1 || d->cout % 256) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_wide: stride 1 and cout %% 256 == 0 only");
+    if (d->ngroups < 1 || d->ngroups > QV2X_MAX_GROUPS) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_wide: 1..%d input groups", QV2X_MAX_GROUPS);
+    if (d->cin_total % 16 || d->out_ctotal % 16 || d->out_c0 % 16 || d->out_ctotal < d->out_c0 + d->cout)
+        return fail(QV2X_EALIGN, "qv2x_conv3x3_i8_wide: cin_total, out_ctotal, out_c0 %% 16; out channel window");
+    if (!(d->out_delta > 0.0f)) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_wide: out_delta must be positive");
+    a.n = d->n; a.hp = d->h + 2; a.wp = d->w + 2; a.cin_total = d->cin_total; a.cout = d->cout;
+    a.ho = d->h; a.wo = d->w;
+    a.tiles_x = (a.wo + TW - 1) / TW; a.tiles_y = (a.ho + TH - 1) / TH;
+    a.out_ctotal = d->out_ctotal; a.out_c0 = d->out_c0; a.relu = d->relu; a.out_delta = d->out_delta; a.out_zp = d->out_zp;
+    a.ngroups = d->ngroups;
+    int n = 0;
+    for (int g = 0; g < QV2X_MAX_GROUPS; ++g) {
+        if (g < d->ngroups) {
+            const int c0 = d->group_c0[g], c = d->group_c[g];
+            if (c <= 0 || c % 64 || c0 % 16 || c0 + c > d->cin_total)
+                return fail(QV2X_EALIGN, "qv2x_conv3x3_i8_wide: group %d (c0=%d, c=%d): channels must come in multiples of 64", g, c0, c);
+            for (int cc = 0; cc < c / 64; ++cc) {
+                if (n >= MAX_CHUNKS) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_wide: more than %d 64-channel chunks", MAX_CHUNKS);
+                a.coff[n++] = c0 + cc * 64;
+            }
+            a.cend[g] = n;
+        } else {
+            a.cend[g] = 1 << 30;
+        }
+    }
+    a.nchunks = n;
+    return QV2X_OK;
+}
+
+}  // namespace
+
+}  // namespace qv2x
+
+extern "C" int qv2x_conv3x3_i8_wide_ok(const qv2x_conv_desc* d) {
+    if (!d || d->stride != 1 || d->cout % 256 || d->ngroups < 1 || d->ngroups > QV2X_MAX_GROUPS) return 0;
+    int chunks = 0;
+    for (int g = 0; g < d->ngroups; ++g) {
+        if (d->group_c[g] <= 0 || d->group_c[g] % 64 || d->group_c0[g] % 16) return 0;
+        chunks += d->group_c[g] / 64;
+    }
+    return chunks <= qv2x::MAX_CHUNKS && (long long)d->n * d->h * d->w >= 16384;
+}
+
+extern "C" int qv2x_conv3x3_i8_pack_wide(const qv2x_conv_desc* d, const int8_t* w, int8_t* w_wide, void* stream) {
+    using namespace qv2x;
+    if (!d || !w || !w_wide) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_pack_wide: null pointer");
+    if (((uintptr_t)w & 15) || ((uintptr_t)w_wide & 15)) return fail(QV2X_EALIGN, "qv2x_conv3x3_i8_pack_wide: 16-byte alignment");
+    WideArgs a{};
+    if (int rc = fill_args(d, a)) return rc;
+    const int ktot = a.nchunks * 9 * 64;
+    const long long units = (long long)d->cout * ktot / 16;
+    pack_wide_kernel<<<(unsigned)((units + 255) / 256), 256, 0, (hipStream_t)stream>>>(w, w_wide, d->cout, ktot, a.nchunks, a);
+    return hip_check(hipGetLastError(), "qv2x_conv3x3_i8_pack_wide launch");
+}
+
+extern "C" int qv2x_conv3x3_i8_wide(const qv2x_conv_desc* d, const int8_t* in, const int8_t* w_wide, const float* scale,
+                                    const int32_t* corr, const int32_t* aw, const float* bias, int8_t* out, void* stream) {
+    using namespace qv2x;
+    if (!d || !in || !w_wide || !scale || !corr || !aw || !bias || !out) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_wide: null pointer");
+    if (((uintptr_t)in & 15) || ((uintptr_t)w_wide & 15) || ((uintptr_t)out & 15)) return fail(QV2X_EALIGN, "qv2x_conv3x3_i8_wide: in / w / out must be 16-byte aligned");
+    WideArgs a{};
+    if (int rc = fill_args(d, a)) return rc;
+    a.in = in; a.wt = w_wide; a.scale = scale; a.corr = corr; a.aw = aw; a.bias = bias; a.out = out;
+    dim3 grid(a.n * a.tiles_x * a.tiles_y, a.cout / BN);
+    hipStream_t st = (hipStream_t)stream;
+    if (d->ngroups > 1) conv3x3_i8_wide_kernel<6, true, 8, 1><<<grid, 512, 0, st>>>(a);
+    else conv3x3_i8_wide_kernel<6, false, 4, 2><<<grid, 256, 0, st>>>(a);
+    return hip_check(hipGetLastError(), "qv2x_conv3x3_i8_wide launch");
+}

@@ -15,6 +15,7 @@ There is no CPU / eager fallback here: if ``libqv2x.so`` is missing, constructio
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -80,6 +81,7 @@ class _ConvLayer:
         self.name, self.stride, self.cout = name, stride, cout
         self.groups = [(int(c0), int(c), int(zx)) for (c0, c, _, zx) in in_groups]
         self.w = _dev(np.concatenate(parts, axis=1).astype(np.int8), dev)
+        self.w_wide = None                                              # tiled copy for qv2x_conv3x3_i8_wide, made on first use
         self.scale = _dev(np.stack(scale).astype(np.float32), dev)
         self.corr = _dev(np.stack(corr).astype(np.int32), dev)
         self.aw = _dev(aw.astype(np.int32), dev)
@@ -274,6 +276,13 @@ class DeployedModel(nn.Module):
         d.out_ctotal = out.shape[-1] if out_ctotal is None else out_ctotal
         d.out_c0, d.relu = out_c0, 1
         d.out_delta, d.out_zp = layer.out_q[0], float(layer.out_q[1])
+        if self.lib.qv2x_conv3x3_i8_wide_ok(C.byref(d)) and os.environ.get("QV2X_CONV_WIDE", "1") != "0":
+            if layer.w_wide is None:                                    # one-off re-tiling of the weights (not capturable)
+                layer.w_wide = torch.empty_like(layer.w)
+                L.check(self.lib.qv2x_conv3x3_i8_pack_wide(C.byref(d), L.ptr(layer.w), L.ptr(layer.w_wide), L.current_stream()), layer.name)
+            L.check(self.lib.qv2x_conv3x3_i8_wide(C.byref(d), L.ptr(x), L.ptr(layer.w_wide), L.ptr(layer.scale), L.ptr(layer.corr),
+                                                  L.ptr(layer.aw), L.ptr(layer.bias), L.ptr(out), L.current_stream()), layer.name)
+            return
         L.check(self.lib.qv2x_conv3x3_i8(C.byref(d), L.ptr(x), L.ptr(layer.w), L.ptr(layer.scale), L.ptr(layer.corr),
                                          L.ptr(layer.aw), L.ptr(layer.bias), L.ptr(out), L.current_stream()), layer.name)
 

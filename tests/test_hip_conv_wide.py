@@ -1,0 +1,101 @@
+"""qv2x_conv3x3_i8_wide (halo-tiled, pre-tiled weights) vs qv2x_conv3x3_i8 and the CPU oracle: bit-exact uint8 codes.
+
+Covers the shapes the end-to-end tests do not reach at small size: one exact 5 x 32 patch, ragged patches on both
+axes, several images, one and three input groups (the concat of the three deblocks, three activation scales)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _layer_state(rng, name, cin, cout):
+    return {
+        name + "/w_code": rng.integers(0, 256, size=(cout, cin, 3, 3), dtype=np.uint8),
+        name + "/w_delta": rng.uniform(0.002, 0.01, size=cout).astype(np.float32),
+        name + "/w_zp": rng.integers(100, 156, size=cout).astype(np.float32),
+        name + "/bias": rng.normal(0, 0.5, size=cout).astype(np.float32),
+        name + "/a_delta": np.float32(0.11), name + "/a_zp": np.float32(3.0), name + "/a_off": np.bool_(False),
+    }
+
+
+def _padded(x_u8, zx_per_channel):
+    """u8 [N,H,W,C] -> padded i8 [N,H+2,W+2,C] with border = zero point (x - zx == 0 there)"""
+    n, h, w, c = x_u8.shape
+    p = np.empty((n, h + 2, w + 2, c), np.int16)
+    p[:] = zx_per_channel.astype(np.int16)
+    p[:, 1:-1, 1:-1] = x_u8
+    return (p - 128).astype(np.int8)
+
+
+@pytest.mark.parametrize("n,h,w,groups", [
+    (1, 5, 32, [(0, 64)]),
+    (1, 10, 16, [(0, 64)]),
+    (1, 20, 32, [(0, 128)]),
+    (2, 13, 37, [(0, 64), (64, 128), (192, 64)]),
+    (1, 7, 50, [(0, 128), (128, 64)]),
+    (3, 25, 16, [(0, 256)]),
+])
+def test_wide_matches_regular_and_oracle(n, h, w, groups):
+    from oracle.spec import Oracle
+    from quantv2x_amd import lib as L
+    from quantv2x_amd.engine import _ConvLayer
+    lib = L.load()
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(h * 1000 + w)
+    cin, cout, name = sum(c for _, c in groups), 256, "layer"
+    state = _layer_state(rng, name, cin, cout)
+    in_q = [(c0, c, np.float32(0.03 + 0.02 * i), 90 + 30 * i) for i, (c0, c) in enumerate(groups)]
+    layer = _ConvLayer(state, name, in_q, 1, dev)
+    x = rng.integers(0, 256, size=(n, h, w, cin), dtype=np.uint8)
+    zx = np.concatenate([np.full(c, z) for (_, c, _, z) in in_q])
+    xin = torch.from_numpy(_padded(x, zx)).to(dev)
+
+    d = L.ConvDesc()
+    d.n, d.h, d.w, d.cin_total, d.stride, d.cout = n, h, w, cin, 1, cout
+    d.ngroups = len(groups)
+    for i, (c0, c, _, z) in enumerate(in_q):
+        d.group_c0[i], d.group_c[i], d.group_zx[i] = c0, c, z
+    d.out_ctotal, d.out_c0, d.relu = cout, 0, 1
+    d.out_delta, d.out_zp = layer.out_q[0], float(layer.out_q[1])
+    st = L.current_stream()
+    outs = []
+    for wide in (False, True):
+        out = torch.full((n, h + 2, w + 2, cout), -77, dtype=torch.int8, device=dev)
+        if wide:
+            w_wide = torch.empty_like(layer.w)
+            L.check(lib.qv2x_conv3x3_i8_pack_wide(C.byref(d), L.ptr(layer.w), L.ptr(w_wide), st), "pack")
+            L.check(lib.qv2x_conv3x3_i8_wide(C.byref(d), L.ptr(xin), L.ptr(w_wide), L.ptr(layer.scale), L.ptr(layer.corr),
+                                             L.ptr(layer.aw), L.ptr(layer.bias), L.ptr(out), st), "wide")
+        else:
+            L.check(lib.qv2x_conv3x3_i8(C.byref(d), L.ptr(xin), L.ptr(layer.w), L.ptr(layer.scale), L.ptr(layer.corr),
+                                        L.ptr(layer.aw), L.ptr(layer.bias), L.ptr(out), st), "regular")
+        torch.cuda.synchronize()
+        outs.append(out.cpu().numpy())
+    np.testing.assert_array_equal(outs[1], outs[0])                    # interior AND the untouched border
+    assert (outs[1][:, 0] == -77).all() and (outs[1][:, :, 0] == -77).all()
+
+    orc = Oracle.__new__(Oracle)
+    orc.s = state
+    want, _ = orc.conv(name, x, in_q)
+    got = (outs[1][:, 1:-1, 1:-1].astype(np.int16) + 128).astype(np.uint8)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_wide_rejects_unsupported():
+    from quantv2x_amd import lib as L
+    lib = L.load()
+    d = L.ConvDesc()
+    d.n, d.h, d.w, d.cin_total, d.stride, d.cout, d.ngroups = 1, 100, 352, 64, 2, 256, 1
+    d.group_c[0], d.out_ctotal, d.out_delta = 64, 256, 0.1
+    assert lib.qv2x_conv3x3_i8_wide_ok(C.byref(d)) == 0               # stride 2
+    d.stride, d.cout = 1, 128
+    assert lib.qv2x_conv3x3_i8_wide_ok(C.byref(d)) == 0               # cout % 256
+    d.cout = 256
+    assert lib.qv2x_conv3x3_i8_wide_ok(C.byref(d)) == 1
+    x = torch.zeros(64, dtype=torch.int8, device="cuda")
+    d.stride = 2
+    rc = lib.qv2x_conv3x3_i8_wide(C.byref(d), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), None)
+    assert rc != 0 and b"stride" in lib.qv2x_last_error()
