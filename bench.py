@@ -63,8 +63,8 @@ def my_scene(world, rank, device):
 
 
 def conv_roofline(eng, iters):
-    """Average launch duration and algorithmic ops of the dominant kernel: the 8-wave wide-layer int8 MFMA convolution
-    ``conv3x3_i8_big_kernel<5, 8, 5, true>`` -- one launch per frame (the shrinker's 3x3 384 -> 256 convolution over the
+    """Average launch duration and algorithmic ops of the dominant kernel: the wide-layer int8 MFMA convolution
+    ``conv3x3_i8_wide_kernel<5, true, 8, 1>`` -- one launch per frame (the shrinker's 3x3 384 -> 256 convolution over the
     three-scale concat, 31.14 GMAC = 40 % of all conv work), timed with HIP events on the launch stream."""
     import torch
     pick = lambda kind, layer: kind == "conv" and layer is eng.shrink0
@@ -83,7 +83,7 @@ def conv_roofline(eng, iters):
     achieved = ops / len(launches) / (us * 1e-6) / 1e12
     return {"bound": "mfma", "achieved": round(achieved, 1), "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s",
             "frac": round(achieved / INT8_MFMA_PEAK_TOPS, 4), "traffic": None,
-            "kernel": "conv3x3_i8_big_kernel<5, 8, 5, true>", "launches_per_frame": len(launches),
+            "kernel": "conv3x3_i8_wide_kernel<5, true, 8, 1>", "launches_per_frame": len(launches),
             "avg_launch_us": round(us, 2), "algorithmic_gop_per_launch": round(ops / len(launches) / 1e9, 3)}
 
 

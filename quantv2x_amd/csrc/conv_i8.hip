@@ -15,7 +15,8 @@
 // (x - zx) = 0 there, which is exactly zero padding in the dequantized domain.
 //
 // Epilogue (spec shared with oracle/qv2x_oracle.c:orc_conv3x3): y = bias + sum_g float(T_g) * scale[g][co]
-// (separate mul and add), ReLU, requantize with IEEE division + rint, store code - 128.
+// (separate mul and add), ReLU, requantize (q_code: equal to IEEE division + rint), store code - 128.
+// Wide stride-1 layers (cout % 256 == 0) have their own kernel and weight layout: conv_i8_wide.hip.
 #include <cstdlib>
 
 #include "common.h"
@@ -29,9 +30,6 @@ struct ConvArgs {
     int ho, wo, M, ktot;
     int out_ctotal, out_c0, relu;
     float out_delta, out_zp;
-    int nsteps;                       // big kernel: number of 64-byte K chunks, A-side byte offset of each, group ends
-    int gend[QV2X_MAX_GROUPS];
-    int aoff[96];
 };
 
 // LDS rows are BK bytes = CH 16-byte chunks; chunk c of row r is stored at c ^ f(r) so that the 16 lanes of a
@@ -474,230 +472,6 @@ static int launch_dma(const ConvArgs& a, hipStream_t st) {
     return hip_check(hipGetLastError(), "qv2x_conv3x3_i8 launch");
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// Wide layers (Cout == 256, the shrinker: 67 % of all conv work): one workgroup of 8 waves owns MT*32 output pixels x
-// all 256 output channels.  Wave w owns channels [32w, 32w+32) for every row tile (MT accumulators), so
-//   - each weight fragment read from LDS feeds MT MFMAs and each activation fragment is shared by the 8 waves,
-//   - 160-pixel tiles give 220 workgroups at V2X-Real size = one round on 256 CUs at 86 % balance
-//     (128-pixel tiles: 275 workgroups = 2 rounds at one workgroup per CU; 256: 138 = 54 % of the CUs),
-//   - non-MFMA instructions per MFMA drop ~3x against the 4-wave 128x128 kernel, whose waves were issue-bound.
-// K is walked in 64-byte chunks through a 5-stage LDS-DMA ring (same protocol as conv3x3_i8_dma_kernel); the A-side
-// byte offset of every chunk comes from a table in the kernel arguments (no div / tap bookkeeping in the loop);
-// fragment reads are software pipelined one k-substep ahead; the v_dot4 window sums are split over the 8 waves
-// (they all see every activation fragment) and combined through LDS at the end of a group.
-template <int MT, int NW, int S, bool MULTI>
-__global__ __launch_bounds__(NW * 64, 2) void conv3x3_i8_big_kernel(const ConvArgs a) {
-    constexpr int BM = MT * 32, BN = NW * 32, BK = 64;
-    constexpr int IA = BM * BK / 1024, IB = BN * BK / 1024;     // 1 KiB DMA instructions per tile
-    constexpr int LA = (IA + NW - 1) / NW, LB = IB / NW, LPS = LA + LB; // per wave per chunk (surplus A slots re-load a block: same bytes)
-    constexpr int STAGE = (BM + BN) * BK;
-    constexpr int NF = MULTI ? 16 : 1;
-
-    __shared__ __attribute__((aligned(16))) int8_t lds[S * STAGE + NW * BM * 4 + BM * 4];
-    int* xbuf = (int*)(lds + S * STAGE);                        // [NW waves][BM] partial window sums
-    int* rowoff = xbuf + NW * BM;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-
-    const int8_t* src[LPS];
-    int dst[LPS];
-#pragma unroll
-    for (int j = 0; j < LPS; ++j) {
-        const bool is_a = j < LA;
-        const int blk = is_a ? (wave * LA + j) % IA : wave * LB + (j - LA);
-        const int p = blk * 64 + lane, row = p >> 2, c = (p & 3) ^ ((row >> 2) & 3);
-        if (is_a) {
-            int m = m0 + row;
-            m = m < a.M ? m : a.M - 1;
-            const int img = m / (a.ho * a.wo), rem = m - img * (a.ho * a.wo);
-            const int yo = rem / a.wo, xo = rem - yo * a.wo;
-            src[j] = a.in + ((size_t)(img * a.hp + yo * a.stride) * a.wp + xo * a.stride) * a.cin_total + c * 16;
-            dst[j] = blk * 1024;
-        } else {
-            src[j] = a.w + (size_t)(n0 + row) * a.ktot + c * 16;
-            dst[j] = BM * BK + blk * 1024;
-        }
-    }
-    for (int t = tid; t < BM; t += NW * 64) {
-        const int m = m0 + t;
-        int off = -1;
-        if (m < a.M) {
-            const int img = m / (a.ho * a.wo), rem = m - img * (a.ho * a.wo);
-            const int yo = rem / a.wo, xo = rem - yo * a.wo;
-            off = (img * (a.ho + 2) + yo + 1) * (a.wo + 2) + xo + 1;
-        }
-        rowoff[t] = off;
-    }
-
-    v16i acc[MT];
-    float facc[MT][NF];
-    int xs[MT];
-    const int co = n0 + wave * 32 + (lane & 31);
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        xs[i] = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0;
-        if (MULTI) {
-            const float b = a.bias[co];
-#pragma unroll
-            for (int r = 0; r < NF; ++r) facc[i][r] = b;
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    const int total = a.nsteps;
-    int i_step = 0;
-    auto issue = [&]() {
-        const int chunk = i_step < total ? i_step : total - 1;
-        const int aoff = a.aoff[chunk], boff = chunk * BK;
-        int8_t* stage = lds + (i_step % S) * STAGE;
-#pragma unroll
-        for (int j = 0; j < LPS; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (j < LA ? aoff : boff)),
-                                             (__attribute__((address_space(3))) void*)(stage + dst[j]), 16, 0, 0);
-        ++i_step;
-    };
-#pragma unroll
-    for (int p = 0; p < S - 1; ++p)
-        if (p < total) issue();
-
-    // fragment read offsets inside a stage: A row tile i / this wave's weight tile, k-substep ks
-    int offA[MT][2], offB[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        const int ch = ks * 2 + (lane >> 5);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) offA[i][ks] = swz<BK>(i * 32 + (lane & 31), ch);
-        offB[ks] = BM * BK + swz<BK>(wave * 32 + (lane & 31), ch);
-    }
-
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);     // provably wave-uniform copy for scalar branches
-    int g = 0;
-    auto fold_group = [&]() {
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int tot = xs[i] + __shfl_xor(xs[i], 32);
-            if (lane < 32) xbuf[wave * BM + i * 32 + lane] = tot;
-            xs[i] = 0;
-        }
-        __syncthreads();
-        for (int t = tid; t < BM; t += NW * 64) {                // combine the waves' partial sums
-            int v = 0;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) v += xbuf[w * BM + t];
-            xbuf[t] = v;
-        }
-        __syncthreads();
-        if (MULTI) {
-            const int awv = a.aw[co];
-            const int cr = a.corr[g * a.cout + co];
-            const float sc = a.scale[g * a.cout + co];
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int r = 0; r < NF; ++r) {
-                    const int T = acc[i][r] + awv * xbuf[i * 32 + mfma32_row(r, lane)] + cr;
-                    facc[i][r] = facc[i][r] + (float)T * sc;
-                    acc[i][r] = 0;
-                }
-            __syncthreads();
-        }
-    };
-
-    // Steady state without per-chunk conditionals: every iteration issues exactly one chunk (past the end: the last chunk
-    // again, into a stage that has already been consumed), so "chunk `step` has landed" is always vmcnt((S-2)*LPS).
-    auto one_step = [&](int step, const int8_t* stg) {
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((S - 2) * LPS) : "memory");
-        __builtin_amdgcn_s_barrier();
-        issue();
-        v4i fa[2][MT], fb[2];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) fa[0][i] = *(const v4i*)(stg + offA[i][0]);
-        fb[0] = *(const v4i*)(stg + offB[0]);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) fa[1][i] = *(const v4i*)(stg + offA[i][1]);
-        fb[1] = *(const v4i*)(stg + offB[1]);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            if (NW == 4 || ks == (wave_u >> 2)) {
-                switch (wave_u & 3) {
-                    case 0: _Pragma("unroll") for (int i = 0; i < MT; ++i) xs[i] = __builtin_amdgcn_sdot4(fa[ks][i][0], 0x01010101, xs[i], false); break;
-                    case 1: _Pragma("unroll") for (int i = 0; i < MT; ++i) xs[i] = __builtin_amdgcn_sdot4(fa[ks][i][1], 0x01010101, xs[i], false); break;
-                    case 2: _Pragma("unroll") for (int i = 0; i < MT; ++i) xs[i] = __builtin_amdgcn_sdot4(fa[ks][i][2], 0x01010101, xs[i], false); break;
-                    default: _Pragma("unroll") for (int i = 0; i < MT; ++i) xs[i] = __builtin_amdgcn_sdot4(fa[ks][i][3], 0x01010101, xs[i], false); break;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ks][i], fb[ks], acc[i], 0, 0, 0);
-        }
-        if (MULTI && step + 1 == a.gend[g]) { fold_group(); ++g; }
-    };
-    int base = 0;
-    for (; base + S <= total; base += S) {
-#pragma unroll
-        for (int u = 0; u < S; ++u) one_step(base + u, lds + u * STAGE);
-    }
-#pragma unroll
-    for (int u = 0; u < S; ++u)
-        if (base + u < total) one_step(base + u, lds + u * STAGE);
-    if (!MULTI) fold_group();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    // ---- epilogue ---------------------------------------------------------------------------------------------------
-    int8_t* stagebuf = lds + wave * 1024;                       // per-wave [32 rows][32 channels] bytes
-    int awv = 0, cr = 0;
-    float sc = 0.f, bs = 0.f;
-    if (!MULTI) { awv = a.aw[co]; cr = a.corr[co]; sc = a.scale[co]; bs = a.bias[co]; }
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = mfma32_row(r, lane);
-            float y;
-            if (MULTI) {
-                y = facc[i][r % NF];
-            } else {
-                const int T = acc[i][r] + awv * xbuf[i * 32 + row] + cr;
-                y = bs + (float)T * sc;
-            }
-            if (a.relu) y = fmaxf(y, 0.0f);
-            stagebuf[row * 32 + (lane & 31)] = (int8_t)((int)q_code(y, a.out_delta, a.out_zp) - 128);
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        {
-            const int row = lane >> 1, chn = lane & 1;
-            const int off = rowoff[i * 32 + row];
-            if (off >= 0)
-                *(v4i*)(a.out + (size_t)off * a.out_ctotal + a.out_c0 + n0 + wave * 32 + chn * 16) = *(const v4i*)(stagebuf + row * 32 + chn * 16);
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-template <int MT, int NW, int S, bool MULTI>
-static int launch_big(ConvArgs& a, hipStream_t st) {
-    // chunk table: (group, tap, 64-channel chunk) -> A-side byte offset; weights advance linearly
-    int n = 0;
-    for (int g = 0; g < a.ngroups; ++g) {
-        for (int tap = 0; tap < 9; ++tap)
-            for (int cc = 0; cc < a.gc[g] / 64; ++cc) {
-                if (n >= 96) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8: more than 96 K-chunks");
-                a.aoff[n++] = ((tap / 3) * a.wp + (tap % 3)) * a.cin_total + a.gc0[g] + cc * 64;
-            }
-        a.gend[g] = n;
-    }
-    for (int g = a.ngroups; g < QV2X_MAX_GROUPS; ++g) a.gend[g] = -1;
-    a.nsteps = n;
-    dim3 grid((a.M + MT * 32 - 1) / (MT * 32), a.cout / (NW * 32));
-    conv3x3_i8_big_kernel<MT, NW, S, MULTI><<<grid, NW * 64, 0, st>>>(a);
-    return hip_check(hipGetLastError(), "qv2x_conv3x3_i8 launch");
-}
-
 template <int BM, int BN, int WM, int WN, int BK, bool MULTI, int MINW>
 static int launch(const ConvArgs& a, hipStream_t st) {
     dim3 grid((a.M + BM - 1) / BM, a.cout / BN);
@@ -746,12 +520,6 @@ extern "C" int qv2x_conv3x3_i8(const qv2x_conv_desc* d, const int8_t* in, const 
     const bool large = force ? (force[0] == 'l') : (a.cout % 128 == 0 && a.M >= 16384);
     static const char* dmaenv = getenv("QV2X_CONV_DMA");     // dev knob: "0" selects the register-staged kernels
     const bool use_dma = !(dmaenv && dmaenv[0] == '0');
-    static const char* bigenv = getenv("QV2X_CONV_BIG");     // dev knob: "0" disables the 8-wave wide-layer kernel
-    if (!(bigenv && bigenv[0] == '0') && a.cout == 256 && a.M >= 16384) {
-        if (bigenv && bigenv[0] == '4') return multi ? launch_big<5, 4, 4, true>(a, st) : launch_big<5, 4, 4, false>(a, st);
-        if (bigenv && bigenv[0] == 'm') return multi ? launch_big<4, 8, 5, true>(a, st) : launch_big<4, 8, 5, false>(a, st);
-        return multi ? launch_big<5, 8, 5, true>(a, st) : launch_big<5, 8, 5, false>(a, st);
-    }
     if (use_dma) {
         if (multi) {
             if (a.cout % 128) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8: multi-group input needs cout %% 128 == 0");

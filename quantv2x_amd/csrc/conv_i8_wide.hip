@@ -1,16 +1,16 @@
 // Wide 3x3 QuantModule convolution (cout % 256 == 0, stride 1): the two shrinker layers of the V2X-Real model
-// (opencood/quant/quant_block.py:552-572 over DoubleConv, downsample_conv.py:17-31), i.e. 52 of the 75 GMAC of the
-// integer backbone.  Same arithmetic as conv_i8.hip (exact i32 sums on the i8 MFMA, per-group fp32 fold), different
-// data movement -- what bounds this layer on gfx950 is the L2 -> LDS fetch rate, not the MFMA pipe:
-//   * one workgroup = a 5 x 32 patch of output pixels (160 GEMM rows) x 256 output channels, 4 waves (one per
-//     SIMD), each wave a 160 x 64 register tile = 5 x 2 accumulators of v_mfma_i32_32x32x32_i8: 14 LDS fragment
-//     reads per 20 MFMAs (the 8-wave 160 x 32 layout needs 12 per 10 and is LDS-read bound);
+// (opencood/quant/quant_block.py:552-572 over DoubleConv, downsample_conv.py:17-31), i.e. 52 of the 77 GMAC of the
+// integer convolution stack.  Same arithmetic as conv_i8.hip (exact i32 sums on the i8 MFMA, per-group fp32 fold),
+// different data movement -- what bounds this layer on gfx950 is the L2 -> LDS fetch rate and the LDS fragment reads,
+// not the MFMA pipe (tools/probes/mfma_i8_wave_tile_probe.hip):
+//   * one workgroup = a 5 x 32 patch of output pixels (160 GEMM rows) x 256 output channels; 8 waves (two per SIMD,
+//     which hides the per-step barrier better than one wave per SIMD with software-pipelined fragment reads did),
+//     each wave a 160 x 32 register tile = 5 accumulators of v_mfma_i32_32x32x32_i8;
 //   * the input is staged as a 7 x 34 pixel HALO tile per 64-channel chunk and the nine taps read it at shifted
 //     pixel offsets: 15.2 KB fetched per nine K-steps instead of 9 x 10 KB;
 //   * the weights are pre-tiled (qv2x_conv3x3_i8_pack_wide) so that the [256][64] tile of one K-step is 16 KB
 //     contiguous: every LDS-DMA instruction reads 1 KiB of whole cache lines (64-byte row gathers run the same
-//     stream at half the rate);
-//   * fragments of K-step s+1 are read from LDS while step s is multiplied (two register sets).
+//     stream at half the rate, measured).
 #include "common.h"
 
 #include <cstdlib>
@@ -25,10 +25,6 @@ constexpr int HBUF = HBLK * 1024;
 constexpr int BM = TH * TW, BN = 256, BSTAGE = BN * 64;
 constexpr int MT = 5;
 constexpr int MAX_CHUNKS = 24;
-#ifndef QV2X_ABL
-#define QV2X_ABL 0
-#endif
-constexpr int ABL = QV2X_ABL;
 
 struct WideArgs {
     const int8_t* in; const int8_t* wt; const float* scale; const int* corr; const int* aw; const float* bias; int8_t* out;
@@ -42,24 +38,10 @@ struct WideArgs {
 
 template <int V> struct IC { static constexpr int value = V; };
 
-// The multi-group kernel carries 160 i32 MFMA accumulators AND 160 fp32 fold accumulators per lane.  Both fit the
-// 512-register file of a lone wave only if 96 of the fp32 values rest in AGPRs next to the MFMA accumulators; the
-// register allocator does not split the array that way by itself, so those are pinned with an "a" constraint.
-constexpr int PIN_MT = 0;
-__device__ __forceinline__ void fput(float& slot, float v, bool pinned) {
-    if (pinned) asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(slot) : "v"(v));
-    else slot = v;
-}
-__device__ __forceinline__ float fget(const float& slot, bool pinned) {
-    if (!pinned) return slot;
-    float v;
-    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(slot));
-    return v;
-}
-
-// NW waves, each a 160 x (NT*32) register tile, NW * NT * 32 == 256:  <4, 2> one wave per SIMD, 0.7 fragment reads per
-// MFMA, two fragment register sets (single-group layers);  <8, 1> two waves per SIMD, 1.2 reads per MFMA, one set --
-// the multi-group layer also carries an fp32 fold accumulator per output, 2 x 160 registers do not fit next to two sets.
+// NW waves, each a 160 x (NT*32) register tile, NW * NT * 32 == 256.  <8, 1> (two waves per SIMD, 1.2 fragment reads
+// per MFMA, one fragment set) is what ships: 31.5 us on the 256->256 shrinker layer against 37.5 us for <4, 2> (one wave
+// per SIMD, 0.7 reads per MFMA, fragments of step s+1 read while step s multiplies), and the multi-group layer's extra
+// fp32 fold accumulator per output (2 x 160 registers at NT = 2) only fits the register file at NT = 1.
 template <int S, bool MULTI, int NW, int NT>
 __global__ __launch_bounds__(NW * 64, 1) void conv3x3_i8_wide_kernel(const WideArgs a) {
     static_assert(NW * NT * 32 == BN, "wave layout");
@@ -111,7 +93,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_i8_wide_kernel(const WideA
             if (MULTI) {
                 const float b = a.bias[n0 + (wave * NT + j) * 32 + (lane & 31)];
 #pragma unroll
-                for (int r = 0; r < NF; ++r) fput(facc[i][j][r], b, i < PIN_MT);
+                for (int r = 0; r < NF; ++r) facc[i][j][r] = b;
             }
         }
     }
@@ -159,7 +141,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_i8_wide_kernel(const WideA
         const int8_t* bs = bst + (step % S) * BSTAGE;
         const int d = (tap / 3) * HWD + (tap % 3);
         int hpl = hp0;
-        if (MULTI) asm volatile("" : "+v"(hpl));                        // keep the 45 tap addresses from being hoisted (and spilled)
+        if (NT == 1) asm volatile("" : "+v"(hpl));                      // keep the 45 tap addresses from being hoisted (and spilled)
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int hp = hpl + HWD * i + d;
@@ -206,7 +188,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_i8_wide_kernel(const WideA
 #pragma unroll
                     for (int r = 0; r < NF; ++r) {
                         const int T = acc[i][j][r] + __mul24(awv, xbuf[i * 32 + mfma32_row(r, lane)]) + cr;
-                        fput(facc[i][j][r], fget(facc[i][j][r], i < PIN_MT) + (float)T * sc, i < PIN_MT);
+                        facc[i][j][r] = facc[i][j][r] + (float)T * sc;
                         acc[i][j][r] = 0;
                     }
             }
@@ -230,12 +212,12 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_i8_wide_kernel(const WideA
         const int step = chunk * 9 + TAP;
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(INFLIGHT) : "memory");
         __builtin_amdgcn_s_barrier();
-        if (ABL != 3) issue_b();
-        if (TAP == 0 && ABL != 2) issue_halo(chunk + 1);
+        issue_b();
+        if (TAP == 0) issue_halo(chunk + 1);
         if (TAP == 0 || NSET == 1) read_frags(IC<0>{}, chunk, TAP, step);
         if (TAP < 8 && NSET == 2) read_frags(IC<(SET ^ 1) % NSET>{}, chunk, TAP + 1, step + 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (ABL != 1 && ((chunk + TAP) & (NW - 1)) == wave_u) {        // window sums: the waves take turns, one step each
+        if (((chunk + TAP) & (NW - 1)) == wave_u) {                   // window sums: the waves take turns, one step each
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -249,10 +231,9 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_i8_wide_kernel(const WideA
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    if (ABL != 4) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[SET][ks][i], fb[SET][ks][j], acc[i][j], 0, 0, 0);
-                    else acc[i][j][0] += fa[SET][ks][i][0] + fb[SET][ks][j][1];
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[SET][ks][i], fb[SET][ks][j], acc[i][j], 0, 0, 0);
     };
-    for (int chunk = 0; chunk < (ABL == 6 ? 1 : a.nchunks); ++chunk) {
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
         one_step(IC<0>{}, chunk); one_step(IC<1>{}, chunk); one_step(IC<2>{}, chunk);
         one_step(IC<3>{}, chunk); one_step(IC<4>{}, chunk); one_step(IC<5>{}, chunk);
         one_step(IC<6>{}, chunk); one_step(IC<7>{}, chunk); one_step(IC<8>{}, chunk);
@@ -281,13 +262,12 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_i8_wide_kernel(const WideA
                 const int row = mfma32_row(r, lane);
                 float y;
                 if (MULTI) {
-                    y = fget(facc[i][j][r % NF], i < PIN_MT);
+                    y = facc[i][j][r % NF];
                 } else {
                     const int T = acc[i][j][r] + __mul24(awv[j], xbuf[i * 32 + row]) + cr[j];
                     y = bsv[j] + (float)T * sc[j];
                 }
                 if (a.relu) y = fmaxf(y, 0.0f);
-                if (ABL == 5) stagebuf[row * (NT * 32) + j * 32 + (lane & 31)] = (int8_t)(int)y; else
                 stagebuf[row * (NT * 32) + j * 32 + (lane & 31)] = (int8_t)((int)q_code(y, a.out_delta, a.out_zp) - 128);
             }
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -392,7 +372,9 @@ extern "C" int qv2x_conv3x3_i8_wide(const qv2x_conv_desc* d, const int8_t* in, c
     a.in = in; a.wt = w_wide; a.scale = scale; a.corr = corr; a.aw = aw; a.bias = bias; a.out = out;
     dim3 grid(a.n * a.tiles_x * a.tiles_y, a.cout / BN);
     hipStream_t st = (hipStream_t)stream;
-    if (d->ngroups > 1) conv3x3_i8_wide_kernel<6, true, 8, 1><<<grid, 512, 0, st>>>(a);
-    else conv3x3_i8_wide_kernel<6, false, 4, 2><<<grid, 256, 0, st>>>(a);
+    static const char* lenv = getenv("QV2X_WIDE_LAYOUT");              // dev knob: "4" = one wave per SIMD, 160 x 64 wave tiles
+    if (d->ngroups > 1) conv3x3_i8_wide_kernel<5, true, 8, 1><<<grid, 512, 0, st>>>(a);
+    else if (lenv && lenv[0] == '4') conv3x3_i8_wide_kernel<5, false, 4, 2><<<grid, 256, 0, st>>>(a);
+    else conv3x3_i8_wide_kernel<5, false, 8, 1><<<grid, 512, 0, st>>>(a);
     return hip_check(hipGetLastError(), "qv2x_conv3x3_i8_wide launch");
 }
