@@ -343,6 +343,18 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_i8_dma_kernel(const ConvArg
     for (int p = 0; p < S - 1; ++p)
         if (p < total) issue();
 
+    // epilogue constants, requested now so their latency hides behind the K loop (they only make the first wait of the
+    // ring slightly stricter: the vmcnt protocol counts "all but the newest (S-2)*LPS", and these are older than any
+    // chunk issued in the loop)
+    int e_aw[NT], e_cr[NT];
+    float e_sc[NT], e_bs[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int co = n0 + wn * TN + j * 32 + (lane & 31);
+        e_aw[j] = 0; e_cr[j] = 0; e_sc[j] = 0.f; e_bs[j] = 0.f;
+        if (!MULTI) { e_aw[j] = a.aw[co]; e_cr[j] = a.corr[co]; e_sc[j] = a.scale[co]; e_bs[j] = a.bias[co]; }
+    }
+
     // per-lane fragment read offsets inside a stage (loop invariant; the stage base is an immediate after unrolling by S)
     constexpr int KS = BK / 32;
     int offA[MT][KS], offB[NT][KS];
@@ -430,10 +442,8 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_i8_dma_kernel(const ConvArg
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const int co = n0 + wn * TN + j * 32 + (lane & 31);
-            int awv = 0, cr = 0;
-            float sc = 0.f, bs = 0.f;
-            if (!MULTI) { awv = a.aw[co]; cr = a.corr[co]; sc = a.scale[co]; bs = a.bias[co]; }
+            const int awv = e_aw[j], cr = e_cr[j];
+            const float sc = e_sc[j], bs = e_bs[j];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mfma32_row(r, lane);
@@ -441,7 +451,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_i8_dma_kernel(const ConvArg
                 if (MULTI) {
                     y = facc[i][j][r % NF];
                 } else {
-                    const int T = acc[i][j][r] + awv * xbuf[wave * TM + i * 32 + row] + cr;
+                    const int T = acc[i][j][r] + __mul24(awv, xbuf[wave * TM + i * 32 + row]) + cr;
                     y = bs + (float)T * sc;
                 }
                 if (a.relu) y = fmaxf(y, 0.0f);

@@ -83,6 +83,8 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_i8_wide_kernel(const WideA
     v16i acc[MT][NT];
     float facc[MT][NT][NF];
     int xs[MT];
+    int c_aw[NT], c_cr[NT];                                            // per-channel constants of the fold / epilogue
+    float c_sc[NT], c_bs[NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         xs[i] = 0;
@@ -180,9 +182,12 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_i8_wide_kernel(const WideA
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int co = n0 + (wave * NT + j) * 32 + (lane & 31);
-                const int awv = a.aw[co];
-                const int cr = a.corr[g * a.cout + co];
-                const float sc = a.scale[g * a.cout + co];
+                const int awv = c_aw[j], cr = c_cr[j];
+                const float sc = c_sc[j];
+                if (g + 1 < a.ngroups) {                               // the next group's constants: in flight during its K steps
+                    c_cr[j] = a.corr[(g + 1) * a.cout + co];
+                    c_sc[j] = a.scale[(g + 1) * a.cout + co];
+                }
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -201,6 +206,16 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_i8_wide_kernel(const WideA
     issue_halo(0);
 #pragma unroll
     for (int p = 0; p < S - 1; ++p) issue_b();
+
+    // per-channel constants of the epilogue (single group) or of the first group's fold, requested now so that their
+    // latency hides behind the K loop; they are older than every DMA issued in the loop, so the vmcnt protocol ("all but
+    // the newest n") is only stricter for the first wait
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int co = n0 + (wave * NT + j) * 32 + (lane & 31);
+        c_aw[j] = a.aw[co]; c_cr[j] = a.corr[co]; c_sc[j] = a.scale[co];
+        c_bs[j] = MULTI ? 0.f : a.bias[co];
+    }
 
     // One K-step = (chunk, tap).  At its barrier: weight tile step+1 and (from tap S-1 on) the next halo have landed for
     // every wave, and every wave is done reading tile step-1 -- the stage the new DMA overwrites.  Taps 0..7 read the
@@ -245,14 +260,6 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_i8_wide_kernel(const WideA
 
     // ---- epilogue: requantize, transpose through LDS, 16-byte stores -----------------------------------------------
     int8_t* stagebuf = lds + wave * (NT * 1024);                       // per wave [32 rows][NT * 32 channels]
-    int awv[NT], cr[NT];
-    float sc[NT], bsv[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int co = n0 + (wave * NT + j) * 32 + (lane & 31);
-        awv[j] = 0; cr[j] = 0; sc[j] = 0.f; bsv[j] = 0.f;
-        if (!MULTI) { awv[j] = a.aw[co]; cr[j] = a.corr[co]; sc[j] = a.scale[co]; bsv[j] = a.bias[co]; }
-    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -264,8 +271,8 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_i8_wide_kernel(const WideA
                 if (MULTI) {
                     y = facc[i][j][r % NF];
                 } else {
-                    const int T = acc[i][j][r] + __mul24(awv[j], xbuf[i * 32 + row]) + cr[j];
-                    y = bsv[j] + (float)T * sc[j];
+                    const int T = acc[i][j][r] + __mul24(c_aw[j], xbuf[i * 32 + row]) + c_cr[j];
+                    y = c_bs[j] + (float)T * c_sc[j];
                 }
                 if (a.relu) y = fmaxf(y, 0.0f);
                 stagebuf[row * (NT * 32) + j * 32 + (lane & 31)] = (int8_t)((int)q_code(y, a.out_delta, a.out_zp) - 128);
