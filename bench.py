@@ -252,6 +252,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()     # RCCL prints its version banner around here: keep the JSON line last
     if line is not None:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)   # RCCL's version banner sits in the C stdio buffer: push it out before the JSON line
         sys.stdout.flush()
         print(json.dumps(line), flush=True)
 

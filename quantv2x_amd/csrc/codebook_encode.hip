@@ -294,9 +294,10 @@ extern "C" int qv2x_codebook_c2_f32(const float* codebook, int kc, float* c2, vo
 extern "C" int qv2x_debug_encode_occupancy(void) {
     using namespace qv2x;
     const size_t smem = (size_t)(2 * ER * LDF + ER + 4 * ER + 4 * ER + ER) * sizeof(float);
-    hipFuncSetAttribute((const void*)codebook_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     int n = -1;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, codebook_encode_kernel, 512, smem);
+    if (hipFuncSetAttribute((const void*)codebook_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, codebook_encode_kernel, 512, smem) != hipSuccess)
+        return -1;
     return n * 1000 + (int)(smem / 1024);
 }
 
