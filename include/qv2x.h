@@ -176,6 +176,12 @@ int qv2x_dequant_i8_f32(const int8_t* in, int n, int h, int w, int c, int zp, fl
 int qv2x_heads_f32(const float* x, int R, int hw, int cout, int cout_pad, const float* w, const float* bias,
                    const float* da, const float* za, float* out, void* stream);
 
+/* *_preds_single (heter_model_baseline.py:224-230) in one launch: qv2x_decode_lut_f32 followed by qv2x_heads_f32 on
+ * every agent's own decoded feature.  codes u8 [levels][R], rows agent-major (R = agents * hw); out f32 [agents][cout][hw]. */
+int qv2x_decode_heads_f32(const uint8_t* codes, int R, int hw, int levels, int kc, const float* lut, const float* lut_bias,
+                          int cout, int cout_pad, const float* w, const float* bias, const float* da, const float* za,
+                          float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

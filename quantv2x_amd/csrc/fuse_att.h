@@ -1,0 +1,105 @@
+// Device side of a7 + a8 + a9 + a10 shared by the standalone kernel (fuse_att.hip) and the fused
+// fuse -> heads kernel (heads_f32.hip): decode (three LUT gathers) + bilinear warp into the ego frame + per-cell attention.
+#pragma once
+#include "common.h"
+
+namespace qv2x {
+
+constexpr int MAXA = 8;
+
+struct FuseArgs {
+    const uint8_t* codes; const float4* lut; const float4* lut_bias; const float4* feats; float4* fused;
+    const double* pairwise;          // device, [L][L][4][4]; row `ego` is used: T[ego][j] = T_j^-1 T_ego
+    int agents, h, w, levels, kc, hw, L, ego;
+    long long code_agent_stride, code_level_stride;
+    double hm, wm, ratio;            // metres covered by the map (H, W) and discrete_ratio of normalize_pairwise_tfm
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__device__ __forceinline__ float4 tap_value(const FuseArgs& a, int agent, int cell, int lane) {
+    if (a.feats) return a.feats[((size_t)agent * a.hw + cell) * 64 + lane];
+    float4 v = a.lut_bias[lane];
+    for (int l = 0; l < a.levels; ++l) {
+        const int code = a.codes[(size_t)agent * a.code_agent_stride + (size_t)l * a.code_level_stride + cell];
+        const float4 t = a.lut[((size_t)l * a.kc + code) * 64 + lane];
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    return v;
+}
+
+// The fused 256-channel feature of one ego BEV cell; the calling wave holds 4 channels per lane.  NA = compile-time bound on
+// the agent count (registers: one float4 per agent).  A bilinear tap of weight exactly 0 is skipped: v * 0 adds +-0 to a
+// sum that starts at +0, so the result is the same bit pattern -- and an agent whose grid lands on cell centres (the ego
+// itself, T = I) costs one decoded tap instead of four.
+template <int NA>
+__device__ __forceinline__ float4 fuse_cell_n(const FuseArgs& a, int cell, int lane) {
+    const int cy = cell / a.w, cx = cell - cy * a.w;
+    const double xn = (2.0 * cx + 1.0) / a.w - 1.0, yn = (2.0 * cy + 1.0) / a.h - 1.0;
+
+    float4 f[NA];
+    float score[NA];
+#pragma unroll
+    for (int ag = 0; ag < NA; ++ag) {
+        f[ag] = make_float4(0.f, 0.f, 0.f, 0.f);
+        score[ag] = 0.f;
+        if (ag < a.agents) {
+            // normalize_pairwise_tfm (transformation_utils.py:68-92) on T[ego][ag]: rows {0,1} x cols {0,1,3}
+            const double* T = a.pairwise + ((size_t)a.ego * a.L + ag) * 16;
+            const double t00 = T[0], t01 = T[1] * a.hm / a.wm, t02 = T[3] / (a.ratio * a.wm) * 2.0;
+            const double t10 = T[4] * a.wm / a.hm, t11 = T[5], t12 = T[7] / (a.ratio * a.hm) * 2.0;
+            const float gx = (float)(t00 * xn + t01 * yn + t02);
+            const float gy = (float)(t10 * xn + t11 * yn + t12);
+            const float ix = ((gx + 1.0f) * (float)a.w - 1.0f) / 2.0f;
+            const float iy = ((gy + 1.0f) * (float)a.h - 1.0f) / 2.0f;
+            const float x0 = floorf(ix), y0 = floorf(iy);
+            const float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+            const float wt[4] = {(x1 - ix) * (y1 - iy), (ix - x0) * (y1 - iy), (x1 - ix) * (iy - y0), (ix - x0) * (iy - y0)};
+            const float tx[4] = {x0, x1, x0, x1}, ty[4] = {y0, y0, y1, y1};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (wt[t] != 0.0f && tx[t] >= 0.0f && tx[t] < (float)a.w && ty[t] >= 0.0f && ty[t] < (float)a.h) {
+                    const float4 v = tap_value(a, ag, (int)ty[t] * a.w + (int)tx[t], lane);
+                    f[ag].x += v.x * wt[t]; f[ag].y += v.y * wt[t]; f[ag].z += v.z * wt[t]; f[ag].w += v.w * wt[t];
+                }
+            }
+        }
+    }
+    float4 fq = f[0];                 // the ego's own feature is the query
+#pragma unroll
+    for (int ag = 1; ag < NA; ++ag)
+        if (ag == a.ego) fq = f[ag];
+    float smax = -INFINITY;
+#pragma unroll
+    for (int ag = 0; ag < NA; ++ag)
+        if (ag < a.agents) {
+            const float part = fq.x * f[ag].x + fq.y * f[ag].y + fq.z * f[ag].z + fq.w * f[ag].w;
+            score[ag] = wave_sum(part) / 16.0f;        // sqrt(256)
+            smax = fmaxf(smax, score[ag]);
+        }
+    float den = 0.f;
+#pragma unroll
+    for (int ag = 0; ag < NA; ++ag)
+        if (ag < a.agents) { score[ag] = expf(score[ag] - smax); den += score[ag]; }
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ag = 0; ag < NA; ++ag)
+        if (ag < a.agents) {
+            const float p = score[ag] / den;
+            o.x += p * f[ag].x; o.y += p * f[ag].y; o.z += p * f[ag].z; o.w += p * f[ag].w;
+        }
+    return o;
+}
+
+// host: smallest compiled bound that covers `agents`
+inline int fuse_bound(int agents) { return agents <= 1 ? 1 : (agents <= 2 ? 2 : (agents <= 4 ? 4 : MAXA)); }
+
+// shared argument checks + FuseArgs from the public descriptor (host)
+int fuse_args_from_desc(const qv2x_fuse_desc* d, const uint8_t* codes, const float* lut, const float* lut_bias, const float* feats,
+                        const double* pairwise, const char* who, FuseArgs& a);
+
+}  // namespace qv2x

@@ -6,97 +6,34 @@
 //   affine_grid(theta, align_corners=False): x_j = (2j + 1)/W - 1, grid = theta . [x, y, 1]  (float64 theta ->
 //   float64 grid, cast to fp32 as the reference's `.to(src)` does), grid_sample bilinear / zeros.
 // Attention (fusion_in_one.py:41-45, 145-147): score_j = <f_0, f_j> / sqrt(C); softmax; out = sum_j p_j f_j.
-#include "common.h"
+#include "fuse_att.h"
 
 namespace qv2x {
 
-constexpr int MAXA = 8;
-
-struct FuseArgs {
-    const uint8_t* codes; const float4* lut; const float4* lut_bias; const float4* feats; float4* fused;
-    const double* pairwise;          // device, [L][L][4][4]; row `ego` is used: T[ego][j] = T_j^-1 T_ego
-    int agents, h, w, levels, kc, hw, L, ego;
-    long long code_agent_stride, code_level_stride;
-    double hm, wm, ratio;            // metres covered by the map (H, W) and discrete_ratio of normalize_pairwise_tfm
-};
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
-
-__device__ __forceinline__ float4 tap_value(const FuseArgs& a, int agent, int cell, int lane) {
-    if (a.feats) return a.feats[((size_t)agent * a.hw + cell) * 64 + lane];
-    float4 v = a.lut_bias[lane];
-    for (int l = 0; l < a.levels; ++l) {
-        const int code = a.codes[(size_t)agent * a.code_agent_stride + (size_t)l * a.code_level_stride + cell];
-        const float4 t = a.lut[((size_t)l * a.kc + code) * 64 + lane];
-        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-    }
-    return v;
-}
-
+template <int NA>
 __global__ __launch_bounds__(256) void fuse_att_kernel(const FuseArgs a) {
     const int lane = threadIdx.x & 63;
     int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
     cell = __builtin_amdgcn_readfirstlane(cell);
     if (cell >= a.hw) return;
-    const int cy = cell / a.w, cx = cell - cy * a.w;
-    const double xn = (2.0 * cx + 1.0) / a.w - 1.0, yn = (2.0 * cy + 1.0) / a.h - 1.0;
+    a.fused[(size_t)cell * 64 + lane] = fuse_cell_n<NA>(a, cell, lane);
+}
 
-    float4 f[MAXA];
-    float score[MAXA];
-#pragma unroll
-    for (int ag = 0; ag < MAXA; ++ag) {
-        f[ag] = make_float4(0.f, 0.f, 0.f, 0.f);
-        score[ag] = 0.f;
-        if (ag < a.agents) {
-            // normalize_pairwise_tfm (transformation_utils.py:68-92) on T[ego][ag]: rows {0,1} x cols {0,1,3}
-            const double* T = a.pairwise + ((size_t)a.ego * a.L + ag) * 16;
-            const double t00 = T[0], t01 = T[1] * a.hm / a.wm, t02 = T[3] / (a.ratio * a.wm) * 2.0;
-            const double t10 = T[4] * a.wm / a.hm, t11 = T[5], t12 = T[7] / (a.ratio * a.hm) * 2.0;
-            const float gx = (float)(t00 * xn + t01 * yn + t02);
-            const float gy = (float)(t10 * xn + t11 * yn + t12);
-            const float ix = ((gx + 1.0f) * (float)a.w - 1.0f) / 2.0f;
-            const float iy = ((gy + 1.0f) * (float)a.h - 1.0f) / 2.0f;
-            const float x0 = floorf(ix), y0 = floorf(iy);
-            const float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
-            const float wt[4] = {(x1 - ix) * (y1 - iy), (ix - x0) * (y1 - iy), (x1 - ix) * (iy - y0), (ix - x0) * (iy - y0)};
-            const float tx[4] = {x0, x1, x0, x1}, ty[4] = {y0, y0, y1, y1};
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (tx[t] >= 0.0f && tx[t] < (float)a.w && ty[t] >= 0.0f && ty[t] < (float)a.h) {
-                    const float4 v = tap_value(a, ag, (int)ty[t] * a.w + (int)tx[t], lane);
-                    f[ag].x += v.x * wt[t]; f[ag].y += v.y * wt[t]; f[ag].z += v.z * wt[t]; f[ag].w += v.w * wt[t];
-                }
-            }
-        }
-    }
-    float4 fq = f[0];                 // the ego's own feature is the query
-#pragma unroll
-    for (int ag = 1; ag < MAXA; ++ag)
-        if (ag == a.ego) fq = f[ag];
-    float smax = -INFINITY;
-#pragma unroll
-    for (int ag = 0; ag < MAXA; ++ag)
-        if (ag < a.agents) {
-            const float part = fq.x * f[ag].x + fq.y * f[ag].y + fq.z * f[ag].z + fq.w * f[ag].w;
-            score[ag] = wave_sum(part) / 16.0f;        // sqrt(256)
-            smax = fmaxf(smax, score[ag]);
-        }
-    float den = 0.f;
-#pragma unroll
-    for (int ag = 0; ag < MAXA; ++ag)
-        if (ag < a.agents) { score[ag] = expf(score[ag] - smax); den += score[ag]; }
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int ag = 0; ag < MAXA; ++ag)
-        if (ag < a.agents) {
-            const float p = score[ag] / den;
-            o.x += p * f[ag].x; o.y += p * f[ag].y; o.z += p * f[ag].z; o.w += p * f[ag].w;
-        }
-    a.fused[(size_t)cell * 64 + lane] = o;
+int fuse_args_from_desc(const qv2x_fuse_desc* d, const uint8_t* codes, const float* lut, const float* lut_bias, const float* feats,
+                        const double* pairwise, const char* who, FuseArgs& a) {
+    if (!d || !pairwise) return fail(QV2X_EINVAL, "%s: null pointer", who);
+    if (!feats && (!codes || !lut || !lut_bias)) return fail(QV2X_EINVAL, "%s: need codes + lut + lut_bias, or feats", who);
+    if (d->agents < 1 || d->agents > MAXA) return fail(QV2X_EINVAL, "%s: 1..%d agents, got %d", who, MAXA, d->agents);
+    if (d->max_cav < d->agents || d->ego < 0 || d->ego >= d->agents) return fail(QV2X_EINVAL, "%s: max_cav / ego out of range", who);
+    if (d->h <= 0 || d->w <= 0 || (!feats && (d->levels < 1 || d->levels > 4 || d->kc < 1 || d->kc > 256)))
+        return fail(QV2X_EINVAL, "%s: bad sizes", who);
+    if (!(d->h_metres > 0) || !(d->w_metres > 0) || !(d->discrete_ratio > 0)) return fail(QV2X_EINVAL, "%s: map extent must be positive", who);
+    a.codes = codes; a.lut = (const float4*)lut; a.lut_bias = (const float4*)lut_bias; a.feats = (const float4*)feats;
+    a.fused = nullptr; a.pairwise = pairwise;
+    a.agents = d->agents; a.h = d->h; a.w = d->w; a.levels = d->levels; a.kc = d->kc; a.hw = d->h * d->w; a.L = d->max_cav; a.ego = d->ego;
+    a.code_agent_stride = d->code_agent_stride; a.code_level_stride = d->code_level_stride;
+    a.hm = d->h_metres; a.wm = d->w_metres; a.ratio = d->discrete_ratio;
+    return QV2X_OK;
 }
 
 }  // namespace qv2x
@@ -104,19 +41,17 @@ __global__ __launch_bounds__(256) void fuse_att_kernel(const FuseArgs a) {
 extern "C" int qv2x_fuse_att_f32(const qv2x_fuse_desc* d, const uint8_t* codes, const float* lut, const float* lut_bias,
                                  const float* feats, const double* pairwise, float* fused, void* stream) {
     using namespace qv2x;
-    if (!d || !pairwise || !fused) return fail(QV2X_EINVAL, "qv2x_fuse_att_f32: null pointer");
-    if (!feats && (!codes || !lut || !lut_bias)) return fail(QV2X_EINVAL, "qv2x_fuse_att_f32: need codes + lut + lut_bias, or feats");
-    if (d->agents < 1 || d->agents > MAXA) return fail(QV2X_EINVAL, "qv2x_fuse_att_f32: 1..%d agents, got %d", MAXA, d->agents);
-    if (d->max_cav < d->agents || d->ego < 0 || d->ego >= d->agents) return fail(QV2X_EINVAL, "qv2x_fuse_att_f32: max_cav / ego out of range");
-    if (d->h <= 0 || d->w <= 0 || (!feats && (d->levels < 1 || d->levels > 4 || d->kc < 1 || d->kc > 256)))
-        return fail(QV2X_EINVAL, "qv2x_fuse_att_f32: bad sizes");
-    if (!(d->h_metres > 0) || !(d->w_metres > 0) || !(d->discrete_ratio > 0)) return fail(QV2X_EINVAL, "qv2x_fuse_att_f32: map extent must be positive");
+    if (!fused) return fail(QV2X_EINVAL, "qv2x_fuse_att_f32: null pointer");
     FuseArgs a;
-    a.codes = codes; a.lut = (const float4*)lut; a.lut_bias = (const float4*)lut_bias; a.feats = (const float4*)feats;
-    a.fused = (float4*)fused; a.pairwise = pairwise;
-    a.agents = d->agents; a.h = d->h; a.w = d->w; a.levels = d->levels; a.kc = d->kc; a.hw = d->h * d->w; a.L = d->max_cav; a.ego = d->ego;
-    a.code_agent_stride = d->code_agent_stride; a.code_level_stride = d->code_level_stride;
-    a.hm = d->h_metres; a.wm = d->w_metres; a.ratio = d->discrete_ratio;
-    fuse_att_kernel<<<(a.hw + 3) / 4, 256, 0, (hipStream_t)stream>>>(a);
+    if (int rc = fuse_args_from_desc(d, codes, lut, lut_bias, feats, pairwise, "qv2x_fuse_att_f32", a)) return rc;
+    a.fused = (float4*)fused;
+    const dim3 grid((a.hw + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    switch (fuse_bound(a.agents)) {
+        case 1: fuse_att_kernel<1><<<grid, 256, 0, st>>>(a); break;
+        case 2: fuse_att_kernel<2><<<grid, 256, 0, st>>>(a); break;
+        case 4: fuse_att_kernel<4><<<grid, 256, 0, st>>>(a); break;
+        default: fuse_att_kernel<MAXA><<<grid, 256, 0, st>>>(a); break;
+    }
     return hip_check(hipGetLastError(), "qv2x_fuse_att_f32 launch");
 }

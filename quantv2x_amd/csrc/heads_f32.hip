@@ -1,90 +1,136 @@
 // a11: 1x1 detection heads (cls | reg | dir stacked on the channel axis) on fp32 rows, fake-quant weights,
 // per-channel output quantizer.  f32 MFMA fma chains (acc0 = bias), results transposed through LDS so that the
 // NCHW store is 128 B contiguous per channel.  Also: decode-only LUT kernel for the *_single heads.
-#include "common.h"
+#include "fuse_att.h"
 
 namespace qv2x {
 
-// wave = (32-row tile, 32-column tile): with <= 96 stacked output channels that is up to three waves per row tile, which
-// keeps all 1024 SIMDs of the chip busy at 35 200 rows (a 96-column wave tile left the second round almost empty).
-__global__ __launch_bounds__(256) void heads_f32_kernel(const float* __restrict__ x, int R, int hw, int cout, int cout_pad,
-                                                        const float* __restrict__ w, const float* __restrict__ bias,
-                                                        const float* __restrict__ da, const float* __restrict__ za,
-                                                        float* __restrict__ out) {
-    __shared__ float tr[4][32][33];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nct = cout_pad >> 5;
-    int tile = blockIdx.x * 4 + wave;
-    tile = __builtin_amdgcn_readfirstlane(tile);
-    const int tm = tile / nct, ct = tile - tm * nct;
-    if (tm * 32 >= R) return;
-    const int par = lane >> 5;
-    int m = tm * 32 + (lane & 31);
-    m = m < R ? m : R - 1;
-    const float4* xr = (const float4*)(x + (size_t)m * 256);
+// One workgroup = one 32-row tile (32 x 256 fp32 = 32 KB in LDS) x all <= 96 stacked output channels.  Where the rows
+// come from is the template parameter:
+//   ROWS_GLOBAL  fp32 rows [R][256] in memory, copied in by LDS-DMA (32 instructions of 1 KiB = one row each;
+//                fragment-shaped global loads of the same rows -- 32 cache lines per instruction -- kept the texture
+//                addresser busy and ran at 44 us per launch);
+//   ROWS_DECODE  each agent's own decoded feature (three LUT gathers) for the *_single heads.
+// k-quad q of row r lives in 16-byte slot q ^ r, so the 16 lanes of a ds_read_b128 service group ({0-3,12-15,20-27},
+// ...) read 16 distinct slots of the 256-byte bank row.  Wave slot ct < cout_pad/32 owns output columns [32 ct, +32);
+// the weights stream from L2 as [64][cout_pad][k0, k2, k1, k3] (one float2 per lane per k-quad, coalesced).  The
+// transpose tiles of the NCHW store reuse the row buffer: 32 KB per workgroup, five workgroups per CU.
+// (Computing the FUSED rows in here as well -- fuse_cell() for 8 cells per wave, then the heads -- was measured slower than
+// the two launches: 62.8 vs 24.0 + 31.7 us at one agent, 198 vs 93 + 32 us at four; the gather-latency-bound fusion wants
+// one short-lived wave per cell and many of them per CU, which a 32-row GEMM tile does not give it.)
+enum { ROWS_GLOBAL = 0, ROWS_DECODE = 2 };
 
+struct HeadArgs {
+    const float* x; int R, hw, cout, cout_pad;
+    const float* w; const float* bias; const float* da; const float* za; float* out;
+};
+
+template <int SRC>
+__global__ __launch_bounds__(256) void rows_heads_kernel(const HeadArgs h, const FuseArgs fa) {
+    __shared__ __attribute__((aligned(16))) float smem[32 * 256];
+    float* rows = smem;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nct = h.cout_pad >> 5;
+    const int tm = blockIdx.x;
+    const int par = lane >> 5;
+
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = wave * 8 + j;
+        const int m = tm * 32 + r;
+        if (SRC == ROWS_GLOBAL) {
+            const int mc = m < h.R ? m : h.R - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(h.x + (size_t)mc * 256 + ((lane ^ r) << 2)),
+                                             (__attribute__((address_space(3))) void*)(rows + r * 256), 16, 0, 0);
+        } else {
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < h.R) {
+                const int agent = m / h.hw;
+                o = tap_value(fa, agent, m - agent * h.hw, lane);
+            }
+            *(float4*)(rows + r * 256 + ((lane ^ r) << 2)) = o;
+        }
+    }
+    // a workgroup's wave i sits on SIMD i: rotate the column tiles over the waves from one row tile to the next, or the
+    // SIMD of the spare wave (cout_pad = 96: three column tiles, four waves) never sees an MFMA
+    const int slot = (wave + tm) & 3;
+    const bool active = slot < nct;
+    const int ct = active ? slot : 0;
+    const float2* wl = (const float2*)h.w + (size_t)(ct * 32 + (lane & 31)) * 2 + par;
+    auto loadB = [&](float2 (&dst)[8], int q0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) dst[t] = wl[(size_t)(q0 + t) * h.cout_pad * 2];
+    };
+    float2 wa[8], wb[8];
     v16f acc;
     {
-        const float b = bias[ct * 32 + (lane & 31)];
+        const float b = h.bias[ct * 32 + (lane & 31)];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = b;
     }
-    // weights: [64][cout_pad][k0, k2, k1, k3] -> one float2 per lane per k-quad; activations: the lane's row, float4 per
-    // k-quad (both half-waves read the same 16 B and keep their parity's pair).  Eight k-quads are requested ahead of
-    // each MFMA block (register double buffer pinned with sched_barrier).
-    const float2* wl = (const float2*)w + (size_t)(ct * 32 + (lane & 31)) * 2 + par;
-    auto loadA = [&](float4 (&dst)[8], int q0) {
+    if (active) loadB(wa, 0);
+    __syncthreads();                                // rows (DMA or ds_write) of every wave have landed
+
+    if (active) {
+        const int r = lane & 31;
+        const float* ar = rows + r * 256;
+        auto block = [&](const float2 (&bv)[8], int q0) __attribute__((always_inline)) {
+            float a0[8], a1[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) dst[t] = xr[q0 + t];
-    };
-    auto loadB = [&](float2 (&dst)[8], int q0) {
+            for (int t = 0; t < 8; ++t) {
+                const float4 av = *(const float4*)(ar + (((q0 + t) ^ r) << 2));
+                a0[t] = par ? av.y : av.x; a1[t] = par ? av.w : av.z;
+            }
 #pragma unroll
-        for (int t = 0; t < 8; ++t) dst[t] = wl[(size_t)(q0 + t) * cout_pad * 2];
-    };
-    auto block = [&](const float4 (&av)[8], const float2 (&bv)[8]) {
-        float a0[8], a1[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) { a0[t] = par ? av[t].y : av[t].x; a1[t] = par ? av[t].w : av[t].z; }
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], bv[t].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], bv[t].y, acc, 0, 0, 0);
+            for (int t = 0; t < 8; ++t) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], bv[t].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], bv[t].y, acc, 0, 0, 0);
+            }
+        };
+        for (int q0 = 0; q0 < 64; q0 += 16) {
+            loadB(wb, q0 + 8);
+            __builtin_amdgcn_sched_barrier(0);
+            block(wa, q0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q0 + 16 < 64) loadB(wa, q0 + 16);
+            __builtin_amdgcn_sched_barrier(0);
+            block(wb, q0 + 8);
+            __builtin_amdgcn_sched_barrier(0);
         }
-    };
-    float4 xa[8], xb[8];
-    float2 wa[8], wb[8];
-    loadA(xa, 0); loadB(wa, 0);
-    for (int q0 = 0; q0 < 64; q0 += 16) {
-        loadA(xb, q0 + 8); loadB(wb, q0 + 8);
-        __builtin_amdgcn_sched_barrier(0);
-        block(xa, wa);
-        __builtin_amdgcn_sched_barrier(0);
-        if (q0 + 16 < 64) { loadA(xa, q0 + 16); loadB(wa, q0 + 16); }
-        __builtin_amdgcn_sched_barrier(0);
-        block(xb, wb);
-        __builtin_amdgcn_sched_barrier(0);
     }
-    {
+    __syncthreads();                                // every wave is done reading the rows: the transpose tiles reuse that LDS
+    if (active) {
+        float (*tr)[33] = (float (*)[33])(smem + ct * 32 * 33);
         const int co = ct * 32 + (lane & 31);
-        const float d = da[co], z = za[co];
+        const float d = h.da[co], z = h.za[co];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float y = acc[r];
+        for (int r2 = 0; r2 < 16; ++r2) {
+            float y = acc[r2];
             if (d > 0.0f) y = (q_code(y, d, z) - z) * d;
-            tr[wave][mfma32_row(r, lane)][lane & 31] = y;
+            tr[mfma32_row(r2, lane)][lane & 31] = y;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): this wave's LDS writes have landed
         __builtin_amdgcn_wave_barrier();
         // lane -> cell lane&31 (128 B contiguous per channel in the NCHW output), channels (lane>>5) + 2*c
         const int mm = tm * 32 + (lane & 31);
-        const int bi = mm / hw, cell = mm - bi * hw;
-        float* ob = out + (size_t)bi * cout * hw + cell;
+        const int bi = mm / h.hw, cell = mm - bi * h.hw;
+        float* ob = h.out + (size_t)bi * h.cout * h.hw + cell;
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             const int ch = ct * 32 + par + 2 * c;
-            if (ch < cout && mm < R) ob[(size_t)ch * hw] = tr[wave][lane & 31][par + 2 * c];
+            if (ch < h.cout && mm < h.R) ob[(size_t)ch * h.hw] = tr[lane & 31][par + 2 * c];
         }
     }
+}
+
+static int head_args(const char* who, int R, int hw, int cout, int cout_pad, const float* w, const float* bias, const float* da,
+                     const float* za, float* out, HeadArgs& h) {
+    if (!w || !bias || !da || !za || !out) return fail(QV2X_EINVAL, "%s: null pointer", who);
+    if (R <= 0 || hw <= 0 || R % hw || cout <= 0 || cout > cout_pad || cout_pad % 32 || cout_pad > 96)
+        return fail(QV2X_EINVAL, "%s: R=%d hw=%d cout=%d cout_pad=%d (cout_pad in {32, 64, 96})", who, R, hw, cout, cout_pad);
+    if ((uintptr_t)w & 15) return fail(QV2X_EALIGN, "%s: w must be 16-byte aligned", who);
+    h.x = nullptr; h.R = R; h.hw = hw; h.cout = cout; h.cout_pad = cout_pad; h.w = w; h.bias = bias; h.da = da; h.za = za; h.out = out;
+    return QV2X_OK;
 }
 
 __global__ __launch_bounds__(256) void decode_lut_kernel(const uint8_t* __restrict__ codes, int R, int levels, int kc,
@@ -131,13 +177,29 @@ extern "C" int qv2x_dequant_i8_f32(const int8_t* in, int n, int h, int w, int c,
 extern "C" int qv2x_heads_f32(const float* x, int R, int hw, int cout, int cout_pad, const float* w, const float* bias,
                               const float* da, const float* za, float* out, void* stream) {
     using namespace qv2x;
-    if (!x || !w || !bias || !da || !za || !out) return fail(QV2X_EINVAL, "qv2x_heads_f32: null pointer");
-    if (R <= 0 || hw <= 0 || R % hw || cout <= 0 || cout > cout_pad || cout_pad % 32 || cout_pad > 96)
-        return fail(QV2X_EINVAL, "qv2x_heads_f32: R=%d hw=%d cout=%d cout_pad=%d (cout_pad in {32, 64, 96})", R, hw, cout, cout_pad);
-    if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return fail(QV2X_EALIGN, "qv2x_heads_f32: x / w must be 16-byte aligned");
-    const int tiles = ((R + 31) / 32) * (cout_pad / 32);
-    heads_f32_kernel<<<(tiles + 3) / 4, 256, 0, (hipStream_t)stream>>>(x, R, hw, cout, cout_pad, w, bias, da, za, out);
+    HeadArgs h;
+    if (!x) return fail(QV2X_EINVAL, "qv2x_heads_f32: null pointer");
+    if (int rc = head_args("qv2x_heads_f32", R, hw, cout, cout_pad, w, bias, da, za, out, h)) return rc;
+    if ((uintptr_t)x & 15) return fail(QV2X_EALIGN, "qv2x_heads_f32: x must be 16-byte aligned");
+    h.x = x;
+    rows_heads_kernel<ROWS_GLOBAL><<<(R + 31) / 32, 256, 0, (hipStream_t)stream>>>(h, FuseArgs{});
     return hip_check(hipGetLastError(), "qv2x_heads_f32 launch");
+}
+
+extern "C" int qv2x_decode_heads_f32(const uint8_t* codes, int R, int hw, int levels, int kc, const float* lut, const float* lut_bias,
+                                     int cout, int cout_pad, const float* w, const float* bias, const float* da, const float* za,
+                                     float* out, void* stream) {
+    using namespace qv2x;
+    if (!codes || !lut || !lut_bias) return fail(QV2X_EINVAL, "qv2x_decode_heads_f32: null pointer");
+    if (levels < 1 || levels > 4 || kc < 1 || kc > 256) return fail(QV2X_EINVAL, "qv2x_decode_heads_f32: bad sizes");
+    HeadArgs h;
+    if (int rc = head_args("qv2x_decode_heads_f32", R, hw, cout, cout_pad, w, bias, da, za, out, h)) return rc;
+    FuseArgs fa{};
+    fa.codes = codes; fa.lut = (const float4*)lut; fa.lut_bias = (const float4*)lut_bias; fa.feats = nullptr;
+    fa.levels = levels; fa.kc = kc; fa.hw = hw;
+    fa.code_agent_stride = hw; fa.code_level_stride = R;           // codes [levels][R], agent-major rows
+    rows_heads_kernel<ROWS_DECODE><<<(R + 31) / 32, 256, 0, (hipStream_t)stream>>>(h, fa);
+    return hip_check(hipGetLastError(), "qv2x_decode_heads_f32 launch");
 }
 
 extern "C" int qv2x_decode_lut_f32(const uint8_t* codes, int R, int levels, int kc, const float* lut, const float* lut_bias,

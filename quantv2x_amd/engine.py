@@ -376,13 +376,18 @@ class DeployedModel(nn.Module):
                                              L.ptr(self.lut_bias), L.ptr(out), L.current_stream()), "qv2x_decode_lut_f32")
         return out
 
-    def fuse(self, codes_ptr, agent_stride, level_stride, feats, pairwise_b, n, out, ego=0):
+    def _fuse_desc(self, agent_stride, level_stride, pairwise_b, n, ego):
         d = L.FuseDesc()
         d.agents, d.h, d.w = n, self.fh, self.fw
         d.levels, d.kc = (self.levels, self.kc) if self.has_codebook else (1, 1)
         d.max_cav, d.ego = pairwise_b.shape[0], ego
         d.code_agent_stride, d.code_level_stride = agent_stride, level_stride
         d.h_metres, d.w_metres, d.discrete_ratio = self.hm, self.wm, self.ratio
+        return d
+
+    def fuse(self, codes_ptr, agent_stride, level_stride, feats, pairwise_b, n, out, ego=0):
+        """a7-a10 alone: the fused fp32 map [H*W, 256] into ``out`` (parity tests, benchmarks)."""
+        d = self._fuse_desc(agent_stride, level_stride, pairwise_b, n, ego)
         lut = L.ptr(self.lut) if self.has_codebook else None
         lb = L.ptr(self.lut_bias) if self.has_codebook else None
         L.check(self.lib.qv2x_fuse_att_f32(C.byref(d), codes_ptr, lut, lb, L.ptr(feats) if feats is not None else None,
@@ -399,13 +404,20 @@ class DeployedModel(nn.Module):
         c, r, _ = self.heads.splits
         return {"cls_preds": preds[:, :c], "reg_preds": preds[:, c:c + r], "dir_preds": preds[:, c + r:], "preds_tensor": preds}
 
+    def _decode_heads_single(self, codes, n_agents: int):
+        hw = self.fh * self.fw
+        hd = self.heads_single
+        sp = torch.empty((n_agents, hd.cout, self.fh, self.fw), dtype=torch.float32, device=self.dev)
+        L.check(self.lib.qv2x_decode_heads_f32(L.ptr(codes), n_agents * hw, hw, self.levels, self.kc, L.ptr(self.lut), L.ptr(self.lut_bias),
+                                               hd.cout, hd.cout_pad, L.ptr(hd.w), L.ptr(hd.bias), L.ptr(hd.da), L.ptr(hd.za),
+                                               L.ptr(sp), L.current_stream()), "qv2x_decode_heads_f32")
+        return sp
+
     def single_preds(self, codes, n_agents: int) -> dict:
         """``*_preds_single`` (heter_model_baseline.py:224-230): the per-agent heads on each agent's own decoded feature."""
         if self.heads_single is None:
             return {}
-        hw = self.fh * self.fw
-        feats = self.decode_rows(codes, n_agents * hw)
-        sp = self._run_heads(self.heads_single, feats, n_agents, hw)
+        sp = self._decode_heads_single(codes, n_agents)
         c, r, _ = self.heads_single.splits
         return {"cls_preds_single": sp[:, :c], "reg_preds_single": sp[:, c:c + r], "dir_preds_single": sp[:, c + r:]}
 
@@ -431,8 +443,6 @@ class DeployedModel(nn.Module):
             feats = bufs["feats"]
             L.check(self.lib.qv2x_dequant_i8_f32(L.ptr(enc), n_total, self.fh, self.fw, 256, int(q[1]), float(q[0]), L.ptr(feats),
                                                  L.current_stream()), "qv2x_dequant_i8_f32")
-        elif self.heads_single is not None:
-            feats = self.decode_rows(enc, n_total * hw).view(n_total, hw, 256)
         fused = torch.empty((nb, hw, 256), dtype=torch.float32, device=self.dev)
         start = 0
         for bi, n in enumerate(lens):
@@ -446,7 +456,7 @@ class DeployedModel(nn.Module):
         c, r, _ = self.heads.splits
         out = {"cls_preds": preds[:, :c], "reg_preds": preds[:, c:c + r], "dir_preds": preds[:, c + r:], "preds_tensor": preds}
         if self.heads_single is not None:
-            sp = self._run_heads(self.heads_single, feats, n_total, hw)
+            sp = self._decode_heads_single(enc, n_total) if self.has_codebook else self._run_heads(self.heads_single, feats, n_total, hw)
             c, r, _ = self.heads_single.splits
             out.update({"cls_preds_single": sp[:, :c], "reg_preds_single": sp[:, c:c + r], "dir_preds_single": sp[:, c + r:]})
         if taps is not None:

@@ -57,3 +57,5 @@ if what in ("rest", "all"):
     t0 = time.perf_counter(); 
     for _ in range(50): eng(dd)
     torch.cuda.synchronize(); print("eager frame ms", (time.perf_counter() - t0) / 50 * 1e3)
+if what in ("rest", "all"):
+    print("decode+single heads (one launch)", timeit(lambda: eng._decode_heads_single(codes, n)))
