@@ -17,4 +17,4 @@ def run(h, w, iters=10):
     for _ in range(iters): f()
     e1.record(); torch.cuda.synchronize()
     print(f"variant {v}: h={h} w={w} blocks={h*w//64} {e0.elapsed_time(e1) / iters * 1e3:.1f} us")
-run(8, 8); run(128, 128)
+run(100, 352)
