@@ -17,6 +17,10 @@
 
 namespace qv2x {
 
+#ifdef QV2X_ENC_TRACE   // dev build (tools/enc_block_trace.py): when and on which CU every workgroup ran
+__device__ unsigned long long g_enc_blk[4096][4];
+#endif
+
 constexpr int ER = 32;              // rows per workgroup (two workgroups share a CU: 4 waves per SIMD)
 constexpr int ERT = ER / 32;        // 32-row MFMA tiles per workgroup
 constexpr int LDF = 258;            // LDS row stride in floats: 32 rows x ds_read_b64 land on 32 distinct bank pairs
@@ -89,15 +93,24 @@ __device__ __forceinline__ void gemm_rows_x32(const float* __restrict__ src, con
     }
 }
 
-// one step of the (value, index) argmin reduction: combine with the lane `shift` positions up inside the 16-lane row
+// (distance, code) as one sortable 64-bit key: the fp32 bits mapped monotonically onto u32 in the high word, the code in
+// the low word.  min(key) = smallest distance, ties to the lower code -- the reference's first-argmin -- with one 64-bit
+// compare per step and no short-circuit branches (the (value, index) pair with `||` / `&&` compiled to ~100 instructions
+// and four exec-mask branches per accumulator register: 8-25 us per level).  Distances are (x2 + c2) - 2 dot: never -0.
+__device__ __forceinline__ unsigned long long dist_key(float d, int code) {
+    unsigned b = __builtin_bit_cast(unsigned, d);
+    b ^= (unsigned)((int)b >> 31) | 0x80000000u;
+    return ((unsigned long long)b << 32) | (unsigned)code;
+}
+
+// one step of the key-min reduction: combine with the lane `shift` positions up inside the 16-lane DPP row
 template <int CTRL>
-__device__ __forceinline__ void argmin_dpp(float& v, int& i) {
-    const int vb = __builtin_bit_cast(int, v);
-    const float ov = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(vb, vb, CTRL, 0xf, 0xf, false));
-    const int oi = __builtin_amdgcn_update_dpp(i, i, CTRL, 0xf, 0xf, false);
-    const bool take = (ov < v) || (ov == v && oi < i);
-    v = take ? ov : v;
-    i = take ? oi : i;
+__device__ __forceinline__ void keymin_dpp(unsigned long long& k) {
+    const int lo = (int)(unsigned)k, hi = (int)(unsigned)(k >> 32);
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+    k = o < k ? o : k;
 }
 
 __device__ __forceinline__ void store_tile(float* __restrict__ dst, int wave, int lane, const v16f (&acc)[ERT]) {
@@ -114,11 +127,17 @@ __global__ __launch_bounds__(512, 4) void codebook_encode_kernel(const EncArgs a
     float* bufB = smem + ER * LDF;            // z
     float* x2 = smem + 2 * ER * LDF;          // [64]
     float* pval = x2 + ER;                    // [4][64]
-    int* pidx = (int*)(pval + 4 * ER);        // [4][64]
-    int* code_s = pidx + 4 * ER;              // [64]
+    unsigned long long* pkey = (unsigned long long*)(pval + 4 * ER);   // [4][ER] (distance, code) keys of the code tiles
+    int* code_s = (int*)(pkey + 4 * ER);      // [ER]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * ER;
+#ifdef QV2X_ENC_TRACE
+    const unsigned long long t_start = __builtin_readcyclecounter();
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+#endif
     // Two workgroups share a CU and run identical phase sequences; started together they hit their MFMA-free phases
     // (|q|^2, argmin, residual gather, barriers) at the same time and the matrix pipe idles.  Delaying every other
     // dispatch wave of workgroups by ~half a level de-phases the pair (speed only; results do not depend on it).
@@ -221,31 +240,26 @@ __global__ __launch_bounds__(512, 4) void codebook_encode_kernel(const EncArgs a
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rt * 32 + mfma32_row(r, lane);
-                float dv = (x2[row] + c2v) - 2.0f * dacc[r];
-                int di = code;
-                // (distance, index) minimum with ties to the lower index, reduced towards lane 0 of each 16-lane row with
-                // DPP row shifts (full-rate VALU; the ds_bpermute butterfly this replaces cost ~20 us per workgroup)
-                argmin_dpp<0x108>(dv, di); argmin_dpp<0x104>(dv, di); argmin_dpp<0x102>(dv, di); argmin_dpp<0x101>(dv, di);
-                // rows 0|1 (lanes 0, 16) and 2|3 (lanes 32, 48) of the wave
-                const float v16 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dv), 16));
-                const int i16 = __builtin_amdgcn_readlane(di, 16);
-                const float v48 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dv), 48));
-                const int i48 = __builtin_amdgcn_readlane(di, 48);
-                const float ov = lane < 32 ? v16 : v48;
-                const int oi = lane < 32 ? i16 : i48;
-                const bool take = (ov < dv) || (ov == dv && oi < di);
-                dv = take ? ov : dv;
-                di = take ? oi : di;
-                if ((lane & 31) == 0) { pval[ct * ER + row] = dv; pidx[ct * ER + row] = di; }
+                unsigned long long key = dist_key((x2[row] + c2v) - 2.0f * dacc[r], code);
+                // reduced towards lane 0 of each 16-lane row with DPP row shifts (full-rate VALU; the ds_bpermute butterfly
+                // this replaces cost ~20 us per workgroup), then rows 0|1 (lanes 0, 16) and 2|3 (lanes 32, 48) of the wave
+                keymin_dpp<0x108>(key); keymin_dpp<0x104>(key); keymin_dpp<0x102>(key); keymin_dpp<0x101>(key);
+                const int klo = (int)(unsigned)key, khi = (int)(unsigned)(key >> 32);
+                const unsigned lo16 = (unsigned)__builtin_amdgcn_readlane(klo, 16), hi16 = (unsigned)__builtin_amdgcn_readlane(khi, 16);
+                const unsigned lo48 = (unsigned)__builtin_amdgcn_readlane(klo, 48), hi48 = (unsigned)__builtin_amdgcn_readlane(khi, 48);
+                const unsigned long long o = lane < 32 ? (((unsigned long long)hi16 << 32) | lo16) : (((unsigned long long)hi48 << 32) | lo48);
+                key = o < key ? o : key;
+                if ((lane & 31) == 0) pkey[ct * ER + row] = key;
             }
         }
         __syncthreads();
         if (tid < ER) {
-            float bv = pval[tid]; int bi = pidx[tid];
+            unsigned long long bk = pkey[tid];
             for (int wv = 1; wv * 32 < a.kc; ++wv) {
-                const float ov = pval[wv * ER + tid]; const int oi = pidx[wv * ER + tid];
-                if (ov < bv) { bv = ov; bi = oi; }                 // strict: lower code tile wins ties
+                const unsigned long long ok = pkey[wv * ER + tid];
+                bk = ok < bk ? ok : bk;                                // code tiles ascend: ties still go to the lower code
             }
+            const int bi = (int)(unsigned)bk;
             code_s[tid] = bi;
             if (m0 + tid < a.M) a.codes[(size_t)l * a.M + m0 + tid] = (uint8_t)bi;
         }
@@ -268,6 +282,12 @@ __global__ __launch_bounds__(512, 4) void codebook_encode_kernel(const EncArgs a
             __syncthreads();
         }
     }
+#ifdef QV2X_ENC_TRACE
+    if (tid == 0 && blockIdx.x < 4096) {
+        g_enc_blk[blockIdx.x][0] = t_start; g_enc_blk[blockIdx.x][1] = __builtin_readcyclecounter();
+        g_enc_blk[blockIdx.x][2] = hwid; g_enc_blk[blockIdx.x][3] = xcc;
+    }
+#endif
 }
 
 __global__ void codebook_c2_kernel(const float* __restrict__ cb, int kc, float* __restrict__ c2) {
@@ -293,7 +313,7 @@ extern "C" int qv2x_codebook_c2_f32(const float* codebook, int kc, float* c2, vo
 
 extern "C" int qv2x_debug_encode_occupancy(void) {
     using namespace qv2x;
-    const size_t smem = (size_t)(2 * ER * LDF + ER + 4 * ER + 4 * ER + ER) * sizeof(float);
+    const size_t smem = (size_t)(2 * ER * LDF + ER + 4 * ER + 8 * ER + ER) * sizeof(float);
     int n = -1;
     if (hipFuncSetAttribute((const void*)codebook_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, codebook_encode_kernel, 512, smem) != hipSuccess)
@@ -320,7 +340,7 @@ extern "C" int qv2x_codebook_encode_f32(const qv2x_encode_desc* d, const int8_t*
         if (l < d->levels && (!a.lvl[l] || ((uintptr_t)a.lvl[l] & 15))) return fail(QV2X_EALIGN, "qv2x_codebook_encode_f32: level %d weights null or unaligned", l);
     }
     static const char* padenv = getenv("QV2X_ENC_SMEM_PAD");
-    const size_t smem = (size_t)(2 * ER * LDF + ER + 4 * ER + 4 * ER + ER) * sizeof(float) + (padenv ? atoi(padenv) * 1024 : 0);
+    const size_t smem = (size_t)(2 * ER * LDF + ER + 4 * ER + 8 * ER + ER) * sizeof(float) + (padenv ? atoi(padenv) * 1024 : 0);
     static bool attr_set = false;
     if (!attr_set) {
         int rc = hip_check(hipFuncSetAttribute((const void*)codebook_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem),
@@ -331,3 +351,9 @@ extern "C" int qv2x_codebook_encode_f32(const qv2x_encode_desc* d, const int8_t*
     codebook_encode_kernel<<<(a.M + ER - 1) / ER, 512, smem, (hipStream_t)stream>>>(a);
     return hip_check(hipGetLastError(), "qv2x_codebook_encode_f32 launch");
 }
+
+#ifdef QV2X_ENC_TRACE
+extern "C" int qv2x_debug_encode_blocks(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(qv2x::g_enc_blk), (size_t)n * 4 * sizeof(unsigned long long));
+}
+#endif
