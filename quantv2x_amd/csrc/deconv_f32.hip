@@ -4,8 +4,10 @@
 // i.e. on the reduction axis, so no integer accumulation can be factored; the sum is an ascending-ci fp32 fma
 // chain, which is exactly what the f32 MFMA computes (k ascending, C-in first; verified bit-exact against fmaf
 // on hardware, tools/probes/mfma_probe.hip).  GEMM view: rows = input pixels, cols = (i*s + j)*Cout + co, K = Cin.
-// One wave = 32 pixels x 64 columns; A converted on the fly from the i8 BEV, B = [Cin/4][cols][4] fp32 from L2.
+// One wave = 32 pixels x 32 columns; A converted on the fly from the i8 BEV, B = [Cin/4][cols][4] fp32 from L2.
 #include "common.h"
+
+#include <cstdlib>
 
 namespace qv2x {
 
@@ -15,10 +17,11 @@ struct DeconvArgs {
     float dx, out_delta, out_zp;
 };
 
+template <int NT>
 __global__ __launch_bounds__(256) void deconv_f32_kernel(const DeconvArgs a) {
     __shared__ int rowbase[4][32];            // per wave: output pixel index of (row, i = 0, j = 0), -1 past the end
     const int lane = threadIdx.x & 63;
-    const int tiles_n = a.ncols >> 6;
+    const int tiles_n = a.ncols / (32 * NT);
     int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     tile = __builtin_amdgcn_readfirstlane(tile);
     const int tiles_m = (a.M + 31) >> 5;
@@ -35,27 +38,27 @@ __global__ __launch_bounds__(256) void deconv_f32_kernel(const DeconvArgs a) {
         const int mm = tm * 32 + lane;
         rowbase[threadIdx.x >> 6][lane] = mm < a.M ? (img * (a.h * a.s + 2) + y * a.s + 1) * (a.wd * a.s + 2) + x * a.s + 1 : -1;
     }
-    const int col0 = tn * 64 + (lane & 31);
+    const int col0 = tn * (32 * NT) + (lane & 31);
     // weights: [Cin/4][cols][k0, k2, k1, k3]; the half-wave of MFMA k-parity `par` reads one float2 = (k_par, k_par+2)
     const float2* wq = (const float2*)a.w + (size_t)col0 * 2 + par;
 
-    v16f acc[2];
+    v16f acc[NT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
     // one step = 16 input channels = 8 MFMA k-steps x 2 column tiles; the next step's operands are requested before the
     // MFMA block of the current one (register double buffer, pinned with sched_barrier: hipcc sinks loads otherwise)
     auto loadA = [&](int k0) { return *(const v4i*)(src + k0); };
-    auto loadB = [&](float2 (&dst)[4][2], int k0) {
+    auto loadB = [&](float2 (&dst)[4][NT], int k0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) dst[q][t] = wq[((size_t)((k0 >> 2) + q) * a.ncols + t * 32) * 2];
+            for (int t = 0; t < NT; ++t) dst[q][t] = wq[((size_t)((k0 >> 2) + q) * a.ncols + t * 32) * 2];
     };
     const int sh = par * 8;
-    auto step = [&](const v4i raw, const float2 (&b)[4][2]) {
+    auto step = [&](const v4i raw, const float2 (&b)[4][NT]) {
         float av[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {              // MFMA k-step j: k = k0 + 2j + par  ->  byte 2*(j&1) + par of word j>>1
@@ -65,11 +68,11 @@ __global__ __launch_bounds__(256) void deconv_f32_kernel(const DeconvArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < NT; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], (j & 1) ? b[j >> 1][t].y : b[j >> 1][t].x, acc[t], 0, 0, 0);
     };
     v4i r0 = loadA(0), r1;
-    float2 b0[4][2], b1[4][2];
+    float2 b0[4][NT], b1[4][NT];
     loadB(b0, 0);
     for (int k0 = 0; k0 < a.cin; k0 += 32) {
         const bool two = k0 + 16 < a.cin;
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256) void deconv_f32_kernel(const DeconvArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) pix[r] = rb[mfma32_row(r, lane)];      // all 16 LDS reads in flight, no per-element branch
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NT; ++t) {
         const int col = col0 + t * 32;
         const int ij = col / a.cout, co = col - ij * a.cout;
         const int di = ij / a.s, dj = ij - di * a.s;
@@ -126,7 +129,12 @@ extern "C" int qv2x_deconv_i8(const qv2x_deconv_desc* d, const int8_t* in, const
     a.n = d->n; a.h = d->h; a.wd = d->w; a.cin = d->cin; a.cout = d->cout; a.s = d->s; a.ax = 128 - d->in_zx;
     a.ncols = d->s * d->s * d->cout; a.M = d->n * d->h * d->w; a.relu = d->relu;
     a.out_ctotal = d->out_ctotal; a.out_c0 = d->out_c0; a.dx = d->in_delta; a.out_delta = d->out_delta; a.out_zp = d->out_zp;
-    const int tiles = ((a.M + 31) / 32) * (a.ncols / 64);
-    deconv_f32_kernel<<<(tiles + 3) / 4, 256, 0, (hipStream_t)stream>>>(a);
+    // 32 x 32 wave tiles: 4416 tiles of 3.9 us on 1024 SIMDs at the 25 x 88 level balance better than 2208 tiles of 7.8 us
+    // (13.7 / 21.4 / 36.4 us against 15.4 / 23.7 / 39.5 us for the three deblocks)
+    static const char* ntenv = getenv("QV2X_DECONV_NT");              // dev knob: column tiles per wave
+    const int nt = ntenv ? atoi(ntenv) : 1;
+    const int tiles = ((a.M + 31) / 32) * (a.ncols / (32 * nt));
+    if (nt == 1) deconv_f32_kernel<1><<<(tiles + 3) / 4, 256, 0, (hipStream_t)stream>>>(a);
+    else deconv_f32_kernel<2><<<(tiles + 3) / 4, 256, 0, (hipStream_t)stream>>>(a);
     return hip_check(hipGetLastError(), "qv2x_deconv_i8 launch");
 }
