@@ -81,8 +81,14 @@ def conv_roofline(eng, iters):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / (iters * len(launches))
     achieved = ops / len(launches) / (us * 1e-6) / 1e12
+    traffic = None       # HBM-side bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (not live)
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_wide_conv.json")
+    if os.path.exists(pmc):
+        with open(pmc) as f:
+            traffic = json.load(f).get("traffic_bytes_per_launch")
     return {"bound": "mfma", "achieved": round(achieved, 1), "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s",
-            "frac": round(achieved / INT8_MFMA_PEAK_TOPS, 4), "traffic": None,
+            "frac": round(achieved / INT8_MFMA_PEAK_TOPS, 4), "traffic": traffic,
+            "traffic_note": "bytes per launch, FETCH_SIZE + WRITE_SIZE of profiles/r01_pmc_wide_conv.json (algorithmic: 23.4 MB)",
             "kernel": "conv3x3_i8_wide_kernel<5, true, 8, 1>", "launches_per_frame": len(launches),
             "avg_launch_us": round(us, 2), "algorithmic_gop_per_launch": round(ops / len(launches) / 1e9, 3)}
 
