@@ -33,7 +33,7 @@ constexpr int D = 256;
 struct EncArgs {
     const int8_t* in; uint8_t* codes;
     const float* lvl[4];
-    int n, h, w, levels, kc, ax, M, stagger;
+    int n, h, w, levels, kc, ax, M;
     float dx;
 };
 
@@ -138,13 +138,6 @@ __global__ __launch_bounds__(512, 4) void codebook_encode_kernel(const EncArgs a
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
 #endif
-    // Two workgroups share a CU and run identical phase sequences; started together they hit their MFMA-free phases
-    // (|q|^2, argmin, residual gather, barriers) at the same time and the matrix pipe idles.  Delaying every other
-    // dispatch wave of workgroups by ~half a level de-phases the pair (speed only; results do not depend on it).
-    if ((blockIdx.x >> 8) & 1) {
-        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-
     {   // ---- load ER rows x 256 channels from the i8 BEV, dequantize ---------------------------------
         constexpr int TPR = 512 / ER;                 // threads per row
         constexpr int CPT = D / TPR;                  // channels per thread (16 for ER = 32)
@@ -333,14 +326,11 @@ extern "C" int qv2x_codebook_encode_f32(const qv2x_encode_desc* d, const int8_t*
     EncArgs a;
     a.in = in; a.codes = codes; a.n = d->n; a.h = d->h; a.w = d->w; a.levels = d->levels; a.kc = d->kc;
     a.ax = 128 - d->in_zx; a.dx = d->in_delta; a.M = d->n * d->h * d->w;
-    static const char* stg = getenv("QV2X_ENC_STAGGER");
-    a.stagger = stg ? atoi(stg) : 6;
     for (int l = 0; l < 4; ++l) {
         a.lvl[l] = l < d->levels ? level_weights[l] : nullptr;
         if (l < d->levels && (!a.lvl[l] || ((uintptr_t)a.lvl[l] & 15))) return fail(QV2X_EALIGN, "qv2x_codebook_encode_f32: level %d weights null or unaligned", l);
     }
-    static const char* padenv = getenv("QV2X_ENC_SMEM_PAD");
-    const size_t smem = (size_t)(2 * ER * LDF + ER + 4 * ER + 8 * ER + ER) * sizeof(float) + (padenv ? atoi(padenv) * 1024 : 0);
+    const size_t smem = (size_t)(2 * ER * LDF + ER + 4 * ER + 8 * ER + ER) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         int rc = hip_check(hipFuncSetAttribute((const void*)codebook_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem),

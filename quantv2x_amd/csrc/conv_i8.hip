@@ -3,9 +3,8 @@
 //   M = N*Ho*Wo output pixels, N = Cout, K = G * 9 * C_g walked as (group, kh, kw, 64-channel chunk).
 //   A (activations): padded i8 BEV, so a K-chunk of a pixel is 64 contiguous bytes, no bounds checks.
 //   B (weights): [Cout][K] i8, K contiguous and in loop order, so the K-chunk offset is linear in the step.
-//   Both are staged through LDS in 64-byte rows (16-byte chunks XOR-swizzled by (row >> 2) & 3 so that the
-//   ds_read_b128 fragment reads of a 16-lane group hit 16 distinct slots), double buffered: the next chunk's
-//   global loads are in flight while the MFMAs of the current one issue.
+//   Both are staged through LDS in rows of one K chunk (16-byte chunks XOR-swizzled so that the ds_read_b128 fragment
+//   reads of a 16-lane group hit 16 distinct slots) by LDS-DMA through a 3- or 4-stage ring (below).
 //
 // Unsigned x unsigned codes on a signed MFMA (SURVEY.md §7 "hard parts"): with xs = x - 128, ws = w - 128,
 // ax = 128 - zx, aw = 128 - zw,
@@ -40,215 +39,11 @@ __device__ __forceinline__ int swz(int row, int chunk) {
     return row * BK + ((chunk ^ ((row >> (CH == 4 ? 2 : (CH == 8 ? 1 : 0))) & (CH - 1))) << 4);
 }
 
-template <int BM, int BN, int WM, int WN, int BK, bool MULTI, int MINW>
-__global__ __launch_bounds__(256, MINW) void conv3x3_i8_kernel(const ConvArgs a) {
-    constexpr int TM = BM / WM, TN = BN / WN;      // wave tile
-    constexpr int MT = TM / 32, NT = TN / 32;      // 32x32 MFMA tiles per wave
-    constexpr int CH = BK / 16;
-    constexpr int LA = BM * CH / 256, LB = BN * CH / 256;      // 16-byte global loads per thread per K-chunk
-    constexpr int NF = MULTI ? 16 : 1;
-    static_assert(WM * WN == 4 && MT >= 1 && NT >= 1 && LA >= 1 && LB >= 1, "tile shape");
-
-    __shared__ __attribute__((aligned(16))) int8_t lds[2 * (BM + BN) * BK + 4 * TM * 4 + BM * 4];
-    int8_t* ldsA = lds;
-    int8_t* ldsB = lds + 2 * BM * BK;
-    int* xbuf = (int*)(lds + 2 * (BM + BN) * BK);  // [4 waves][TM] window sums
-    int* rowoff = xbuf + 4 * TM;                    // [BM] output pixel offset (in pixels), -1 = past the end
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-
-    // ---- per-thread global source addresses --------------------------------------------------------
-    const int8_t* srcA[LA];
-    int dstA[LA];
-#pragma unroll
-    for (int i = 0; i < LA; ++i) {
-        const int id = tid + i * 256, row = id / CH, ch = id % CH;
-        int m = m0 + row;
-        m = m < a.M ? m : a.M - 1;
-        const int img = m / (a.ho * a.wo), rem = m - img * (a.ho * a.wo);
-        const int yo = rem / a.wo, xo = rem - yo * a.wo;
-        srcA[i] = a.in + ((size_t)(img * a.hp + yo * a.stride) * a.wp + xo * a.stride) * a.cin_total + ch * 16;
-        dstA[i] = swz<BK>(row, ch);
-    }
-    if (tid < BM) {
-        const int m = m0 + tid;
-        int off = -1;
-        if (m < a.M) {
-            const int img = m / (a.ho * a.wo), rem = m - img * (a.ho * a.wo);
-            const int yo = rem / a.wo, xo = rem - yo * a.wo;
-            off = (img * (a.ho + 2) + yo + 1) * (a.wo + 2) + xo + 1;
-        }
-        rowoff[tid] = off;
-    }
-    const int8_t* srcB[LB];
-    int dstB[LB];
-#pragma unroll
-    for (int i = 0; i < LB; ++i) {
-        const int id = tid + i * 256, row = id / CH, ch = id % CH;
-        srcB[i] = a.w + (size_t)(n0 + row) * a.ktot + ch * 16;
-        dstB[i] = swz<BK>(row, ch);
-    }
-
-    v16i acc[MT][NT];
-    float facc[MT][NT][NF];
-    int xs[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        xs[i] = 0;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
-            if (MULTI) {
-                const float b = a.bias[n0 + wn * TN + j * 32 + (lane & 31)];
-#pragma unroll
-                for (int r = 0; r < NF; ++r) facc[i][j][r] = b;
-            }
-        }
-    }
-
-    v4i ra[LA], rb[LB];
-    int kofs = 0;      // byte offset into a weight row == BK * (chunks consumed so far)
-    int cur = 0;
-
-    for (int g = 0; g < (MULTI ? a.ngroups : 1); ++g) {
-        const int chunks = a.gc[g] / BK;
-        const int steps = 9 * chunks;
-        // (tap, cc) of the chunk being PREFETCHED; advanced without divisions
-        int p_tap = 0, p_cc = 0;
-        auto next_off = [&]() {
-            const int kh = p_tap >= 6 ? 2 : (p_tap >= 3 ? 1 : 0), kw = p_tap - kh * 3;
-            const int off = (kh * a.wp + kw) * a.cin_total + a.gc0[g] + p_cc * BK;
-            if (++p_cc == chunks) { p_cc = 0; ++p_tap; }
-            return off;
-        };
-        {   // prologue: chunk 0 of this group
-            const int ao = next_off();
-#pragma unroll
-            for (int i = 0; i < LA; ++i) ra[i] = *(const v4i*)(srcA[i] + ao);
-#pragma unroll
-            for (int i = 0; i < LB; ++i) rb[i] = *(const v4i*)(srcB[i] + kofs);
-#pragma unroll
-            for (int i = 0; i < LA; ++i) *(v4i*)(ldsA + cur * BM * BK + dstA[i]) = ra[i];
-#pragma unroll
-            for (int i = 0; i < LB; ++i) *(v4i*)(ldsB + cur * BN * BK + dstB[i]) = rb[i];
-            __syncthreads();
-        }
-        for (int s = 0; s < steps; ++s) {
-            const bool more = (s + 1) < steps;
-            if (more) {
-                const int ao = next_off();
-#pragma unroll
-                for (int i = 0; i < LA; ++i) ra[i] = *(const v4i*)(srcA[i] + ao);
-#pragma unroll
-                for (int i = 0; i < LB; ++i) rb[i] = *(const v4i*)(srcB[i] + kofs + BK);
-            }
-            const int8_t* bufA = ldsA + cur * BM * BK;
-            const int8_t* bufB = ldsB + cur * BN * BK;
-#pragma unroll
-            for (int ks = 0; ks < BK / 32; ++ks) {
-                v4i fa[MT], fb[NT];
-                const int ch = ks * 2 + (lane >> 5);
-#pragma unroll
-                for (int i = 0; i < MT; ++i) fa[i] = *(const v4i*)(bufA + swz<BK>(wm * TM + i * 32 + (lane & 31), ch));
-#pragma unroll
-                for (int j = 0; j < NT; ++j) fb[j] = *(const v4i*)(bufB + swz<BK>(wn * TN + j * 32 + (lane & 31), ch));
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) xs[i] = __builtin_amdgcn_sdot4(fa[i][q], 0x01010101, xs[i], false);
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
-                }
-            }
-            if (more) {
-#pragma unroll
-                for (int i = 0; i < LA; ++i) *(v4i*)(ldsA + (cur ^ 1) * BM * BK + dstA[i]) = ra[i];
-#pragma unroll
-                for (int i = 0; i < LB; ++i) *(v4i*)(ldsB + (cur ^ 1) * BN * BK + dstB[i]) = rb[i];
-            }
-            __syncthreads();
-            cur ^= more ? 1 : 0;
-            kofs += BK;
-        }
-        // ---- window sums of this group to LDS (C-fragment rows differ from A-fragment rows) -----------
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int tot = xs[i] + __shfl_xor(xs[i], 32);
-            if (lane < 32) xbuf[wave * TM + i * 32 + lane] = tot;
-            xs[i] = 0;
-        }
-        __syncthreads();
-        if (MULTI) {       // fold this group into the fp32 accumulator with its own activation scale
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int co = n0 + wn * TN + j * 32 + (lane & 31);
-                const int awv = a.aw[co];
-                const int cr = a.corr[g * a.cout + co];
-                const float sc = a.scale[g * a.cout + co];
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-#pragma unroll
-                    for (int r = 0; r < NF; ++r) {
-                        const int T = acc[i][j][r] + awv * xbuf[wave * TM + i * 32 + mfma32_row(r, lane)] + cr;
-                        facc[i][j][r] = facc[i][j][r] + (float)T * sc;
-                        acc[i][j][r] = 0;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
-
-    // ---- epilogue: (single group: bias + T * scale), ReLU, requantize; the 32 x TN byte tile of each MFMA row block
-    // is transposed through LDS (the K-loop buffers are free now) so that every lane stores 16 contiguous channels.
-    int8_t* stage = lds + wave * (32 * TN);            // per-wave [32 rows][TN] bytes, inside the (dead) A/B buffers
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int co = n0 + wn * TN + j * 32 + (lane & 31);
-            int awv = 0, cr = 0;
-            float sc = 0.f, bs = 0.f;
-            if (!MULTI) { awv = a.aw[co]; cr = a.corr[co]; sc = a.scale[co]; bs = a.bias[co]; }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mfma32_row(r, lane);
-                float y;
-                if (MULTI) {
-                    y = facc[i][j][r % NF];
-                } else {
-                    const int T = acc[i][j][r] + awv * xbuf[wave * TM + i * 32 + row] + cr;
-                    y = bs + (float)T * sc;
-                }
-                if (a.relu) y = fmaxf(y, 0.0f);
-                stage[row * TN + j * 32 + (lane & 31)] = (int8_t)((int)q_code(y, a.out_delta, a.out_zp) - 128);
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        constexpr int CPR = TN / 16;                     // 16-byte chunks per row
-#pragma unroll
-        for (int t = 0; t < (32 * CPR + 63) / 64; ++t) {
-            const int id = lane + t * 64, row = id / CPR, chn = id % CPR;
-            if (id < 32 * CPR) {
-                const int off = rowoff[wm * TM + i * 32 + row];
-                if (off >= 0)
-                    *(v4i*)(a.out + (size_t)off * a.out_ctotal + a.out_c0 + n0 + wn * TN + chn * 16) = *(const v4i*)(stage + row * TN + chn * 16);
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------------
-// Same implicit GEMM with the operand tiles streamed by LDS-DMA (global_load_lds_dwordx4: HBM/L2 -> LDS without a
-// VGPR round trip) through an S-stage ring, so several K-chunks are in flight per workgroup and the per-chunk
-// latency (the limiter of the register-staged variant above: one chunk of prefetch, ~1 us per chunk exposed on the
-// small layers) is covered.  One s_barrier per chunk:
+// The operand tiles are streamed by LDS-DMA (global_load_lds_dwordx4: HBM/L2 -> LDS without a VGPR round trip) through
+// an S-stage ring, so several K-chunks are in flight per workgroup and the per-chunk latency is covered (a
+// register-staged double buffer, one chunk of prefetch, left ~1 us per chunk exposed on the small layers).  One
+// s_barrier per chunk:
 //     wait vmcnt((S-2)*LPS)  ->  s_barrier  ->  issue chunk s+S-1 into the stage freed by chunk s-1  ->  MFMAs of chunk s
 // The DMA writes LDS lane-linearly (wave-uniform base + lane*16), so the XOR swizzle is applied to the per-lane SOURCE
 // address and again on the fragment reads (cdna guide rule 21).  All LDS is one array (a second __shared__ object makes
@@ -482,13 +277,6 @@ static int launch_dma(const ConvArgs& a, hipStream_t st) {
     return hip_check(hipGetLastError(), "qv2x_conv3x3_i8 launch");
 }
 
-template <int BM, int BN, int WM, int WN, int BK, bool MULTI, int MINW>
-static int launch(const ConvArgs& a, hipStream_t st) {
-    dim3 grid((a.M + BM - 1) / BM, a.cout / BN);
-    conv3x3_i8_kernel<BM, BN, WM, WN, BK, MULTI, MINW><<<grid, 256, 0, st>>>(a);
-    return hip_check(hipGetLastError(), "qv2x_conv3x3_i8 launch");
-}
-
 }  // namespace qv2x
 
 extern "C" int qv2x_conv3x3_i8(const qv2x_conv_desc* d, const int8_t* in, const int8_t* w, const float* scale,
@@ -526,25 +314,12 @@ extern "C" int qv2x_conv3x3_i8(const qv2x_conv_desc* d, const int8_t* in, const 
     bool k128 = true;
     for (int g = 0; g < a.ngroups; ++g) k128 = k128 && (a.gc[g] % 128 == 0);
     const bool multi = a.ngroups > 1;
-    static const char* force = getenv("QV2X_CONV_TILE");      // dev knob: "large" | "small"
-    const bool large = force ? (force[0] == 'l') : (a.cout % 128 == 0 && a.M >= 16384);
-    static const char* dmaenv = getenv("QV2X_CONV_DMA");     // dev knob: "0" selects the register-staged kernels
-    const bool use_dma = !(dmaenv && dmaenv[0] == '0');
-    if (use_dma) {
-        if (multi) {
-            if (a.cout % 128) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8: multi-group input needs cout %% 128 == 0");
-            return launch_dma<128, 128, 2, 2, 64, true, 4, 2>(a, st);
-        }
-        if (large && a.cout % 128 == 0) return launch_dma<128, 128, 2, 2, 64, false, 3, 3>(a, st);
-        static const char* k256env = getenv("QV2X_CONV_BK256");  // dev knob
-        if (a.gc[0] % 256 == 0 && !(k256env && k256env[0] == '0')) return launch_dma<64, 64, 2, 2, 256, false, 3, 1>(a, st);
-        return k128 ? launch_dma<64, 64, 2, 2, 128, false, 4, 2>(a, st) : launch_dma<64, 64, 2, 2, 64, false, 4, 4>(a, st);
-    }
+    const bool large = a.cout % 128 == 0 && a.M >= 16384;
     if (multi) {
         if (a.cout % 128) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8: multi-group input needs cout %% 128 == 0");
-        return launch<128, 128, 2, 2, 64, true, 2>(a, st);
+        return launch_dma<128, 128, 2, 2, 64, true, 4, 2>(a, st);
     }
-    if (large && a.cout % 128 == 0)
-        return k128 ? launch<128, 128, 2, 2, 128, false, 2>(a, st) : launch<128, 128, 2, 2, 64, false, 3>(a, st);
-    return k128 ? launch<64, 64, 2, 2, 128, false, 4>(a, st) : launch<64, 64, 2, 2, 64, false, 4>(a, st);
+    if (large) return launch_dma<128, 128, 2, 2, 64, false, 3, 3>(a, st);
+    if (a.gc[0] % 256 == 0) return launch_dma<64, 64, 2, 2, 256, false, 3, 1>(a, st);     // 256-byte K chunks: fewest barriers
+    return k128 ? launch_dma<64, 64, 2, 2, 128, false, 4, 2>(a, st) : launch_dma<64, 64, 2, 2, 64, false, 4, 4>(a, st);
 }
