@@ -17,6 +17,7 @@ SYMBOLS = [
     "qv2x_conv3x3_i8_wide_ok", "qv2x_conv3x3_i8_pack_wide", "qv2x_conv3x3_i8_wide",
     "qv2x_deconv_i8", "qv2x_codebook_level_floats", "qv2x_codebook_c2_f32", "qv2x_codebook_encode_f32", "qv2x_fuse_att_f32",
     "qv2x_decode_lut_f32", "qv2x_dequant_i8_f32", "qv2x_heads_f32", "qv2x_decode_heads_f32", "qv2x_voxelize_workspace_bytes", "qv2x_voxelize_f32",
+    "qv2x_postprocess_workspace_bytes", "qv2x_postprocess_f32",
 ]
 
 
@@ -52,6 +53,12 @@ class FuseDesc(C.Structure):
                 ("max_cav", C.c_int32), ("ego", C.c_int32),
                 ("code_agent_stride", C.c_int64), ("code_level_stride", C.c_int64),
                 ("h_metres", C.c_double), ("w_metres", C.c_double), ("discrete_ratio", C.c_double)]
+
+
+class PostprocessDesc(C.Structure):
+    _fields_ = [("h", C.c_int32), ("w", C.c_int32), ("anchors_per_cell", C.c_int32), ("num_bins", C.c_int32),
+                ("score_threshold", C.c_float), ("nms_threshold", C.c_float), ("dir_offset", C.c_float),
+                ("range", C.c_float * 6), ("transform", C.c_float * 16), ("max_boxes", C.c_int32)]
 
 
 class Qv2xError(RuntimeError):
@@ -95,8 +102,11 @@ def load() -> C.CDLL:
     lib.qv2x_voxelize_workspace_bytes.restype = C.c_int64
     lib.qv2x_voxelize_f32.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int,
                                       vp, C.c_int64, vp, vp, vp, vp, vp]
+    lib.qv2x_postprocess_workspace_bytes.argtypes = [C.POINTER(PostprocessDesc)]
+    lib.qv2x_postprocess_workspace_bytes.restype = C.c_int64
+    lib.qv2x_postprocess_f32.argtypes = [C.POINTER(PostprocessDesc), vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp]
     for s in SYMBOLS:
-        if s not in ("qv2x_last_error", "qv2x_codebook_level_floats", "qv2x_voxelize_workspace_bytes"):
+        if s not in ("qv2x_last_error", "qv2x_codebook_level_floats", "qv2x_voxelize_workspace_bytes", "qv2x_postprocess_workspace_bytes"):
             getattr(lib, s).restype = C.c_int
     _lib = lib
     return lib

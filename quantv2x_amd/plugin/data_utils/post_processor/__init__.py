@@ -1,0 +1,12 @@
+from .voxel_postprocessor import VoxelPostprocessor  # noqa: F401
+
+__all__ = {"VoxelPostprocessor": VoxelPostprocessor}
+
+
+def build_postprocessor(anchor_cfg, train):
+    """``opencood/data_utils/post_processor/__init__.py:18-27``: lookup by ``core_method``."""
+    name = anchor_cfg["core_method"]
+    if name not in __all__:
+        raise NotImplementedError(f"post-processor {name!r}: only the single-class anchor post-processor is built "
+                                  f"(VoxelPostprocessor3Heads / Bev / CiaSSD / FPVRCNN: SURVEY.md §8(f))")
+    return __all__[name](anchor_params=anchor_cfg, train=train)

@@ -1,0 +1,113 @@
+"""``VoxelPostprocessor`` of ``opencood/data_utils/post_processor/voxel_postprocessor.py`` for inference: same
+constructor, ``generate_anchor_box`` (:30-83) and ``post_process(data_dict, output_dict)`` (:245-405) contract, the
+work done by ``qv2x_postprocess_f32`` (``csrc/postprocess.hip``).  Training-side members (``generate_label``,
+``collate_batch``, ``visualize``) are out of scope (datasets / training).
+
+``post_process`` handles what intermediate fusion produces: ``output_dict`` with the ego entry only.  The head maps
+must live on the GPU (they come from ``DeployedModel``); there is no CPU fallback.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from ....lib import PostprocessDesc, check, current_stream, load, ptr
+
+
+def load_point_pillar_anchor_args(hypes: dict) -> dict:
+    """``yaml_utils.load_point_pillar_params`` (hypes_yaml/yaml_utils.py:106-146), the post-process part: fills
+    ``vw, vh, vd, W, H, D`` of ``hypes['postprocess']['anchor_args']`` from the lidar range and the voxel size."""
+    r = hypes["preprocess"]["cav_lidar_range"]
+    vw, vh, vd = hypes["preprocess"]["args"]["voxel_size"]
+    a = hypes["postprocess"]["anchor_args"]
+    a.update(vw=vw, vh=vh, vd=vd, W=math.ceil((r[3] - r[0]) / vw), H=math.ceil((r[4] - r[1]) / vh), D=math.ceil((r[5] - r[2]) / vd))
+    return hypes
+
+
+class VoxelPostprocessor:
+    def __init__(self, anchor_params, train):
+        self.params = anchor_params
+        self.train = train
+        self.bbx_dict = {}
+        self.anchor_num = self.params["anchor_args"]["num"]
+        self._ws = None
+        self._anchors_dev = None
+
+    def generate_anchor_box(self):
+        a = self.params["anchor_args"]
+        r = [math.radians(e) for e in a["r"]]
+        assert self.anchor_num == len(r)
+        stride = a.get("feature_stride", 2)
+        lr = a["cav_lidar_range"]
+        x = np.linspace(lr[0] + a["vw"], lr[3] - a["vw"], a["W"] // stride)
+        y = np.linspace(lr[1] + a["vh"], lr[4] - a["vh"], a["H"] // stride)
+        cx, cy = np.meshgrid(x, y)
+        cx = np.tile(cx[..., np.newaxis], self.anchor_num)
+        cy = np.tile(cy[..., np.newaxis], self.anchor_num)
+        cz = np.ones_like(cx) * -1.0
+        w, l, h = np.ones_like(cx) * a["w"], np.ones_like(cx) * a["l"], np.ones_like(cx) * a["h"]
+        r_ = np.ones_like(cx)
+        for i in range(self.anchor_num):
+            r_[..., i] = r[i]
+        if self.params["order"] == "hwl":
+            return np.stack([cx, cy, cz, h, w, l, r_], axis=-1)
+        if self.params["order"] == "lhw":
+            return np.stack([cx, cy, cz, l, h, w, r_], axis=-1)
+        raise SystemExit("Unknown bbx order.")
+
+    # ---- inference -------------------------------------------------------------------------------------------
+    def post_process(self, data_dict, output_dict, max_boxes: int = 1000):
+        """-> (pred_box3d_tensor [K, 8, 3], scores [K]) on the GPU, or (None, None) when nothing passes."""
+        if self.params["order"] != "hwl":
+            raise NotImplementedError("deployed post-process: box order 'hwl' (PointPillar)")
+        if len(output_dict) != 1:
+            raise NotImplementedError("deployed post-process: one CAV (intermediate / early fusion); late fusion is not built")
+        cav_id = next(iter(output_dict))
+        out, cav = output_dict[cav_id], data_dict[cav_id]
+        cls = out["cls_preds"] if "cls_preds" in out else out["psm"]
+        reg = out["reg_preds"] if "reg_preds" in out else out["rm"]
+        dirp = out.get("dir_preds", out.get("dm"))
+        if not cls.is_cuda:
+            raise RuntimeError("VoxelPostprocessor.post_process runs on the GPU (libqv2x): the head maps must be CUDA tensors")
+        if cls.shape[0] != 1 or cls.shape[1] != self.anchor_num:
+            raise ValueError(f"cls_preds {tuple(cls.shape)}: batch 1 and {self.anchor_num} anchors per cell expected")
+        lib = load()
+        dev = cls.device
+        h, w = int(cls.shape[2]), int(cls.shape[3])
+        anchors = cav["anchor_box"]
+        if self._anchors_dev is None or self._anchors_dev[0] is not anchors:
+            a32 = torch.as_tensor(np.asarray(anchors.cpu() if torch.is_tensor(anchors) else anchors)).to(torch.float32)
+            if tuple(a32.shape) != (h, w, self.anchor_num, 7):
+                raise ValueError(f"anchor_box {tuple(a32.shape)} does not match the head maps ({h}, {w}, {self.anchor_num}, 7)")
+            self._anchors_dev = (anchors, a32.reshape(-1, 7).contiguous().to(dev))
+        d = PostprocessDesc()
+        d.h, d.w, d.anchors_per_cell = h, w, self.anchor_num
+        d.num_bins = int(self.params["dir_args"]["num_bins"]) if dirp is not None else 0
+        d.score_threshold = float(self.params["target_args"]["score_threshold"])
+        d.nms_threshold = float(self.params["nms_thresh"])
+        d.dir_offset = float(self.params["dir_args"]["dir_offset"]) if dirp is not None else 0.0
+        for i, v in enumerate(self.params["gt_range"]):
+            d.range[i] = float(v)
+        t = cav["transformation_matrix"]
+        t = np.asarray(t.detach().cpu() if torch.is_tensor(t) else t, dtype=np.float32).reshape(16)
+        for i in range(16):
+            d.transform[i] = float(t[i])
+        d.max_boxes = max_boxes
+        need = lib.qv2x_postprocess_workspace_bytes(C.byref(d))
+        if need < 0:
+            check(-1, "qv2x_postprocess_workspace_bytes")
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        corners = torch.empty((max_boxes, 8, 3), dtype=torch.float32, device=dev)
+        scores = torch.empty((max_boxes,), dtype=torch.float32, device=dev)
+        count = torch.zeros((1,), dtype=torch.int32, device=dev)
+        f32 = lambda x: x.to(torch.float32).contiguous()
+        cls, reg = f32(cls), f32(reg)
+        dirp = f32(dirp) if dirp is not None else None
+        check(lib.qv2x_postprocess_f32(C.byref(d), ptr(cls), ptr(reg), ptr(dirp), ptr(self._anchors_dev[1]), ptr(self._ws), need,
+                                       ptr(corners), ptr(scores), ptr(count), current_stream()), "qv2x_postprocess_f32")
+        k = int(count.item())                            # the one host synchronisation of the frame (the reference goes to numpy here)
+        if k == 0:
+            return None, None
+        return corners[:k], scores[:k]

@@ -346,8 +346,54 @@ def gen_codebook():
     print("codebook.npz", {k: v.shape for k, v in out.items()})
 
 
+def gen_postprocess():
+    """f2: VoxelPostprocessor.post_process (voxel_postprocessor.py:245-405) on random head maps.  shapely is absent here, so
+    the reference's flow is run with ``nms_rotated`` replaced by "keep everything, in score order": every step but the
+    polygon IoU itself is the reference's own code (anchors, sigmoid, delta_to_boxes3d, threshold, direction fix,
+    corners, projection, size / z filters, range mask)."""
+    import types
+    stub = types.ModuleType("opencood.utils.box_overlaps"); stub.bbox_overlaps = lambda *a, **k: None
+    sys.modules.setdefault("opencood.utils.box_overlaps", stub)
+    from opencood.data_utils.post_processor.voxel_postprocessor import VoxelPostprocessor
+    from opencood.utils import box_utils
+    rng = np.random.default_rng(11)
+    lidar = [-12.8, -6.4, -3.0, 12.8, 6.4, 1.0]
+    params = {"core_method": "VoxelPostprocessor", "gt_range": lidar, "order": "hwl", "max_num": 100, "nms_thresh": 0.15,
+              "anchor_args": {"cav_lidar_range": lidar, "l": 3.9, "w": 1.6, "h": 1.56, "r": [0, 90], "feature_stride": 2, "num": 2,
+                              "vw": 0.4, "vh": 0.4, "vd": 4.0, "W": 64, "H": 32, "D": 1},
+              "target_args": {"pos_threshold": 0.6, "neg_threshold": 0.45, "score_threshold": 0.2},
+              "dir_args": {"dir_offset": 0.7853, "num_bins": 2, "anchor_yaw": [0, 90]}}
+    pp = VoxelPostprocessor(params, train=False)
+    anchors = pp.generate_anchor_box()                      # [H/2, W/2, 2, 7] float64
+    h, w = anchors.shape[:2]
+    cls = rng.normal(-3.0, 1.6, size=(1, 2, h, w)).astype(np.float32)
+    reg = rng.normal(0.0, 0.25, size=(1, 14, h, w)).astype(np.float32)
+    reg[:, 2::7] = rng.normal(0.0, 0.1, size=(1, 2, h, w))  # keep z inside [-3, 1] for most boxes
+    dirp = rng.normal(0.0, 1.0, size=(1, 4, h, w)).astype(np.float32)
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = np.array([[np.cos(0.2), -np.sin(0.2), 0], [np.sin(0.2), np.cos(0.2), 0], [0, 0, 1]], dtype=np.float32)
+    T[:3, 3] = [0.7, -0.4, 0.05]
+    out = {"anchors": anchors, "cls": cls, "reg": reg, "dir": dirp, "T": T,
+           "score_threshold": np.float64(0.2), "dir_offset": np.float64(0.7853), "lidar_range": np.array(lidar)}
+    box3d = VoxelPostprocessor.delta_to_boxes3d(torch.from_numpy(reg), torch.from_numpy(anchors))
+    out["delta_to_boxes3d"] = np32(box3d)
+    keep_all = lambda boxes, scores, thr: np.argsort(-scores.cpu().numpy(), kind="stable").astype(np.int32)
+    orig = box_utils.nms_rotated
+    box_utils.nms_rotated = keep_all
+    try:
+        for tag, tm in (("ident", np.eye(4, dtype=np.float32)), ("moved", T)):
+            data = {"ego": {"transformation_matrix": torch.from_numpy(tm), "anchor_box": torch.from_numpy(anchors)}}
+            od = {"ego": {"cls_preds": torch.from_numpy(cls.copy()), "reg_preds": torch.from_numpy(reg.copy()), "dir_preds": torch.from_numpy(dirp.copy())}}
+            boxes, scores = pp.post_process(data, od)
+            out[f"{tag}_boxes"], out[f"{tag}_scores"] = np32(boxes), np32(scores)
+    finally:
+        box_utils.nms_rotated = orig
+    np.savez_compressed(os.path.join(HERE, "postprocess.npz"), **out)
+    print("postprocess.npz", {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["fp32", "w8a8", "uaq", "geometry", "codebook"]
+    which = sys.argv[1:] or ["fp32", "w8a8", "uaq", "geometry", "codebook", "postprocess"]
     with torch.no_grad():
         pass
     if "fp32" in which: gen_fp32()
@@ -355,3 +401,4 @@ if __name__ == "__main__":
     if "uaq" in which: gen_uaq_units()
     if "geometry" in which: gen_geometry()
     if "codebook" in which: gen_codebook()
+    if "postprocess" in which: gen_postprocess()
