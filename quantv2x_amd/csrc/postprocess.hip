@@ -155,7 +155,14 @@ __global__ __launch_bounds__(256) void pp_iou_kernel(const PPArgs p) {
         if (vi && j > i && j < n && p.key_out[j] != 0u) {
             double qj[4][2];
             load_quad(p, j, qj);
-            const double inter = quad_inter_area(qi, qj);
+            double ix0 = qi[0][0], ix1 = qi[0][0], iy0 = qi[0][1], iy1 = qi[0][1], jx0 = qj[0][0], jx1 = qj[0][0], jy0 = qj[0][1], jy1 = qj[0][1];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                ix0 = fmin(ix0, qi[k][0]); ix1 = fmax(ix1, qi[k][0]); iy0 = fmin(iy0, qi[k][1]); iy1 = fmax(iy1, qi[k][1]);
+                jx0 = fmin(jx0, qj[k][0]); jx1 = fmax(jx1, qj[k][0]); jy0 = fmin(jy0, qj[k][1]); jy1 = fmax(jy1, qj[k][1]);
+            }
+            const bool apart = ix1 < jx0 || jx1 < ix0 || iy1 < jy0 || jy1 < iy0;     // disjoint bounding boxes: intersection 0
+            const double inter = apart ? 0.0 : quad_inter_area(qi, qj);
             const double uni = ai + quad_area(qj) - inter;
             sup = uni > 0.0 && inter / uni > (double)p.nms_thr;
         }
