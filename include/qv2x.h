@@ -182,26 +182,36 @@ int qv2x_decode_heads_f32(const uint8_t* codes, int R, int hw, int levels, int k
                           int cout, int cout_pad, const float* w, const float* bias, const float* da, const float* za,
                           float* out, void* stream);
 
-/* f2.  Head maps -> boxes for one CAV: VoxelPostprocessor.post_process (data_utils/post_processor/voxel_postprocessor.py:
- * 245-405; anchor-based, one class): sigmoid + score threshold, delta_to_boxes3d (:408-453), direction-bin fix
- * (:316-331), corners (utils/box_utils.py:152-204), projection by `transform` (:278-316), remove_large_pred_bbx /
- * remove_bbx_abnormal_z (:916-966), rotated NMS on the bottom faces over the `max_boxes` best scores (:769-814; the
- * reference takes 1000), range mask on all corners (:384-421).
- *   cls f32 [A][H][W], reg f32 [7A][H][W], dir f32 [num_bins*A][H][W] (NULL with num_bins == 0),
- *   anchors f32 [H*W*A][7] = (x, y, z, h, w, l, yaw), the reference's generate_anchor_box in (h, w, a) order;
- *   out_corners f32 [max_boxes][8][3], out_scores f32 [max_boxes], out_count i32 [1] (device): boxes in descending score
- *   order.  Deterministic: candidates keep the (h, w, a) order, equal scores keep it through the stable sort. */
+/* f2.  Head maps -> boxes for one CAV.
+ * num_classes == 1: VoxelPostprocessor.post_process (data_utils/post_processor/voxel_postprocessor.py:245-405):
+ *   sigmoid + score threshold, delta_to_boxes3d (:408-453), direction-bin fix (:316-331), corners
+ *   (utils/box_utils.py:152-204), projection by `transform` (:278-316), remove_large_pred_bbx / remove_bbx_abnormal_z
+ *   (:916-966: max_extent 6, z in [-3, 1]), rotated NMS on the bottom faces over the `max_boxes` best scores (:769-814;
+ *   the reference takes 1000), range mask on all corners (:384-421).
+ * num_classes  > 1: VoxelPostprocessor3Heads.post_process (voxel_postprocessor_3heads.py:318-478): `anchors_per_cell`
+ *   counts every anchor of a cell over all anchor sets, the score is the largest of the `num_classes` class
+ *   probabilities of an anchor and the label its index + 1 (:362-373), no direction fix (num_bins = 0), the size / z
+ *   limits of utils/box_utils_mc.py (max_extent 100, z in [-100, 100]) and its x-y-only range mask (:388-419,
+ *   range_xy_only = 1, range = the reference's GT_RANGE).
+ *   cls f32 [A*num_classes][H][W], reg f32 [7A][H][W], dir f32 [num_bins*A][H][W] (NULL with num_bins == 0),
+ *   anchors f32 [H*W*A][7] = (x, y, z, h, w, l, yaw) in (h, w, a) order;
+ *   out_corners f32 [max_boxes][8][3], out_scores f32 [max_boxes], out_labels i32 [max_boxes] (may be NULL),
+ *   out_count i32 [1] (device): boxes in descending score order.
+ * Deterministic: candidates keep the (h, w, a) order, equal scores keep it through the stable sort. */
 typedef struct {
     int32_t h, w, anchors_per_cell, num_bins;
     float score_threshold, nms_threshold, dir_offset;
-    float range[6];                 /* x0, y0, z0, x1, y1, z1 of gt_range */
+    float range[6];                 /* x0, y0, z0, x1, y1, z1 */
     float transform[16];            /* row-major 4x4, CAV -> ego */
     int32_t max_boxes;              /* 1..1024 */
+    int32_t num_classes;            /* 1..8 */
+    int32_t range_xy_only;
+    float max_extent, z_min, z_max;
 } qv2x_postprocess_desc;
 int64_t qv2x_postprocess_workspace_bytes(const qv2x_postprocess_desc* desc /* host */);
 int qv2x_postprocess_f32(const qv2x_postprocess_desc* desc /* host */, const float* cls, const float* reg, const float* dir,
                          const float* anchors, void* workspace, int64_t workspace_bytes, float* out_corners,
-                         float* out_scores, int32_t* out_count, void* stream);
+                         float* out_scores, int32_t* out_labels, int32_t* out_count, void* stream);
 
 #ifdef __cplusplus
 }

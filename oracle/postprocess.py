@@ -1,4 +1,4 @@
-"""CPU restatement of the single-class post-processing -- TEST INFRASTRUCTURE ONLY.
+"""CPU restatement of the anchor-head post-processing -- TEST INFRASTRUCTURE ONLY.
 
 Follows ``VoxelPostprocessor.post_process`` (opencood/data_utils/post_processor/voxel_postprocessor.py:245-405) for
 one CAV (intermediate fusion: ``data_dict`` holds the ego only):
@@ -42,6 +42,35 @@ def generate_anchor_box(lidar_range, grid_w, grid_h, vw, vh, l=3.9, w=1.6, h=1.5
     for i in range(a):
         r_[..., i] = r[i]
     return np.stack([cx, cy, cz, np.ones_like(cx) * h, np.ones_like(cx) * w, np.ones_like(cx) * l, r_], axis=-1)
+
+
+def generate_anchor_boxes_3heads(lidar_range, grid_w, grid_h, configs, order="hwl"):
+    """VoxelPostprocessor3Heads.generate_anchor_box (voxel_postprocessor_3heads.py:63-132): one [H', W', R, 7] array per
+    anchor set (class), and the anchors per location of each set."""
+    out, per_loc = [], []
+    for cfg in configs:
+        gs = np.array([grid_w, grid_h]) // cfg["feature_map_stride"]
+        size, rot, height = cfg["anchor_sizes"], cfg["anchor_rotations"], cfg["anchor_bottom_heights"]
+        per_loc.append(len(rot) * len(size) * len(height))
+        if cfg.get("align_center", False):
+            xs, ys = (lidar_range[3] - lidar_range[0]) / gs[0], (lidar_range[4] - lidar_range[1]) / gs[1]
+            xo, yo = xs / 2, ys / 2
+        else:
+            xs, ys = (lidar_range[3] - lidar_range[0]) / (gs[0] - 1), (lidar_range[4] - lidar_range[1]) / (gs[1] - 1)
+            xo, yo = 0, 0
+        x = np.arange(lidar_range[0] + xo, lidar_range[3] + 1e-5, step=xs)
+        y = np.arange(lidar_range[1] + yo, lidar_range[4] + 1e-5, step=ys)
+        z = np.array(height)
+        rot, size = np.array(rot), np.array(size)
+        xg, yg, zg = np.meshgrid(x, y, z)
+        a = np.concatenate([xg, yg, zg], axis=-1)
+        sz = np.tile(size.reshape(1, -1, 3), (*a.shape[0:2], 1))
+        sz = sz[..., [2, 1, 0]] if order == "hwl" else sz[..., [0, 2, 1]]
+        a = np.concatenate((a, sz), axis=-1)
+        a = np.tile(a[:, :, None, :], (1, 1, len(rot), 1))
+        r = np.tile(rot.reshape(1, 1, -1, 1), (*a.shape[0:2], len(size), 1))
+        out.append(np.concatenate([a, r], axis=-1))
+    return out, per_loc
 
 
 def sigmoid(x):
@@ -147,29 +176,45 @@ def nms_rotated(corners, scores, thresh, top=1000):
 
 
 def post_process(cls, reg, dirp, anchors, t, lidar_range, score_threshold=0.2, nms_thresh=0.15, dir_offset=0.7853,
-                 num_bins=2, nms=True):
-    """-> (corners f32 [K, 8, 3], scores f32 [K]) in descending score order; ``nms=False`` keeps every filtered box."""
-    prob = sigmoid(np.transpose(cls, (0, 2, 3, 1))).reshape(-1)
+                 num_bins=2, nms=True, num_classes=1, max_extent=6.0, z_lim=(-3.0, 1.0), range_xy_only=False, return_labels=False):
+    """-> (corners f32 [K, 8, 3], scores f32 [K]) in descending score order; ``nms=False`` keeps every filtered box.
+
+    ``num_classes > 1`` is VoxelPostprocessor3Heads.post_process (voxel_postprocessor_3heads.py:318-478): ``anchors`` is
+    then [H, W, A_all, 7] with the anchor sets already interleaved per cell ((h, w, class set, rotation) order, :354-358),
+    the score the largest class probability, no direction fix; box_utils_mc's limits are ``max_extent=100``,
+    ``z_lim=(-100, 100)``, ``range_xy_only=True`` with ``lidar_range`` = GT_RANGE."""
+    if num_classes == 1:
+        prob = sigmoid(np.transpose(cls, (0, 2, 3, 1))).reshape(-1)
+        labels = np.ones(prob.shape, np.int64)
+    else:
+        pk = sigmoid(np.transpose(cls, (0, 2, 3, 1))).reshape(-1, num_classes)
+        prob, labels = pk.max(axis=-1), pk.argmax(axis=-1) + 1
     boxes = delta_to_boxes3d(reg, anchors)
     mask = prob > F(score_threshold)
-    boxes, scores = boxes[mask], prob[mask]
+    boxes, scores, labels = boxes[mask], prob[mask], labels[mask]
+    empty = (np.zeros((0, 8, 3), F), np.zeros((0,), F)) + ((np.zeros((0,), np.int64),) if return_labels else ())
     if boxes.shape[0] == 0:
-        return np.zeros((0, 8, 3), F), np.zeros((0,), F)
+        return empty
     if dirp is not None:
         dm = np.transpose(dirp, (0, 2, 3, 1)).reshape(-1, num_bins)[mask]
-        labels = np.argmax(dm, axis=-1).astype(F)
+        dl = np.argmax(dm, axis=-1).astype(F)
         period = 2 * np.pi / num_bins
         rot = limit_period(boxes[:, 6] - F(dir_offset), 0.0, period)
-        boxes[:, 6] = rot + F(dir_offset) + F(period) * labels
+        boxes[:, 6] = rot + F(dir_offset) + F(period) * dl
         boxes[:, 6] = limit_period(boxes[:, 6], 0.5, 2 * np.pi)
     corners = project_box3d(boxes_to_corners_3d(boxes), t)
     xl = corners[:, :, 0].max(1) - corners[:, :, 0].min(1)
     yl = corners[:, :, 1].max(1) - corners[:, :, 1].min(1)
-    keep = (xl <= 6) & (yl <= 6) & (yl != 0)                       # remove_large_pred_bbx, quirk kept
-    keep &= (corners[:, :, 2].min(1) >= -3) & (corners[:, :, 2].max(1) <= 1)
-    corners, scores = corners[keep], scores[keep]
+    keep = (xl <= max_extent) & (yl <= max_extent) & (yl != 0)     # remove_large_pred_bbx, quirk kept
+    keep &= (corners[:, :, 2].min(1) >= z_lim[0]) & (corners[:, :, 2].max(1) <= z_lim[1])
+    corners, scores, labels = corners[keep], scores[keep], labels[keep]
     idx = nms_rotated(corners, scores, nms_thresh) if nms else np.argsort(-scores, kind="stable")
-    corners, scores = corners[idx], scores[idx]
+    corners, scores, labels = corners[idx], scores[idx], labels[idx]
     lo, hi = np.asarray(lidar_range[:3], F), np.asarray(lidar_range[3:], F)
-    inside = ((corners >= lo) & (corners <= hi)).all(axis=2).sum(axis=1) >= 8
+    if range_xy_only:
+        inside = ((corners[:, :, :2] >= lo[:2]) & (corners[:, :, :2] <= hi[:2])).all(axis=2).all(axis=1)
+    else:
+        inside = ((corners >= lo) & (corners <= hi)).all(axis=2).sum(axis=1) >= 8
+    if return_labels:
+        return corners[inside], scores[inside], labels[inside]
     return corners[inside], scores[inside]

@@ -23,21 +23,30 @@ constexpr int TOPK_MAX = 1024;                       // bit-matrix row = 16 x u6
 
 struct PPArgs {
     const float* cls; const float* reg; const float* dir; const float* anchors;
-    int h, w, a, na, num_bins, topk;
-    float thr, nms_thr, dir_offset;
+    int h, w, a, na, num_bins, topk, ncls, xy_only;
+    float thr, nms_thr, dir_offset, max_extent, z_lo, z_hi;
     float range[6], t[16];
     // workspace
     float* prob; int* flag; int* pos; float* cand_corners; float* cand_score; unsigned* key_in; unsigned* key_out;
     int* idx_in; int* idx_out; unsigned long long* mask;
-    float* out_corners; float* out_scores; int* out_count;
+    int* label; int* cand_label;
+    float* out_corners; float* out_scores; int* out_labels; int* out_count;
 };
 
 __global__ void pp_score_kernel(const PPArgs p) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;          // anchor index in (h, w, a) order
     if (i >= p.na) return;
     const int a = i % p.a, cell = i / p.a;
-    const float x = p.cls[(size_t)a * p.h * p.w + cell];
-    const float s = 1.0f / (1.0f + expf(-x));
+    const size_t hw = (size_t)p.h * p.w;
+    // one score class: the anchor's logit; several (voxel_postprocessor_3heads.py:362-373): channel a * ncls + k, the score is
+    // the largest class probability (first one on ties), the label its index + 1
+    float s = 1.0f / (1.0f + expf(-p.cls[(size_t)(a * p.ncls) * hw + cell]));
+    int lab = 1;
+    for (int k = 1; k < p.ncls; ++k) {
+        const float v = 1.0f / (1.0f + expf(-p.cls[(size_t)(a * p.ncls + k) * hw + cell]));
+        if (v > s) { s = v; lab = k + 1; }
+    }
+    p.label[i] = lab;
     p.prob[i] = s;
     p.flag[i] = s > p.thr ? 1 : 0;
     p.key_in[i] = 0u;                                              // slots past the candidates sort last
@@ -91,9 +100,10 @@ __global__ void pp_decode_kernel(const PPArgs p) {
         zmin = fminf(zmin, pz); zmax = fmaxf(zmax, pz);
     }
     const float xl = xmax - xmin, yl = ymax - ymin;
-    const bool keep = xl <= 6.0f && yl <= 6.0f && yl != 0.0f && zmin >= -3.0f && zmax <= 1.0f;
+    const bool keep = xl <= p.max_extent && yl <= p.max_extent && yl != 0.0f && zmin >= p.z_lo && zmax <= p.z_hi;
     const float s = p.prob[i];
     p.cand_score[c] = s;
+    p.cand_label[c] = p.label[i];
     p.key_in[c] = keep ? __builtin_bit_cast(unsigned, s) : 0u;     // positive floats order like their bit patterns
 }
 
@@ -202,8 +212,8 @@ __global__ __launch_bounds__(256) void pp_sweep_kernel(const PPArgs p) {
         const float* c = p.cand_corners + (size_t)p.idx_out[picked[t]] * 24;
         bool in = true;
         for (int k = 0; k < 8; ++k)
-            in = in && c[k * 3] >= p.range[0] && c[k * 3 + 1] >= p.range[1] && c[k * 3 + 2] >= p.range[2] &&
-                 c[k * 3] <= p.range[3] && c[k * 3 + 1] <= p.range[4] && c[k * 3 + 2] <= p.range[5];
+            in = in && c[k * 3] >= p.range[0] && c[k * 3 + 1] >= p.range[1] && c[k * 3] <= p.range[3] && c[k * 3 + 1] <= p.range[4] &&
+                 (p.xy_only || (c[k * 3 + 2] >= p.range[2] && c[k * 3 + 2] <= p.range[5]));
         inside[t] = in ? 1 : 0;
     }
     __syncthreads();
@@ -219,11 +229,12 @@ __global__ __launch_bounds__(256) void pp_sweep_kernel(const PPArgs p) {
         const int cand = p.idx_out[picked[t]];
         for (int k = 0; k < 24; ++k) p.out_corners[(size_t)o * 24 + k] = p.cand_corners[(size_t)cand * 24 + k];
         p.out_scores[o] = p.cand_score[cand];
+        if (p.out_labels) p.out_labels[o] = p.cand_label[cand];
     }
 }
 
 struct Layout {
-    size_t prob, flag, pos, corners, score, key_in, key_out, idx_in, idx_out, mask, cub, cub_bytes, total;
+    size_t prob, flag, pos, corners, score, key_in, key_out, idx_in, idx_out, mask, label, cand_label, cub, cub_bytes, total;
 };
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -236,6 +247,7 @@ Layout layout(int na) {
     l.corners = take((size_t)na * 96); l.score = take((size_t)na * 4);
     l.key_in = take((size_t)na * 4); l.key_out = take((size_t)na * 4); l.idx_in = take((size_t)na * 4); l.idx_out = take((size_t)na * 4);
     l.mask = take((size_t)TOPK_MAX * (TOPK_MAX / 64) * 8);
+    l.label = take((size_t)na * 4); l.cand_label = take((size_t)na * 4);
     size_t a = 0, b = 0;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, a, (int*)nullptr, (int*)nullptr, na);
     (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, b, (unsigned*)nullptr, (unsigned*)nullptr, (int*)nullptr, (int*)nullptr, na, 0, 32);
@@ -248,6 +260,8 @@ Layout layout(int na) {
 int check_desc(const qv2x_postprocess_desc* d, const char* who) {
     if (!d) return fail(QV2X_EINVAL, "%s: null descriptor", who);
     if (d->h <= 0 || d->w <= 0 || d->anchors_per_cell <= 0 || d->anchors_per_cell > 16) return fail(QV2X_EINVAL, "%s: bad head map shape", who);
+    if (d->num_classes < 1 || d->num_classes > 8) return fail(QV2X_EINVAL, "%s: num_classes in 1..8", who);
+    if (!(d->max_extent > 0.0f) || !(d->z_max > d->z_min)) return fail(QV2X_EINVAL, "%s: max_extent > 0 and z_max > z_min", who);
     if (d->num_bins < 0 || d->num_bins > 8) return fail(QV2X_EINVAL, "%s: num_bins in 0..8", who);
     if (d->max_boxes < 1 || d->max_boxes > TOPK_MAX) return fail(QV2X_EINVAL, "%s: max_boxes in 1..%d", who, TOPK_MAX);
     if (!(d->score_threshold > 0.0f)) return fail(QV2X_EINVAL, "%s: score_threshold must be positive (scores are ordered by their bit patterns)", who);
@@ -266,7 +280,7 @@ extern "C" int64_t qv2x_postprocess_workspace_bytes(const qv2x_postprocess_desc*
 
 extern "C" int qv2x_postprocess_f32(const qv2x_postprocess_desc* d, const float* cls, const float* reg, const float* dir,
                                     const float* anchors, void* workspace, int64_t workspace_bytes, float* out_corners,
-                                    float* out_scores, int32_t* out_count, void* stream) {
+                                    float* out_scores, int32_t* out_labels, int32_t* out_count, void* stream) {
     using namespace qv2x;
     if (int rc = check_desc(d, "qv2x_postprocess_f32")) return rc;
     if (!cls || !reg || !anchors || !workspace || !out_corners || !out_scores || !out_count) return fail(QV2X_EINVAL, "qv2x_postprocess_f32: null pointer");
@@ -281,13 +295,15 @@ extern "C" int qv2x_postprocess_f32(const qv2x_postprocess_desc* d, const float*
     p.h = d->h; p.w = d->w; p.a = d->anchors_per_cell; p.na = na; p.num_bins = d->num_bins;
     p.topk = d->max_boxes < na ? d->max_boxes : na;
     p.thr = d->score_threshold; p.nms_thr = d->nms_threshold; p.dir_offset = d->dir_offset;
+    p.ncls = d->num_classes; p.xy_only = d->range_xy_only; p.max_extent = d->max_extent; p.z_lo = d->z_min; p.z_hi = d->z_max;
     for (int i = 0; i < 6; ++i) p.range[i] = d->range[i];
     for (int i = 0; i < 16; ++i) p.t[i] = d->transform[i];
     p.prob = (float*)(ws + l.prob); p.flag = (int*)(ws + l.flag); p.pos = (int*)(ws + l.pos);
     p.cand_corners = (float*)(ws + l.corners); p.cand_score = (float*)(ws + l.score);
     p.key_in = (unsigned*)(ws + l.key_in); p.key_out = (unsigned*)(ws + l.key_out);
     p.idx_in = (int*)(ws + l.idx_in); p.idx_out = (int*)(ws + l.idx_out); p.mask = (unsigned long long*)(ws + l.mask);
-    p.out_corners = out_corners; p.out_scores = out_scores; p.out_count = out_count;
+    p.label = (int*)(ws + l.label); p.cand_label = (int*)(ws + l.cand_label);
+    p.out_corners = out_corners; p.out_scores = out_scores; p.out_labels = out_labels; p.out_count = out_count;
     hipStream_t st = (hipStream_t)stream;
     const int blocks = (na + 255) / 256;
     int rc;

@@ -58,7 +58,9 @@ class FuseDesc(C.Structure):
 class PostprocessDesc(C.Structure):
     _fields_ = [("h", C.c_int32), ("w", C.c_int32), ("anchors_per_cell", C.c_int32), ("num_bins", C.c_int32),
                 ("score_threshold", C.c_float), ("nms_threshold", C.c_float), ("dir_offset", C.c_float),
-                ("range", C.c_float * 6), ("transform", C.c_float * 16), ("max_boxes", C.c_int32)]
+                ("range", C.c_float * 6), ("transform", C.c_float * 16), ("max_boxes", C.c_int32),
+                ("num_classes", C.c_int32), ("range_xy_only", C.c_int32),
+                ("max_extent", C.c_float), ("z_min", C.c_float), ("z_max", C.c_float)]
 
 
 class Qv2xError(RuntimeError):
@@ -104,7 +106,7 @@ def load() -> C.CDLL:
                                       vp, C.c_int64, vp, vp, vp, vp, vp]
     lib.qv2x_postprocess_workspace_bytes.argtypes = [C.POINTER(PostprocessDesc)]
     lib.qv2x_postprocess_workspace_bytes.restype = C.c_int64
-    lib.qv2x_postprocess_f32.argtypes = [C.POINTER(PostprocessDesc), vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp]
+    lib.qv2x_postprocess_f32.argtypes = [C.POINTER(PostprocessDesc), vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp]
     for s in SYMBOLS:
         if s not in ("qv2x_last_error", "qv2x_codebook_level_floats", "qv2x_voxelize_workspace_bytes", "qv2x_postprocess_workspace_bytes"):
             getattr(lib, s).restype = C.c_int

@@ -25,6 +25,45 @@ def load_point_pillar_anchor_args(hypes: dict) -> dict:
     return hypes
 
 
+def gpu_post_process(owner, cls, reg, dirp, anchors_dev, transformation_matrix, *, anchors_per_cell, num_classes, num_bins, dir_offset,
+                     rng, range_xy_only, max_extent, z_lim, max_boxes):
+    """One ``qv2x_postprocess_f32`` call; ``owner`` keeps the workspace between frames.  -> (corners [K, 8, 3], scores [K],
+    labels i32 [K]) on the GPU, or (None, None, None)."""
+    lib = load()
+    dev = cls.device
+    d = PostprocessDesc()
+    d.h, d.w, d.anchors_per_cell, d.num_bins = int(cls.shape[2]), int(cls.shape[3]), anchors_per_cell, num_bins
+    d.score_threshold = float(owner.params["target_args"]["score_threshold"])
+    d.nms_threshold = float(owner.params["nms_thresh"])
+    d.dir_offset = dir_offset
+    for i, v in enumerate(rng):
+        d.range[i] = float(v)
+    t = transformation_matrix
+    t = np.asarray(t.detach().cpu() if torch.is_tensor(t) else t, dtype=np.float32).reshape(16)
+    for i in range(16):
+        d.transform[i] = float(t[i])
+    d.max_boxes, d.num_classes, d.range_xy_only = max_boxes, num_classes, int(range_xy_only)
+    d.max_extent, d.z_min, d.z_max = max_extent, z_lim[0], z_lim[1]
+    need = lib.qv2x_postprocess_workspace_bytes(C.byref(d))
+    if need < 0:
+        check(-1, "qv2x_postprocess_workspace_bytes")
+    if owner._ws is None or owner._ws.numel() < need or owner._ws.device != dev:
+        owner._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    corners = torch.empty((max_boxes, 8, 3), dtype=torch.float32, device=dev)
+    scores = torch.empty((max_boxes,), dtype=torch.float32, device=dev)
+    labels = torch.empty((max_boxes,), dtype=torch.int32, device=dev)
+    count = torch.zeros((1,), dtype=torch.int32, device=dev)
+    f32 = lambda x: x.to(torch.float32).contiguous()
+    cls, reg = f32(cls), f32(reg)
+    dirp = f32(dirp) if dirp is not None and num_bins > 0 else None
+    check(lib.qv2x_postprocess_f32(C.byref(d), ptr(cls), ptr(reg), ptr(dirp), ptr(anchors_dev), ptr(owner._ws), need,
+                                   ptr(corners), ptr(scores), ptr(labels), ptr(count), current_stream()), "qv2x_postprocess_f32")
+    k = int(count.item())                            # the one host synchronisation of the frame (the reference goes to numpy here)
+    if k == 0:
+        return None, None, None
+    return corners[:k], scores[:k], labels[:k]
+
+
 class VoxelPostprocessor:
     def __init__(self, anchor_params, train):
         self.params = anchor_params
@@ -72,42 +111,16 @@ class VoxelPostprocessor:
             raise RuntimeError("VoxelPostprocessor.post_process runs on the GPU (libqv2x): the head maps must be CUDA tensors")
         if cls.shape[0] != 1 or cls.shape[1] != self.anchor_num:
             raise ValueError(f"cls_preds {tuple(cls.shape)}: batch 1 and {self.anchor_num} anchors per cell expected")
-        lib = load()
-        dev = cls.device
         h, w = int(cls.shape[2]), int(cls.shape[3])
         anchors = cav["anchor_box"]
         if self._anchors_dev is None or self._anchors_dev[0] is not anchors:
             a32 = torch.as_tensor(np.asarray(anchors.cpu() if torch.is_tensor(anchors) else anchors)).to(torch.float32)
             if tuple(a32.shape) != (h, w, self.anchor_num, 7):
                 raise ValueError(f"anchor_box {tuple(a32.shape)} does not match the head maps ({h}, {w}, {self.anchor_num}, 7)")
-            self._anchors_dev = (anchors, a32.reshape(-1, 7).contiguous().to(dev))
-        d = PostprocessDesc()
-        d.h, d.w, d.anchors_per_cell = h, w, self.anchor_num
-        d.num_bins = int(self.params["dir_args"]["num_bins"]) if dirp is not None else 0
-        d.score_threshold = float(self.params["target_args"]["score_threshold"])
-        d.nms_threshold = float(self.params["nms_thresh"])
-        d.dir_offset = float(self.params["dir_args"]["dir_offset"]) if dirp is not None else 0.0
-        for i, v in enumerate(self.params["gt_range"]):
-            d.range[i] = float(v)
-        t = cav["transformation_matrix"]
-        t = np.asarray(t.detach().cpu() if torch.is_tensor(t) else t, dtype=np.float32).reshape(16)
-        for i in range(16):
-            d.transform[i] = float(t[i])
-        d.max_boxes = max_boxes
-        need = lib.qv2x_postprocess_workspace_bytes(C.byref(d))
-        if need < 0:
-            check(-1, "qv2x_postprocess_workspace_bytes")
-        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
-        corners = torch.empty((max_boxes, 8, 3), dtype=torch.float32, device=dev)
-        scores = torch.empty((max_boxes,), dtype=torch.float32, device=dev)
-        count = torch.zeros((1,), dtype=torch.int32, device=dev)
-        f32 = lambda x: x.to(torch.float32).contiguous()
-        cls, reg = f32(cls), f32(reg)
-        dirp = f32(dirp) if dirp is not None else None
-        check(lib.qv2x_postprocess_f32(C.byref(d), ptr(cls), ptr(reg), ptr(dirp), ptr(self._anchors_dev[1]), ptr(self._ws), need,
-                                       ptr(corners), ptr(scores), ptr(count), current_stream()), "qv2x_postprocess_f32")
-        k = int(count.item())                            # the one host synchronisation of the frame (the reference goes to numpy here)
-        if k == 0:
-            return None, None
-        return corners[:k], scores[:k]
+            self._anchors_dev = (anchors, a32.reshape(-1, 7).contiguous().to(cls.device))
+        boxes, scores, _ = gpu_post_process(
+            self, cls, reg, dirp, self._anchors_dev[1], cav["transformation_matrix"], anchors_per_cell=self.anchor_num,
+            num_classes=1, num_bins=int(self.params["dir_args"]["num_bins"]) if dirp is not None else 0,
+            dir_offset=float(self.params["dir_args"]["dir_offset"]) if dirp is not None else 0.0,
+            rng=self.params["gt_range"], range_xy_only=False, max_extent=6.0, z_lim=(-3.0, 1.0), max_boxes=max_boxes)
+        return boxes, scores

@@ -392,8 +392,58 @@ def gen_postprocess():
     print("postprocess.npz", {k: getattr(v, "shape", v) for k, v in out.items()})
 
 
+def gen_postprocess_mc():
+    """f2, multi-class: VoxelPostprocessor3Heads.post_process (voxel_postprocessor_3heads.py:318-478), the V2X-Real yaml's
+    post-processor, with ``nms_rotated`` replaced as in gen_postprocess.  ``box_utils_mc`` reads GT_RANGE from the datasets
+    package (whose import pulls every dataset class): a module holding the same constant stands in for it."""
+    import types
+    stub = types.ModuleType("opencood.utils.box_overlaps"); stub.bbox_overlaps = lambda *a, **k: None
+    sys.modules.setdefault("opencood.utils.box_overlaps", stub)
+    import re
+    gt = eval(re.search(r"^GT_RANGE = (\[.*\])", open(os.path.join(_refimport.REF_ROOT, "opencood/data_utils/datasets/__init__.py")).read(), re.M).group(1))
+    ds = types.ModuleType("opencood.data_utils.datasets"); ds.GT_RANGE = gt
+    sys.modules.setdefault("opencood.data_utils.datasets", ds)
+    from opencood.data_utils.post_processor.voxel_postprocessor_3heads import VoxelPostprocessor3Heads
+    from opencood.utils import box_utils_mc
+    rng = np.random.default_rng(12)
+    lidar = [-12.8, -6.4, -3.0, 12.8, 6.4, 1.0]
+    cfgs = [dict(class_name=n, anchor_sizes=[sz], anchor_rotations=[0, 1.57], anchor_bottom_heights=[zb], align_center=True,
+                 feature_map_stride=2, matched_threshold=0.6, unmatched_threshold=0.45)
+            for n, sz, zb in (("vehicle", [3.9, 1.6, 1.56], -1.78), ("pedestrian", [0.8, 0.6, 1.73], -0.6), ("truck", [8, 3, 3], -1.78))]
+    params = {"core_method": "VoxelPostprocessor3Heads", "gt_range": lidar, "order": "hwl", "max_num": 150, "nms_thresh": 0.15,
+              "anchor_args": {"cav_lidar_range": lidar, "l": 3.9, "w": 1.6, "h": 1.56, "r": [0, 90], "feature_stride": 2, "num": 2,
+                              "vw": 0.4, "vh": 0.4, "vd": 4.0, "W": 64, "H": 32, "D": 1, "anchor_generator_config": cfgs},
+              "target_args": {"pos_threshold": 0.6, "neg_threshold": 0.45, "score_threshold": 0.2},
+              "dir_args": {"dir_offset": 0.7853, "num_bins": 2, "anchor_yaw": [0, 90]}}
+    pp = VoxelPostprocessor3Heads(params, train=False)
+    all_anchors, per_loc = pp.generate_anchor_box()
+    all_anchors = np.array(all_anchors)                       # [3, H', W', 2, 7], as the dataset collates it
+    _, h, w = all_anchors.shape[:3]
+    cls = rng.normal(-3.6, 1.7, size=(1, 18, h, w)).astype(np.float32)
+    reg = rng.normal(0.0, 0.25, size=(1, 42, h, w)).astype(np.float32)
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = np.array([[np.cos(-0.3), -np.sin(-0.3), 0], [np.sin(-0.3), np.cos(-0.3), 0], [0, 0, 1]], dtype=np.float32)
+    T[:3, 3] = [1.5, 0.6, -0.1]
+    out = {"all_anchors": all_anchors, "num_anchors_per_location": np.array(per_loc), "cls": cls, "reg": reg, "T": T,
+           "gt_range": np.array(gt, dtype=np.float64), "lidar_range": np.array(lidar)}
+    keep_all = lambda boxes, scores, thr: np.argsort(-scores.cpu().numpy(), kind="stable").astype(np.int32)
+    orig = box_utils_mc.nms_rotated
+    box_utils_mc.nms_rotated = keep_all
+    try:
+        for tag, tm in (("ident", np.eye(4, dtype=np.float32)), ("moved", T)):
+            data = {"ego": {"transformation_matrix": torch.from_numpy(tm), "all_anchors": torch.from_numpy(all_anchors),
+                            "num_anchors_per_location": per_loc}}
+            od = {"ego": {"cls_preds": torch.from_numpy(cls.copy()), "reg_preds": torch.from_numpy(reg.copy())}}
+            boxes, score_labels = pp.post_process(data, od)
+            out[f"{tag}_boxes"], out[f"{tag}_score_labels"] = np32(boxes), np32(score_labels)
+    finally:
+        box_utils_mc.nms_rotated = orig
+    np.savez_compressed(os.path.join(HERE, "postprocess_mc.npz"), **out)
+    print("postprocess_mc.npz", {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["fp32", "w8a8", "uaq", "geometry", "codebook", "postprocess"]
+    which = sys.argv[1:] or ["fp32", "w8a8", "uaq", "geometry", "codebook", "postprocess", "postprocess_mc"]
     with torch.no_grad():
         pass
     if "fp32" in which: gen_fp32()
@@ -402,3 +452,4 @@ if __name__ == "__main__":
     if "geometry" in which: gen_geometry()
     if "codebook" in which: gen_codebook()
     if "postprocess" in which: gen_postprocess()
+    if "postprocess_mc" in which: gen_postprocess_mc()

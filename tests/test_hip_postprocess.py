@@ -110,16 +110,77 @@ def test_errors():
     lib = L.load()
     d = L.PostprocessDesc()
     d.h, d.w, d.anchors_per_cell, d.max_boxes, d.score_threshold = 16, 32, 2, 5000, 0.2
+    d.num_classes, d.max_extent, d.z_min, d.z_max = 1, 6.0, -3.0, 1.0
     assert lib.qv2x_postprocess_workspace_bytes(C.byref(d)) == -1 and b"max_boxes" in lib.qv2x_last_error()
     d.max_boxes = 1000
     need = lib.qv2x_postprocess_workspace_bytes(C.byref(d))
     assert need > 0
     x = torch.zeros(1024, dtype=torch.float32, device="cuda")
-    rc = lib.qv2x_postprocess_f32(C.byref(d), L.ptr(x), L.ptr(x), None, L.ptr(x), L.ptr(x), 16, L.ptr(x), L.ptr(x), L.ptr(x), None)
+    rc = lib.qv2x_postprocess_f32(C.byref(d), L.ptr(x), L.ptr(x), None, L.ptr(x), L.ptr(x), 16, L.ptr(x), L.ptr(x), None, L.ptr(x), None)
     assert rc != 0 and b"workspace" in lib.qv2x_last_error()
     from quantv2x_amd.plugin.data_utils.post_processor import build_postprocessor
     with pytest.raises(NotImplementedError):
-        build_postprocessor({"core_method": "VoxelPostprocessor3Heads"}, train=False)
+        build_postprocessor({"core_method": "BevPostprocessor"}, train=False)
     pp = build_postprocessor(_params([-12.8, -6.4, -3.0, 12.8, 6.4, 1.0], 64, 32), train=False)
     with pytest.raises(RuntimeError):                                   # CPU tensors: no fallback
         pp.post_process({"ego": {}}, {"ego": {"cls_preds": torch.zeros(1, 2, 16, 32), "reg_preds": torch.zeros(1, 14, 16, 32)}})
+
+
+# ---- multi-class (VoxelPostprocessor3Heads) ------------------------------------------------------------------------------
+def _run_gpu_mc(params, cls, reg, all_anchors, t):
+    from quantv2x_amd.plugin.data_utils.post_processor import build_postprocessor
+    pp = build_postprocessor(params, train=False)
+    out = {"ego": {"cls_preds": torch.from_numpy(cls).cuda(), "reg_preds": torch.from_numpy(reg).cuda()}}
+    data = {"ego": {"transformation_matrix": torch.from_numpy(t), "all_anchors": torch.from_numpy(all_anchors), "num_anchors_per_location": [2, 2, 2]}}
+    boxes, sl = pp.post_process(data, out)
+    return (None, None) if boxes is None else (boxes.cpu().numpy(), sl.cpu().numpy())
+
+
+def _oracle_mc(cls, reg, all_anchors, t, gt_range):
+    from test_postprocess_oracle import interleave
+    return P.post_process(cls, reg, None, interleave(all_anchors), t, gt_range, num_classes=3, max_extent=100.0, z_lim=(-100.0, 100.0),
+                          range_xy_only=True, return_labels=True)
+
+
+@pytest.mark.parametrize("tag", ["ident", "moved"])
+def test_mc_golden_inputs_match_oracle(tag):
+    from test_postprocess_oracle import mc_params
+    with np.load(os.path.join(os.path.dirname(__file__), "golden", "postprocess_mc.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    t = np.eye(4, dtype=np.float32) if tag == "ident" else g["T"]
+    wb, ws, wl = _oracle_mc(g["cls"], g["reg"], g["all_anchors"], t, g["gt_range"])
+    gb, gsl = _run_gpu_mc(mc_params(g["lidar_range"], 64, 32), g["cls"], g["reg"], g["all_anchors"], t)
+    assert gb.shape == wb.shape and 0 < len(ws) < len(g[tag + "_boxes"])
+    np.testing.assert_array_equal(gsl[:, 1].astype(np.int64), wl)
+    np.testing.assert_allclose(gsl[:, 0], ws, **TOL)
+    np.testing.assert_allclose(gb, wb, **TOL)
+
+
+def test_mc_deployed_model_heads_to_boxes():
+    """The multi-class deployed model's own head maps (tiny shape, 3 agents) through the GPU post-processor == the oracle
+    post-processor on the same maps: the frame ends in boxes without leaving the GPU except for the box count."""
+    from _common import calibrated_plugin, scene_np
+    from test_postprocess_oracle import MC_CFGS, mc_params
+    from quantv2x_amd import synth
+    from quantv2x_amd.engine import deploy
+    from quantv2x_amd.ptq_state import export_ptq_state
+    eng = deploy(state=export_ptq_state(calibrated_plugin()))
+    out = eng(synth.scene_to_torch(scene_np(3), "cuda"))
+    lidar, vox = synth.SHAPES["tiny"][0], synth.SHAPES["tiny"][1]
+    gw, gh, _ = synth.grid_size(lidar, vox)
+    aa, _ = P.generate_anchor_boxes_3heads(lidar, gw, gh, MC_CFGS)
+    all_anchors = np.array(aa)
+    cls, reg = out["cls_preds"].cpu().numpy(), out["reg_preds"].cpu().numpy()
+    assert cls.shape[1] == 18 and reg.shape[1] == 42
+    t = np.eye(4, dtype=np.float32)
+    from quantv2x_amd.plugin.data_utils.post_processor import build_postprocessor
+    pp = build_postprocessor(mc_params(lidar, gw, gh), train=False)
+    data = {"ego": {"transformation_matrix": torch.from_numpy(t), "all_anchors": torch.from_numpy(all_anchors), "num_anchors_per_location": [2, 2, 2]}}
+    boxes, sl = pp.post_process(data, {"ego": out})
+    wb, ws, wl = _oracle_mc(cls, reg, all_anchors, t, pp.gt_range)
+    if boxes is None:
+        assert len(ws) == 0
+        return
+    assert boxes.shape[0] == len(ws)
+    np.testing.assert_allclose(sl[:, 0].cpu().numpy(), ws, **TOL)
+    np.testing.assert_allclose(boxes.cpu().numpy(), wb, **TOL)

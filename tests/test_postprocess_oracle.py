@@ -64,3 +64,51 @@ def test_nms_is_greedy_in_score_order(gold):
     for j in dropped:                                                # every dropped box overlaps a kept, better one
         assert any(i < j and P.quad_intersection_area(quads[i], quads[j]) /
                    (P.quad_area(quads[i]) + P.quad_area(quads[j]) - P.quad_intersection_area(quads[i], quads[j])) > 0.15 for i in keep)
+
+
+# ---- multi-class (VoxelPostprocessor3Heads, the V2X-Real yaml) ---------------------------------------------------------
+MC_CFGS = [dict(class_name=n, anchor_sizes=[sz], anchor_rotations=[0, 1.57], anchor_bottom_heights=[zb], align_center=True,
+                feature_map_stride=2, matched_threshold=0.6, unmatched_threshold=0.45)
+           for n, sz, zb in (("vehicle", [3.9, 1.6, 1.56], -1.78), ("pedestrian", [0.8, 0.6, 1.73], -0.6), ("truck", [8, 3, 3], -1.78))]
+
+
+def mc_params(lidar, grid_w, grid_h):
+    return {"core_method": "VoxelPostprocessor3Heads", "gt_range": list(lidar), "order": "hwl", "nms_thresh": 0.15,
+            "anchor_args": {"cav_lidar_range": list(lidar), "W": grid_w, "H": grid_h, "anchor_generator_config": MC_CFGS},
+            "target_args": {"score_threshold": 0.2}}
+
+
+@pytest.fixture(scope="module")
+def gold_mc():
+    with np.load(os.path.join(os.path.dirname(__file__), "golden", "postprocess_mc.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def interleave(all_anchors):
+    """(num_class, H, W, A, 7) -> (H, W, num_class * A, 7), voxel_postprocessor_3heads.py:354-358"""
+    a = np.transpose(all_anchors, (1, 2, 0, 3, 4))
+    return a.reshape(a.shape[0], a.shape[1], -1, 7)
+
+
+def test_mc_anchor_boxes_equal_reference(gold_mc):
+    aa, per_loc = P.generate_anchor_boxes_3heads(gold_mc["lidar_range"], 64, 32, MC_CFGS)
+    np.testing.assert_array_equal(np.array(aa), gold_mc["all_anchors"])
+    assert per_loc == list(gold_mc["num_anchors_per_location"])
+    from quantv2x_amd.plugin.data_utils.post_processor import build_postprocessor
+    pp = build_postprocessor(mc_params([float(v) for v in gold_mc["lidar_range"]], 64, 32), train=False)
+    got, per_loc2 = pp.generate_anchor_box()
+    np.testing.assert_array_equal(np.array(got), gold_mc["all_anchors"])
+    assert per_loc2 == per_loc and pp.gt_range == [float(v) for v in gold_mc["gt_range"]]
+
+
+@pytest.mark.parametrize("tag", ["ident", "moved"])
+def test_mc_flow_without_nms_matches_reference(gold_mc, tag):
+    t = np.eye(4, dtype=np.float32) if tag == "ident" else gold_mc["T"]
+    boxes, scores, labels = P.post_process(gold_mc["cls"], gold_mc["reg"], None, interleave(gold_mc["all_anchors"]), t, gold_mc["gt_range"],
+                                           nms=False, num_classes=3, max_extent=100.0, z_lim=(-100.0, 100.0), range_xy_only=True,
+                                           return_labels=True)
+    want = gold_mc[tag + "_score_labels"]
+    assert boxes.shape == gold_mc[tag + "_boxes"].shape
+    np.testing.assert_array_equal(labels, want[:, 1].astype(np.int64))
+    np.testing.assert_allclose(scores, want[:, 0], **TOL)
+    np.testing.assert_allclose(boxes, gold_mc[tag + "_boxes"], **TOL)
