@@ -1,5 +1,7 @@
-// f2: detection-head maps -> 3-D boxes on the GPU, single-class anchor heads:
-// VoxelPostprocessor.post_process (opencood/data_utils/post_processor/voxel_postprocessor.py:245-405) for one CAV.
+// f2: detection-head maps -> 3-D boxes on the GPU for the anchor heads, one CAV per call:
+// VoxelPostprocessor.post_process (opencood/data_utils/post_processor/voxel_postprocessor.py:245-405; line numbers below)
+// and, with num_classes > 1, VoxelPostprocessor3Heads.post_process (voxel_postprocessor_3heads.py:318-478: score = largest
+// class probability + label, no direction fix, the limits of box_utils_mc.py, x-y range mask).
 //   1. score = sigmoid(cls) per anchor, flag = score > threshold                                    (:289-304)
 //   2. exclusive scan of the flags: candidates keep the reference's (h, w, anchor) order -- no atomics decide an order
 //   3. per candidate: delta_to_boxes3d (:408-453), direction-bin fix (:316-331), 8 corners (box_utils.py:152-204),
@@ -10,7 +12,7 @@
 //      over the bit matrix in LDS                                                                    (:769-814)
 //   6. range mask on all eight corners (box_utils.py:384-421), outputs compacted in score order.
 // The reference's polygon IoU is shapely's (un-vendored): oracle/postprocess.py restates it with the same clipping as
-// here; everything else is pinned against the reference by tests/golden/postprocess.npz.
+// here; everything else is pinned against the reference by tests/golden/postprocess.npz and postprocess_mc.npz.
 #include <hipcub/hipcub.hpp>
 
 #include "common.h"
