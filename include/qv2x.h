@@ -119,6 +119,11 @@ typedef struct {
 int qv2x_deconv_i8(const qv2x_deconv_desc* desc /* host */, const int8_t* in, const float* w, const float* bias,
                    int8_t* out, void* stream);
 
+/* Up to 4 such layers in one launch (the deblocks only feed the concat: one pool of wave tiles instead of one tail per
+ * layer).  Arrays of `n` host-side entries; results identical to `n` qv2x_deconv_i8 calls. */
+int qv2x_deconv_i8_batch(const qv2x_deconv_desc* descs /* host */, int n, const int8_t* const* ins /* host array */,
+                         const float* const* ws, const float* const* biases, int8_t* const* outs, void* stream);
+
 /* a6.  UMGMQuantizer.encode (opencood/models/sub_modules/codebook.py:330-337 -> :231-239 -> :106-131), m = 1,
  * D = 256, up to 3 residual levels, Kc <= 128 codes per level, on the dequantized shrinker output.
  *   in: padded i8 BEV [N][H+2][W+2][256] with (in_delta, in_zx)

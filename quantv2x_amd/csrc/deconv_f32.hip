@@ -17,13 +17,11 @@ struct DeconvArgs {
     float dx, out_delta, out_zp;
 };
 
+// one wave tile (`tile` is wave-uniform); rowbase: this wave's 32 ints of LDS
 template <int NT>
-__global__ __launch_bounds__(256) void deconv_f32_kernel(const DeconvArgs a) {
-    __shared__ int rowbase[4][32];            // per wave: output pixel index of (row, i = 0, j = 0), -1 past the end
+__device__ __forceinline__ void deconv_tile(const DeconvArgs& a, const int tile, int (*rowbase)[32]) {
     const int lane = threadIdx.x & 63;
     const int tiles_n = a.ncols / (32 * NT);
-    int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    tile = __builtin_amdgcn_readfirstlane(tile);
     const int tiles_m = (a.M + 31) >> 5;
     if (tile >= tiles_m * tiles_n) return;
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
@@ -115,20 +113,54 @@ __global__ __launch_bounds__(256) void deconv_f32_kernel(const DeconvArgs a) {
     }
 }
 
-}  // namespace qv2x
+template <int NT>
+__global__ __launch_bounds__(256) void deconv_f32_kernel(const DeconvArgs a) {
+    __shared__ int rowbase[4][32];            // per wave: output pixel index of (row, i = 0, j = 0), -1 past the end
+    deconv_tile<NT>(a, __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))), rowbase);
+}
 
-extern "C" int qv2x_deconv_i8(const qv2x_deconv_desc* d, const int8_t* in, const float* w, const float* bias, int8_t* out, void* stream) {
-    using namespace qv2x;
-    if (!d || !in || !w || !bias || !out) return fail(QV2X_EINVAL, "qv2x_deconv_i8: null pointer");
-    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->s < 1 || d->s > 8) return fail(QV2X_EINVAL, "qv2x_deconv_i8: bad shape");
-    if (d->cin % 16 || (d->s * d->s * d->cout) % 64 || d->cout % 32) return fail(QV2X_EALIGN, "qv2x_deconv_i8: cin %% 16, cout %% 32, s*s*cout %% 64");
-    if (((uintptr_t)in & 15) || ((uintptr_t)w & 15)) return fail(QV2X_EALIGN, "qv2x_deconv_i8: in / w must be 16-byte aligned");
-    if (!(d->out_delta > 0.0f)) return fail(QV2X_EINVAL, "qv2x_deconv_i8: out_delta must be positive");
-    DeconvArgs a;
+// Several deblocks in one launch (they only feed the concat, so all of them can run once the last block is done): one pool
+// of wave tiles instead of three launches with three tails.
+constexpr int MAX_BATCH = 4;
+struct DeconvBatch {
+    DeconvArgs a[MAX_BATCH];
+    int tile_end[MAX_BATCH];                  // running total of wave tiles
+    int n;
+};
+
+__global__ __launch_bounds__(256) void deconv_f32_batch_kernel(const DeconvBatch b) {
+    __shared__ int rowbase[4][32];
+    const int tile = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    int l = 0, begin = 0;
+    while (l < b.n - 1 && tile >= b.tile_end[l]) { begin = b.tile_end[l]; ++l; }
+    if (tile >= b.tile_end[b.n - 1]) return;
+    switch (l) {                              // constant indices: the argument structs stay in SGPRs / kernarg loads
+        case 0: deconv_tile<1>(b.a[0], tile - begin, rowbase); break;
+        case 1: deconv_tile<1>(b.a[1], tile - begin, rowbase); break;
+        case 2: deconv_tile<1>(b.a[2], tile - begin, rowbase); break;
+        default: deconv_tile<1>(b.a[3], tile - begin, rowbase); break;
+    }
+}
+
+static int deconv_args(const qv2x_deconv_desc* d, const int8_t* in, const float* w, const float* bias, int8_t* out, const char* who, DeconvArgs& a) {
+    if (!d || !in || !w || !bias || !out) return fail(QV2X_EINVAL, "%s: null pointer", who);
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->s < 1 || d->s > 8) return fail(QV2X_EINVAL, "%s: bad shape", who);
+    if (d->cin % 16 || (d->s * d->s * d->cout) % 64 || d->cout % 32) return fail(QV2X_EALIGN, "%s: cin %% 16, cout %% 32, s*s*cout %% 64", who);
+    if (((uintptr_t)in & 15) || ((uintptr_t)w & 15)) return fail(QV2X_EALIGN, "%s: in / w must be 16-byte aligned", who);
+    if (!(d->out_delta > 0.0f)) return fail(QV2X_EINVAL, "%s: out_delta must be positive", who);
     a.in = in; a.w = w; a.bias = bias; a.out = out;
     a.n = d->n; a.h = d->h; a.wd = d->w; a.cin = d->cin; a.cout = d->cout; a.s = d->s; a.ax = 128 - d->in_zx;
     a.ncols = d->s * d->s * d->cout; a.M = d->n * d->h * d->w; a.relu = d->relu;
     a.out_ctotal = d->out_ctotal; a.out_c0 = d->out_c0; a.dx = d->in_delta; a.out_delta = d->out_delta; a.out_zp = d->out_zp;
+    return QV2X_OK;
+}
+
+}  // namespace qv2x
+
+extern "C" int qv2x_deconv_i8(const qv2x_deconv_desc* d, const int8_t* in, const float* w, const float* bias, int8_t* out, void* stream) {
+    using namespace qv2x;
+    DeconvArgs a;
+    if (int rc = deconv_args(d, in, w, bias, out, "qv2x_deconv_i8", a)) return rc;
     // 32 x 32 wave tiles: 4416 tiles of 3.9 us on 1024 SIMDs at the 25 x 88 level balance better than 2208 tiles of 7.8 us
     // (13.7 / 21.4 / 36.4 us against 15.4 / 23.7 / 39.5 us for the three deblocks)
     static const char* ntenv = getenv("QV2X_DECONV_NT");              // dev knob: column tiles per wave
@@ -137,4 +169,21 @@ extern "C" int qv2x_deconv_i8(const qv2x_deconv_desc* d, const int8_t* in, const
     if (nt == 1) deconv_f32_kernel<1><<<(tiles + 3) / 4, 256, 0, (hipStream_t)stream>>>(a);
     else deconv_f32_kernel<2><<<(tiles + 3) / 4, 256, 0, (hipStream_t)stream>>>(a);
     return hip_check(hipGetLastError(), "qv2x_deconv_i8 launch");
+}
+
+extern "C" int qv2x_deconv_i8_batch(const qv2x_deconv_desc* descs, int n, const int8_t* const* ins, const float* const* ws,
+                                    const float* const* biases, int8_t* const* outs, void* stream) {
+    using namespace qv2x;
+    if (!descs || !ins || !ws || !biases || !outs) return fail(QV2X_EINVAL, "qv2x_deconv_i8_batch: null pointer");
+    if (n < 1 || n > MAX_BATCH) return fail(QV2X_EINVAL, "qv2x_deconv_i8_batch: 1..%d layers", MAX_BATCH);
+    DeconvBatch b{};
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (int rc = deconv_args(&descs[i], ins[i], ws[i], biases[i], outs[i], "qv2x_deconv_i8_batch", b.a[i])) return rc;
+        total += ((b.a[i].M + 31) / 32) * (b.a[i].ncols / 32);
+        b.tile_end[i] = total;
+    }
+    b.n = n;
+    deconv_f32_batch_kernel<<<(total + 3) / 4, 256, 0, (hipStream_t)stream>>>(b);
+    return hip_check(hipGetLastError(), "qv2x_deconv_i8_batch launch");
 }

@@ -286,13 +286,26 @@ class DeployedModel(nn.Module):
         L.check(self.lib.qv2x_conv3x3_i8(C.byref(d), L.ptr(x), L.ptr(layer.w), L.ptr(layer.scale), L.ptr(layer.corr),
                                          L.ptr(layer.aw), L.ptr(layer.bias), L.ptr(out), L.current_stream()), layer.name)
 
-    def _deconv(self, de: _DeconvLayer, x, n, h, w, out, out_c0):
+    def _deconv_desc(self, de: _DeconvLayer, n, h, w, out, out_c0):
         d = L.DeconvDesc()
         d.n, d.h, d.w, d.cin, d.cout, d.s = n, h, w, de.cin, de.cout, de.s
         d.in_zx, d.in_delta = int(de.in_q[1]), float(de.in_q[0])
         d.out_ctotal, d.out_c0, d.relu = out.shape[-1], out_c0, 1
         d.out_delta, d.out_zp = de.out_q[0], float(de.out_q[1])
+        return d
+
+    def _deconv(self, de: _DeconvLayer, x, n, h, w, out, out_c0):
+        d = self._deconv_desc(de, n, h, w, out, out_c0)
         L.check(self.lib.qv2x_deconv_i8(C.byref(d), L.ptr(x), L.ptr(de.w), L.ptr(de.bias), L.ptr(out), L.current_stream()), de.name)
+
+    def _deconv_batch(self, items, n):
+        """items: [(layer, x, h, w, out, out_c0)] -> one launch"""
+        k = len(items)
+        descs = (L.DeconvDesc * k)(*[self._deconv_desc(de, n, h, w, out, c0) for (de, x, h, w, out, c0) in items])
+        arr = lambda ts: (C.c_void_p * k)(*[t.data_ptr() for t in ts])
+        L.check(self.lib.qv2x_deconv_i8_batch(descs, k, arr([it[1] for it in items]), arr([it[0].w for it in items]),
+                                              arr([it[0].bias for it in items]), arr([it[4] for it in items]), L.current_stream()),
+                "qv2x_deconv_i8_batch")
 
     def _run_heads(self, hd: _Heads, rows, nb, hw):
         out = torch.empty((nb, hd.cout, self.fh, self.fw), dtype=torch.float32, device=self.dev)
@@ -324,15 +337,30 @@ class DeployedModel(nn.Module):
         return plan
 
     def run_plan(self, n_agents: int, only=None, taps: Optional[dict] = None):
+        pending = []                                  # the deblocks only feed the concat: they run as ONE launch before the shrinker
+
+        def flush():
+            if len(pending) == 1:
+                de, x, h, w, out, c0 = pending[0]
+                self._deconv(de, x, n_agents, h, w, out, c0)
+            elif pending:
+                self._deconv_batch(pending, n_agents)
+            pending.clear()
+
         for (kind, layer, x, h, w, out, c0, _) in self.conv_plan(n_agents):
             if only is not None and not only(kind, layer):
                 continue
             if kind == "conv":
+                if layer is self.shrink0:
+                    flush()
                 self._conv(layer, x, n_agents, h, w, out)
                 if taps is not None:
                     taps[layer.name] = out.clone()
             else:
-                self._deconv(layer, x, n_agents, h, w, out, c0)
+                pending.append((layer, x, h, w, out, c0))
+                if os.environ.get("QV2X_DECONV_BATCH", "1") == "0":
+                    flush()
+        flush()
 
     def pillars_to_canvas(self, inputs: dict, n_agents: int):
         """a1 + a2: clear the canvas, run the PFN and scatter."""
