@@ -187,6 +187,14 @@ int qv2x_decode_heads_f32(const uint8_t* codes, int R, int hw, int levels, int k
                           int cout, int cout_pad, const float* w, const float* bias, const float* da, const float* za,
                           float* out, void* stream);
 
+/* qv2x_heads_f32 on the fused rows AND qv2x_decode_heads_f32 on the agents' own codes in one launch (same results): the
+ * two 1x1-head passes of a frame are independent of each other. */
+int qv2x_heads_pair_f32(const float* x, int R, int hw, int cout, int cout_pad, const float* w, const float* bias,
+                        const float* da, const float* za, float* out,
+                        const uint8_t* codes, int R1, int levels, int kc, const float* lut, const float* lut_bias,
+                        int cout1, int cout_pad1, const float* w1, const float* bias1, const float* da1,
+                        const float* za1, float* out1, void* stream);
+
 /* f2.  Head maps -> boxes for one CAV.
  * num_classes == 1: VoxelPostprocessor.post_process (data_utils/post_processor/voxel_postprocessor.py:245-405):
  *   sigmoid + score threshold, delta_to_boxes3d (:408-453), direction-bin fix (:316-331), corners

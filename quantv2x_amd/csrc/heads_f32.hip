@@ -26,12 +26,10 @@ struct HeadArgs {
 };
 
 template <int SRC>
-__global__ __launch_bounds__(256) void rows_heads_kernel(const HeadArgs h, const FuseArgs fa) {
-    __shared__ __attribute__((aligned(16))) float smem[32 * 256];
+__device__ __forceinline__ void rows_heads_tile(const HeadArgs& h, const FuseArgs& fa, const int tm, float* smem) {
     float* rows = smem;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nct = h.cout_pad >> 5;
-    const int tm = blockIdx.x;
     const int par = lane >> 5;
 
 #pragma unroll
@@ -123,6 +121,23 @@ __global__ __launch_bounds__(256) void rows_heads_kernel(const HeadArgs h, const
     }
 }
 
+template <int SRC>
+__global__ __launch_bounds__(256) void rows_heads_kernel(const HeadArgs h, const FuseArgs fa) {
+    __shared__ __attribute__((aligned(16))) float smem[32 * 256];
+    rows_heads_tile<SRC>(h, fa, blockIdx.x, smem);
+}
+
+// The fused-feature heads (rows from memory) and the *_single heads (rows decoded from the codes) of one frame in ONE
+// launch, blockIdx.y = job: two 1100-workgroup grids whose copy-in / GEMM / store phases interleave, one launch gap less.
+__global__ __launch_bounds__(256) void rows_heads_pair_kernel(const HeadArgs h0, const HeadArgs h1, const FuseArgs fa1) {
+    __shared__ __attribute__((aligned(16))) float smem[32 * 256];
+    if (blockIdx.y == 0) {
+        if ((int)blockIdx.x * 32 < h0.R) rows_heads_tile<ROWS_GLOBAL>(h0, fa1, blockIdx.x, smem);
+    } else {
+        if ((int)blockIdx.x * 32 < h1.R) rows_heads_tile<ROWS_DECODE>(h1, fa1, blockIdx.x, smem);
+    }
+}
+
 static int head_args(const char* who, int R, int hw, int cout, int cout_pad, const float* w, const float* bias, const float* da,
                      const float* za, float* out, HeadArgs& h) {
     if (!w || !bias || !da || !za || !out) return fail(QV2X_EINVAL, "%s: null pointer", who);
@@ -209,4 +224,26 @@ extern "C" int qv2x_decode_lut_f32(const uint8_t* codes, int R, int levels, int 
     if (R <= 0 || levels < 1 || levels > 4 || kc < 1 || kc > 256) return fail(QV2X_EINVAL, "qv2x_decode_lut_f32: bad sizes");
     decode_lut_kernel<<<(R + 3) / 4, 256, 0, (hipStream_t)stream>>>(codes, R, levels, kc, (const float4*)lut, (const float4*)lut_bias, (float4*)out);
     return hip_check(hipGetLastError(), "qv2x_decode_lut_f32 launch");
+}
+
+extern "C" int qv2x_heads_pair_f32(const float* x, int R, int hw, int cout, int cout_pad, const float* w, const float* bias,
+                                   const float* da, const float* za, float* out,
+                                   const uint8_t* codes, int R1, int levels, int kc, const float* lut, const float* lut_bias,
+                                   int cout1, int cout_pad1, const float* w1, const float* bias1, const float* da1,
+                                   const float* za1, float* out1, void* stream) {
+    using namespace qv2x;
+    HeadArgs h0, h1;
+    if (!x || !codes || !lut || !lut_bias) return fail(QV2X_EINVAL, "qv2x_heads_pair_f32: null pointer");
+    if (int rc = head_args("qv2x_heads_pair_f32", R, hw, cout, cout_pad, w, bias, da, za, out, h0)) return rc;
+    if (int rc = head_args("qv2x_heads_pair_f32", R1, hw, cout1, cout_pad1, w1, bias1, da1, za1, out1, h1)) return rc;
+    if ((uintptr_t)x & 15) return fail(QV2X_EALIGN, "qv2x_heads_pair_f32: x must be 16-byte aligned");
+    if (levels < 1 || levels > 4 || kc < 1 || kc > 256) return fail(QV2X_EINVAL, "qv2x_heads_pair_f32: bad sizes");
+    h0.x = x;
+    FuseArgs fa{};
+    fa.codes = codes; fa.lut = (const float4*)lut; fa.lut_bias = (const float4*)lut_bias; fa.feats = nullptr;
+    fa.levels = levels; fa.kc = kc; fa.hw = hw;
+    fa.code_agent_stride = hw; fa.code_level_stride = R1;
+    const int tiles = ((R > R1 ? R : R1) + 31) / 32;
+    rows_heads_pair_kernel<<<dim3(tiles, 2), 256, 0, (hipStream_t)stream>>>(h0, h1, fa);
+    return hip_check(hipGetLastError(), "qv2x_heads_pair_f32 launch");
 }

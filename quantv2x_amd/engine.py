@@ -480,11 +480,23 @@ class DeployedModel(nn.Module):
             else:
                 self.fuse(None, 0, 0, feats[start:start + n], pairwise[bi], n, fused[bi])
             start += n
-        preds = self._run_heads(self.heads, fused, nb, hw)
+        sp = None
+        if self.heads_single is not None and self.has_codebook:
+            # the heads on the fused map and the *_single heads on every agent's own decoded feature: one launch
+            hd, hs = self.heads, self.heads_single
+            preds = torch.empty((nb, hd.cout, self.fh, self.fw), dtype=torch.float32, device=self.dev)
+            sp = torch.empty((n_total, hs.cout, self.fh, self.fw), dtype=torch.float32, device=self.dev)
+            L.check(self.lib.qv2x_heads_pair_f32(L.ptr(fused), nb * hw, hw, hd.cout, hd.cout_pad, L.ptr(hd.w), L.ptr(hd.bias), L.ptr(hd.da),
+                                                 L.ptr(hd.za), L.ptr(preds), L.ptr(enc), n_total * hw, self.levels, self.kc,
+                                                 L.ptr(self.lut), L.ptr(self.lut_bias), hs.cout, hs.cout_pad, L.ptr(hs.w), L.ptr(hs.bias),
+                                                 L.ptr(hs.da), L.ptr(hs.za), L.ptr(sp), L.current_stream()), "qv2x_heads_pair_f32")
+        else:
+            preds = self._run_heads(self.heads, fused, nb, hw)
         c, r, _ = self.heads.splits
         out = {"cls_preds": preds[:, :c], "reg_preds": preds[:, c:c + r], "dir_preds": preds[:, c + r:], "preds_tensor": preds}
         if self.heads_single is not None:
-            sp = self._decode_heads_single(enc, n_total) if self.has_codebook else self._run_heads(self.heads_single, feats, n_total, hw)
+            if sp is None:
+                sp = self._run_heads(self.heads_single, feats, n_total, hw)
             c, r, _ = self.heads_single.splits
             out.update({"cls_preds_single": sp[:, :c], "reg_preds_single": sp[:, c:c + r], "dir_preds_single": sp[:, c + r:]})
         if taps is not None:
