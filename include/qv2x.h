@@ -57,7 +57,9 @@ int qv2x_voxelize_f32(const float* points, int n_points, const float* lidar_rang
  *   voxel_features f32 [M][32][4], voxel_coords i32 [M][4] = (agent, z, y, x), voxel_num_points i32 [M]
  *   w f32 [64][10] fake-quantized folded weight, b f32 [64]; (d1, z1) Linear output quantizer,
  *   (d2, z2) the second quantizer after the ReLU; vox/off = voxel size and (voxel/2 + range_min), xyz.
- *   canvas: padded i8 BEV [N][ny+2][nx+2][64], already filled with (z2 - 128). */
+ *   canvas: padded i8 BEV [N][ny+2][nx+2][64], already filled with (z2 - 128). 
+ * Slots past voxel_num_points must hold zeros (the voxel generator's padding; the reference's mean over all slots
+ * relies on it too): only the filled slots are read. */
 typedef struct {
     float w[64 * 10];
     float b[64];

@@ -19,8 +19,12 @@ __global__ __launch_bounds__(256) void pfn_scatter_kernel(const float4* __restri
     const int4 c = coords[m];                 // (agent, z, y, x)
     const int np = npts[m];
 
-    float sx = 0.f, sy = 0.f, sz = 0.f;       // ascending-slot sums over all P slots (padded slots hold zeros)
-    for (int p = 0; p < P; ++p) {
+    // Ascending-slot sums.  The reference sums all P slots (pillar_vfe.py:118-119); the padded ones hold zeros -- the voxel
+    // generator's contract, and the reference's own mean is wrong otherwise -- and x + 0.0f == x, so stopping at the point
+    // count gives the same bits while reading ~2 slots per pillar instead of 32.
+    const int filled = np < P ? np : P;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int p = 0; p < filled; ++p) {
         const float4 q = pts[p];
         sx += q.x; sy += q.y; sz += q.z;
     }
