@@ -153,3 +153,20 @@ def test_empty_agent_and_agent_count_limits(tiny):
     sc9 = synth.make_scene("tiny", n_agents=9, seed=11, n_points=500, max_cav=9)
     with pytest.raises(L.Qv2xError):
         eng(synth.scene_to_torch(sc9, "cuda"))
+
+
+@pytest.mark.parametrize("n_agents", [1, 3])
+def test_sharded_stage_functions_equal_forward(tiny, n_agents):
+    """``forward`` runs the two head passes as one launch; the multi-GPU driver (quantv2x_amd/dist.py) calls
+    ``encode_agents`` / ``fuse_and_heads`` / ``single_preds`` one by one.  Same frame, bit-identical outputs."""
+    from quantv2x_amd import synth
+    state, orc, eng = tiny
+    dd = synth.scene_to_torch(scene_np(n_agents), "cuda")
+    want = {k: v.clone() for k, v in eng(dd).items()}
+    codes = eng.encode_agents(dd["inputs_m1"], n_agents).clone()           # [levels, n, hw]
+    levels, n, hw = codes.shape
+    got = eng.fuse_and_heads(codes, hw, n * hw, dd["pairwise_t_matrix"][0].contiguous(), n_agents, 0)
+    got.update(eng.single_preds(codes, n_agents))
+    torch.cuda.synchronize()
+    for key in ("preds_tensor", "cls_preds", "reg_preds", "dir_preds", "cls_preds_single", "reg_preds_single", "dir_preds_single"):
+        assert torch.equal(got[key], want[key]), key
