@@ -58,10 +58,13 @@ class AgentShardedModel:
         if self._gathered is None:
             self._gathered = torch.empty((self.world, levels, hw), dtype=codes.dtype, device=codes.device)
         gathered = exchange_codes(codes.view(levels, hw), self.group, self._gathered)
+        ego = 0 if self.ego_only else self.rank
+        if hasattr(eng, "fuse_heads_and_single") and not (self.ego_only and self.rank != 0):
+            # fusion as the ego of this viewpoint + the *_single heads of this rank's own agent (one launch for both head passes)
+            return eng.fuse_heads_and_single(gathered, *gathered_strides(levels, hw), pairwise_t_matrix, self.world, ego, codes, 1)
         single = eng.single_preds(codes, 1) if hasattr(eng, "single_preds") else {}     # this rank's own agent
         if self.ego_only and self.rank != 0:
             return None
-        ego = 0 if self.ego_only else self.rank
         out = eng.fuse_and_heads(gathered, *gathered_strides(levels, hw), pairwise_t_matrix, self.world, ego)
         out.update(single)
         return out

@@ -441,6 +441,37 @@ class DeployedModel(nn.Module):
                                                L.ptr(sp), L.current_stream()), "qv2x_decode_heads_f32")
         return sp
 
+    def _heads_pair(self, fused, nb, codes, n_agents):
+        """heads on the fused rows [nb*hw, 256] + *_single heads on the agents' own codes [levels, n_agents*hw]: one launch"""
+        hw = self.fh * self.fw
+        hd, hs = self.heads, self.heads_single
+        preds = torch.empty((nb, hd.cout, self.fh, self.fw), dtype=torch.float32, device=self.dev)
+        sp = torch.empty((n_agents, hs.cout, self.fh, self.fw), dtype=torch.float32, device=self.dev)
+        L.check(self.lib.qv2x_heads_pair_f32(L.ptr(fused), nb * hw, hw, hd.cout, hd.cout_pad, L.ptr(hd.w), L.ptr(hd.bias), L.ptr(hd.da),
+                                             L.ptr(hd.za), L.ptr(preds), L.ptr(codes), n_agents * hw, self.levels, self.kc,
+                                             L.ptr(self.lut), L.ptr(self.lut_bias), hs.cout, hs.cout_pad, L.ptr(hs.w), L.ptr(hs.bias),
+                                             L.ptr(hs.da), L.ptr(hs.za), L.ptr(sp), L.current_stream()), "qv2x_heads_pair_f32")
+        return preds, sp
+
+    def fuse_heads_and_single(self, codes, agent_stride, level_stride, pairwise_b, n_agents, ego, own_codes, n_own: int = 1) -> dict:
+        """``fuse_and_heads`` on the gathered codes plus ``single_preds`` on this rank's own codes, the two head passes in one
+        launch (what one rank of the multi-GPU driver does after the all-gather)."""
+        if self.heads_single is None or not self.has_codebook:
+            out = self.fuse_and_heads(codes, agent_stride, level_stride, pairwise_b, n_agents, ego)
+            out.update(self.single_preds(own_codes, n_own))
+            return out
+        hw = self.fh * self.fw
+        if pairwise_b.dtype != torch.float64 or not pairwise_b.is_contiguous():
+            pairwise_b = pairwise_b.to(torch.float64).contiguous()
+        fused = torch.empty((1, hw, 256), dtype=torch.float32, device=self.dev)
+        self.fuse(L.ptr(codes), agent_stride, level_stride, None, pairwise_b, n_agents, fused[0], ego)
+        preds, sp = self._heads_pair(fused, 1, own_codes, n_own)
+        c, r, _ = self.heads.splits
+        out = {"cls_preds": preds[:, :c], "reg_preds": preds[:, c:c + r], "dir_preds": preds[:, c + r:], "preds_tensor": preds}
+        c, r, _ = self.heads_single.splits
+        out.update({"cls_preds_single": sp[:, :c], "reg_preds_single": sp[:, c:c + r], "dir_preds_single": sp[:, c + r:]})
+        return out
+
     def single_preds(self, codes, n_agents: int) -> dict:
         """``*_preds_single`` (heter_model_baseline.py:224-230): the per-agent heads on each agent's own decoded feature."""
         if self.heads_single is None:
@@ -483,13 +514,7 @@ class DeployedModel(nn.Module):
         sp = None
         if self.heads_single is not None and self.has_codebook:
             # the heads on the fused map and the *_single heads on every agent's own decoded feature: one launch
-            hd, hs = self.heads, self.heads_single
-            preds = torch.empty((nb, hd.cout, self.fh, self.fw), dtype=torch.float32, device=self.dev)
-            sp = torch.empty((n_total, hs.cout, self.fh, self.fw), dtype=torch.float32, device=self.dev)
-            L.check(self.lib.qv2x_heads_pair_f32(L.ptr(fused), nb * hw, hw, hd.cout, hd.cout_pad, L.ptr(hd.w), L.ptr(hd.bias), L.ptr(hd.da),
-                                                 L.ptr(hd.za), L.ptr(preds), L.ptr(enc), n_total * hw, self.levels, self.kc,
-                                                 L.ptr(self.lut), L.ptr(self.lut_bias), hs.cout, hs.cout_pad, L.ptr(hs.w), L.ptr(hs.bias),
-                                                 L.ptr(hs.da), L.ptr(hs.za), L.ptr(sp), L.current_stream()), "qv2x_heads_pair_f32")
+            preds, sp = self._heads_pair(fused, nb, enc, n_total)
         else:
             preds = self._run_heads(self.heads, fused, nb, hw)
         c, r, _ = self.heads.splits

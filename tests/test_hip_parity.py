@@ -167,6 +167,8 @@ def test_sharded_stage_functions_equal_forward(tiny, n_agents):
     levels, n, hw = codes.shape
     got = eng.fuse_and_heads(codes, hw, n * hw, dd["pairwise_t_matrix"][0].contiguous(), n_agents, 0)
     got.update(eng.single_preds(codes, n_agents))
+    both = eng.fuse_heads_and_single(codes, hw, n * hw, dd["pairwise_t_matrix"][0].contiguous(), n_agents, 0, codes, n_agents)
     torch.cuda.synchronize()
     for key in ("preds_tensor", "cls_preds", "reg_preds", "dir_preds", "cls_preds_single", "reg_preds_single", "dir_preds_single"):
         assert torch.equal(got[key], want[key]), key
+        assert torch.equal(both[key], want[key]), key
