@@ -117,6 +117,8 @@ typedef struct {
     float in_delta;
     int32_t out_ctotal, out_c0, relu;
     float out_delta, out_zp;
+    int32_t out_h, out_w;      /* interior size of the padded destination [n][out_h+2][out_w+2][out_ctotal]: must equal
+                                * (h*s, w*s), else QV2X_EINVAL (the reference's torch.cat raises on such a mismatch) */
 } qv2x_deconv_desc;
 int qv2x_deconv_i8(const qv2x_deconv_desc* desc /* host */, const int8_t* in, const float* w, const float* bias,
                    int8_t* out, void* stream);

@@ -29,6 +29,7 @@ constexpr int LDF = 258;            // LDS row stride in floats: 32 rows x ds_re
 // dependent MFMAs issue back to back (an extra VALU between two MFMAs on one accumulator costs ~45 cycles on gfx950).
 __device__ __forceinline__ int kpos(int c) { return (c & ~3) | ((c & 1) << 1) | ((c >> 1) & 1); }
 constexpr int D = 256;
+constexpr int ENC_SMEM_FLOATS = 2 * ER * LDF + ER + 4 * ER + 8 * ER + ER;
 
 struct EncArgs {
     const int8_t* in; uint8_t* codes;
@@ -122,7 +123,8 @@ __device__ __forceinline__ void store_tile(float* __restrict__ dst, int wave, in
 }
 
 __global__ __launch_bounds__(512, 4) void codebook_encode_kernel(const EncArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // static LDS (67.8 KB; two workgroups per CU): no per-device hipFuncSetAttribute state to keep (include/qv2x.h:12)
+    __shared__ __attribute__((aligned(16))) float smem[ENC_SMEM_FLOATS];
     float* bufA = smem;                       // x, then q, then next x
     float* bufB = smem + ER * LDF;            // z
     float* x2 = smem + 2 * ER * LDF;          // [64]
@@ -304,16 +306,6 @@ extern "C" int qv2x_codebook_c2_f32(const float* codebook, int kc, float* c2, vo
     return hip_check(hipGetLastError(), "qv2x_codebook_c2_f32 launch");
 }
 
-extern "C" int qv2x_debug_encode_occupancy(void) {
-    using namespace qv2x;
-    const size_t smem = (size_t)(2 * ER * LDF + ER + 4 * ER + 8 * ER + ER) * sizeof(float);
-    int n = -1;
-    if (hipFuncSetAttribute((const void*)codebook_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, codebook_encode_kernel, 512, smem) != hipSuccess)
-        return -1;
-    return n * 1000 + (int)(smem / 1024);
-}
-
 extern "C" int64_t qv2x_codebook_level_floats(int kc) { return qv2x::level_floats(kc); }
 
 extern "C" int qv2x_codebook_encode_f32(const qv2x_encode_desc* d, const int8_t* in, const float* const* level_weights,
@@ -330,15 +322,7 @@ extern "C" int qv2x_codebook_encode_f32(const qv2x_encode_desc* d, const int8_t*
         a.lvl[l] = l < d->levels ? level_weights[l] : nullptr;
         if (l < d->levels && (!a.lvl[l] || ((uintptr_t)a.lvl[l] & 15))) return fail(QV2X_EALIGN, "qv2x_codebook_encode_f32: level %d weights null or unaligned", l);
     }
-    const size_t smem = (size_t)(2 * ER * LDF + ER + 4 * ER + 8 * ER + ER) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        int rc = hip_check(hipFuncSetAttribute((const void*)codebook_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem),
-                           "qv2x_codebook_encode_f32 smem attribute");
-        if (rc) return rc;
-        attr_set = true;
-    }
-    codebook_encode_kernel<<<(a.M + ER - 1) / ER, 512, smem, (hipStream_t)stream>>>(a);
+    codebook_encode_kernel<<<(a.M + ER - 1) / ER, 512, 0, (hipStream_t)stream>>>(a);
     return hip_check(hipGetLastError(), "qv2x_codebook_encode_f32 launch");
 }
 

@@ -379,9 +379,14 @@ extern "C" int qv2x_conv3x3_i8_wide(const qv2x_conv_desc* d, const int8_t* in, c
     a.in = in; a.wt = w_wide; a.scale = scale; a.corr = corr; a.aw = aw; a.bias = bias; a.out = out;
     dim3 grid(a.n * a.tiles_x * a.tiles_y, a.cout / BN);
     hipStream_t st = (hipStream_t)stream;
-    static const char* lenv = getenv("QV2X_WIDE_LAYOUT");              // dev knob: "4" = one wave per SIMD, 160 x 64 wave tiles
+#ifdef QV2X_DEV_KNOBS                                                  // dev build only: "4" = one wave per SIMD, 160 x 64 wave tiles
+    static const char* lenv = getenv("QV2X_WIDE_LAYOUT");
+    if (d->ngroups == 1 && lenv && lenv[0] == '4') {
+        conv3x3_i8_wide_kernel<5, false, 4, 2><<<grid, 256, 0, st>>>(a);
+        return hip_check(hipGetLastError(), "qv2x_conv3x3_i8_wide launch");
+    }
+#endif
     if (d->ngroups > 1) conv3x3_i8_wide_kernel<5, true, 8, 1><<<grid, 512, 0, st>>>(a);
-    else if (lenv && lenv[0] == '4') conv3x3_i8_wide_kernel<5, false, 4, 2><<<grid, 256, 0, st>>>(a);
     else conv3x3_i8_wide_kernel<5, false, 8, 1><<<grid, 512, 0, st>>>(a);
     return hip_check(hipGetLastError(), "qv2x_conv3x3_i8_wide launch");
 }

@@ -148,6 +148,9 @@ static int deconv_args(const qv2x_deconv_desc* d, const int8_t* in, const float*
     if (d->cin % 16 || (d->s * d->s * d->cout) % 64 || d->cout % 32) return fail(QV2X_EALIGN, "%s: cin %% 16, cout %% 32, s*s*cout %% 64", who);
     if (((uintptr_t)in & 15) || ((uintptr_t)w & 15)) return fail(QV2X_EALIGN, "%s: in / w must be 16-byte aligned", who);
     if (!(d->out_delta > 0.0f)) return fail(QV2X_EINVAL, "%s: out_delta must be positive", who);
+    if (d->out_h != d->h * d->s || d->out_w != d->w * d->s)
+        return fail(QV2X_EINVAL, "%s: destination is %d x %d, this layer writes %d x %d", who, d->out_h, d->out_w, d->h * d->s, d->w * d->s);
+    if (d->out_c0 < 0 || d->out_ctotal < d->out_c0 + d->cout) return fail(QV2X_EINVAL, "%s: out channel window", who);
     a.in = in; a.w = w; a.bias = bias; a.out = out;
     a.n = d->n; a.h = d->h; a.wd = d->w; a.cin = d->cin; a.cout = d->cout; a.s = d->s; a.ax = 128 - d->in_zx;
     a.ncols = d->s * d->s * d->cout; a.M = d->n * d->h * d->w; a.relu = d->relu;
@@ -163,8 +166,12 @@ extern "C" int qv2x_deconv_i8(const qv2x_deconv_desc* d, const int8_t* in, const
     if (int rc = deconv_args(d, in, w, bias, out, "qv2x_deconv_i8", a)) return rc;
     // 32 x 32 wave tiles: 4416 tiles of 3.9 us on 1024 SIMDs at the 25 x 88 level balance better than 2208 tiles of 7.8 us
     // (13.7 / 21.4 / 36.4 us against 15.4 / 23.7 / 39.5 us for the three deblocks)
-    static const char* ntenv = getenv("QV2X_DECONV_NT");              // dev knob: column tiles per wave
+#ifdef QV2X_DEV_KNOBS                                                  // dev build only: column tiles per wave
+    static const char* ntenv = getenv("QV2X_DECONV_NT");
     const int nt = ntenv ? atoi(ntenv) : 1;
+#else
+    const int nt = 1;
+#endif
     const int tiles = ((a.M + 31) / 32) * (a.ncols / (32 * nt));
     if (nt == 1) deconv_f32_kernel<1><<<(tiles + 3) / 4, 256, 0, (hipStream_t)stream>>>(a);
     else deconv_f32_kernel<2><<<(tiles + 3) / 4, 256, 0, (hipStream_t)stream>>>(a);

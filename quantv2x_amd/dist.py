@@ -41,6 +41,9 @@ class AgentShardedModel:
     """Drives a ``DeployedModel`` (or any object with the same three stage methods) with agents sharded over ranks."""
 
     def __init__(self, engine, group=None, ego_only: bool = False):
+        if not getattr(engine, "has_codebook", True):
+            raise NotImplementedError("AgentShardedModel exchanges the codebook's uint8 code planes: the codebook-less model "
+                                      "has no compressed wire format (run it single-process through DeployedModel.forward)")
         self.engine = engine
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0

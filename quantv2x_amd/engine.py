@@ -1,7 +1,10 @@
 """Deployed W8A8 hot path on MI355X: host side of ``libqv2x.so``.
 
 ``deploy(qt_model)`` takes a calibrated ``QuantModel`` (the reference's ``opencood.quant.QuantModel`` or this
-build's mirror -- only attribute names are read), freezes its PTQ state (``ptq_state.export_ptq_state``) and
+build's mirror -- only attribute names are read) of the ONE network shape this engine hard-wires -- PointPillar
+encoder, BaseBEVBackbone, shrinker, optional codebook, AttFusion, 1x1 heads, BN folded, ReLU on every conv / deconv;
+``ptq_state.export_ptq_state`` raises ``NotImplementedError`` for anything else (max fusion, post-fusion
+``shrink_header``, ``compressor``, unfolded BN, ``disable_act_quant`` off the heads) -- freezes its PTQ state and
 returns a ``DeployedModel``: an ``nn.Module`` with the reference's model contract
 
     out = model(data_dict)      # data_dict = batch['ego'];  out: cls_preds / reg_preds / dir_preds / preds_tensor
@@ -15,7 +18,6 @@ There is no CPU / eager fallback here: if ``libqv2x.so`` is missing, constructio
 from __future__ import annotations
 
 import ctypes as C
-import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -142,6 +144,8 @@ class DeployedModel(nn.Module):
         self.state = state
         self.dev = torch.device(device)
         s = state
+        if str(s.get("meta/fusion_method", "att")) != "att":
+            raise NotImplementedError(f"deployed path: fusion_method {s['meta/fusion_method']!r} (only 'att' = AttFusion is built)")
         self.nx, self.ny, _ = (int(v) for v in s["meta/grid"])
         self.hm, self.wm = (float(v) for v in s["meta/HW_metres"])
         self.ratio = float(s["meta/discrete_ratio"])
@@ -205,7 +209,8 @@ class DeployedModel(nn.Module):
         self.heads = _Heads(s, "", dev)
         self.heads_single = _Heads(s, "_single", dev) if (self.emit_single and "cls_head_single/w_code" in s) else None
         self._bufs: Dict[int, dict] = {}
-        self._graphs: Dict[tuple, tuple] = {}
+        # launch-plan switches for the ablation tools (tools/bench_*_abl.py); the defaults are the shipped configuration
+        self.use_wide_conv, self.batch_deconvs = True, True
 
     # ------------------------------------------------------------------------------------------------------
     def _level_blob(self, l: int) -> torch.Tensor:
@@ -250,6 +255,12 @@ class DeployedModel(nn.Module):
             b["lvl"].append((pair, h, w))
         (_, h0, w0) = b["lvl"][0]
         self.fh, self.fw = h0 * self.ups[0], w0 * self.ups[0]
+        for lvl, (_, hl, wl) in enumerate(b["lvl"]):
+            # the reference's torch.cat raises on mismatched deblock outputs (base_bev_backbone.py:116); the deconv kernel
+            # derives its row pitch from (h*s + 2, w*s + 2), so a mismatch would write out of bounds in the concat tensor
+            if (hl * self.ups[lvl], wl * self.ups[lvl]) != (self.fh, self.fw):
+                raise ValueError(f"deblock {lvl} upsamples {hl}x{wl} by {self.ups[lvl]} to {hl * self.ups[lvl]}x{wl * self.ups[lvl]}, "
+                                 f"level 0 gives {self.fh}x{self.fw}: the grid does not line up across backbone levels")
         cat = torch.empty((n, self.fh + 2, self.fw + 2, self.cat_channels), dtype=torch.int8, device=self.dev)
         c0 = 0
         for de in self.deblocks:
@@ -276,7 +287,7 @@ class DeployedModel(nn.Module):
         d.out_ctotal = out.shape[-1] if out_ctotal is None else out_ctotal
         d.out_c0, d.relu = out_c0, 1
         d.out_delta, d.out_zp = layer.out_q[0], float(layer.out_q[1])
-        if self.lib.qv2x_conv3x3_i8_wide_ok(C.byref(d)) and os.environ.get("QV2X_CONV_WIDE", "1") != "0":
+        if self.use_wide_conv and self.lib.qv2x_conv3x3_i8_wide_ok(C.byref(d)):
             if layer.w_wide is None:                                    # one-off re-tiling of the weights (not capturable)
                 layer.w_wide = torch.empty_like(layer.w)
                 L.check(self.lib.qv2x_conv3x3_i8_pack_wide(C.byref(d), L.ptr(layer.w), L.ptr(layer.w_wide), L.current_stream()), layer.name)
@@ -292,6 +303,7 @@ class DeployedModel(nn.Module):
         d.in_zx, d.in_delta = int(de.in_q[1]), float(de.in_q[0])
         d.out_ctotal, d.out_c0, d.relu = out.shape[-1], out_c0, 1
         d.out_delta, d.out_zp = de.out_q[0], float(de.out_q[1])
+        d.out_h, d.out_w = out.shape[1] - 2, out.shape[2] - 2
         return d
 
     def _deconv(self, de: _DeconvLayer, x, n, h, w, out, out_c0):
@@ -358,7 +370,7 @@ class DeployedModel(nn.Module):
                     taps[layer.name] = out.clone()
             else:
                 pending.append((layer, x, h, w, out, c0))
-                if os.environ.get("QV2X_DECONV_BATCH", "1") == "0":
+                if not self.batch_deconvs:
                     flush()
         flush()
 
@@ -491,7 +503,13 @@ class DeployedModel(nn.Module):
         if pairwise.dtype != torch.float64 or not pairwise.is_contiguous():
             pairwise = pairwise.to(torch.float64).contiguous()
         nb = pairwise.shape[0]
-        lens = [n_total] if nb == 1 else [int(v) for v in data_dict["record_len"].tolist()]
+        if nb == 1:
+            lens = [n_total]
+        else:
+            rl = data_dict["record_len"]
+            if isinstance(rl, torch.Tensor) and rl.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise ValueError("record_len on the GPU cannot be read during HIP-graph capture: pass a CPU tensor")
+            lens = [int(v) for v in (rl.tolist() if isinstance(rl, torch.Tensor) else rl)]
         enc = self.encode_agents(data_dict["inputs_m1"], n_total, taps)
         hw = self.fh * self.fw
         bufs = self._workspace(n_total)
@@ -533,7 +551,14 @@ class DeployedModel(nn.Module):
     # ---- HIP-graph replay of a fixed-shape frame ---------------------------------------------------------------
     def capture(self, data_dict: dict):
         """Capture one frame into a HIP graph (torch.cuda.CUDAGraph on ROCm).  The returned callable replays it on
-        the same input tensors (refresh their contents in place between replays) and returns the same output dict."""
+        the same input tensors (refresh their contents in place between replays) and returns the same output dict.
+
+        The pillar count M = ``voxel_features.shape[0]`` is baked into the graph: keep M fixed across replays and pad
+        unused rows with an out-of-range agent index (``voxel_coords[:, 0] = -1``), which ``pfn_scatter_kernel`` drops.
+        ``record_len`` (several scenes per call) must be a CPU tensor: its values shape the launch list."""
+        rl = data_dict.get("record_len")
+        if data_dict["pairwise_t_matrix"].shape[0] > 1 and isinstance(rl, torch.Tensor) and rl.is_cuda:
+            data_dict = dict(data_dict, record_len=rl.cpu())
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

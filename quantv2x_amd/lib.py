@@ -40,7 +40,7 @@ class DeconvDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32),
                 ("s", C.c_int32), ("in_zx", C.c_int32), ("in_delta", C.c_float),
                 ("out_ctotal", C.c_int32), ("out_c0", C.c_int32), ("relu", C.c_int32),
-                ("out_delta", C.c_float), ("out_zp", C.c_float)]
+                ("out_delta", C.c_float), ("out_zp", C.c_float), ("out_h", C.c_int32), ("out_w", C.c_int32)]
 
 
 class EncodeDesc(C.Structure):

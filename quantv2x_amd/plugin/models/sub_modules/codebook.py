@@ -21,7 +21,6 @@ import math
 from typing import Callable, Dict, List, Tuple, Union
 
 import torch
-import torch.distributed as dist
 import torch.nn.functional as F
 from torch import nn
 
@@ -57,9 +56,6 @@ class _multiCodebookQuantization(nn.Module):
         self._bound = LowerBound(Eps)
         self._permutationRate = permutationRate
 
-    def syncCodebook(self):
-        dist.broadcast(self._codebook, 0)
-
     def _distance(self, x: torch.Tensor) -> torch.Tensor:
         """[n, m*d] -> squared distances [n, m, k] as |x|^2 + |c|^2 - 2 x.c (this op order)."""
         xs = x.reshape(x.shape[0], self._m, self._d)
@@ -74,42 +70,17 @@ class _multiCodebookQuantization(nn.Module):
     def _logit(self, x):
         return -1 * self._distance(x) / self._scale
 
-    def _permute(self, sample):
-        if self._permutationRate < Eps:
-            return sample
-        pick = torch.rand_like(sample[..., 0]) < self._permutationRate
-        sample[pick] = F.one_hot(torch.randint(self._k, (int(pick.sum()),), device=sample.device),
-                                 num_classes=self._k).float()
-        return sample
-
     def _sample(self, x, temperature: float):
         logit = self._logit(x) * self._bound(self._temperature)
-        return self._permute(gumbelSoftmax(logit, temperature, True)), logit
+        if self._permutationRate >= Eps:
+            raise NotImplementedError("code permutation is a training-time augmentation (outside the inference path)")
+        return gumbelSoftmax(logit, temperature, True), logit
 
     def forward(self, x):
         sample, logit = self._sample(x, 1.0)
         code = logit.argmax(-1, keepdim=True)
         one_hot = torch.zeros_like(logit).scatter_(-1, code, 1)
         return sample, code[..., 0], one_hot, logit
-
-    def reAssignCodebook(self, freq: torch.Tensor) -> torch.Tensor:
-        """Training-time dead-code revival (reference ``:77-100``)."""
-        book = self._codebook.clone().detach()
-        freq = freq.to(self._codebook.device).clone().detach()
-        for m, (group, f) in enumerate(zip(self._codebook, freq)):
-            dead = f < Eps
-            n_dead = int(dead.sum())
-            if n_dead > self._k // 2:
-                mask = torch.zeros((n_dead,), device=self._codebook.device)
-                mask[torch.randperm(len(mask))[self._k // 2:]] = 1.
-                f[dead] = mask
-                dead = f < Eps
-                n_dead = int(dead.sum())
-            alive = group[torch.argsort(f, descending=True)[:(self._k - n_dead)]]
-            book.data[m, dead] = alive[torch.randperm(len(alive))[:n_dead]]
-        changed = ((book - self._codebook) ** 2).sum(-1) > 1e-6
-        self._codebook.data.copy_(book)
-        return changed.flatten()
 
 
 class _multiCodebookDeQuantization(nn.Module):
@@ -139,12 +110,6 @@ class _quantizerEncoder(nn.Module):
     @property
     def Codebook(self):
         return self._quantizer._codebook
-
-    def syncCodebook(self):
-        self._quantizer.syncCodebook()
-
-    def reAssignCodebook(self, freq):
-        return self._quantizer.reAssignCodebook(freq)
 
     def encode(self, x):
         z = self._latentStageEncoder(x)
@@ -227,11 +192,6 @@ class UMGMQuantizer(BaseQuantizer):
             out = dec.decode(code, out)
         return out
 
-    def syncCodebook(self):
-        dist.barrier()
-        for enc in self._encoders:
-            enc.syncCodebook()
-
     def updateFreq(self, onehot_list):
         for lvl, one_hot in enumerate(onehot_list):
             hist = one_hot.sum(0)
@@ -239,10 +199,6 @@ class UMGMQuantizer(BaseQuantizer):
 
     def normalFreq(self):
         return [(f / f.sum(-1, keepdim=True)).clone().detach() for f in self._freqEMA]
-
-    def reAssignCodebook(self) -> torch.Tensor:
-        changed = [enc.reAssignCodebook(f) for enc, f in zip(self._encoders, self.normalFreq())]
-        return torch.cat(changed).float().mean()
 
     def forward(self, x: torch.Tensor):
         target = x.detach()

@@ -48,16 +48,44 @@ def weight_codes(qm) -> np.ndarray:
     return _np(torch.clamp(code + zp, 0, wq.n_levels - 1)).astype(np.uint8)
 
 
+def _check_structure(model) -> None:
+    """The deployed engine hard-wires one network shape.  Anything else the plugin / the reference can
+    build must be refused here, not silently run as a different network."""
+    fusion = getattr(model, "fusion_net", None)
+    if type(fusion).__name__ != "AttFusion":
+        raise NotImplementedError(f"deployed path: fusion_net must be AttFusion (fusion_method 'att'), got {type(fusion).__name__}")
+    if getattr(model, "shrink_flag", False):
+        raise NotImplementedError("deployed path: a post-fusion shrink_conv ('shrink_header' in the model args) is not built")
+    if getattr(model, "compress", False):
+        raise NotImplementedError("deployed path: the NaiveCompressor ('compressor' in the model args) is not built")
+    for name, m in model.named_modules():
+        if not _is_quant_module(m):
+            continue
+        if type(getattr(m, "norm_function", None)).__name__ != "StraightThrough":
+            raise NotImplementedError(f"{name}: an unfolded norm_function ({type(m.norm_function).__name__}); build the QuantModel "
+                                      "with is_fusing=True (BN folded into the convolution)")
+        head = name.split(".")[-1].replace("_single", "") in _HEADS
+        if m.disable_act_quant and not head:
+            raise NotImplementedError(f"{name}: disable_act_quant is only supported on the output heads")
+        act = type(getattr(m, "activation_function", None)).__name__
+        if act not in (("StraightThrough",) if (head or name.endswith("pfn_layers.0.linear")) else ("ReLU",)):
+            raise NotImplementedError(f"{name}: activation {act} (the deployed path has ReLU on every conv / deconv, none on the heads "
+                                      "and the PFN linear)")
+
+
 def export_ptq_state(qt_model) -> Dict[str, np.ndarray]:
     model = qt_model.model if hasattr(qt_model, "model") and not _is_quant_module(qt_model) else qt_model
+    _check_structure(model)
     out: Dict[str, np.ndarray] = {}
+    out["meta/fusion_method"] = np.array("att")
     names = []
     for name, m in model.named_modules():
         if not _is_quant_module(m):
             continue
         if m.weight_quantizer.n_bits != 8 or m.act_quantizer.n_bits != 8:
             raise ValueError(f"{name}: the deployed path is W8A8 only")
-        if not (m.weight_quantizer.inited and m.act_quantizer.inited):
+        # AdaRoundQuantizer (adaptive_rounding.py:6-21) has no `inited`: it is built from an initialised quantizer
+        if not (getattr(m.weight_quantizer, "inited", True) and m.act_quantizer.inited):
             raise ValueError(f"{name}: quantizers must be frozen (set_inited(True)) before export")
         names.append(name)
         wq, aq = m.weight_quantizer, m.act_quantizer

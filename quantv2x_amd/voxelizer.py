@@ -27,6 +27,9 @@ class GpuVoxelizer:
         """points f32 [P, 4] on the device -> (voxel_features [M,32,4], voxel_coords [M,4] (agent,z,y,x), voxel_num_points [M])"""
         points = points.contiguous()
         p = int(points.shape[0])
+        if p == 0:                       # an empty sweep: no pillar (the contract oracle returns empty arrays too)
+            return (torch.empty((0, self.max_points, 4), dtype=torch.float32, device=self.dev),
+                    torch.empty((0, 4), dtype=torch.int32, device=self.dev), torch.empty((0,), dtype=torch.int32, device=self.dev))
         need = int(self.lib.qv2x_voxelize_workspace_bytes(p))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.dev)

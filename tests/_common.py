@@ -64,3 +64,55 @@ def hard_forward(model, dd, taps=None):
 def sub8(t):
     a = t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
     return a[:, ::8]
+
+
+# ---- GPU vs oracle, whole frame (used by the -m gpu suites) ---------------------------------------------------------
+FUSE_TOL = dict(rtol=2e-5, atol=2e-5)      # fp32 re-association in the 256-wide dot products + expf
+
+
+def interior_u8(t):
+    """padded i8 BEV [N, H+2, W+2, C] (device) -> uint8 codes [N, H, W, C] (numpy)"""
+    return (t[:, 1:-1, 1:-1, :].to(torch.int16) + 128).to(torch.uint8).cpu().numpy()
+
+
+def head_lsb(state, suffix=""):
+    return max(float(state[k + suffix + "/a_delta"]) for k in ("cls_head", "reg_head", "dir_head"))
+
+
+def compare_frame(orc, eng, sc_np, state, every_layer=True, preds_exact_tol=None):
+    """One frame through the CPU oracle and through the HIP engine (C ABI): every uint8 activation and every codebook
+    index bit-exact, the fused fp32 map within FUSE_TOL, predictions equal up to rare +-1 LSB flips of the head
+    quantizer (or within ``preds_exact_tol`` when the head output quantizer is disabled)."""
+    otaps, gtaps = {}, {}
+    want = orc.forward(sc_np, otaps)
+    got = eng(synth.scene_to_torch(sc_np, "cuda"), gtaps)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(interior_u8(gtaps["canvas"]), otaps["canvas"], err_msg="canvas")
+    checked = 0
+    for name, arr in otaps.items():
+        if (name.startswith("backbone_m1.blocks") or name.startswith("shrinker_m1")) and not name.endswith("_q") and name in gtaps:
+            if every_layer or name.startswith("shrinker_m1"):
+                np.testing.assert_array_equal(interior_u8(gtaps[name]), arr, err_msg=name)
+                checked += 1
+    assert checked >= 2
+    c0 = 0
+    for lvl in range(len(eng.deblocks)):
+        name = f"backbone_m1.deblocks.{lvl}.0"
+        c = otaps[name].shape[-1]
+        np.testing.assert_array_equal(interior_u8(gtaps["cat"])[..., c0:c0 + c], otaps[name], err_msg=name)
+        c0 += c
+    if eng.has_codebook:
+        np.testing.assert_array_equal(gtaps["codes"].cpu().numpy().reshape(otaps["codes"].shape), otaps["codes"], err_msg="codebook indices")
+    h, w = otaps["fused"].shape[1:3]
+    np.testing.assert_allclose(gtaps["fused"].cpu().numpy().reshape(-1, h, w, 256), otaps["fused"], **FUSE_TOL)
+    keys = ["cls_preds", "reg_preds", "dir_preds", "preds_tensor"]
+    if "cls_preds_single" in want:
+        keys += ["cls_preds_single", "reg_preds_single", "dir_preds_single"]
+    for key in keys:
+        d = np.abs(got[key].cpu().numpy() - want[key])
+        if preds_exact_tol is not None:
+            assert d.max() <= preds_exact_tol, (key, d.max())
+        else:
+            lsb = head_lsb(state, "_single" if key.endswith("_single") else "")
+            assert d.max() <= lsb * 1.001 and (d > 1e-5).mean() < 1e-3, (key, d.max(), (d > 1e-5).mean())
+    return otaps, gtaps, want, got

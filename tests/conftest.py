@@ -14,6 +14,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """``gpu``-marked tests are skipped (not failed) where they cannot run: no MI355X, or libqv2x.so not built."""
+    import torch
+    reason = None
+    if not torch.cuda.is_available():
+        reason = "no GPU (torch.cuda.is_available() is False)"
+    elif not os.path.exists(os.path.join(ROOT, "quantv2x_amd", "libqv2x.so")):
+        reason = "quantv2x_amd/libqv2x.so is not built"
+    if reason is None:
+        return
+    skip = pytest.mark.skip(reason=reason)
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np

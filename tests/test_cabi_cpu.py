@@ -31,7 +31,7 @@ def test_struct_layouts_match_header():
     from quantv2x_amd import lib
     assert C.sizeof(lib.PfnParams) == (640 + 64 + 4 + 6) * 4
     assert C.sizeof(lib.ConvDesc) == (7 + 3 * 4 + 3) * 4 + 8
-    assert C.sizeof(lib.DeconvDesc) == 13 * 4
+    assert C.sizeof(lib.DeconvDesc) == 15 * 4
     assert C.sizeof(lib.EncodeDesc) == 7 * 4
     assert C.sizeof(lib.FuseDesc) == 7 * 4 + 4 + 2 * 8 + 3 * 8      # 4 bytes of padding before the int64 fields
 
@@ -104,3 +104,97 @@ def test_ptq_state_roundtrip(tmp_path):
     assert sorted(back) == sorted(st)
     for k in st:
         np.testing.assert_array_equal(back[k], st[k])
+
+
+def test_export_refuses_networks_the_engine_does_not_build():
+    """a QuantModel whose structure the engine hard-wires differently must raise, not deploy as another network."""
+    import copy
+    import torch
+    from _common import build_plugin, quant_wrap, act_quantizers, scene
+    from quantv2x_amd import synth
+    from quantv2x_amd.plugin.quant import QuantModel
+    from quantv2x_amd.plugin.tools import train_utils
+    from quantv2x_amd.plugin.tools.inference_quant import calibrate_minmax
+    from quantv2x_amd.ptq_state import export_ptq_state
+
+    def plugin(mutate):
+        hy = synth.make_hypes("tiny")
+        mutate(hy["model"]["args"])
+        m = train_utils.create_model(copy.deepcopy(hy)).eval()
+        synth.load_state_dict_numpy(m, synth.make_state_dict(m.state_dict(), seed=1))
+        return m
+
+    # max fusion
+    qt = calibrate_minmax(quant_wrap(plugin(lambda a: a.update(fusion_method="max"))), [scene(2)])
+    with pytest.raises(NotImplementedError, match="AttFusion"):
+        export_ptq_state(qt)
+    # post-fusion shrink_conv
+    sh = {"kernal_size": [3], "stride": [1], "padding": [1], "dim": [256], "input_dim": 256}
+    qt = calibrate_minmax(quant_wrap(plugin(lambda a: a.update(shrink_header=sh))), [scene(2)])
+    with pytest.raises(NotImplementedError, match="shrink"):
+        export_ptq_state(qt)
+    # unfolded BN (is_fusing=False)
+    wq = dict(n_bits=8, channel_wise=True, scale_method="minmax")
+    aq = dict(n_bits=8, channel_wise=False, scale_method="minmax", leaf_param=True, prob=0.5)
+    qt = QuantModel(build_plugin(), wq, aq, is_fusing=False).eval()
+    for q in act_quantizers(qt):
+        q.set_inited(True)
+    for m in qt.modules():
+        if hasattr(m, "weight_quantizer"):
+            m.weight_quantizer.set_inited(True)
+    with pytest.raises(NotImplementedError, match="norm_function"):
+        export_ptq_state(qt)
+    # disable_act_quant on a backbone layer
+    from _common import calibrated_plugin
+    qt = calibrated_plugin()
+    qt.model.backbone_m1.blocks[0][1].disable_act_quant = True
+    with pytest.raises(NotImplementedError, match="disable_act_quant"):
+        export_ptq_state(qt)
+    # and the golden recipe still exports, carrying the fusion method
+    st = export_ptq_state(calibrated_plugin())
+    assert str(st["meta/fusion_method"]) == "att"
+
+
+def test_sharded_driver_refuses_codebookless_engine():
+    from quantv2x_amd.dist import AgentShardedModel
+
+    class _E:
+        has_codebook = False
+    with pytest.raises(NotImplementedError, match="code planes"):
+        AgentShardedModel(_E())
+
+
+def test_adaround_mse_and_output_off_states_export():
+    """The export of the three non-default PTQ states equals what the torch quantizers themselves compute, and the oracle
+    runs them (the GPU side is tests/test_hip_deploy_states.py)."""
+    import torch
+    from _common import scene_np
+    from _states import adaround_plugin, mse_plugin, output_quant_off_plugin
+    from oracle.spec import Oracle
+    from quantv2x_amd.plugin.quant import QuantModule
+    from quantv2x_amd.ptq_state import export_ptq_state
+    qt = adaround_plugin()
+    st = export_ptq_state(qt)
+    n = 0
+    for name, m in qt.model.named_modules():
+        if isinstance(m, QuantModule):
+            with torch.no_grad():
+                want = m.weight_quantizer(m.weight).numpy()                      # floor(w/d) + (alpha >= 0), clamped, dequantized
+            shape = [-1] + [1] * (want.ndim - 1)
+            got = (st[name + "/w_code"].astype(np.float32) - st[name + "/w_zp"].reshape(shape)) * st[name + "/w_delta"].reshape(shape)
+            np.testing.assert_array_equal(got.astype(np.float32), want, err_msg=name)
+            nearest = np.clip(np.round(m.weight.detach().numpy() / st[name + "/w_delta"].reshape(shape)) + st[name + "/w_zp"].reshape(shape), 0, 255)
+            n += int((nearest != st[name + "/w_code"]).sum())
+    assert n > 1000                                   # the hard masks really differ from round-to-nearest
+    out = Oracle(st).forward(scene_np(2))
+    assert np.isfinite(out["preds_tensor"]).all()
+    st = export_ptq_state(output_quant_off_plugin())
+    assert bool(st["cls_head/a_off"]) and bool(st["dir_head_single/a_off"]) and not bool(st["backbone_m1.blocks.0.1/a_off"])
+    st_mse, st_mm = export_ptq_state(mse_plugin()), export_ptq_state(calibrated_plugin_cached())
+    k = "backbone_m1.blocks.1.2/w_delta"
+    assert not np.array_equal(st_mse[k], st_mm[k])
+
+
+def calibrated_plugin_cached():
+    from _common import calibrated_plugin
+    return calibrated_plugin()

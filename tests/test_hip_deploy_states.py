@@ -1,0 +1,42 @@
+"""Deploy inputs other than the min-max recipe, on the GPU against the oracle: an AdaRound hard-mask
+state, heads with the output quantizer disabled, an MSE-calibrated state.  Tiny shape; same bar as test_hip_parity."""
+import numpy as np
+import pytest
+import torch
+
+from _common import compare_frame, scene_np
+from _states import adaround_plugin, mse_plugin, output_quant_off_plugin
+
+pytestmark = pytest.mark.gpu
+torch.set_num_threads(8)
+
+
+def _deploy(qt):
+    from oracle.spec import Oracle
+    from quantv2x_amd.engine import deploy
+    from quantv2x_amd.ptq_state import export_ptq_state
+    state = export_ptq_state(qt)
+    return state, Oracle(state), deploy(state=state)
+
+
+@pytest.mark.parametrize("n_agents", [1, 3])
+def test_adaround_hard_mask_state(n_agents):
+    state, orc, eng = _deploy(adaround_plugin())
+    compare_frame(orc, eng, scene_np(n_agents), state)
+
+
+def test_heads_without_output_quantizer():
+    """a_off: the heads return the fp32 accumulator (+ bias); no LSB to flip, so the bound is the fp32 one"""
+    state, orc, eng = _deploy(output_quant_off_plugin())
+    assert all(bool(state[h + "/a_off"]) for h in ("cls_head", "reg_head", "dir_head"))
+    _, _, want, got = compare_frame(orc, eng, scene_np(2), state, preds_exact_tol=2e-4)
+    # and they are not on a quantization grid any more
+    d = float(state["cls_head_single/a_delta"])
+    frac = np.abs(got["cls_preds"].cpu().numpy() / d - np.round(got["cls_preds"].cpu().numpy() / d))
+    assert (frac > 1e-3).mean() > 0.5
+
+
+@pytest.mark.parametrize("n_agents", [2])
+def test_mse_calibrated_state(n_agents):
+    state, orc, eng = _deploy(mse_plugin())
+    compare_frame(orc, eng, scene_np(n_agents), state)

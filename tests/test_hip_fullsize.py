@@ -1,21 +1,31 @@
-"""Full-size (BASELINE.json shapes) checks on the GPU: the oracle still finishes in seconds at V2X-Real size on the GPU
-box's host, so the N = 1 frame is compared exactly; larger agent counts are covered by size-independent properties."""
+"""Full-size (BASELINE.json shapes) checks on the GPU.  The C/OpenMP oracle finishes a V2X-Real agent-frame in well under
+a second on the GPU box's host cores, so every BASELINE config is compared EXACTLY end to end (uint8 activations and
+codebook indices bit-exact, fused map 2e-5, predictions up to rare +-1 LSB head-quantizer flips):
+
+  configs[1]  V2X-Real, 1 agent                  test_v2xreal_frames_exact[1]
+  configs[2]  V2X-Real, 2 agents (line layout)   test_v2xreal_frames_exact[2]
+  configs[3]  V2X-Real, 4 agents (ring layout)   test_v2xreal_frames_exact[4]
+  configs[4]  OPV2V 512 x 512 grid, 1 and 8 agents (max_cav raised to 8), single-class heads   test_opv2v_*
+
+plus size-independent properties at the 4-agent shape."""
 import os
 
 import numpy as np
 import pytest
 import torch
 
+from _common import compare_frame, head_lsb
+
 pytestmark = pytest.mark.gpu
 
 
-def _calibrated(shape):
+def _calibrated(shape, **kw):
     import copy
     from quantv2x_amd import synth
     from quantv2x_amd.plugin.tools import inference_quant, train_utils
     from quantv2x_amd.ptq_state import export_ptq_state
     torch.set_num_threads(min(32, os.cpu_count() or 8))
-    model = train_utils.create_model(copy.deepcopy(synth.make_hypes(shape))).eval()
+    model = train_utils.create_model(copy.deepcopy(synth.make_hypes(shape, **kw))).eval()
     synth.load_state_dict_numpy(model, synth.make_state_dict(model.state_dict(), seed=1))
     calib = synth.scene_to_torch(synth.make_scene(shape, n_agents=1, seed=3, n_points=60000))
     return export_ptq_state(inference_quant.calibrate_minmax(inference_quant.wrap(model), [calib]))
@@ -23,41 +33,53 @@ def _calibrated(shape):
 
 @pytest.fixture(scope="module")
 def v2xreal():
+    from oracle.spec import Oracle
     from quantv2x_amd.engine import deploy
     state = _calibrated("v2xreal")
-    return state, deploy(state=state)
+    return state, deploy(state=state), Oracle(state)
 
 
-def _interior(t):
-    return (t[:, 1:-1, 1:-1, :].to(torch.int16) + 128).to(torch.uint8).cpu().numpy()
-
-
-def test_v2xreal_single_agent_frame_exact(v2xreal):
-    """BASELINE.json configs[1]: 60k points, 704 x 200 grid.  Every uint8 activation of the last backbone level, the
-    concat, the shrinker, and all 3 x 35 200 codebook indices bit-exact; predictions within one head LSB."""
+@pytest.fixture(scope="module")
+def opv2v():
     from oracle.spec import Oracle
+    from quantv2x_amd.engine import deploy
+    state = _calibrated("opv2v", multiclass=False)
+    return state, deploy(state=state), Oracle(state)
+
+
+@pytest.mark.parametrize("n_agents,layout,seed", [(1, "line", 3), (2, "line", 3), (4, "ring", 5)])
+def test_v2xreal_frames_exact(v2xreal, n_agents, layout, seed):
+    """BASELINE.json configs[1..3]: 60k points per agent, 704 x 200 grid, 3 x 35 200 indices per agent."""
     from quantv2x_amd import synth
-    state, eng = v2xreal
-    sc = synth.make_scene("v2xreal", n_agents=1, seed=3, n_points=60000)
-    ot, gt = {}, {}
-    want = Oracle(state).forward(sc, ot)
-    got = eng(synth.scene_to_torch(sc, "cuda"), gt)
-    torch.cuda.synchronize()
-    np.testing.assert_array_equal(_interior(gt["canvas"]), ot["canvas"])
-    for name in ("backbone_m1.blocks.0.4", "backbone_m1.blocks.1.6", "backbone_m1.blocks.2.9",
-                 "shrinker_m1.layers.0.double_conv.0", "shrinker_m1.layers.0.double_conv.1"):
-        np.testing.assert_array_equal(_interior(gt[name]), ot[name], err_msg=name)
-    np.testing.assert_array_equal(gt["codes"].cpu().numpy().reshape(ot["codes"].shape), ot["codes"])
-    lsb = max(float(state[k + "/a_delta"]) for k in ("cls_head", "reg_head", "dir_head"))
-    d = np.abs(got["preds_tensor"].cpu().numpy() - want["preds_tensor"])
-    assert d.max() <= lsb * 1.001 and (d > 1e-5).mean() < 1e-3
+    state, eng, orc = v2xreal
+    sc = synth.make_scene("v2xreal", n_agents=n_agents, seed=seed, n_points=60000, layout=layout)
+    compare_frame(orc, eng, sc, state)
+
+
+def test_opv2v_single_agent_frame_exact(opv2v):
+    """configs[4] shape, one agent: 256 x 256 maps (ragged 5 x 32 wide-conv patches, 65 536-row encode)."""
+    from quantv2x_amd import synth
+    state, eng, orc = opv2v
+    sc = synth.make_scene("opv2v", n_agents=1, seed=3, n_points=60000)
+    _, gt, _, got = compare_frame(orc, eng, sc, state)
+    assert gt["codes"].shape[-1] == 65536 and got["preds_tensor"].shape == (1, 20, 256, 256)
+
+
+def test_opv2v_eight_agents_exact(opv2v):
+    """configs[4]: 8-agent dense scene (ring layout, max_cav 8), single-class heads -- the whole frame against the oracle."""
+    from quantv2x_amd import synth
+    state, eng, orc = opv2v
+    sc = synth.make_scene("opv2v", n_agents=8, seed=7, n_points=60000, layout="ring")
+    _, gt, _, got = compare_frame(orc, eng, sc, state, every_layer=False)
+    assert got["preds_tensor"].shape == (1, 20, 256, 256) and got["cls_preds_single"].shape == (8, 2, 256, 256)
+    assert gt["codes"].shape == (3, 8, 65536)
 
 
 def test_v2xreal_properties_four_agents(v2xreal):
     """configs[3] shape (4 agents, ring layout): agent permutation-equivariance of the encode, determinism, identity-pose
     fusion of identical agents returns the agent itself, and the N = 1 slice of a batch equals the single-agent run."""
     from quantv2x_amd import synth
-    state, eng = v2xreal
+    state, eng, _ = v2xreal
     sc = synth.make_scene("v2xreal", n_agents=4, seed=5, n_points=60000, layout="ring")
     dd = synth.scene_to_torch(sc, "cuda")
     t1, t2 = {}, {}
@@ -80,26 +102,5 @@ def test_v2xreal_properties_four_agents(v2xreal):
     eye = torch.eye(4, dtype=torch.float64, device="cuda").expand(5, 5, 4, 4).contiguous()
     one = eng.fuse_and_heads(codes_solo.contiguous(), hw, hw, eye, 1)["preds_tensor"].clone()
     three = eng.fuse_and_heads(rep, hw, 3 * hw, eye, 3)["preds_tensor"]
-    lsb = max(float(state[k + "/a_delta"]) for k in ("cls_head", "reg_head", "dir_head"))
     d = (one - three).abs()
-    assert float(d.max()) <= lsb * 1.001 and float((d > 1e-5).float().mean()) < 1e-3
-
-
-def test_opv2v_eight_agents_runs():
-    """configs[4] shape: 512 x 512 grid, 8 agents, single-class heads (max_cav raised to 8)."""
-    from quantv2x_amd import synth
-    from quantv2x_amd.engine import deploy
-    import copy
-    from quantv2x_amd.plugin.tools import inference_quant, train_utils
-    from quantv2x_amd.ptq_state import export_ptq_state
-    torch.set_num_threads(min(32, os.cpu_count() or 8))
-    hy = synth.make_hypes("opv2v", multiclass=False)
-    model = train_utils.create_model(copy.deepcopy(hy)).eval()
-    synth.load_state_dict_numpy(model, synth.make_state_dict(model.state_dict(), seed=1))
-    calib = synth.scene_to_torch(synth.make_scene("opv2v", n_agents=1, seed=3, n_points=60000))
-    eng = deploy(state=export_ptq_state(inference_quant.calibrate_minmax(inference_quant.wrap(model), [calib])))
-    dd = synth.scene_to_torch(synth.make_scene("opv2v", n_agents=8, seed=7, n_points=60000, layout="ring"), "cuda")
-    out = eng(dd)
-    torch.cuda.synchronize()
-    assert out["preds_tensor"].shape == (1, 20, 256, 256) and bool(torch.isfinite(out["preds_tensor"]).all())
-    assert out["cls_preds_single"].shape == (8, 2, 256, 256)
+    assert float(d.max()) <= head_lsb(state) * 1.001 and float((d > 1e-5).float().mean()) < 1e-3

@@ -37,6 +37,18 @@ def test_gpu_voxelizer_small(n, max_points, max_voxels):
 
 
 @pytest.mark.gpu
+def test_gpu_voxelizer_empty_sweep():
+    """a sweep with no point gives no pillar (and an agent without pillars is a valid model input)"""
+    import torch
+    from quantv2x_amd.voxelizer import GpuVoxelizer
+    vox = GpuVoxelizer(RANGE, VS, 32, 64)
+    f, c, m = vox.one(torch.empty((0, 4), dtype=torch.float32, device="cuda"), agent=0)
+    assert f.shape == (0, 32, 4) and c.shape == (0, 4) and m.shape == (0,)
+    both = vox([torch.empty((0, 4), dtype=torch.float32, device="cuda"), torch.from_numpy(_cloud(300, 4)).cuda()])
+    assert (both["voxel_coords"][:, 0] == 1).all() and both["voxel_features"].shape[0] > 0
+
+
+@pytest.mark.gpu
 def test_gpu_voxelizer_full_size_feeds_the_model_inputs():
     """60k-point V2X-Real sweeps, two agents: identical to the numpy generator the rest of the suite uses."""
     import torch
