@@ -106,6 +106,25 @@ int qv2x_conv3x3_i8_wide(const qv2x_conv_desc* desc /* host */, const int8_t* in
                          const float* scale, const int32_t* corr, const int32_t* aw, const float* bias,
                          int8_t* out, void* stream);
 
+/* a3, one backbone level in ONE launch.  A chain of `depth` (1..4) such convolutions with 64 input and 64 output channels
+ * each (level 0 of BaseBEVBackbone, base_bev_backbone.py:96-119 / quant_block.py:243-303): layer 0 has stride `stride0`
+ * (the ZeroPad2d + stride-2 convolution, or 1), the others stride 1; every layer has one input group.  Intermediate maps stay
+ * in LDS; results are identical to `depth` qv2x_conv3x3_i8 calls.
+ *   in     : padded i8 BEV [N][in_h+2][in_w+2][64];  out: padded i8 BEV [N][h+2][w+2][64] (interior written)
+ *   w_chain: i8 (code - 128) [depth][2][9][2][64][16]: the B fragments of v_mfma_i32_32x32x32_i8 in load order --
+ *            [layer][cout / 32][tap][cin / 32][lane][16 B], lane = 32 * ((cin / 16) & 1) + cout % 32, bytes = cin % 16
+ *   scale, bias f32 [depth][64]; corr, aw i32 [depth][64] (as qv2x_conv3x3_i8, one group);
+ *   out_delta / out_zp: the output quantizer of every layer (the pad code of layer l's map is out_zp[l] - 128). */
+typedef struct {
+    int32_t n, h, w;           /* output map of every layer */
+    int32_t in_h, in_w;        /* input map of layer 0 */
+    int32_t depth, stride0, relu;
+    float out_delta[4], out_zp[4];
+} qv2x_chain_desc;
+int qv2x_conv3x3_i8_chain64(const qv2x_chain_desc* desc /* host */, const int8_t* in, const int8_t* w_chain,
+                            const float* scale, const int32_t* corr, const int32_t* aw, const float* bias,
+                            int8_t* out, void* stream);
+
 /* a3 deblocks.  QuantModule over ConvTranspose2d with kernel == stride == s, + bias + ReLU + output quantizer.
  * The reference's per-dim-0 weight scales are per C_in here (quant_layer.py:192-195 on a [Cin,Cout,s,s]
  * weight), i.e. on the reduction axis, so the sum runs in fp32 on the f32 MFMA as an ascending-ci fmaf chain:

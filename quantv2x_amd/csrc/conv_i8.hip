@@ -138,18 +138,6 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_i8_dma_kernel(const ConvArg
     for (int p = 0; p < S - 1; ++p)
         if (p < total) issue();
 
-    // epilogue constants, requested now so their latency hides behind the K loop (they only make the first wait of the
-    // ring slightly stricter: the vmcnt protocol counts "all but the newest (S-2)*LPS", and these are older than any
-    // chunk issued in the loop)
-    int e_aw[NT], e_cr[NT];
-    float e_sc[NT], e_bs[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int co = n0 + wn * TN + j * 32 + (lane & 31);
-        e_aw[j] = 0; e_cr[j] = 0; e_sc[j] = 0.f; e_bs[j] = 0.f;
-        if (!MULTI) { e_aw[j] = a.aw[co]; e_cr[j] = a.corr[co]; e_sc[j] = a.scale[co]; e_bs[j] = a.bias[co]; }
-    }
-
     // per-lane fragment read offsets inside a stage (loop invariant; the stage base is an immediate after unrolling by S)
     constexpr int KS = BK / 32;
     int offA[MT][KS], offB[NT][KS];
@@ -218,10 +206,12 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_i8_dma_kernel(const ConvArg
 #pragma unroll
                         for (int q = 0; q < 4; ++q) xs[i] = __builtin_amdgcn_sdot4(fa[i][q], 0x01010101, xs[i], false);
 #pragma unroll
-                        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = MULTI ? __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0)
+                                              : __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[j], fa[i], acc[i][j], 0, 0, 0);
                     }
                 }
-                if (step + 1 == g_end) {
+                if (MULTI && step + 1 == g_end) {
                     fold_group();
                     ++g;
                     g_end += 9 * (a.gc[g < QV2X_MAX_GROUPS ? g : 0] / BK);
@@ -232,23 +222,73 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_i8_dma_kernel(const ConvArg
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                            // ring is idle: its first bytes become the epilogue staging tile
 
+    if (!MULTI) {
+        // Single group: the weights were the A operand, so lane l holds ONE pixel (l & 31) of M tile i and, of N tile j, the 16
+        // channels 8 (r >> 2) + 4 (l >> 5) + (r & 3): four runs of four consecutive bytes of the output row.  The window sum is
+        // the lane's own (no exchange), the per-channel constants come as 16-byte loads, four results are requantized and packed
+        // at a time (q_pack4) and a tile is staged with four ds_write_b32 per lane -- ~13 VALU instructions per output where the
+        // pixel-per-row form (one ds_write_b8 and the whole coordinate logic per element) spent ~85.
+        constexpr int SP = TN + 16;                              // staging row pitch: 2-way bank spread for the dword writes
+        static_assert(4 * TM * SP <= S * STAGE, "epilogue staging fits the idle ring");
+        int8_t* stage = lds + wave * (TM * SP);                  // this wave's [TM pixels][TN channels]
+        const float rd = 1.0f / a.out_delta, lo = a.relu ? 0.0f : -3.0e38f;
+        const int half = lane >> 5, l31 = lane & 31;
+        int tot[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) tot[i] = xs[i] + __shfl_xor(xs[i], 32);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            int c_aw[16], c_cr[16];
+            float c_sc[16], c_bs[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = n0 + wn * TN + j * 32 + 8 * g + 4 * half;
+                const v4i xa = *(const v4i*)(a.aw + c0), xc = *(const v4i*)(a.corr + c0);
+                const v4f xsc = *(const v4f*)(a.scale + c0), xb = *(const v4f*)(a.bias + c0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { c_aw[4 * g + e] = xa[e]; c_cr[4 * g + e] = xc[e]; c_sc[4 * g + e] = xsc[e]; c_bs[4 * g + e] = xb[e]; }
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float y[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g + e;
+                        const int T = acc[i][j][r] + __mul24(c_aw[r], tot[i]) + c_cr[r];
+                        y[e] = fmaxf(c_bs[r] + (float)T * c_sc[r], lo);
+                    }
+                    *(int*)(stage + (i * 32 + l31) * SP + j * 32 + 8 * g + 4 * half) = q_pack4(y[0], y[1], y[2], y[3], a.out_delta, rd, a.out_zp);
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        constexpr int CPR = TN / 16;
+#pragma unroll
+        for (int t = 0; t < (TM * CPR + 63) / 64; ++t) {
+            const int id = lane + t * 64, row = id / CPR, chn = id % CPR;
+            if (id < TM * CPR) {
+                const int off = rowoff[wm * TM + row];
+                if (off >= 0)
+                    *(v4i*)(a.out + (size_t)off * a.out_ctotal + a.out_c0 + n0 + wn * TN + chn * 16) = *(const v4i*)(stage + row * SP + chn * 16);
+            }
+        }
+        return;
+    }
+
+    // several input groups (the shrinker's first layer when it does not take the wide kernel): pixels are the rows of the C
+    // fragment and the per-group fp32 fold has already produced y
     int8_t* stage = lds + wave * (32 * TN);
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const int awv = e_aw[j], cr = e_cr[j];
-            const float sc = e_sc[j], bs = e_bs[j];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mfma32_row(r, lane);
-                float y;
-                if (MULTI) {
-                    y = facc[i][j][r % NF];
-                } else {
-                    const int T = acc[i][j][r] + __mul24(awv, xbuf[wave * TM + i * 32 + row]) + cr;
-                    y = bs + (float)T * sc;
-                }
+                float y = facc[i][j][r % NF];
                 if (a.relu) y = fmaxf(y, 0.0f);
                 stage[row * TN + j * 32 + (lane & 31)] = (int8_t)((int)q_code(y, a.out_delta, a.out_zp) - 128);
             }

@@ -22,7 +22,7 @@ namespace {
 constexpr int TH = 5, TW = 32, HWD = TW + 2, HPIX = (TH + 2) * HWD;    // 238 halo pixels
 constexpr int HBLK = (HPIX * 64 + 1023) / 1024;                       // 15 DMA instructions of 1 KiB
 constexpr int HBUF = HBLK * 1024;
-constexpr int BM = TH * TW, BN = 256, BSTAGE = BN * 64;
+constexpr int BM = TH * TW, WTILE = 256;                             // pixels per workgroup; rows of one pre-tiled weight tile
 constexpr int MT = 5;
 constexpr int MAX_CHUNKS = 24;
 
@@ -42,20 +42,34 @@ template <int V> struct IC { static constexpr int value = V; };
 // per MFMA, one fragment set) is what ships: 31.5 us on the 256->256 shrinker layer against 37.5 us for <4, 2> (one wave
 // per SIMD, 0.7 reads per MFMA, fragments of step s+1 read while step s multiplies), and the multi-group layer's extra
 // fp32 fold accumulator per output (2 x 160 registers at NT = 2) only fits the register file at NT = 1.
-template <int S, bool MULTI, int NW, int NT>
-__global__ __launch_bounds__(NW * 64, 1) void conv3x3_i8_wide_kernel(const WideArgs a) {
-    static_assert(NW * NT * 32 == BN, "wave layout");
+//
+// BN = output channels per workgroup.  BN = 256 is one workgroup per CU (110 KB of LDS, 220 workgroups at V2X-Real size: 36
+// CUs idle).  BN = 128 (<S, MULTI, 4, 1, 128>) halves the weight stage (74 KB of LDS): 440 four-wave workgroups, two per CU, the
+// same two waves per SIMD -- but the two are independent workgroups, so the prologue / fold / epilogue of one overlaps the K
+// loop of the other, and every CU has work.  The two channel halves of a patch get block ids 8 apart (same XCD: the halo
+// tile they both fetch is served by one L2).
+template <int S, bool MULTI, int NW, int NT, int BN>
+__global__ __launch_bounds__(NW * 64, 512 / (NW * 64)) void conv3x3_i8_wide_kernel(const WideArgs a) {
+    static_assert(NW * NT * 32 == BN && WTILE % BN == 0, "wave layout");
+    constexpr int BSTAGE = BN * 64, NB = WTILE / BN;
     constexpr int LH = (HBLK + NW - 1) / NW, LB = BSTAGE / 1024 / NW;  // DMA instructions per wave: halo tile, weight tile
     constexpr int NF = MULTI ? 16 : 1;
-    __shared__ __attribute__((aligned(16))) int8_t lds[2 * HBUF + S * BSTAGE + NW * BM * 4];
+    static_assert(NT == 1, "the epilogue below is written for one 32-channel tile per wave");
+    constexpr int NG = MULTI ? QV2X_MAX_GROUPS : 1;
+    __shared__ __attribute__((aligned(16))) int8_t lds[2 * HBUF + S * BSTAGE + NW * BM * 4 + NG * BN * 16];
     int8_t* hbuf = lds;
     int8_t* bst = lds + 2 * HBUF;
     int* xbuf = (int*)(bst + S * BSTAGE);                              // [NW][BM] partial window sums
+    v4i* ctab = (v4i*)(xbuf + NW * BM);                                // [group][BN] {aw, corr_g, scale_g (bits), bias (bits)} per channel
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int txi = blockIdx.x % a.tiles_x, tyi = (blockIdx.x / a.tiles_x) % a.tiles_y, img = blockIdx.x / (a.tiles_x * a.tiles_y);
-    const int y0 = tyi * TH, x0 = txi * TW, n0 = blockIdx.y * BN;
+    // block id -> (patch, channel block): id = ((patch / 8) * nblk + cb) * 8 + patch % 8
+    const int nblk = a.cout / BN;
+    const int patch = (blockIdx.x / (8 * nblk)) * 8 + (blockIdx.x & 7), cb = (blockIdx.x >> 3) % nblk;
+    if (patch >= a.n * a.tiles_x * a.tiles_y) return;
+    const int txi = patch % a.tiles_x, tyi = (patch / a.tiles_x) % a.tiles_y, img = patch / (a.tiles_x * a.tiles_y);
+    const int y0 = tyi * TH, x0 = txi * TW, n0 = cb * BN;
     const int total = a.nchunks * 9;
 
     // ---- DMA sources (the LDS side of global_load_lds is lane-linear, so the XOR swizzle lives in the source address)
@@ -77,26 +91,32 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_i8_wide_kernel(const WideA
     const int8_t* srcB;
     {
         const int p = wave * LB * 64 + lane, row = p >> 2, c = (p & 3) ^ ((row >> 2) & 3);
-        srcB = a.wt + (size_t)blockIdx.y * total * BSTAGE + row * 64 + c * 16;   // + j KiB per instruction: rows advance by 16
+        // weight tiles are [256][64] per step; this workgroup reads rows [(cb % NB) * BN, + BN) of tile cb / NB
+        srcB = a.wt + (size_t)(cb / NB) * total * (WTILE * 64) + (cb % NB) * BSTAGE + row * 64 + c * 16;   // + j KiB per instruction: rows advance by 16
     }
 
     v16i acc[MT][NT];
     float facc[MT][NT][NF];
     int xs[MT];
-    int c_aw[NT], c_cr[NT];                                            // per-channel constants of the fold / epilogue
-    float c_sc[NT], c_bs[NT];
+    // The WEIGHTS are the A operand of the MFMA (out^T = W x^T): lane l holds pixel (l & 31) of every M tile and the 16 channels
+    //   cl(r) = 32 wave + 8 (r >> 2) + 4 (l >> 5) + (r & 3)
+    // of this wave's tile -- the window sum is per lane, the constants of a channel come as one ds_read_b128 from `ctab`, and
+    // four consecutive channels pack into one dword of the output row (see conv_i8.hip).
+    const int half = lane >> 5;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         xs[i] = 0;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0;
+    }
+    if (MULTI) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
-            if (MULTI) {
-                const float b = a.bias[n0 + (wave * NT + j) * 32 + (lane & 31)];
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const v4f b = *(const v4f*)(a.bias + n0 + wave * 32 + 8 * g4 + 4 * half);
 #pragma unroll
-                for (int r = 0; r < NF; ++r) facc[i][j][r] = b;
-            }
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) facc[i][0][4 * g4 + e] = b[e];
         }
     }
 
@@ -104,7 +124,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_i8_wide_kernel(const WideA
     auto issue_b = [&]() __attribute__((always_inline)) {
         const int st = b_step < total ? b_step : total - 1;
         int8_t* stage = bst + (b_step % S) * BSTAGE + wave * LB * 1024;
-        const int8_t* s0 = srcB + (size_t)st * BSTAGE;
+        const int8_t* s0 = srcB + (size_t)st * (WTILE * 64);
 #pragma unroll
         for (int j = 0; j < LB; ++j)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s0 + j * 1024),
@@ -125,7 +145,6 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_i8_wide_kernel(const WideA
     // hp = r + 34 (i + dy) + dx, its 16-byte chunk ch stored at ch ^ ((hp >> 2) & 3).  The 32 lanes of a half-wave read 32
     // CONSECUTIVE halo pixels, so every 16-lane service group of ds_read_b128 ({0-3,12-15,20-27}, ...) covers 16
     // distinct hp mod 16 = 16 distinct 16-byte slots of the 256-byte bank row, whatever the tap shift.
-    const int half = lane >> 5;
     const int hp0 = lane & 31;
     int offB[NT][2];
 #pragma unroll
@@ -179,23 +198,20 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_i8_wide_kernel(const WideA
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (MULTI) {
+            int totv[MT];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int co = n0 + (wave * NT + j) * 32 + (lane & 31);
-                const int awv = c_aw[j], cr = c_cr[j];
-                const float sc = c_sc[j];
-                if (g + 1 < a.ngroups) {                               // the next group's constants: in flight during its K steps
-                    c_cr[j] = a.corr[(g + 1) * a.cout + co];
-                    c_sc[j] = a.scale[(g + 1) * a.cout + co];
+            for (int i = 0; i < MT; ++i) totv[i] = xbuf[i * 32 + (lane & 31)];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const v4i c = ctab[g * BN + wave * 32 + 8 * (r >> 2) + 4 * half + (r & 3)];
+                const int sci = c[2];                                  // (bit_cast straight from the vector element reads element 0)
+                const float sc = __int_as_float(sci);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int T = acc[i][0][r] + __mul24(c[0], totv[i]) + c[1];
+                    facc[i][0][r] = facc[i][0][r] + (float)T * sc;
+                    acc[i][0][r] = 0;
                 }
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int r = 0; r < NF; ++r) {
-                        const int T = acc[i][j][r] + __mul24(awv, xbuf[i * 32 + mfma32_row(r, lane)]) + cr;
-                        facc[i][j][r] = facc[i][j][r] + (float)T * sc;
-                        acc[i][j][r] = 0;
-                    }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                              // xbuf is rewritten by the next fold
@@ -207,14 +223,21 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_i8_wide_kernel(const WideA
 #pragma unroll
     for (int p = 0; p < S - 1; ++p) issue_b();
 
-    // per-channel constants of the epilogue (single group) or of the first group's fold, requested now so that their
-    // latency hides behind the K loop; they are older than every DMA issued in the loop, so the vmcnt protocol ("all but
-    // the newest n") is only stricter for the first wait
+    // per-channel constants -> LDS table (younger than the prologue DMAs: waiting for them also lands the prologue, which the
+    // first K step needs anyway)
+    if (tid < BN) {
+        const int co = n0 + tid;
+        const int awv = a.aw[co];
+        const float bs = a.bias[co];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int co = n0 + (wave * NT + j) * 32 + (lane & 31);
-        c_aw[j] = a.aw[co]; c_cr[j] = a.corr[co]; c_sc[j] = a.scale[co];
-        c_bs[j] = MULTI ? 0.f : a.bias[co];
+        for (int gg = 0; gg < NG; ++gg) {
+            if (gg < a.ngroups) {
+                v4i c;
+                c[0] = awv; c[1] = a.corr[gg * a.cout + co];
+                c[2] = __float_as_int(a.scale[gg * a.cout + co]); c[3] = __float_as_int(bs);
+                ctab[gg * BN + tid] = c;
+            }
+        }
     }
 
     // One K-step = (chunk, tap).  At its barrier: weight tile step+1 and (from tap S-1 on) the next halo have landed for
@@ -246,7 +269,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_i8_wide_kernel(const WideA
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[SET][ks][i], fb[SET][ks][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[SET][ks][j], fa[SET][ks][i], acc[i][j], 0, 0, 0);
     };
     for (int chunk = 0; chunk < a.nchunks; ++chunk) {
         one_step(IC<0>{}, chunk); one_step(IC<1>{}, chunk); one_step(IC<2>{}, chunk);
@@ -258,34 +281,41 @@ __global__ __launch_bounds__(NW * 64, 1) void conv3x3_i8_wide_kernel(const WideA
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    // ---- epilogue: requantize, transpose through LDS, 16-byte stores -----------------------------------------------
-    int8_t* stagebuf = lds + wave * (NT * 1024);                       // per wave [32 rows][NT * 32 channels]
+    // ---- epilogue: requantize four channels at a time, stage [pixel][32 channels] per M tile, 16-byte stores ---------------
+    constexpr int SP = 48;                                             // staging row pitch (2-way bank spread for the dword writes)
+    int8_t* stagebuf = lds + wave * (32 * SP);
+    const float rd = 1.0f / a.out_delta, lo = a.relu ? 0.0f : -3.0e38f;
+    int totv[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) totv[i] = MULTI ? 0 : xbuf[i * 32 + (lane & 31)];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int g4 = 0; g4 < 4; ++g4) {
+            float y[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mfma32_row(r, lane);
-                float y;
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g4 + e;
                 if (MULTI) {
-                    y = facc[i][j][r % NF];
+                    y[e] = facc[i][0][r];
                 } else {
-                    const int T = acc[i][j][r] + __mul24(c_aw[j], xbuf[i * 32 + row]) + c_cr[j];
-                    y = c_bs[j] + (float)T * c_sc[j];
+                    const v4i c = ctab[wave * 32 + 8 * g4 + 4 * half + e];
+                    const int T = acc[i][0][r] + __mul24(c[0], totv[i]) + c[1];
+                    const int sci = c[2], bsi = c[3];
+                    y[e] = __int_as_float(bsi) + (float)T * __int_as_float(sci);
                 }
-                if (a.relu) y = fmaxf(y, 0.0f);
-                stagebuf[row * (NT * 32) + j * 32 + (lane & 31)] = (int8_t)((int)q_code(y, a.out_delta, a.out_zp) - 128);
+                y[e] = fmaxf(y[e], lo);
             }
+            *(int*)(stagebuf + (lane & 31) * SP + 8 * g4 + 4 * half) = q_pack4(y[0], y[1], y[2], y[3], a.out_delta, rd, a.out_zp);
+        }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < NT; ++q) {
-            const int u = q * 64 + lane, row = u / (2 * NT), chn = u % (2 * NT);
+        {
+            const int row = lane >> 1, chn = lane & 1;
             const int yo = y0 + i, xo = x0 + row;
             if (yo < a.ho && xo < a.wo)
-                *(v4i*)(a.out + ((size_t)(img * (a.ho + 2) + yo + 1) * (a.wo + 2) + xo + 1) * a.out_ctotal + a.out_c0 + n0 + wave * (NT * 32) + chn * 16) =
-                    *(const v4i*)(stagebuf + row * (NT * 32) + chn * 16);
+                *(v4i*)(a.out + ((size_t)(img * (a.ho + 2) + yo + 1) * (a.wo + 2) + xo + 1) * a.out_ctotal + a.out_c0 + n0 + wave * 32 + chn * 16) =
+                    *(const v4i*)(stagebuf + row * SP + chn * 16);
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
@@ -377,16 +407,19 @@ extern "C" int qv2x_conv3x3_i8_wide(const qv2x_conv_desc* d, const int8_t* in, c
     WideArgs a{};
     if (int rc = fill_args(d, a)) return rc;
     a.in = in; a.wt = w_wide; a.scale = scale; a.corr = corr; a.aw = aw; a.bias = bias; a.out = out;
-    dim3 grid(a.n * a.tiles_x * a.tiles_y, a.cout / BN);
     hipStream_t st = (hipStream_t)stream;
-#ifdef QV2X_DEV_KNOBS                                                  // dev build only: "4" = one wave per SIMD, 160 x 64 wave tiles
-    static const char* lenv = getenv("QV2X_WIDE_LAYOUT");
-    if (d->ngroups == 1 && lenv && lenv[0] == '4') {
-        conv3x3_i8_wide_kernel<5, false, 4, 2><<<grid, 256, 0, st>>>(a);
-        return hip_check(hipGetLastError(), "qv2x_conv3x3_i8_wide launch");
-    }
+    const int patches8 = (a.n * a.tiles_x * a.tiles_y + 7) / 8 * 8;   // block ids come in groups of 8 (one per XCD)
+#ifndef QV2X_WIDE_BN
+#define QV2X_WIDE_BN 256
 #endif
-    if (d->ngroups > 1) conv3x3_i8_wide_kernel<5, true, 8, 1><<<grid, 512, 0, st>>>(a);
-    else conv3x3_i8_wide_kernel<5, false, 8, 1><<<grid, 512, 0, st>>>(a);
+    if (QV2X_WIDE_BN == 128) {
+        const dim3 grid(patches8 * (a.cout / 128));
+        if (d->ngroups > 1) conv3x3_i8_wide_kernel<5, true, 4, 1, 128><<<grid, 256, 0, st>>>(a);
+        else conv3x3_i8_wide_kernel<5, false, 4, 1, 128><<<grid, 256, 0, st>>>(a);
+    } else {
+        const dim3 grid(patches8 * (a.cout / 256));
+        if (d->ngroups > 1) conv3x3_i8_wide_kernel<5, true, 8, 1, 256><<<grid, 512, 0, st>>>(a);
+        else conv3x3_i8_wide_kernel<5, false, 8, 1, 256><<<grid, 512, 0, st>>>(a);
+    }
     return hip_check(hipGetLastError(), "qv2x_conv3x3_i8_wide launch");
 }

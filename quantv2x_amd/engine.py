@@ -92,6 +92,32 @@ class _ConvLayer:
         assert np.abs(np.stack(corr)).max() < 2 ** 31
 
 
+class _ChainLayers:
+    """Consecutive 64 -> 64 channel conv layers of one backbone level as ONE launch (qv2x_conv3x3_i8_chain64): the B
+    fragments of v_mfma_i32_32x32x32_i8 in load order ``[layer][cout/32][tap][cin/32][lane][16]`` and the per-layer
+    epilogue constants stacked ``[layer][64]``."""
+    MAX_DEPTH = 4
+
+    @staticmethod
+    def eligible(convs) -> bool:
+        return (1 <= len(convs) <= _ChainLayers.MAX_DEPTH and all(c.cout == 64 and len(c.groups) == 1 and c.groups[0][1] == 64 for c in convs)
+                and all(c.stride == 1 for c in convs[1:]))
+
+    def __init__(self, convs, dev):
+        self.convs = convs
+        self.name = convs[-1].name                                    # the tensor it produces is the last layer's output
+        packed = []
+        for c in convs:
+            w = c.w.cpu().numpy().reshape(2, 32, 9, 2, 2, 16)          # [cout/32][n][tap][ks][half][16]
+            packed.append(w.transpose(0, 2, 3, 4, 1, 5))               # [cout/32][tap][ks][half][n][16]: lane = 32 * half + n
+        self.w = _dev(np.stack(packed).astype(np.int8), dev)
+        cat = lambda ts: torch.cat([t.reshape(-1) for t in ts]).contiguous()
+        self.scale, self.corr = cat([c.scale for c in convs]), cat([c.corr for c in convs])
+        self.aw, self.bias = cat([c.aw for c in convs]), cat([c.bias for c in convs])
+        self.stride0 = convs[0].stride
+        self.out_q = convs[-1].out_q
+
+
 class _DeconvLayer:
     def __init__(self, state, name, in_q, dev):
         code = state[name + "/w_code"].astype(np.float32)            # [Cin, Cout, s, s]; scales per C_in (dim 0)
@@ -174,6 +200,7 @@ class DeployedModel(nn.Module):
 
         # ---- a3: backbone ----------------------------------------------------------------------------------
         self.blocks: List[List[_ConvLayer]] = []
+        self.chains: List[Optional[_ChainLayers]] = []                 # per level: its conv layers as one launch, where built
         self.deblocks: List[_DeconvLayer] = []
         cat_groups, c0 = [], 0
         cin = 64
@@ -185,6 +212,7 @@ class DeployedModel(nn.Module):
                 convs.append(layer)
                 q, cin = layer.out_q, layer.cout
             self.blocks.append(convs)
+            self.chains.append(_ChainLayers(convs, dev) if _ChainLayers.eligible(convs) else None)
             de = _DeconvLayer(s, f"backbone_m1.deblocks.{lvl}.0", q, dev)
             self.deblocks.append(de)
             cat_groups.append((c0, de.cout, de.out_q[0], de.out_q[1]))
@@ -210,7 +238,7 @@ class DeployedModel(nn.Module):
         self.heads_single = _Heads(s, "_single", dev) if (self.emit_single and "cls_head_single/w_code" in s) else None
         self._bufs: Dict[int, dict] = {}
         # launch-plan switches for the ablation tools (tools/bench_*_abl.py); the defaults are the shipped configuration
-        self.use_wide_conv, self.batch_deconvs = True, True
+        self.use_wide_conv, self.batch_deconvs, self.use_chains = True, True, True
 
     # ------------------------------------------------------------------------------------------------------
     def _level_blob(self, l: int) -> torch.Tensor:
@@ -297,6 +325,17 @@ class DeployedModel(nn.Module):
         L.check(self.lib.qv2x_conv3x3_i8(C.byref(d), L.ptr(x), L.ptr(layer.w), L.ptr(layer.scale), L.ptr(layer.corr),
                                          L.ptr(layer.aw), L.ptr(layer.bias), L.ptr(out), L.current_stream()), layer.name)
 
+    def _chain(self, ch: _ChainLayers, x, n, h, w, out):
+        """``x``: padded input [n][h+2][w+2][64] of the first layer; ``out``: padded output of the last one."""
+        d = L.ChainDesc()
+        d.n, d.in_h, d.in_w = n, h, w
+        d.h, d.w = out.shape[1] - 2, out.shape[2] - 2
+        d.depth, d.stride0, d.relu = len(ch.convs), ch.stride0, 1
+        for i, c in enumerate(ch.convs):
+            d.out_delta[i], d.out_zp[i] = c.out_q[0], float(c.out_q[1])
+        L.check(self.lib.qv2x_conv3x3_i8_chain64(C.byref(d), L.ptr(x), L.ptr(ch.w), L.ptr(ch.scale), L.ptr(ch.corr), L.ptr(ch.aw),
+                                                 L.ptr(ch.bias), L.ptr(out), L.current_stream()), ch.name)
+
     def _deconv_desc(self, de: _DeconvLayer, n, h, w, out, out_c0):
         d = L.DeconvDesc()
         d.n, d.h, d.w, d.cin, d.cout, d.s = n, h, w, de.cin, de.cout, de.s
@@ -329,23 +368,30 @@ class DeployedModel(nn.Module):
     def conv_plan(self, n_agents: int):
         """Static launch list of a3 + a4 for ``n_agents`` agents: ``(kind, layer, x, h, w, out, out_c0, macs)``."""
         b = self._workspace(n_agents)
-        if "plan" in b:
-            return b["plan"]
+        key = ("plan", self.use_chains)
+        if key in b:
+            return b[key]
         plan = []
         x, h, w, c0 = b["canvas"], self.ny, self.nx, 0
         for lvl, convs in enumerate(self.blocks):
             pair, ho, wo = b["lvl"][lvl]
-            for i, layer in enumerate(convs):
-                out = pair[i % 2]
-                plan.append(("conv", layer, x, h, w, out, 0, n_agents * ho * wo * layer.cout * layer.w.shape[1]))
+            macs = [n_agents * ho * wo * layer.cout * layer.w.shape[1] for layer in convs]
+            if self.use_chains and self.chains[lvl] is not None:
+                out = pair[(len(convs) - 1) % 2]
+                plan.append(("chain", self.chains[lvl], x, h, w, out, 0, sum(macs)))
                 x, h, w = out, ho, wo
+            else:
+                for i, layer in enumerate(convs):
+                    out = pair[i % 2]
+                    plan.append(("conv", layer, x, h, w, out, 0, macs[i]))
+                    x, h, w = out, ho, wo
             de = self.deblocks[lvl]
             plan.append(("deconv", de, x, h, w, b["cat"], c0, n_agents * h * w * de.cin * de.cout * de.s * de.s))
             c0 += de.cout
         hw = n_agents * self.fh * self.fw
         plan.append(("conv", self.shrink0, b["cat"], self.fh, self.fw, b["s0"], 0, hw * self.shrink0.cout * self.shrink0.w.shape[1]))
         plan.append(("conv", self.shrink1, b["s0"], self.fh, self.fw, b["s1"], 0, hw * self.shrink1.cout * self.shrink1.w.shape[1]))
-        b["plan"] = plan
+        b[key] = plan
         return plan
 
     def run_plan(self, n_agents: int, only=None, taps: Optional[dict] = None):
@@ -362,7 +408,11 @@ class DeployedModel(nn.Module):
         for (kind, layer, x, h, w, out, c0, _) in self.conv_plan(n_agents):
             if only is not None and not only(kind, layer):
                 continue
-            if kind == "conv":
+            if kind == "chain":
+                self._chain(layer, x, n_agents, h, w, out)
+                if taps is not None:
+                    taps[layer.name] = out.clone()
+            elif kind == "conv":
                 if layer is self.shrink0:
                     flush()
                 self._conv(layer, x, n_agents, h, w, out)

@@ -14,7 +14,7 @@ MAX_GROUPS = 4
 
 SYMBOLS = [
     "qv2x_last_error", "qv2x_version", "qv2x_fill_i8", "qv2x_pfn_scatter_i8", "qv2x_conv3x3_i8",
-    "qv2x_conv3x3_i8_wide_ok", "qv2x_conv3x3_i8_pack_wide", "qv2x_conv3x3_i8_wide",
+    "qv2x_conv3x3_i8_wide_ok", "qv2x_conv3x3_i8_pack_wide", "qv2x_conv3x3_i8_wide", "qv2x_conv3x3_i8_chain64",
     "qv2x_deconv_i8", "qv2x_deconv_i8_batch", "qv2x_codebook_level_floats", "qv2x_codebook_c2_f32", "qv2x_codebook_encode_f32", "qv2x_fuse_att_f32",
     "qv2x_decode_lut_f32", "qv2x_dequant_i8_f32", "qv2x_heads_f32", "qv2x_decode_heads_f32", "qv2x_heads_pair_f32", "qv2x_voxelize_workspace_bytes", "qv2x_voxelize_f32",
     "qv2x_postprocess_workspace_bytes", "qv2x_postprocess_f32",
@@ -34,6 +34,12 @@ class ConvDesc(C.Structure):
                 ("group_zx", C.c_int32 * MAX_GROUPS),
                 ("out_ctotal", C.c_int32), ("out_c0", C.c_int32), ("relu", C.c_int32),
                 ("out_delta", C.c_float), ("out_zp", C.c_float)]
+
+
+class ChainDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("in_h", C.c_int32), ("in_w", C.c_int32),
+                ("depth", C.c_int32), ("stride0", C.c_int32), ("relu", C.c_int32),
+                ("out_delta", C.c_float * 4), ("out_zp", C.c_float * 4)]
 
 
 class DeconvDesc(C.Structure):
@@ -88,6 +94,7 @@ def load() -> C.CDLL:
     lib.qv2x_pfn_scatter_i8.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(PfnParams), vp, C.c_int, C.c_int, C.c_int, vp]
     lib.qv2x_conv3x3_i8.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp]
     lib.qv2x_conv3x3_i8_wide.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.qv2x_conv3x3_i8_chain64.argtypes = [C.POINTER(ChainDesc), vp, vp, vp, vp, vp, vp, vp, vp]
     lib.qv2x_conv3x3_i8_pack_wide.argtypes = [C.POINTER(ConvDesc), vp, vp, vp]
     lib.qv2x_conv3x3_i8_wide_ok.argtypes = [C.POINTER(ConvDesc)]
     lib.qv2x_deconv_i8.argtypes = [C.POINTER(DeconvDesc), vp, vp, vp, vp, vp]

@@ -6,12 +6,10 @@ import numpy as np
 import pytest
 import torch
 
-from _common import calibrated_plugin, scene, scene_np
+from _common import FUSE_TOL, calibrated_plugin, compare_frame, scene, scene_np
 
 pytestmark = pytest.mark.gpu
 torch.set_num_threads(8)
-
-FUSE_TOL = dict(rtol=2e-5, atol=2e-5)      # fp32 re-association in the 256-wide dot products + expf
 
 
 def _interior(t):
@@ -29,43 +27,35 @@ def tiny():
 
 
 def _compare(orc, eng, sc_np, n_agents, state):
-    otaps, gtaps = {}, {}
-    want = orc.forward(sc_np, otaps)
-    from quantv2x_amd import synth
-    got = eng(synth.scene_to_torch(sc_np, "cuda"), gtaps)
-    torch.cuda.synchronize()
-    np.testing.assert_array_equal(_interior(gtaps["canvas"]), otaps["canvas"])
-    for name, arr in otaps.items():
-        if name.startswith("backbone_m1.blocks") or name.startswith("shrinker_m1"):
-            if name.endswith("_q"):
-                continue
-            np.testing.assert_array_equal(_interior(gtaps[name]), arr, err_msg=name)
-    c0 = 0
-    for lvl in range(3):
-        name = f"backbone_m1.deblocks.{lvl}.0"
-        c = otaps[name].shape[-1]
-        np.testing.assert_array_equal(_interior(gtaps["cat"])[..., c0:c0 + c], otaps[name], err_msg=name)
-        c0 += c
-    codes = gtaps["codes"].cpu().numpy()
-    np.testing.assert_array_equal(codes.reshape(otaps["codes"].shape), otaps["codes"])      # bit-exact indices
-    h, w = otaps["fused"].shape[1:3]
-    np.testing.assert_allclose(gtaps["fused"].cpu().numpy().reshape(-1, h, w, 256), otaps["fused"], **FUSE_TOL)
-    lsb = max(float(state[k + "/a_delta"]) for k in ("cls_head", "reg_head", "dir_head"))
-    for key in ("cls_preds", "reg_preds", "dir_preds", "preds_tensor"):
-        d = np.abs(got[key].cpu().numpy() - want[key])
-        # the head output quantizer rounds an fp32 value that differs by ~1e-6 between the two attention sums:
-        # identical grid point except for rare +-1 LSB flips
-        assert d.max() <= lsb * 1.001 and (d > 1e-5).mean() < 1e-3, key
-    for key in ("cls_preds_single", "reg_preds_single", "dir_preds_single"):
-        d = np.abs(got[key].cpu().numpy() - want[key])
-        assert d.max() <= max(float(state[k + "_single/a_delta"]) for k in ("cls_head", "reg_head", "dir_head")) * 1.001
-        assert (d > 1e-5).mean() < 1e-3, key
+    compare_frame(orc, eng, sc_np, state)
 
 
 @pytest.mark.parametrize("n_agents", [1, 2, 3])
 def test_tiny_end_to_end(tiny, n_agents):
     state, orc, eng = tiny
     _compare(orc, eng, scene_np(n_agents), n_agents, state)
+
+
+@pytest.mark.parametrize("n_agents", [1, 3])
+def test_tiny_layer_by_layer_launches(tiny, n_agents):
+    """The shipped plan runs backbone level 0 as one fused launch (conv_i8_chain.hip), whose intermediate maps never reach
+    HBM.  With the chains off every layer is its own launch and EVERY layer's uint8 map is compared with the oracle; the
+    two plans must agree bit for bit on everything downstream."""
+    state, orc, eng = tiny
+    sc = scene_np(n_agents)
+    assert eng.use_chains and eng.chains[0] is not None
+    _, fused_taps, _, fused_out = compare_frame(orc, eng, sc, state)
+    fused_out = {k: v.clone() for k, v in fused_out.items()}
+    eng.use_chains = False
+    try:
+        _, taps, _, out = compare_frame(orc, eng, sc, state)
+        assert "backbone_m1.blocks.0.2" in taps and "backbone_m1.blocks.0.2" not in fused_taps
+        for k in ("backbone_m1.blocks.0.4", "cat", "codes"):
+            assert torch.equal(taps[k], fused_taps[k]), k
+        for k in out:
+            assert torch.equal(out[k], fused_out[k]), k
+    finally:
+        eng.use_chains = True
 
 
 def test_tiny_ragged_pillars(tiny):

@@ -8,8 +8,10 @@ from quantv2x_amd.engine import deploy
 
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+chains = (sys.argv[3] != "nochain") if len(sys.argv) > 3 else True
 eng = deploy(path=os.path.join(os.path.dirname(os.path.abspath(__file__)), "cache", "v2xreal_state.npz"))
 dd = synth.scene_to_torch(synth.make_scene("v2xreal", n_agents=n, seed=3, n_points=60000), "cuda")
+eng.use_chains = chains
 eng(dd); torch.cuda.synchronize()
 
 
@@ -33,13 +35,16 @@ def timeit(fn, iters=30):
 if what in ("conv", "all"):
     tot_us, tot_ops = 0, 0
     for (kind, layer, x, h, w, out, c0, macs) in eng.conv_plan(n):
-        if kind == "conv":
+        if kind == "chain":
+            us = timeit(lambda: eng._chain(layer, x, n, h, w, out))
+            unit = "TOPS"
+        elif kind == "conv":
             us = timeit(lambda: eng._conv(layer, x, n, h, w, out))
             unit = "TOPS"
         else:
             us = timeit(lambda: eng._deconv(layer, x, n, h, w, out, c0))
             unit = "TFLOPS"
-        tot_us += us; tot_ops += 2 * macs if kind == "conv" else 0
+        tot_us += us; tot_ops += 2 * macs if kind != "deconv" else 0
         print(f"{kind:6s} {layer.name:42s} h={h:4d} w={w:4d} macs={macs/1e9:7.3f}G  {us:8.1f} us  {2*macs/us/1e6:8.1f} {unit}")
     print(f"total {tot_us:.1f} us; conv {tot_ops/1e9:.1f} GOP")
 if what in ("encode", "all"):
