@@ -1,19 +1,26 @@
 #!/usr/bin/env python
 """bench.py -- frames/s of the quantized per-agent encode + intermediate-fusion hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--inflight F]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A *step* is one pass of the whole hot path (a1-a11: PFN + scatter, int8 backbone + shrinker, codebook encode,
-exchange, decode + warp + attention, heads) over one synthetic V2X-Real-shaped frame.  With N GPUs, rank r owns
-agent r (one process per GPU, RCCL all-gather of the code planes) and every rank is the ego of its own view, so a
-step produces N fused N-agent frames; ``value`` = N * K / (max-over-ranks time).  Per-GPU work is fixed as N grows
-(one agent encoded per GPU): ``"scaling": "weak"``.
+A *step* is one pass of the whole hot path (a1-a11: PFN + scatter, int8 backbone + shrinker, codebook encode, exchange,
+decode + warp + attention, heads) over one batch of B synthetic V2X-Real-shaped frames (default B = 4: the reference's
+model contract has a batch dimension, ``record_len`` / ``pairwise_t_matrix[B]``), replayed as HIP graphs; at N = 1, F = 2
+such batches are in flight on two streams (the next batch's PFN / backbone fill the tail of the previous batch's encode).
+``value`` = frames per second over exactly K steps; the p50 latency of ONE frame run alone is reported next to it, and
+``value_one_frame_at_a_time`` is its reciprocal throughput (round 1's ``value``).
 
-Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line (contract in the task prompt),
-with ``roofline`` for the dominant kernel (the wide-layer int8 MFMA convolution) measured live with HIP events,
-and ``cpu_baseline`` = the CPU oracle (``oracle/``, the checker -- never the product) timed on the host cores.
+With N GPUs, rank r owns agent r (one process per GPU): every step each rank encodes B frames of its agent, ONE RCCL
+all-gather moves the code planes + poses, and every rank fuses as the ego of its own view, so a step yields N x B fused
+N-agent frames; ``value`` = N * B * K / (max-over-ranks time).  Per-GPU work is fixed as N grows: ``"scaling": "weak"``.
+
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line (contract in the task prompt) with
+  roofline         the dominant kernel by time (codebook_encode_kernel: f32 MFMA), launch duration from HIP events
+  roofline_stages  every stage of the frame against its own bound (int8 MFMA / f32 MFMA / HBM), same method
+  cpu_baseline     the CPU oracle (``oracle/``, the checker -- never the product) on the host cores; and
+  cpu_baseline_torch  the torch restatement of the reference (plugin mirror) in fp32 and W8A8 fake-quant, all host cores
 """
 import argparse
 import json
@@ -24,9 +31,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-INT8_MFMA_PEAK_TOPS = 5000.0     # dense int8 peak of MI355X (2 x the 2.5 PF bf16 dense peak), MI355X_MICROARCH.md
+# MI355X_MICROARCH.md: dense bf16 MFMA 2.5 PF (int8 = 2 x), f32 MFMA = f32 vector peak, HBM3E 8 TB/s
+INT8_MFMA_PEAK_TOPS = 5000.0
+F32_MFMA_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBS = 8000.0
 SHAPE = "v2xreal"
 N_POINTS = 60000
+ENCODE_GFLOP_PER_AGENT_FRAME = 43.84       # 21.92 GMAC fp32, reference op order
 
 
 def build_engine(n_threads):
@@ -41,110 +52,120 @@ def build_engine(n_threads):
     # -> weight quantizers -> one min-max observer pass (torch, on the host) -> freeze -> deploy on the HIP path
     model = train_utils.create_model(copy.deepcopy(synth.make_hypes(SHAPE))).eval()
     synth.load_state_dict_numpy(model, synth.make_state_dict(model.state_dict(), seed=1))
+    fp_model = copy.deepcopy(model)
     calib = synth.scene_to_torch(synth.make_scene(SHAPE, n_agents=1, seed=3, n_points=N_POINTS))
     qt = inference_quant.calibrate_minmax(inference_quant.wrap(model), [calib])
     state = export_ptq_state(qt)
-    return state, deploy(state=state)
+    return state, deploy(state=state), fp_model, qt
 
 
-def my_scene(world, rank, device):
-    """Scene with `world` agents; returns (inputs of agent `rank` re-indexed to batch 0, full scene on device)."""
+def frame_batch(world, rank, frames, device):
+    """`frames` scenes of `world` agents (different sweeps, same poses).  Returns the numpy scene 0, the model input of a
+    single-GPU batch (every agent of every frame, batch index = frame * world + agent), this rank's input (its own agent of every
+    frame, batch index = frame) and the agents' world poses."""
+    import numpy as np
     import torch
     from quantv2x_amd import synth
-    sc = synth.make_scene(SHAPE, n_agents=world, seed=3, n_points=N_POINTS, layout="ring" if world > 2 else "line")
-    full = synth.scene_to_torch(sc, device)
-    co = full["inputs_m1"]["voxel_coords"]
-    mine = co[:, 0] == rank
-    inp = {"voxel_features": full["inputs_m1"]["voxel_features"][mine].contiguous(),
-           "voxel_coords": co[mine].clone().contiguous(),
-           "voxel_num_points": full["inputs_m1"]["voxel_num_points"][mine].contiguous()}
-    inp["voxel_coords"][:, 0] = 0
-    return sc, full, inp
+    layout = "ring" if world > 2 else "line"
+    scenes = [synth.make_scene(SHAPE, n_agents=world, seed=3 + f, n_points=N_POINTS, layout=layout) for f in range(frames)]
+    full_parts, mine_parts = [], []
+    for f, sc in enumerate(scenes):
+        co = sc["inputs_m1"]["voxel_coords"]
+        part = {k: v.copy() for k, v in sc["inputs_m1"].items()}
+        part["voxel_coords"][:, 0] += f * world
+        full_parts.append(part)
+        sel = co[:, 0] == rank
+        m = {k: v[sel].copy() for k, v in sc["inputs_m1"].items()}
+        m["voxel_coords"][:, 0] = f
+        mine_parts.append(m)
+    cat = lambda parts: {k: torch.from_numpy(np.concatenate([p[k] for p in parts])).to(device) for k in parts[0]}
+    full = {"inputs_m1": cat(full_parts), "agent_modality_list": ["m1"] * (world * frames),
+            "record_len": torch.full((frames,), world, dtype=torch.int64),
+            "pairwise_t_matrix": torch.from_numpy(np.concatenate([sc["pairwise_t_matrix"] for sc in scenes])).to(device)}
+    return scenes[0], full, cat(mine_parts), synth.agent_poses(world, layout)
 
 
-def conv_roofline(eng, iters):
-    """Average launch duration and algorithmic ops of the dominant kernel: the wide-layer int8 MFMA convolution
-    ``conv3x3_i8_wide_kernel<5, true, 8, 1>`` -- one launch per frame (the shrinker's 3x3 384 -> 256 convolution over the
-    three-scale concat, 31.14 GMAC = 40 % of all conv work), timed with HIP events on the launch stream."""
+def event_time_us(fn, iters, launches_per_call=1):
+    """average duration of one launch: HIP events on the launch stream around `iters` back-to-back calls"""
     import torch
-    pick = lambda kind, layer: kind == "conv" and layer is eng.shrink0
-    launches = [p for p in eng.conv_plan(1) if pick(p[0], p[1])]
-    ops = sum(2.0 * p[7] for p in launches)
     for _ in range(3):
-        eng.run_plan(1, only=pick)
+        fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
     for _ in range(iters):
-        eng.run_plan(1, only=pick)
+        fn()
     e1.record()
     torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / (iters * len(launches))
-    achieved = ops / len(launches) / (us * 1e-6) / 1e12
-    traffic = None       # HBM-side bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (not live)
-    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_wide_conv.json")
-    if os.path.exists(pmc):
-        with open(pmc) as f:
-            traffic = json.load(f).get("traffic_bytes_per_launch")
-    return {"bound": "mfma", "achieved": round(achieved, 1), "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s",
-            "frac": round(achieved / INT8_MFMA_PEAK_TOPS, 4), "traffic": traffic,
-            "traffic_note": "bytes per launch, FETCH_SIZE + WRITE_SIZE of profiles/r01_pmc_wide_conv.json (algorithmic: 23.4 MB)",
-            "kernel": "conv3x3_i8_wide_kernel<5, true, 8, 1>", "launches_per_frame": len(launches),
-            "avg_launch_us": round(us, 2), "algorithmic_gop_per_launch": round(ops / len(launches) / 1e9, 3)}
+    return e0.elapsed_time(e1) * 1e3 / (iters * launches_per_call)
 
 
-def stage_times(eng, dd, iters=20):
-    """Per-stage ms of one eager frame (outside the timed region)."""
+def rooflines(eng, full, frames, iters):
+    """``roofline`` (the dominant kernel) and ``roofline_stages``: live HIP-event time of every stage at the bench's batch
+    size against the algorithmic work of SURVEY.md §8(d) x the agent-frames one launch processes."""
     import torch
-    n = len(dd["agent_modality_list"])
+    n = frames                                            # one agent per frame at N = 1
     hw = eng.fh * eng.fw
+    inp = full["inputs_m1"]
+    pillars = int(inp["voxel_features"].shape[0])
+    plan = eng.conv_plan(n)
+    bb = [p for p in plan if p[0] in ("conv", "chain") and p[1].name.startswith("backbone")]
+    sh = [p for p in plan if p[0] == "conv" and p[1].name.startswith("shrinker")]
+    de = [p for p in plan if p[0] == "deconv"]
     stages = {}
 
-    def timed(name, fn):
-        fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize(); e0.record()
-        for _ in range(iters):
-            fn()
-        e1.record(); torch.cuda.synchronize()
-        stages[name] = round(e0.elapsed_time(e1) / iters, 4)
-    timed("pfn_scatter", lambda: eng.pillars_to_canvas(dd["inputs_m1"], n))
-    timed("backbone_convs", lambda: eng.run_plan(n, only=lambda k, l: k == "conv" and l.name.startswith("backbone")))
-    timed("backbone_deconvs", lambda: eng.run_plan(n, only=lambda k, l: k == "deconv"))
-    timed("shrinker_convs", lambda: eng.run_plan(n, only=lambda k, l: k == "conv" and l.name.startswith("shrinker")))
-    timed("codebook_encode", lambda: eng.encode_codes(n))
+    def stage(name, fn, bound, work, unit, peak, launches, note):
+        us = event_time_us(fn, iters)
+        ach = work / (us * 1e-6) / (1e12 if unit != "GB/s" else 1e9)
+        stages[name] = {"bound": bound, "us_per_batch": round(us, 2), "launches": launches, "achieved": round(ach, 1), "peak": peak, "unit": unit,
+                        "frac": round(ach / peak, 4), "work": note}
+
+    eng.pillars_to_canvas(inp, n)
+    stage("pfn_scatter+clear", lambda: eng.pillars_to_canvas(inp, n), "hbm",
+          pillars * (32 * 16 + 16 + 4) + n * 64 * eng.ny * eng.nx, "GB/s", HBM_PEAK_GBS, 2,
+          f"{pillars} pillars x 532 B read + {n} x 9.0 MB u8 canvas written (SURVEY 8(d) a1+a2)")
+    stage("backbone_convs_i8", lambda: eng.run_plan(n, only=lambda k, l: k in ("conv", "chain") and l.name.startswith("backbone")), "mfma-i8",
+          sum(2.0 * p[7] for p in bb), "TOP/s", INT8_MFMA_PEAK_TOPS, len(bb),
+          f"{sum(2.0 * p[7] for p in bb) / 1e9:.1f} GOP: 19 conv layers (level 0 = one fused launch)")
+    stage("backbone_deconvs_f32", lambda: eng.run_plan(n, only=lambda k, l: k == "deconv"), "mfma-f32",
+          sum(2.0 * p[7] for p in de), "TFLOP/s", F32_MFMA_PEAK_TFLOPS, 1, f"{sum(2.0 * p[7] for p in de) / 1e9:.2f} GFLOP: 3 deblocks, one launch")
+    stage("shrinker_convs_i8", lambda: eng.run_plan(n, only=lambda k, l: k == "conv" and l.name.startswith("shrinker")), "mfma-i8",
+          sum(2.0 * p[7] for p in sh), "TOP/s", INT8_MFMA_PEAK_TOPS, len(sh), f"{sum(2.0 * p[7] for p in sh) / 1e9:.1f} GOP: 3x3 384->256 + 3x3 256->256")
+    stage("codebook_encode_f32", lambda: eng.encode_codes(n), "mfma-f32", ENCODE_GFLOP_PER_AGENT_FRAME * 1e9 * n, "TFLOP/s",
+          F32_MFMA_PEAK_TFLOPS, 1, f"{n} x {ENCODE_GFLOP_PER_AGENT_FRAME} GFLOP (11 chained 256-wide GEMMs per cell, reference op order)")
     codes = eng._workspace(n)["codes"]
-    pw = dd["pairwise_t_matrix"][0].contiguous()
-    timed("fuse_and_heads", lambda: eng.fuse_and_heads(codes, hw, n * hw, pw, n, 0))
-    return stages
+    pw = full["pairwise_t_matrix"].contiguous()
+    fused = torch.empty((n, hw, 256), dtype=torch.float32, device=eng.dev)
+    import ctypes as C
 
-
-def frames_in_flight(state, dd, steps, n_flight=2):
-    """Throughput with ``n_flight`` independent frames in flight (one engine + HIP graph + stream each): the small backbone
-    layers leave most CUs idle, a second frame fills them.  Reported next to ``value`` (one frame at a time), SURVEY.md
-    §8(d) "throughput also at the best frame-batch"."""
-    import torch
-    from quantv2x_amd.engine import deploy
-    engs = [deploy(state=state) for _ in range(n_flight)]
-    streams = [torch.cuda.Stream() for _ in range(n_flight)]
-    reps = []
-    for e, st in zip(engs, streams):
-        with torch.cuda.stream(st):
-            reps.append(e.capture(dd))
-    torch.cuda.synchronize()
-
-    def round_():
-        for r, st in zip(reps, streams):
-            with torch.cuda.stream(st):
-                r()
-    for _ in range(10):
-        round_()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        round_()
-    torch.cuda.synchronize()
-    return round(n_flight * steps / (time.perf_counter() - t0), 2)
+    def fuse_all():
+        for f in range(n):
+            eng.fuse(C.c_void_p(codes.data_ptr() + f * hw), hw, n * hw, None, pw[f], 1, fused[f])
+    stage("decode_warp_attfuse", fuse_all, "hbm", n * (3 * hw + 3 * 128 * 1024 + hw * 1024), "GB/s", HBM_PEAK_GBS, n,
+          f"{n} x (105.6 KB codes + 384 KiB LUT read, 36.0 MB fp32 fused map written)")
+    stage("heads_f32", lambda: eng._heads_pair(fused, n, codes, n), "mfma-f32", n * 2 * 2 * 0.649e9, "TFLOP/s", F32_MFMA_PEAK_TFLOPS, 1,
+          f"{n} x 2 x 0.649 GMAC: heads on the fused map + *_single heads on the decoded own feature, one launch")
+    enc = stages["codebook_encode_f32"]
+    traffic, note = None, "no PMC profile committed for this round yet"
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_encode.json")
+    if os.path.exists(pmc):
+        with open(pmc) as f:
+            j = json.load(f)
+        traffic, note = j.get("traffic_bytes_per_launch"), j.get("note", "")
+    roof = {"bound": "mfma", "achieved": enc["achieved"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": enc["frac"],
+            "traffic": traffic, "traffic_note": "STORED figure, not measured by this run: " + note,
+            "kernel": "codebook_encode_kernel (f32 MFMA v_mfma_f32_32x32x2_f32; the dominant kernel by time)", "launches_per_batch": 1,
+            "avg_launch_us": enc["us_per_batch"], "agent_frames_per_launch": n,
+            "algorithmic_gflop_per_launch": round(ENCODE_GFLOP_PER_AGENT_FRAME * n, 2),
+            "share_of_batch_time": None}
+    total = sum(s["us_per_batch"] for s in stages.values())
+    roof["share_of_batch_time"] = round(enc["us_per_batch"] / total, 3)
+    int8_us = stages["backbone_convs_i8"]["us_per_batch"] + stages["shrinker_convs_i8"]["us_per_batch"]
+    int8_ops = sum(2.0 * p[7] for p in bb + sh)
+    stages["int8_conv_stack_total"] = {"bound": "mfma-i8", "us_per_batch": round(int8_us, 2), "achieved": round(int8_ops / (int8_us * 1e-6) / 1e12, 1),
+                                       "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s", "frac": round(int8_ops / (int8_us * 1e-6) / 1e12 / INT8_MFMA_PEAK_TOPS, 4),
+                                       "work": "backbone convs + shrinker (the north_star's int8-MFMA fraction)"}
+    return roof, stages
 
 
 def cpu_baseline(state, sc_np, budget_s=12.0, max_frames=6):
@@ -162,15 +183,42 @@ def cpu_baseline(state, sc_np, budget_s=12.0, max_frames=6):
             "sample": f"{frames} full single-agent V2X-Real frames (whole hot path) through oracle/ in {dt:.1f} s, OpenMP on {cores} threads"}
 
 
+def cpu_baseline_torch(fp_model, qt, sc_np, cores, budget_s=10.0):
+    """SURVEY.md §8(d) / BASELINE.md §4: the torch restatement of the reference (the plugin mirror: same modules, same torch
+    ops) on the host cores -- fp32, and W8A8 fake-quant (quantize -> dequantize in fp32 around fp32 F.conv2d, the reference's
+    only execution mode).  1 warm-up + up to 3 timed frames each."""
+    import torch
+    from quantv2x_amd import synth
+    # torch's CPU convolutions lose to thread oversubscription on a 256-thread host (45 s per fp32 frame with 256 threads,
+    # measured): 32 threads is where the per-frame time bottoms out, so `cores` here is the thread count actually used
+    threads = min(cores, 32)
+    torch.set_num_threads(threads)
+    dd = synth.scene_to_torch(sc_np)
+    out = {"cores": threads, "host_cores": cores, "unit": "frames/s", "kind": "torch restatement of the reference (plugin mirror)"}
+    for name, m in (("fp32", fp_model), ("w8a8_fake_quant", qt)):
+        with torch.no_grad():
+            torch.manual_seed(0)
+            m(dd)
+            t0, n = time.time(), 0
+            while n < 3 and (time.time() - t0) < budget_s:
+                m(dd)
+                n += 1
+        dt = time.time() - t0
+        out[name] = round(n / dt, 4)
+        out[name + "_sample"] = f"{n} single-agent V2X-Real frames in {dt:.1f} s"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4, help="frames per step (per rank)")
+    ap.add_argument("--inflight", type=int, default=2, help="batches in flight at N = 1 (streams / engines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-inflight", action="store_true", help="skip the extra 2-frames-in-flight throughput measurement")
-    ap.add_argument("--force-sharded", action="store_true",
-                    help="run the N>1 code path (eager launches + all_gather of the code planes) even with one rank")
+    ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path (two HIP graphs around the collective) with one rank")
+    ap.add_argument("--link", default="torch", choices=["torch", "rccl"], help="N>1 collective: torch.distributed or qv2x_allgather_codes")
     args = ap.parse_args()
 
     import torch
@@ -182,7 +230,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1 or args.force_sharded:
+    sharded_mode = world > 1 or args.force_sharded
+    if sharded_mode:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
@@ -190,18 +239,39 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     cores = os.cpu_count() or 8
-    state, eng = build_engine(max(1, min(32, cores // max(world, 1))))
-    sc_np, full, mine = my_scene(world, rank, device)
-    pairwise = full["pairwise_t_matrix"][0].contiguous()
+    B = max(1, args.batch)
+    state, eng, fp_model, qt = build_engine(max(1, min(32, cores // max(world, 1))))
+    sc_np, full, mine, poses = frame_batch(world, rank, B, device)
 
-    if world == 1 and not args.force_sharded:
-        step = eng.capture(full)            # HIP graph of the whole frame
-        launch = "hipGraph replay of the whole frame"
+    if not sharded_mode:
+        from quantv2x_amd.engine import deploy
+        F = max(1, args.inflight)
+        engines = [eng] + [deploy(state=state) for _ in range(F - 1)]
+        streams = [torch.cuda.Stream() for _ in range(F)]
+        reps = []
+        for e, st in zip(engines, streams):
+            with torch.cuda.stream(st):
+                reps.append(e.capture(full))            # one HIP graph = one batch of B frames
+        torch.cuda.synchronize()
+        it = [0]
+
+        def step():
+            i = it[0] % F
+            it[0] += 1
+            with torch.cuda.stream(streams[i]):
+                reps[i]()
+        launch = f"hipGraph replay of a {B}-frame batch, {F} batches in flight on {F} streams"
+        frames_per_step = B
     else:
         from quantv2x_amd.dist import AgentShardedModel
-        sharded = AgentShardedModel(eng)
-        step = lambda: sharded.forward(mine, pairwise)
-        launch = "eager launches + RCCL all_gather_into_tensor of the code planes"
+        F = 1
+        sharded = AgentShardedModel(eng, frames=B, link=args.link, max_cav=5)
+        pose = torch.from_numpy(poses[rank]).to(device)
+        step = lambda: sharded.forward(mine, pose)
+        launch = (f"per rank: hipGraph (a1-a6, {B} frames) -> all-gather of code planes + poses "
+                  f"({'torch.distributed nccl = RCCL' if args.link == 'torch' else 'qv2x_allgather_codes (RCCL)'}) -> hipGraph (a7-a11)")
+        frames_per_step = B * world
+        print(f"[bench] rank {rank}/{world} on cuda:{local}: RCCL world size {dist.get_world_size()}", file=sys.stderr, flush=True)
 
     def barrier():
         if dist.is_initialized():
@@ -221,17 +291,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # p50 per-frame latency (one frame at a time, device-synchronised), outside the timed region
+    # p50 latency of ONE frame run alone (device-synchronised), outside the timed region
     lat = []
-    for _ in range(min(50, args.steps)):
-        torch.cuda.synchronize(); a = time.perf_counter()
-        step(); torch.cuda.synchronize()
+    if not sharded_mode:
+        _, one, _, _ = frame_batch(1, 0, 1, device)
+        solo = eng.capture(one)
+    else:
+        _, _, mine1, _ = frame_batch(world, rank, 1, device)
+        sh1 = AgentShardedModel(eng, frames=1, link=args.link, max_cav=5)
+        solo = lambda: sh1.forward(mine1, pose)
+    for _ in range(10):
+        solo()
+    for _ in range(50):
+        barrier()
+        a = time.perf_counter()
+        solo()
+        torch.cuda.synchronize()
         lat.append((time.perf_counter() - a) * 1e3)
     lat.sort()
+    barrier()
+    ta = time.perf_counter()
+    for _ in range(50):
+        solo()
+    barrier()
+    one_at_a_time = 50 * (world if sharded_mode else 1) / (time.perf_counter() - ta)
 
     if rank == 0:
         line = {
-            "metric": "frames/sec/node (N-agent int8 BEV fusion)", "value": round(world * args.steps / dt, 2), "unit": "frames/s",
+            "metric": "frames/sec/node (N-agent int8 BEV fusion)", "value": round(frames_per_step * args.steps / dt, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i8", "data": "synthetic",
             "config": {"workload": "Single-agent int8 PointPillar + BEV backbone on 1xMI355X, synthetic V2X-Real point cloud "
@@ -239,19 +326,20 @@ def main():
                                    f"{world}-agent intermediate fusion with codebook-compressed BEV features, one agent per GPU",
                        "stages": "pfn+scatter, 19 conv + 3 deconv backbone, shrinker, 3-level codebook encode, decode+warp+attention, heads (+ *_single heads)",
                        "grid": "704x200x1 voxels -> 256x100x352 feature map", "agents_per_frame": world,
-                       "pillars_agent0": int(mine["voxel_features"].shape[0]) if world > 1 else int(full["inputs_m1"]["voxel_features"].shape[0]),
+                       "frames_per_step": frames_per_step, "batch_per_rank": B, "batches_in_flight": F,
+                       "pillars_per_step_rank0": int((mine if sharded_mode else full["inputs_m1"])["voxel_features"].shape[0]),
                        "frame_definition": "one ego-view fused detection frame; with N GPUs every rank is the ego of its own view",
-                       "launch": launch, "quantization": "W8A8 min-max PTQ (reference QuantModel recipe), random He-init weights"},
+                       "launch": launch, "quantization": "W8A8 min-max PTQ (reference QuantModel recipe), random He-init weights",
+                       "rccl_world_size": dist.get_world_size() if dist.is_initialized() else 1},
             "latency_ms_p50": round(lat[len(lat) // 2], 4), "latency_ms_p95": round(lat[int(len(lat) * 0.95) - 1], 4),
+            "latency_note": "one frame run alone (batch 1, nothing else in flight), host-timed around launch + device sync",
+            "value_one_frame_at_a_time": round(one_at_a_time, 2),
         }
-        line["roofline"] = conv_roofline(eng, iters=max(10, args.steps // 4))
-        solo = full if world == 1 else None
-        if solo is not None:
-            line["stage_ms"] = stage_times(eng, solo)
-            if not args.no_inflight:
-                line["throughput_2_frames_in_flight"] = frames_in_flight(state, solo, max(20, args.steps // 2))
+        roof, stages = rooflines(eng, full if not sharded_mode else frame_batch(1, 0, B, device)[1], B, iters=max(10, args.steps // 5))
+        line["roofline"], line["roofline_stages"] = roof, stages
         if not args.no_cpu_baseline and world == 1:       # reported on rank 0 at N = 1 only
-            line["cpu_baseline"] = cpu_baseline(state, sc_np)
+            line["cpu_baseline"] = cpu_baseline(state, frame_batch(1, 0, 1, "cpu")[0])
+            line["cpu_baseline_torch"] = cpu_baseline_torch(fp_model, qt, frame_batch(1, 0, 1, "cpu")[0], cores)
     else:
         line = None
     if dist.is_initialized():

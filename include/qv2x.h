@@ -249,6 +249,31 @@ int qv2x_postprocess_f32(const qv2x_postprocess_desc* desc /* host */, const flo
                          const float* anchors, void* workspace, int64_t workspace_bytes, float* out_corners,
                          float* out_scores, int32_t* out_labels, int32_t* out_count, void* stream);
 
+/* ---- the V2X link: one agent per GPU --------------------------------------------------------------------
+ * The reference simulates the link in-process: all agents are rows of one batch (heter_model_baseline.py:216) and
+ * fusion_in_one.py:131-151 regroups them; get_pairwise_transformation (utils/transformation_utils.py:21-66) builds the
+ * pairwise matrix from every agent's pose on the host.  Here each rank sends ONE fixed-size payload
+ *     [ uint8 code planes, levels x frames x H*W ][ float64 world pose, 4 x 4 row-major = 128 B ]
+ * and receives all of them (all-gather).  float64 because the reference's pose path is float64 end to end.
+ *
+ * qv2x_comm_*: an opt-in RCCL communicator owned by the caller -- the library's only state.  RCCL is bound at run time (dlopen),
+ * libqv2x.so does not link against it.  qv2x_comm_unique_id on one rank, distribute the 128 bytes by any means, then
+ * qv2x_comm_init on every rank (collective).  quantv2x_amd/dist.py can use torch.distributed's communicator instead. */
+#define QV2X_COMM_ID_BYTES 128
+int qv2x_comm_unique_id(void* id /* host, QV2X_COMM_ID_BYTES */);
+int qv2x_comm_init(const void* id /* host */, int world, int rank, void** comm);
+int qv2x_comm_destroy(void* comm);
+/* ncclAllGather of bytes_per_rank bytes: recv = [world][bytes_per_rank], rank-major = agent-major.  Enqueued on `stream`. */
+int qv2x_allgather_codes(void* comm, const uint8_t* send, uint8_t* recv, int64_t bytes_per_rank, void* stream);
+
+/* The reference's pairwise matrix from the gathered poses: pairwise[i][j] = T_j^-1 T_i = solve(T_j, T_i) for i, j < world,
+ * identity elsewhere (get_pairwise_transformation, transformation_utils.py:21-66; np.linalg.solve there, a fixed-order float64
+ * elimination with partial pivoting here: oracle/geometry.py:solve4 is the same arithmetic, equal to LAPACK's to a few ulp).
+ *   gathered: [world][agent_stride_bytes], the pose of agent a at a * agent_stride_bytes + pose_offset_bytes
+ *   pairwise: f64 [max_cav][max_cav][4][4] (what qv2x_fuse_att_f32 takes) */
+int qv2x_pairwise_from_poses_f64(const uint8_t* gathered, int world, int64_t agent_stride_bytes, int64_t pose_offset_bytes,
+                                 int max_cav, double* pairwise, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,3 +65,47 @@ def att_fuse(warped):
     p = np.exp(score)
     p = p / p.sum(axis=-1, keepdims=True)
     return np.einsum("hwn,nhwc->hwc", p.astype(np.float32), warped).astype(np.float32)
+
+
+# ---- pairwise transforms from the gathered world poses (the multi-GPU link carries poses, not the pairwise matrix) ----------
+
+def solve4(a, b):
+    """X with ``a @ X = b`` for 4 x 4 float64 matrices: Gaussian elimination with partial pivoting (first largest pivot), every
+    update a separate multiply and subtract, then back substitution -- the fixed operation order ``qv2x_pairwise_from_poses_f64``
+    uses on the device (bit-identical to it; equal to ``np.linalg.solve``, the reference's call at
+    ``opencood/utils/transformation_utils.py:60``, up to a few ulp)."""
+    a = [[np.float64(v) for v in row] for row in np.asarray(a, dtype=np.float64)]
+    b = [[np.float64(v) for v in row] for row in np.asarray(b, dtype=np.float64)]
+    for k in range(4):
+        p = k
+        for r in range(k + 1, 4):
+            if abs(a[r][k]) > abs(a[p][k]):
+                p = r
+        a[k], a[p] = a[p], a[k]
+        b[k], b[p] = b[p], b[k]
+        for r in range(k + 1, 4):
+            m = a[r][k] / a[k][k]
+            for c in range(k + 1, 4):
+                a[r][c] = a[r][c] - m * a[k][c]
+            for c in range(4):
+                b[r][c] = b[r][c] - m * b[k][c]
+    x = [[np.float64(0.0)] * 4 for _ in range(4)]
+    for c in range(4):
+        for r in range(3, -1, -1):
+            s = b[r][c]
+            for q in range(r + 1, 4):
+                s = s - a[r][q] * x[q][c]
+            x[r][c] = s / a[r][r]
+    return np.array(x, dtype=np.float64)
+
+
+def pairwise_from_poses(poses, max_cav):
+    """``T[i, j] = T_j^-1 T_i`` identity-padded to ``[L, L, 4, 4]`` (``get_pairwise_transformation``,
+    transformation_utils.py:21-66) from the agents' 4 x 4 world poses."""
+    n = len(poses)
+    t = np.tile(np.eye(4, dtype=np.float64), (max_cav, max_cav, 1, 1))
+    for i in range(n):
+        for j in range(n):
+            if i != j:
+                t[i, j] = solve4(poses[j], poses[i])
+    return t

@@ -354,12 +354,19 @@ extern "C" int qv2x_conv3x3_i8(const qv2x_conv_desc* d, const int8_t* in, const 
     bool k128 = true;
     for (int g = 0; g < a.ngroups; ++g) k128 = k128 && (a.gc[g] % 128 == 0);
     const bool multi = a.ngroups > 1;
-    const bool large = a.cout % 128 == 0 && a.M >= 16384;
+#ifndef QV2X_CONV_FORCE
+#define QV2X_CONV_FORCE 0     // dev builds: 1 never the 128 x 128 variant, 2 also BK = 128 instead of 256, 3 only BK = 128 instead of 256
+#endif
+    const bool large = a.cout % 128 == 0 && a.M >= 16384 && QV2X_CONV_FORCE != 1 && QV2X_CONV_FORCE != 2;
     if (multi) {
         if (a.cout % 128) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8: multi-group input needs cout %% 128 == 0");
         return launch_dma<128, 128, 2, 2, 64, true, 4, 2>(a, st);
     }
     if (large) return launch_dma<128, 128, 2, 2, 64, false, 3, 3>(a, st);
-    if (a.gc[0] % 256 == 0) return launch_dma<64, 64, 2, 2, 256, false, 3, 1>(a, st);     // 256-byte K chunks: fewest barriers
+    // 256-byte K chunks (fewest barriers, 98 KB of LDS: one workgroup per CU) while the grid fits the chip in one round; beyond
+    // that two resident workgroups per CU with 128-byte chunks win (25 x 88 x 256 layers: 10.0 vs 10.9 us for one frame, 27.0 vs
+    // 21.1 us for a batch of four, profiles/r02_conv_dispatch_ablation.log)
+    const long long wgs64 = (long long)((a.M + 63) / 64) * (a.cout / 64);
+    if (a.gc[0] % 256 == 0 && (QV2X_CONV_FORCE ? QV2X_CONV_FORCE < 2 : wgs64 <= 256)) return launch_dma<64, 64, 2, 2, 256, false, 3, 1>(a, st);
     return k128 ? launch_dma<64, 64, 2, 2, 128, false, 4, 2>(a, st) : launch_dma<64, 64, 2, 2, 64, false, 4, 4>(a, st);
 }

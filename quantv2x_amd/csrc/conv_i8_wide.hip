@@ -412,14 +412,14 @@ extern "C" int qv2x_conv3x3_i8_wide(const qv2x_conv_desc* d, const int8_t* in, c
 #ifndef QV2X_WIDE_BN
 #define QV2X_WIDE_BN 256
 #endif
-    if (QV2X_WIDE_BN == 128) {
-        const dim3 grid(patches8 * (a.cout / 128));
-        if (d->ngroups > 1) conv3x3_i8_wide_kernel<5, true, 4, 1, 128><<<grid, 256, 0, st>>>(a);
-        else conv3x3_i8_wide_kernel<5, false, 4, 1, 128><<<grid, 256, 0, st>>>(a);
-    } else {
-        const dim3 grid(patches8 * (a.cout / 256));
-        if (d->ngroups > 1) conv3x3_i8_wide_kernel<5, true, 8, 1, 256><<<grid, 512, 0, st>>>(a);
-        else conv3x3_i8_wide_kernel<5, false, 8, 1, 256><<<grid, 512, 0, st>>>(a);
-    }
+#if QV2X_WIDE_BN == 128                                               // ablation build: 440 four-wave workgroups, two per CU (measured: no gain)
+    const dim3 grid(patches8 * (a.cout / 128));
+    if (d->ngroups > 1) conv3x3_i8_wide_kernel<5, true, 4, 1, 128><<<grid, 256, 0, st>>>(a);
+    else conv3x3_i8_wide_kernel<5, false, 4, 1, 128><<<grid, 256, 0, st>>>(a);
+#else
+    const dim3 grid(patches8 * (a.cout / 256));
+    if (d->ngroups > 1) conv3x3_i8_wide_kernel<5, true, 8, 1, 256><<<grid, 512, 0, st>>>(a);
+    else conv3x3_i8_wide_kernel<5, false, 8, 1, 256><<<grid, 512, 0, st>>>(a);
+#endif
     return hip_check(hipGetLastError(), "qv2x_conv3x3_i8_wide launch");
 }

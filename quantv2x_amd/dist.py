@@ -1,26 +1,43 @@
-"""One agent per GPU: the V2X link as an RCCL all-gather of the compressed code planes.
+"""One agent per GPU: the V2X link as an RCCL all-gather of compressed code planes + poses.
 
-The reference has no inference-time collective -- agents are rows of one batch on one GPU and the link is
-simulated in-process (``heter_model_baseline.py:216`` stacks all agents).  Here rank r owns agent r:
+The reference has no inference-time collective -- agents are rows of one batch on one GPU, the link is simulated
+in-process (``heter_model_baseline.py:216`` stacks all agents, ``fusion_in_one.py:131-151`` regroups them) and the dataset
+builds ``pairwise_t_matrix`` on the host from every agent's pose (``utils/transformation_utils.py:21-66``).  Here rank r
+owns agent r and a step is
 
-    a1-a6  encode own agent            -> codes u8 [levels, H*W]        (no communication)
-    link   all_gather_into_tensor      -> codes u8 [A, levels, H*W]     (one fixed-size collective: 105.6 KB/agent
-                                                                          at V2X-Real shape vs 36 MB of fp32 feature)
-    a7-a11 fuse + heads as the ego of rank r's own viewpoint (``ego = rank``), or only on rank 0
-           (``ego_only=True``: the parity configuration, identical to the single-process output)
+    pre   a1-a6 on the own agent (``frames`` frames per step)      -> payload: codes u8 [levels, frames, H*W] | poses f64 [frames, 4, 4]
+    link  ONE fixed-size all-gather of the payload (RCCL over xGMI) -> gathered u8 [world, payload_bytes]
+    post  pairwise matrix from the gathered poses, a7-a11 as the ego of this rank's own viewpoint (``ego = rank``), or only
+          on rank 0 (``ego_only=True``: the parity configuration, identical to the single-process output)
 
-``torch.distributed`` with backend "nccl" is RCCL on ROCm; the CPU tests use "gloo" with a stand-in encoder.
+``pre`` and ``post`` are each ONE HIP-graph replay once the input buffers are fixed; the collective sits between them on the
+same stream.  105.6 KB of codes + 128 B of pose per agent-frame at V2X-Real shape (vs 36 MB of fp32 feature): the link is
+latency-bound, not bandwidth-bound.
+
+The collective is ``torch.distributed.all_gather_into_tensor`` by default (backend "nccl" IS RCCL on ROCm; "gloo" in the CPU
+tests) or, with ``link="rccl"``, the C ABI's own ``qv2x_allgather_codes`` on a communicator created through
+``qv2x_comm_init`` (the unique id is distributed with ``torch.distributed.broadcast_object_list``).
 """
 from __future__ import annotations
 
-from typing import Callable, Optional
+import ctypes as C
+from typing import Optional
 
 import torch
 import torch.distributed as dist
 
+POSE_BYTES = 128            # one 4 x 4 float64 world pose
+
+
+def payload_layout(levels: int, frames: int, hw: int):
+    """(codes_bytes, pose_offset, payload_bytes) of one rank's payload; the pose block is 8-byte aligned."""
+    codes = levels * frames * hw
+    pose_off = (codes + 7) // 8 * 8
+    return codes, pose_off, pose_off + frames * POSE_BYTES
+
 
 def exchange_codes(codes: torch.Tensor, group=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """codes u8 [levels, H*W] of this rank's agent -> [world, levels, H*W] (rank-major = agent-major)."""
+    """One rank's contiguous payload -> [world, ...] (rank-major = agent-major) through torch.distributed."""
     world = dist.get_world_size(group)
     codes = codes.contiguous()
     if out is None:
@@ -33,41 +50,128 @@ def exchange_codes(codes: torch.Tensor, group=None, out: Optional[torch.Tensor] 
 
 
 def gathered_strides(levels: int, hw: int):
-    """(agent_stride, level_stride) of the all-gathered layout for ``qv2x_fuse_att_f32``."""
+    """(agent_stride, level_stride) of bare all-gathered code planes [world, levels, hw] for ``qv2x_fuse_att_f32``."""
     return levels * hw, hw
 
 
 class AgentShardedModel:
-    """Drives a ``DeployedModel`` (or any object with the same three stage methods) with agents sharded over ranks."""
+    """Drives a ``DeployedModel`` (or any object with the same stage interface: ``wire_shape``, ``encode_into``,
+    ``pairwise_from_poses``, ``fuse_frames_and_heads``) with the agents of a scene sharded over ranks."""
 
-    def __init__(self, engine, group=None, ego_only: bool = False):
+    def __init__(self, engine, group=None, ego_only: bool = False, frames: int = 1, link: str = "torch", graphs: Optional[bool] = None,
+                 max_cav: Optional[int] = None):
         if not getattr(engine, "has_codebook", True):
             raise NotImplementedError("AgentShardedModel exchanges the codebook's uint8 code planes: the codebook-less model "
                                       "has no compressed wire format (run it single-process through DeployedModel.forward)")
-        self.engine = engine
-        self.group = group
+        if link not in ("torch", "rccl"):
+            raise ValueError("link: 'torch' (torch.distributed's communicator) or 'rccl' (qv2x_allgather_codes)")
+        self.engine, self.group, self.ego_only, self.frames, self.link = engine, group, ego_only, int(frames), link
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.ego_only = ego_only
-        self._gathered = None
+        self.max_cav = max(self.world, max_cav or 0)
+        self.levels, self.hw = engine.wire_shape()
+        self.codes_bytes, self.pose_off, self.payload_bytes = payload_layout(self.levels, self.frames, self.hw)
+        self.graphs = graphs
+        self._dev = None
+        self._comm = None
+        self._captured = None
 
+    # ---- buffers ----------------------------------------------------------------------------------------------------------
+    def _alloc(self, device):
+        self._dev = device
+        self.payload = torch.zeros(self.payload_bytes, dtype=torch.uint8, device=device)
+        self.gathered = torch.zeros((self.world, self.payload_bytes), dtype=torch.uint8, device=device)
+        self.pairwise = torch.zeros((self.frames, self.max_cav, self.max_cav, 4, 4), dtype=torch.float64, device=device)
+        self.my_codes = self.payload[:self.codes_bytes].view(self.levels, self.frames, self.hw)
+        self.my_poses = self.payload[self.pose_off:].view(torch.float64).view(self.frames, 4, 4)
+        if self.graphs is None:
+            self.graphs = device.type == "cuda"
+        if self.link == "rccl":
+            self._init_comm()
+
+    def _init_comm(self):
+        from . import lib as L
+        lib = L.load()
+        uid = (C.c_char * L.COMM_ID_BYTES)()
+        if self.rank == 0:
+            L.check(lib.qv2x_comm_unique_id(uid), "qv2x_comm_unique_id")
+        box = [bytes(uid)]
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=0, group=self.group)
+        uid = (C.c_char * L.COMM_ID_BYTES).from_buffer_copy(box[0])
+        comm = C.c_void_p()
+        L.check(lib.qv2x_comm_init(uid, self.world, self.rank, C.byref(comm)), "qv2x_comm_init")
+        self._comm, self._lib = comm, lib
+
+    def close(self):
+        if self._comm is not None:
+            self._lib.qv2x_comm_destroy(self._comm)
+            self._comm = None
+
+    # ---- the three phases ---------------------------------------------------------------------------------------------------
+    def _pre(self, my_inputs: dict, my_pose: torch.Tensor):
+        self.engine.encode_into(my_inputs, self.frames, self.my_codes)
+        self.my_poses.copy_(my_pose.to(torch.float64).expand(self.frames, 4, 4))
+
+    def _exchange(self):
+        if self.link == "rccl":
+            from . import lib as L
+            L.check(self._lib.qv2x_allgather_codes(self._comm, L.ptr(self.payload), L.ptr(self.gathered), self.payload_bytes,
+                                                   L.current_stream()), "qv2x_allgather_codes")
+        else:
+            exchange_codes(self.payload, self.group, self.gathered)
+
+    def _post(self) -> dict:
+        eng, ego = self.engine, (0 if self.ego_only else self.rank)
+        for f in range(self.frames):
+            eng.pairwise_from_poses(self.gathered, self.world, self.payload_bytes, self.pose_off + f * POSE_BYTES, self.max_cav, self.pairwise[f])
+        return eng.fuse_frames_and_heads(self.gathered, self.payload_bytes, self.frames * self.hw, self.hw, self.pairwise,
+                                         self.world, ego, self.my_codes, self.frames)
+
+    # ---- one step -----------------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def forward(self, my_inputs: dict, pairwise_t_matrix: torch.Tensor) -> Optional[dict]:
-        """``my_inputs``: the ``inputs_m1`` dict of THIS rank's agent (batch index 0);
-        ``pairwise_t_matrix`` f64 [L, L, 4, 4] known to every rank (poses are exchanged with the codes in a real link)."""
-        eng = self.engine
-        codes = eng.encode_agents(my_inputs, 1)                      # [levels, 1, hw]
-        levels, _, hw = codes.shape
-        if self._gathered is None:
-            self._gathered = torch.empty((self.world, levels, hw), dtype=codes.dtype, device=codes.device)
-        gathered = exchange_codes(codes.view(levels, hw), self.group, self._gathered)
-        ego = 0 if self.ego_only else self.rank
-        if hasattr(eng, "fuse_heads_and_single") and not (self.ego_only and self.rank != 0):
-            # fusion as the ego of this viewpoint + the *_single heads of this rank's own agent (one launch for both head passes)
-            return eng.fuse_heads_and_single(gathered, *gathered_strides(levels, hw), pairwise_t_matrix, self.world, ego, codes, 1)
-        single = eng.single_preds(codes, 1) if hasattr(eng, "single_preds") else {}     # this rank's own agent
-        if self.ego_only and self.rank != 0:
-            return None
-        out = eng.fuse_and_heads(gathered, *gathered_strides(levels, hw), pairwise_t_matrix, self.world, ego)
-        out.update(single)
+    def forward(self, my_inputs: dict, my_pose: torch.Tensor) -> Optional[dict]:
+        """``my_inputs``: the ``inputs_m1`` dict of THIS rank's agent, batch index = frame (0 .. frames-1); ``my_pose``: its 4 x 4
+        world pose (``x_to_world(lidar_pose)``), one for the step or ``[frames, 4, 4]``.  Returns the model's output dict for
+        ``frames`` scenes seen from this rank, or None on the non-ego ranks of ``ego_only``."""
+        if self._dev is None:
+            self._alloc(my_inputs["voxel_features"].device)
+        skip_post = self.ego_only and self.rank != 0
+        if not self.graphs:
+            self._pre(my_inputs, my_pose)
+            self._exchange()
+            return None if skip_post else self._post()
+        key = (my_inputs["voxel_features"].data_ptr(), my_inputs["voxel_coords"].data_ptr(), my_inputs["voxel_num_points"].data_ptr(),
+               my_pose.data_ptr(), tuple(my_inputs["voxel_features"].shape))
+        if self._captured is None or self._captured[0] != key:
+            self._captured = (key,) + self._capture(my_inputs, my_pose, skip_post)
+        _, pre, post, out = self._captured
+        pre.replay()
+        self._exchange()
+        if post is not None:
+            post.replay()
         return out
+
+    def _capture(self, my_inputs, my_pose, skip_post):
+        """Two HIP graphs around the collective.  The pillar count and the input addresses are baked in: refresh the input
+        tensors in place between steps (pad unused pillar rows with agent index -1)."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):                                   # warm-up outside capture (lazy one-off work: weight re-tiling, allocations)
+                self._pre(my_inputs, my_pose)
+                self._exchange()
+                if not skip_post:
+                    self._post()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        pre = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(pre):
+            self._pre(my_inputs, my_pose)
+        self._exchange()
+        post, out = None, None
+        if not skip_post:
+            post = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(post):
+                out = self._post()
+        return pre, post, out

@@ -439,15 +439,56 @@ class DeployedModel(nn.Module):
                                              L.ptr(canvas), n_agents, self.ny, self.nx, st), "qv2x_pfn_scatter_i8")
         return canvas
 
-    def encode_codes(self, n_agents: int):
-        """a6 on the shrinker output already in the workspace."""
+    def encode_codes(self, n_agents: int, out: Optional[torch.Tensor] = None):
+        """a6 on the shrinker output already in the workspace; ``out``: u8 [levels, n_agents, H*W] (default: the workspace's)."""
         b = self._workspace(n_agents)
+        codes = b["codes"] if out is None else out
+        if codes.dtype != torch.uint8 or not codes.is_contiguous() or codes.numel() != self.levels * n_agents * self.fh * self.fw:
+            raise ValueError("encode_codes: out must be a contiguous uint8 tensor [levels, n_agents, H*W]")
         d = L.EncodeDesc()
         d.n, d.h, d.w, d.levels, d.kc = n_agents, self.fh, self.fw, self.levels, self.kc
         d.in_zx, d.in_delta = int(self.shrink1.out_q[1]), float(self.shrink1.out_q[0])
-        L.check(self.lib.qv2x_codebook_encode_f32(C.byref(d), L.ptr(b["s1"]), self.level_ptrs, L.ptr(b["codes"]),
+        L.check(self.lib.qv2x_codebook_encode_f32(C.byref(d), L.ptr(b["s1"]), self.level_ptrs, L.ptr(codes),
                                                   L.current_stream()), "qv2x_codebook_encode_f32")
-        return b["codes"]
+        return codes
+
+    # ---- stage interface of the multi-GPU driver (quantv2x_amd/dist.py) -----------------------------------------------------
+    def wire_shape(self):
+        """(levels, H*W) of one agent-frame's code planes -- the payload of the V2X link."""
+        self._workspace(1)
+        return self.levels, self.fh * self.fw
+
+    def encode_into(self, inputs: dict, frames: int, codes_out: torch.Tensor):
+        """a1-a6 for ``frames`` frames of ONE agent (batch index = frame); codes u8 [levels, frames, H*W] written to ``codes_out``."""
+        self.pillars_to_canvas(inputs, frames)
+        self.run_plan(frames)
+        return self.encode_codes(frames, out=codes_out)
+
+    def pairwise_from_poses(self, gathered: torch.Tensor, world: int, agent_stride: int, pose_offset: int, max_cav: int, out: torch.Tensor):
+        """pairwise f64 [max_cav, max_cav, 4, 4] from the poses inside the gathered payloads (qv2x_pairwise_from_poses_f64)."""
+        L.check(self.lib.qv2x_pairwise_from_poses_f64(L.ptr(gathered), world, agent_stride, pose_offset, max_cav, L.ptr(out),
+                                                      L.current_stream()), "qv2x_pairwise_from_poses_f64")
+
+    def fuse_frames_and_heads(self, gathered: torch.Tensor, agent_stride: int, level_stride: int, frame_stride: int, pairwise: torch.Tensor,
+                              n_agents: int, ego: int, own_codes: Optional[torch.Tensor], frames: int) -> dict:
+        """a7-a11 for ``frames`` scenes whose agents' code planes lie ``agent_stride`` bytes apart in ``gathered`` (frame f at
+        ``+ f * frame_stride``); ``pairwise`` f64 [frames, L, L, 4, 4].  With ``own_codes`` (u8 [levels, frames, H*W]) the
+        ``*_single`` heads of this rank's own agent run in the same launch as the heads on the fused maps."""
+        hw = self.fh * self.fw
+        fused = torch.empty((frames, hw, 256), dtype=torch.float32, device=self.dev)
+        for f in range(frames):
+            self.fuse(C.c_void_p(gathered.data_ptr() + f * frame_stride), agent_stride, level_stride, None, pairwise[f], n_agents, fused[f], ego)
+        sp = None
+        if self.heads_single is not None and own_codes is not None:
+            preds, sp = self._heads_pair(fused, frames, own_codes, frames)
+        else:
+            preds = self._run_heads(self.heads, fused, frames, hw)
+        c, r, _ = self.heads.splits
+        out = {"cls_preds": preds[:, :c], "reg_preds": preds[:, c:c + r], "dir_preds": preds[:, c + r:], "preds_tensor": preds}
+        if sp is not None:
+            c, r, _ = self.heads_single.splits
+            out.update({"cls_preds_single": sp[:, :c], "reg_preds_single": sp[:, c:c + r], "dir_preds_single": sp[:, c + r:]})
+        return out
 
     def encode_agents(self, inputs: dict, n_agents: int, taps: Optional[dict] = None):
         """a1-a6 for ``n_agents`` agents.  Returns codes u8 [levels, n, H*W] (or the i8 shrinker output without a codebook)."""

@@ -18,7 +18,9 @@ SYMBOLS = [
     "qv2x_deconv_i8", "qv2x_deconv_i8_batch", "qv2x_codebook_level_floats", "qv2x_codebook_c2_f32", "qv2x_codebook_encode_f32", "qv2x_fuse_att_f32",
     "qv2x_decode_lut_f32", "qv2x_dequant_i8_f32", "qv2x_heads_f32", "qv2x_decode_heads_f32", "qv2x_heads_pair_f32", "qv2x_voxelize_workspace_bytes", "qv2x_voxelize_f32",
     "qv2x_postprocess_workspace_bytes", "qv2x_postprocess_f32",
+    "qv2x_comm_unique_id", "qv2x_comm_init", "qv2x_comm_destroy", "qv2x_allgather_codes", "qv2x_pairwise_from_poses_f64",
 ]
+COMM_ID_BYTES = 128
 
 
 class PfnParams(C.Structure):
@@ -117,6 +119,11 @@ def load() -> C.CDLL:
     lib.qv2x_postprocess_workspace_bytes.argtypes = [C.POINTER(PostprocessDesc)]
     lib.qv2x_postprocess_workspace_bytes.restype = C.c_int64
     lib.qv2x_postprocess_f32.argtypes = [C.POINTER(PostprocessDesc), vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp]
+    lib.qv2x_comm_unique_id.argtypes = [vp]
+    lib.qv2x_comm_init.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.qv2x_comm_destroy.argtypes = [vp]
+    lib.qv2x_allgather_codes.argtypes = [vp, vp, vp, C.c_int64, vp]
+    lib.qv2x_pairwise_from_poses_f64.argtypes = [vp, C.c_int, C.c_int64, C.c_int64, C.c_int, vp, vp]
     for s in SYMBOLS:
         if s not in ("qv2x_last_error", "qv2x_codebook_level_floats", "qv2x_voxelize_workspace_bytes", "qv2x_postprocess_workspace_bytes"):
             getattr(lib, s).restype = C.c_int

@@ -20,90 +20,127 @@ def _free_port():
 
 
 class _OracleEngine:
-    """Same three stage methods as DeployedModel, backed by the CPU oracle (tests only)."""
+    """The stage interface of DeployedModel that AgentShardedModel drives, backed by the CPU oracle (tests only)."""
+    has_codebook = True
 
     def __init__(self, state):
         from oracle.spec import Oracle
         self.orc = Oracle(state)
         self.calls = []
+        nx, ny = self.orc.nx, self.orc.ny
+        self.h, self.w = ny // 2, nx // 2
 
-    def encode_agents(self, inputs, n_agents):
+    def wire_shape(self):
+        return 3, self.h * self.w
+
+    def encode_into(self, inputs, frames, codes_out):
         sc = {"inputs_m1": {k: v.numpy() for k, v in inputs.items()}}
-        _, canvas, cq = self.orc.pfn_scatter(sc, n_agents)
+        _, canvas, cq = self.orc.pfn_scatter(sc, frames)
         cat, cat_q = self.orc.backbone(canvas, cq)
         shr, shr_q = self.orc.shrinker(cat, cat_q)
-        self.hw = shr.shape[1] * shr.shape[2]
-        self.shape = shr.shape
-        codes = self.orc.encode(shr, shr_q)                       # [levels, n*hw]
-        return torch.from_numpy(codes.reshape(codes.shape[0], n_agents, -1))
+        codes = self.orc.encode(shr, shr_q)                       # [levels, frames*hw]
+        codes_out.copy_(torch.from_numpy(codes.reshape(codes.shape[0], frames, -1)))
 
-    def fuse_and_heads(self, codes, agent_stride, level_stride, pairwise_b, n_agents, ego=0):
-        self.calls.append((tuple(codes.shape), agent_stride, level_stride, n_agents, ego))
-        flat = codes.numpy().reshape(-1)
-        levels = codes.shape[1]
-        planes = np.stack([[flat[a * agent_stride + l * level_stride: a * agent_stride + l * level_stride + self.hw]
-                            for a in range(n_agents)] for l in range(levels)])            # [levels, A, hw]
-        feats = self.orc.decode(planes.reshape(levels, -1)).reshape(n_agents, self.shape[1], self.shape[2], 256)
-        order = [ego] + [a for a in range(n_agents) if a != ego]
-        # the oracle fuses in agent order with agent 0 as the ego: present the ego first and its pairwise row
-        t = pairwise_b.numpy()[None]
-        t_ego = t[:, order][:, :, order]
-        fused = self.orc.fuse(feats[order], t_ego, [n_agents])
-        return {"preds_tensor": torch.from_numpy(np.concatenate(self.orc.heads(fused), axis=1))}
+    def pairwise_from_poses(self, gathered, world, agent_stride, pose_offset, max_cav, out):
+        from oracle import geometry
+        g = gathered.numpy().reshape(world, -1)
+        poses = [g[a, pose_offset:pose_offset + 128].copy().view(np.float64).reshape(4, 4) for a in range(world)]
+        out.copy_(torch.from_numpy(geometry.pairwise_from_poses(poses, max_cav)))
+
+    def fuse_frames_and_heads(self, gathered, agent_stride, level_stride, frame_stride, pairwise, n_agents, ego, own_codes, frames):
+        self.calls.append((tuple(gathered.shape), agent_stride, level_stride, frame_stride, n_agents, ego))
+        flat = gathered.numpy().reshape(-1)
+        hw, outs = self.h * self.w, []
+        for f in range(frames):
+            planes = np.stack([[flat[a * agent_stride + l * level_stride + f * frame_stride:][:hw] for a in range(n_agents)] for l in range(3)])
+            feats = self.orc.decode(planes.reshape(3, -1)).reshape(n_agents, self.h, self.w, 256)
+            order = [ego] + [a for a in range(n_agents) if a != ego]
+            # the oracle fuses in agent order with agent 0 as the ego: present the ego first and its pairwise row
+            t = pairwise[f].numpy()[None]
+            t_ego = t[:, order][:, :, order]
+            fused = self.orc.fuse(feats[order], t_ego, [n_agents])
+            outs.append(np.concatenate(self.orc.heads(fused), axis=1))
+        return {"preds_tensor": torch.from_numpy(np.concatenate(outs))}
 
 
-def _worker(rank, world, port, state, out_q):
+def _worker(rank, world, port, state, out_q, frames):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        from quantv2x_amd import synth
         from quantv2x_amd.dist import AgentShardedModel
         torch.set_num_threads(1)
-        sc = scene_np(world)
-        co = sc["inputs_m1"]["voxel_coords"]
-        mine = co[:, 0] == rank
-        inp = {k: torch.from_numpy(v[mine].copy()) for k, v in sc["inputs_m1"].items()}
-        inp["voxel_coords"][:, 0] = 0
+        # `frames` scenes (different sweeps, same poses); this rank contributes agent `rank` of each, batch index = frame
+        parts = []
+        for f in range(frames):
+            sc = scene_np(world, seed=3 + f)
+            co = sc["inputs_m1"]["voxel_coords"]
+            mine = co[:, 0] == rank
+            part = {k: v[mine].copy() for k, v in sc["inputs_m1"].items()}
+            part["voxel_coords"][:, 0] = f
+            parts.append(part)
+        inp = {k: torch.from_numpy(np.concatenate([p[k] for p in parts])) for k in parts[0]}
+        pose = torch.from_numpy(synth.agent_poses(world, "line")[rank])
         eng = _OracleEngine(state)
-        model = AgentShardedModel(eng)
-        pw = torch.from_numpy(sc["pairwise_t_matrix"][0])
-        out = model.forward(inp, pw)
-        out_q.put((rank, out["preds_tensor"].numpy(), model._gathered.numpy().copy(), eng.calls))
-        ego_only = AgentShardedModel(eng, ego_only=True).forward(inp, pw)
+        model = AgentShardedModel(eng, frames=frames)
+        out = model.forward(inp, pose)
+        out_q.put((rank, out["preds_tensor"].numpy(), model.gathered.numpy().copy(), eng.calls, model.pairwise.numpy().copy()))
+        ego_only = AgentShardedModel(eng, ego_only=True, frames=frames).forward(inp, pose)
         assert (ego_only is None) == (rank != 0)
     finally:
         dist.barrier()
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_agents_match_single_process(world):
+@pytest.mark.parametrize("world,frames", [(2, 1), (3, 1), (2, 2)])
+def test_sharded_agents_match_single_process(world, frames):
+    from quantv2x_amd import synth
+    from quantv2x_amd.dist import payload_layout
     from quantv2x_amd.ptq_state import export_ptq_state
+    from oracle import geometry
     from oracle.spec import Oracle
     state = export_ptq_state(calibrated_plugin())
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, state, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, state, q, frames)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    taps = {}
-    want = Oracle(state).forward(scene_np(world), taps)
-    single_codes = taps["codes"].reshape(3, world, -1)
-    for rank, preds, gathered, calls in results:
-        assert gathered.shape == (world, 3, single_codes.shape[-1])
-        np.testing.assert_array_equal(gathered, single_codes.transpose(1, 0, 2))          # agent-major wire layout
-        shape, a_stride, l_stride, n, ego = calls[0]
-        assert (a_stride, l_stride, n, ego) == (3 * single_codes.shape[-1], single_codes.shape[-1], world, rank)
-    np.testing.assert_allclose(results[0][1], want["preds_tensor"], rtol=1e-5, atol=1e-6)   # rank 0 = the reference's ego
+    orc = Oracle(state)
+    wants, codes = [], []
+    for f in range(frames):
+        taps = {}
+        sc = scene_np(world, seed=3 + f)
+        wants.append(orc.forward(sc, taps)["preds_tensor"])
+        codes.append(taps["codes"].reshape(3, world, -1))
+    hw = codes[0].shape[-1]
+    cbytes, pose_off, pbytes = payload_layout(3, frames, hw)
+    poses = synth.agent_poses(world, "line")
+    for rank, preds, gathered, calls, pairwise in results:
+        assert gathered.shape == (world, pbytes)
+        for a in range(world):                                                   # agent-major wire layout: codes, then the pose
+            planes = gathered[a, :cbytes].reshape(3, frames, hw)
+            for f in range(frames):
+                np.testing.assert_array_equal(planes[:, f], codes[f][:, a])
+            for f in range(frames):
+                got_pose = gathered[a, pose_off + 128 * f: pose_off + 128 * (f + 1)].copy().view(np.float64).reshape(4, 4)
+                np.testing.assert_array_equal(got_pose, poses[a])
+        shape, a_stride, l_stride, f_stride, n, ego = calls[0]
+        assert (a_stride, l_stride, f_stride, n, ego) == (pbytes, frames * hw, hw, world, rank)
+        np.testing.assert_array_equal(pairwise[0], geometry.pairwise_from_poses(poses, world))
+        # the pairwise matrix built from the gathered poses is the dataset's (np.linalg.solve) up to rounding
+        np.testing.assert_allclose(pairwise[0], scene_np(world)["pairwise_t_matrix"][0][:world, :world], rtol=0, atol=1e-12)
+    want = np.concatenate(wants)
+    np.testing.assert_allclose(results[0][1], want, rtol=1e-5, atol=1e-6)   # rank 0 = the reference's ego
     # other ranks see the scene from their own pose: a different, finite prediction map of the same shape
-    for rank, preds, _, _ in results[1:]:
-        assert preds.shape == want["preds_tensor"].shape and np.isfinite(preds).all()
-        assert not np.allclose(preds, want["preds_tensor"])
+    for rank, preds, _, _, _ in results[1:]:
+        assert preds.shape == want.shape and np.isfinite(preds).all()
+        assert not np.allclose(preds, want)
 
 
 def test_exchange_world_one_is_a_copy():
@@ -115,5 +152,7 @@ def test_exchange_world_one_is_a_copy():
         g = exchange_codes(c)
         assert g.shape == (1, 3, 8) and torch.equal(g[0], c)
         assert gathered_strides(3, 8) == (24, 8)
+        from quantv2x_amd.dist import payload_layout
+        assert payload_layout(3, 1, 35200) == (105600, 105600, 105728) and payload_layout(3, 2, 15) == (90, 96, 352)
     finally:
         dist.destroy_process_group()
