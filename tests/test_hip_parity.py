@@ -162,3 +162,24 @@ def test_sharded_stage_functions_equal_forward(tiny, n_agents):
     for key in ("preds_tensor", "cls_preds", "reg_preds", "dir_preds", "cls_preds_single", "reg_preds_single", "dir_preds_single"):
         assert torch.equal(got[key], want[key]), key
         assert torch.equal(both[key], want[key]), key
+
+
+def test_padding_pillar_rows_are_dropped(tiny):
+    """A fixed pillar count M (HIP-graph replay, ``DeployedModel.capture``) is kept by padding the pillar arrays with rows whose
+    agent index is out of range (-1) and whose point count is 0: ``pfn_scatter_kernel`` drops them, every output is unchanged."""
+    from quantv2x_amd import synth
+    state, orc, eng = tiny
+    sc = scene_np(2)
+    dd = synth.scene_to_torch(sc, "cuda")
+    want = {k: v.clone() for k, v in eng(dd).items()}
+    pad = 37
+    inp = dd["inputs_m1"]
+    vf = torch.cat([inp["voxel_features"], torch.zeros((pad, 32, 4), device="cuda")])
+    co = torch.cat([inp["voxel_coords"], torch.tensor([[-1, 0, 3, 5]] * pad, dtype=inp["voxel_coords"].dtype, device="cuda")])
+    npt = torch.cat([inp["voxel_num_points"], torch.zeros(pad, dtype=inp["voxel_num_points"].dtype, device="cuda")])
+    perm = torch.randperm(vf.shape[0], generator=torch.Generator().manual_seed(0)).cuda()       # padding anywhere, not only at the end
+    dd2 = dict(dd, inputs_m1={"voxel_features": vf[perm].contiguous(), "voxel_coords": co[perm].contiguous(), "voxel_num_points": npt[perm].contiguous()})
+    got = eng(dd2)
+    torch.cuda.synchronize()
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
