@@ -32,19 +32,28 @@ __device__ __forceinline__ float q_code(float y, float delta, float zp) {
 }
 
 // Four outputs -> one dword of (code - 128) bytes (byte e = element e), the same values q_code gives.  `rdelta` = 1.0f / delta,
-// hoisted by the caller.  The |t| < 1100 gate of q_code is dropped: beyond it a doubtful lane only takes the division path
-// needlessly (both results clamp).  The clamped code is read from the low mantissa byte of (code + 2^23).
+// hoisted by the caller.  t = y * rdelta is within 1.8e-7 |t| of fl(y / delta); a code only depends on rint(.) for |t| < 256.5
+// (0 <= zp <= 255: beyond that both values clamp to 0 or 255 even when they differ by one), where the gap is < 4.7e-5, so
+// the two round alike unless t lies within 1e-4 of a half-integer.  One test per group of four: max |t - rint(t)| > 0.4999 on
+// any lane sends the wave through the exact divisions (5 % of the groups).  The clamped code is read from the low mantissa byte
+// of (code + 2^23), with zp + 2^23 added in one step (exact: both are integers below 2^24).
 __device__ __forceinline__ int q_pack4(float y0, float y1, float y2, float y3, float delta, float rdelta, float zp) {
     const float y[4] = {y0, y1, y2, y3};
-    unsigned b[4];
+    float k[4], dmax = 0.0f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float t = y[e] * rdelta;
-        float k = rintf(t);
-        if (__builtin_amdgcn_ballot_w64(fabsf(t - k) > 0.4997f) != 0) k = rintf(y[e] / delta);
-        const float c = fminf(fmaxf(k + zp, 0.0f), 255.0f) + 8388608.0f;
-        b[e] = __builtin_bit_cast(unsigned, c);
+        k[e] = rintf(t);
+        dmax = fmaxf(dmax, fabsf(t - k[e]));
     }
+    if (__builtin_amdgcn_ballot_w64(dmax > 0.4999f) != 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) k[e] = rintf(y[e] / delta);
+    }
+    const float zm = zp + 8388608.0f;
+    unsigned b[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b[e] = __builtin_bit_cast(unsigned, fminf(fmaxf(k[e] + zm, 8388608.0f), 8388863.0f));
     const unsigned lo = __builtin_amdgcn_perm(b[1], b[0], 0x0c0c0400u);      // byte 0 of b0, byte 0 of b1
     const unsigned hi = __builtin_amdgcn_perm(b[3], b[2], 0x0c0c0400u);
     return (int)(__builtin_amdgcn_perm(hi, lo, 0x05040100u) ^ 0x80808080u);
