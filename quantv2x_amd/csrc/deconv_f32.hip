@@ -4,7 +4,10 @@
 // i.e. on the reduction axis, so no integer accumulation can be factored; the sum is an ascending-ci fp32 fma
 // chain, which is exactly what the f32 MFMA computes (k ascending, C-in first; verified bit-exact against fmaf
 // on hardware, tools/probes/mfma_probe.hip).  GEMM view: rows = input pixels, cols = (i*s + j)*Cout + co, K = Cin.
-// One wave = 32 pixels x 32 columns; A converted on the fly from the i8 BEV, B = [Cin/4][cols][4] fp32 from L2.
+// One wave = 32 pixels x 32 columns; the pixels converted on the fly from the i8 BEV, the weights [Cin/4][cols][4] fp32 from L2.
+// The WEIGHTS are the A operand (out^T = W^T x^T, the same ascending-ci chain per output): a lane then holds one pixel and 16
+// output channels in four runs of four, which requantize four at a time (q_pack4) and leave as 16-byte stores through a small
+// LDS stage -- instead of sixteen 1-byte global stores per lane.
 #include "common.h"
 
 #include <cstdlib>
@@ -17,9 +20,11 @@ struct DeconvArgs {
     float dx, out_delta, out_zp;
 };
 
-// one wave tile (`tile` is wave-uniform); rowbase: this wave's 32 ints of LDS
+// one wave tile (`tile` is wave-uniform); stagebuf: this wave's 32 x 48 bytes of LDS
+constexpr int DSP = 48;                       // staging pitch per pixel: 32 channel bytes + 16 (2-way bank spread of the dword writes)
+
 template <int NT>
-__device__ __forceinline__ void deconv_tile(const DeconvArgs& a, const int tile, int (*rowbase)[32]) {
+__device__ __forceinline__ void deconv_tile(const DeconvArgs& a, const int tile, int8_t (*stagebuf)[32 * DSP]) {
     const int lane = threadIdx.x & 63;
     const int tiles_n = a.ncols / (32 * NT);
     const int tiles_m = (a.M + 31) >> 5;
@@ -32,10 +37,8 @@ __device__ __forceinline__ void deconv_tile(const DeconvArgs& a, const int tile,
     const int img = m / (a.h * a.wd), rem = m - img * (a.h * a.wd);
     const int y = rem / a.wd, x = rem - y * a.wd;
     const int8_t* src = a.in + ((size_t)(img * (a.h + 2) + y + 1) * (a.wd + 2) + x + 1) * a.cin;
-    if (lane < 32) {
-        const int mm = tm * 32 + lane;
-        rowbase[threadIdx.x >> 6][lane] = mm < a.M ? (img * (a.h * a.s + 2) + y * a.s + 1) * (a.wd * a.s + 2) + x * a.s + 1 : -1;
-    }
+    // padded output pixel index of this lane's pixel at sub-position (i = 0, j = 0); -1 past the end
+    const int pixbase = (tm * 32 + (lane & 31)) < a.M ? (img * (a.h * a.s + 2) + y * a.s + 1) * (a.wd * a.s + 2) + x * a.s + 1 : -1;
     const int col0 = tn * (32 * NT) + (lane & 31);
     // weights: [Cin/4][cols][k0, k2, k1, k3]; the half-wave of MFMA k-parity `par` reads one float2 = (k_par, k_par+2)
     const float2* wq = (const float2*)a.w + (size_t)col0 * 2 + par;
@@ -67,7 +70,7 @@ __device__ __forceinline__ void deconv_tile(const DeconvArgs& a, const int tile,
         for (int j = 0; j < 8; ++j)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], (j & 1) ? b[j >> 1][t].y : b[j >> 1][t].x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32((j & 1) ? b[j >> 1][t].y : b[j >> 1][t].x, av[j], acc[t], 0, 0, 0);
     };
     v4i r0 = loadA(0), r1;
     float2 b0[4][NT], b1[4][NT];
@@ -86,37 +89,39 @@ __device__ __forceinline__ void deconv_tile(const DeconvArgs& a, const int tile,
         }
     }
 
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    const int* rb = rowbase[threadIdx.x >> 6];
+    // lane l now holds pixel (l & 31) and, of column tile t, the 16 columns 8 (r >> 2) + 4 (l >> 5) + (r & 3); Cout is a multiple
+    // of 32, so the tile's 32 columns are 32 consecutive output channels of ONE sub-position (di, dj)
+    int8_t* stage = stagebuf[threadIdx.x >> 6];
     const int orow = a.wd * a.s + 2;             // output pixels per padded row
-    int pix[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) pix[r] = rb[mfma32_row(r, lane)];      // all 16 LDS reads in flight, no per-element branch
+    const float rd = 1.0f / a.out_delta, lo = a.relu ? 0.0f : -3.0e38f;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int pb = __shfl(pixbase, lane >> 1);   // the copy-out below moves 16 bytes per lane: pixel lane >> 1, chunk lane & 1
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int col = col0 + t * 32;
-        const int ij = col / a.cout, co = col - ij * a.cout;
+        const int col = tn * (32 * NT) + t * 32;
+        const int ij = col / a.cout, co0 = col - ij * a.cout;
         const int di = ij / a.s, dj = ij - di * a.s;
-        const float bias = a.bias[co];
-        const int obase = (di * orow + dj) * a.out_ctotal + a.out_c0 + co;   // byte offsets fit 32 bits (tensor < 2 GiB)
-        int8_t q[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float yv = acc[t][r] + bias;
-            if (a.relu) yv = fmaxf(yv, 0.0f);
-            q[r] = (int8_t)((int)q_code(yv, a.out_delta, a.out_zp) - 128);
+        for (int g = 0; g < 4; ++g) {
+            const v4f b4 = *(const v4f*)(a.bias + co0 + 8 * g + 4 * half);
+            float yv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) yv[e] = fmaxf(acc[t][4 * g + e] + b4[e], lo);
+            *(int*)(stage + l31 * DSP + 8 * g + 4 * half) = q_pack4(yv[0], yv[1], yv[2], yv[3], a.out_delta, rd, a.out_zp);
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (pix[r] >= 0) a.out[(unsigned)(obase + pix[r] * a.out_ctotal)] = q[r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        if (pb >= 0)
+            *(v4i*)(a.out + (size_t)(pb + di * orow + dj) * a.out_ctotal + a.out_c0 + co0 + (lane & 1) * 16) = *(const v4i*)(stage + (lane >> 1) * DSP + (lane & 1) * 16);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
 template <int NT>
 __global__ __launch_bounds__(256) void deconv_f32_kernel(const DeconvArgs a) {
-    __shared__ int rowbase[4][32];            // per wave: output pixel index of (row, i = 0, j = 0), -1 past the end
-    deconv_tile<NT>(a, __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))), rowbase);
+    __shared__ __attribute__((aligned(16))) int8_t stagebuf[4][32 * DSP];     // per wave: [32 pixels][32 channels] of one tile
+    deconv_tile<NT>(a, __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))), stagebuf);
 }
 
 // Several deblocks in one launch (they only feed the concat, so all of them can run once the last block is done): one pool
@@ -129,16 +134,16 @@ struct DeconvBatch {
 };
 
 __global__ __launch_bounds__(256) void deconv_f32_batch_kernel(const DeconvBatch b) {
-    __shared__ int rowbase[4][32];
+    __shared__ __attribute__((aligned(16))) int8_t stagebuf[4][32 * DSP];
     const int tile = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     int l = 0, begin = 0;
     while (l < b.n - 1 && tile >= b.tile_end[l]) { begin = b.tile_end[l]; ++l; }
     if (tile >= b.tile_end[b.n - 1]) return;
     switch (l) {                              // constant indices: the argument structs stay in SGPRs / kernarg loads
-        case 0: deconv_tile<1>(b.a[0], tile - begin, rowbase); break;
-        case 1: deconv_tile<1>(b.a[1], tile - begin, rowbase); break;
-        case 2: deconv_tile<1>(b.a[2], tile - begin, rowbase); break;
-        default: deconv_tile<1>(b.a[3], tile - begin, rowbase); break;
+        case 0: deconv_tile<1>(b.a[0], tile - begin, stagebuf); break;
+        case 1: deconv_tile<1>(b.a[1], tile - begin, stagebuf); break;
+        case 2: deconv_tile<1>(b.a[2], tile - begin, stagebuf); break;
+        default: deconv_tile<1>(b.a[3], tile - begin, stagebuf); break;
     }
 }
 
@@ -151,6 +156,8 @@ static int deconv_args(const qv2x_deconv_desc* d, const int8_t* in, const float*
     if (d->out_h != d->h * d->s || d->out_w != d->w * d->s)
         return fail(QV2X_EINVAL, "%s: destination is %d x %d, this layer writes %d x %d", who, d->out_h, d->out_w, d->h * d->s, d->w * d->s);
     if (d->out_c0 < 0 || d->out_ctotal < d->out_c0 + d->cout) return fail(QV2X_EINVAL, "%s: out channel window", who);
+    if (d->out_ctotal % 16 || d->out_c0 % 16 || ((uintptr_t)out & 15) || ((uintptr_t)bias & 15))
+        return fail(QV2X_EALIGN, "%s: out_ctotal, out_c0 %% 16; out / bias 16-byte aligned (16-byte stores)", who);
     a.in = in; a.w = w; a.bias = bias; a.out = out;
     a.n = d->n; a.h = d->h; a.wd = d->w; a.cin = d->cin; a.cout = d->cout; a.s = d->s; a.ax = 128 - d->in_zx;
     a.ncols = d->s * d->s * d->cout; a.M = d->n * d->h * d->w; a.relu = d->relu;
