@@ -6,7 +6,7 @@
         bench.py --gpus N --steps K --warmup W
 
 A *step* is one pass of the whole hot path (a1-a11: PFN + scatter, int8 backbone + shrinker, codebook encode, exchange,
-decode + warp + attention, heads) over one batch of B synthetic V2X-Real-shaped frames (default B = 4: the reference's
+decode + warp + attention, heads) over one batch of B synthetic V2X-Real-shaped frames (default B = 8: the reference's
 model contract has a batch dimension, ``record_len`` / ``pairwise_t_matrix[B]``), replayed as HIP graphs; at N = 1, F = 2
 such batches are in flight on two streams (the next batch's PFN / backbone fill the tail of the previous batch's encode).
 ``value`` = frames per second over exactly K steps; the p50 latency of ONE frame run alone is reported next to it, and
@@ -214,7 +214,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=4, help="frames per step (per rank)")
+    ap.add_argument("--batch", type=int, default=8, help="frames per step (per rank)")
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight at N = 1 (streams / engines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path (two HIP graphs around the collective) with one rank")

@@ -43,3 +43,51 @@ def calibrate_minmax(qt, batches, seed=0):
     for a in activation_quantizers(qt):
         a.set_inited(True)
     return qt
+
+
+# ---- reconstruction path of the driver (inference_quant.py:236-243, 268-322) ------------------------------------------------
+def wrap_pair(model, scale_method="minmax", prob=0.5):
+    """``(fp_model, qt_model)`` as the driver builds them: the fp twin keeps its BatchNorm layers (``is_fusing=False``) and runs
+    with quantization off -- its BN statistics drive the distribution correction -- the quantized one is folded."""
+    import copy
+    wq, aq = quant_params(scale_method=scale_method, prob=prob)
+    fp = QuantModel(copy.deepcopy(model), wq, aq, is_fusing=False).eval()
+    fp.set_quant_state(False, False)
+    qt = QuantModel(model, wq, aq).eval()
+    set_weight_quantize_params(qt)
+    return fp, qt
+
+
+def recon_kwargs(cali_data, iters_w=5000, weight=0.01, b_start=20, b_end=2, warmup=0.2, lr=4e-5, input_prob=0.5, keep_cpu=False,
+                 lamb_r=0.2, T=7.0, bn_lr=1e-3, lamb_c=0.02, **extra):
+    """the ``kwargs`` dict of the driver (``:279-283``; defaults = its argparse defaults, ``:89-131``)"""
+    return dict(cali_data=cali_data, iters=iters_w, weight=weight, b_range=(b_start, b_end), warmup=warmup, opt_mode='mse', lr=lr,
+                input_prob=input_prob, keep_gpu=not keep_cpu, lamb_r=lamb_r, T=T, bn_lr=bn_lr, lamb_c=lamb_c, **extra)
+
+
+def recon_model(qt_model, fp_model, kwargs, log=print):
+    """Walk the two module trees in step and reconstruct every quantized unit in forward order (``recon_model``, ``:286-317``):
+    a bare ``QuantModule`` -> layer, a backbone / shrinker / compressor block -> block, the pillar feature net -> encoder."""
+    from ..quant.block_recon import block_reconstruction
+    from ..quant.encoder_recon import encoder_reconstruction
+    from ..quant.layer_recon import layer_reconstruction
+    from ..quant.quant_block import QuantBaseBEVBackbone, QuantDownsampleConv, QuantNaiveCompressor, QuantPFNLayer
+    from ..quant.quant_layer import QuantModule
+
+    def walk(qt, fp):
+        for (name, module), (_, fp_module) in zip(qt.named_children(), fp.named_children()):
+            if isinstance(module, QuantModule):
+                log('Reconstruction for layer {}'.format(name))
+                layer_reconstruction(qt_model, fp_model, module, fp_module, **kwargs)
+            elif isinstance(module, (QuantDownsampleConv, QuantBaseBEVBackbone, QuantNaiveCompressor)):
+                log('Reconstruction for block {}'.format(name))
+                block_reconstruction(qt_model, fp_model, module, fp_module, **kwargs)
+            elif isinstance(module, QuantPFNLayer):
+                log('Reconstruction for PointPillar PFN {}'.format(name))
+                encoder_reconstruction(qt_model, fp_model, module, fp_module, **kwargs)
+            else:
+                walk(module, fp_module)
+    walk(qt_model, fp_model)
+    qt_model.set_quant_state(weight_quant=True, act_quant=True)
+    qt_model.eval()
+    return qt_model

@@ -442,8 +442,71 @@ def gen_postprocess_mc():
     print("postprocess_mc.npz", {k: getattr(v, "shape", v) for k, v in out.items()})
 
 
+def gen_recon():
+    """Reconstruction pieces of the reference that run without a GPU (the loops themselves call .cuda()): the loss of
+    block_recon.py / layer_recon.py on the reference's own AdaRound-swapped backbone block, the temperature schedule, the
+    forward-hook capture of a block's input (data_utils.GetLayerInpOut), extract_prediction_tensor, forward_from_shrinker."""
+    from opencood.quant import block_recon as ref_block, layer_recon as ref_layer
+    from opencood.quant.data_utils import GetLayerInpOut
+    from opencood.quant.encoder_recon_utils import extract_prediction_tensor
+    out = {}
+    qt = quant_wrap(build_ref())
+    for a in act_quantizers(qt):
+        a.set_inited(False)
+    qt.set_quant_state(True, True)
+    dd = scene(2)
+    with torch.no_grad():
+        torch.manual_seed(0)
+        res = qt(dd)
+    for a in act_quantizers(qt):
+        a.set_inited(True)
+    out['pred/preds_tensor_checksum'] = np.float64(extract_prediction_tensor(res).double().abs().sum().item())
+    out['pred/from_parts_checksum'] = np.float64(extract_prediction_tensor({k: res[k] for k in ('cls_preds', 'reg_preds', 'dir_preds')}).double().abs().sum().item())
+    # capture of the backbone's and the shrinker's input inside the quantized model
+    for name in ('backbone_m1', 'shrinker_m1'):
+        blk = getattr(qt.model, name)
+        x = GetLayerInpOut(qt, blk, device=torch.device('cpu'))(dd)
+        out[f'capture/{name}_shape'] = np.array(x.shape)
+        out[f'capture/{name}_abs_sum'] = np.float64(x.double().abs().sum().item())
+    # AdaRound swap with seeded alphas on the shrinker block, then the reference's loss at several counts
+    blk = qt.model.shrinker_m1
+    g = torch.Generator().manual_seed(5)
+    alphas = []
+    for m in blk.modules():
+        if isinstance(m, QuantModule):
+            m.weight_quantizer = AdaRoundQuantizer(uaq=m.weight_quantizer, round_mode='learned_hard_sigmoid', weight_tensor=m.org_weight.data)
+            m.weight_quantizer.soft_targets = True
+            with torch.no_grad():
+                m.weight_quantizer.alpha.add_(torch.randn(m.weight_quantizer.alpha.shape, generator=g) * 0.7)
+            alphas.append(m.weight_quantizer.alpha.detach().numpy().copy())
+    out['loss/alpha0_sub'] = alphas[0].reshape(-1)[::997].astype(np.float32)
+    out['loss/alpha_checksums'] = np.array([float(np.abs(a.astype(np.float64)).sum()) for a in alphas])
+    pred = torch.randn(2, 256, 16, 32, generator=g)
+    tgt = pred + 0.1 * torch.randn(2, 256, 16, 32, generator=g)
+    oq = torch.randn(2, 72, 16, 32, generator=g)
+    of = oq + 0.05 * torch.randn(2, 72, 16, 32, generator=g)
+    out['loss/pred'], out['loss/tgt'], out['loss/oq'], out['loss/of'] = (t.numpy()[:, ::16, ::4, ::4] for t in (pred, tgt, oq, of))
+    out['loss/seed'] = np.int64(5)
+    with torch.no_grad():
+        lf = ref_block.LossFunction(blk, round_loss='relaxation', weight=0.01, max_count=100, rec_loss='mse', b_range=(20, 2),
+                                    decay_start=0, warmup=0.2, p=2.0, lam=0.2, T=7.0)
+        vals = []
+        for c in range(60):
+            v = lf(pred, tgt, oq if c % 2 else None, of if c % 2 else None)
+            vals.append(float(v))
+        out['loss/block_values'] = np.array(vals)
+        ll = ref_layer.LossFunction(blk, round_loss='relaxation', weight=0.001, max_count=100, rec_loss='mse', b_range=(20, 2),
+                                    decay_start=0, warmup=0.2, p=2.0, lam=0.2, T=7.0)
+        out['loss/layer_values'] = np.array([float(ll(pred, tgt, None, None)) for _ in range(60)])
+        td = ref_block.LinearTempDecay(100, rel_start_decay=0.2, start_b=20, end_b=2)
+        out['loss/temp'] = np.array([td(t) for t in range(0, 101, 5)], dtype=np.float64)
+        out['shrinker_heads/abs_sum'] = np.float64(ref_block.forward_from_shrinker(qt.model, pred).double().abs().sum().item())
+    np.savez_compressed(os.path.join(HERE, "recon_units.npz"), **out)
+    print("recon_units.npz", {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["fp32", "w8a8", "uaq", "geometry", "codebook", "postprocess", "postprocess_mc"]
+    which = sys.argv[1:] or ["fp32", "w8a8", "uaq", "geometry", "codebook", "postprocess", "postprocess_mc", "recon"]
     with torch.no_grad():
         pass
     if "fp32" in which: gen_fp32()
@@ -453,3 +516,4 @@ if __name__ == "__main__":
     if "codebook" in which: gen_codebook()
     if "postprocess" in which: gen_postprocess()
     if "postprocess_mc" in which: gen_postprocess_mc()
+    if "recon" in which: gen_recon()

@@ -40,3 +40,23 @@ def test_heads_without_output_quantizer():
 def test_mse_calibrated_state(n_agents):
     state, orc, eng = _deploy(mse_plugin())
     compare_frame(orc, eng, scene_np(n_agents), state)
+
+
+def test_reconstruction_on_the_gpu_then_deploy():
+    """SURVEY §8(f) rank 4 end to end: the AdaRound / QDrop reconstruction loops run on the MI355X in PyTorch-ROCm (autograd),
+    the frozen result (hard rounding masks, learned activation step sizes) deploys on the HIP int8 path, bit-exact vs the oracle."""
+    from _common import build_plugin, scene
+    from quantv2x_amd.plugin.quant import AdaRoundQuantizer, QuantModule
+    from quantv2x_amd.plugin.tools import inference_quant as IQ
+    fp, qt = IQ.wrap_pair(build_plugin("tiny"))
+    fp.cuda(); qt.cuda()
+    cali = [scene(2, seed=3 + i, device="cuda") for i in range(3)]
+    seen = []
+    IQ.recon_model(qt, fp, IQ.recon_kwargs(cali, iters_w=25, dc_iters=3, verbose=False, seed=0), log=seen.append)
+    assert len(seen) == 9
+    for m in qt.modules():
+        if isinstance(m, QuantModule):
+            assert isinstance(m.weight_quantizer, AdaRoundQuantizer) and m.weight_quantizer.alpha.is_cuda and m.trained
+    state, orc, eng = _deploy(qt)
+    for n_agents in (1, 2):
+        compare_frame(orc, eng, scene_np(n_agents), state)
