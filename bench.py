@@ -337,6 +337,22 @@ def main():
         }
         roof, stages = rooflines(eng, full if not sharded_mode else frame_batch(1, 0, B, device)[1], B, iters=max(10, args.steps // 5))
         line["roofline"], line["roofline_stages"] = roof, stages
+        if world == 1 and not sharded_mode:
+            # the same frame on the fp32 HIP path (the un-quantized model, engine_fp32.py): what W8A8 buys on this GPU
+            from quantv2x_amd.engine import deploy as _deploy
+            e32 = _deploy(fp_model)
+            r32 = e32.capture(frame_batch(1, 0, 1, device)[1])
+            for _ in range(3):
+                r32()
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            for _ in range(20):
+                r32()
+            torch.cuda.synchronize()
+            ms32 = (time.perf_counter() - tb) / 20 * 1e3
+            line["fp32_hip_path"] = {"ms_per_frame": round(ms32, 3), "frames_per_s": round(1e3 / ms32, 1),
+                                     "note": "un-quantized model, one frame at a time, f32-MFMA convolutions; compare value_one_frame_at_a_time"}
+            del e32, r32
         if not args.no_cpu_baseline and world == 1:       # reported on rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(state, frame_batch(1, 0, 1, "cpu")[0])
             line["cpu_baseline_torch"] = cpu_baseline_torch(fp_model, qt, frame_batch(1, 0, 1, "cpu")[0], cores)

@@ -249,6 +249,35 @@ int qv2x_postprocess_f32(const qv2x_postprocess_desc* desc /* host */, const flo
                          const float* anchors, void* workspace, int64_t workspace_bytes, float* out_corners,
                          float* out_scores, int32_t* out_labels, int32_t* out_count, void* stream);
 
+/* ---- the un-quantized model (SURVEY.md §8(b) "fp32 fall-backs for un-quantized mode") ------------------------------------------
+ * What the reference's plain opencood/tools/inference.py:106-170 flow runs in fp32 -- PillarVFE (pillar_vfe.py:105-155) +
+ * PointPillarScatter, BaseBEVBackbone (base_bev_backbone.py:96-119), DownsampleConv (downsample_conv.py:26-51) -- as f32-MFMA
+ * kernels; the codebook, the fusion and the heads are fp32 in both modes.  BatchNorm folded by the host (fold_bn.py:19-127).
+ * fp32 activations: NHWC with a one-pixel zero border, [N][H+2][W+2][C].
+ *
+ * qv2x_conv3x3_f32: 3x3, padding 1, stride 1 | 2:  out[co] = relu(sum_k x_k w[co][k] + bias[co]) over K = 9 * cin, k = tap * cin + ci.
+ * qv2x_deconv_f32 : ConvTranspose2d with kernel == stride == s: column (i*s + j) * cout + co over K = cin.
+ * Both: ONE fp32 fma chain per output, K walked in groups of 8 in the order k0, k4, k1, k5, k2, k6, k3, k7, acc0 = 0, then + bias
+ * (oracle/qv2x_oracle.c:orc_gemm_f32 is the same chain).
+ *   w: f32 [K / 8][columns][2][4] -- element [g][col][half][e] = W[col][8 g + 4 half + e]; columns % 64 == 0, cin % 8 == 0
+ *   input channel window [cin0, cin0 + cin) of a cin_total-channel tensor, output window [out_c0, out_c0 + cout) of out_ctotal. */
+typedef struct {
+    int32_t n, h, w;             /* input map */
+    int32_t cin_total, cin0, cin;
+    int32_t stride;              /* conv: 1 | 2; deconv: s */
+    int32_t cout;
+    int32_t out_ctotal, out_c0, relu;
+} qv2x_f32conv_desc;
+int qv2x_conv3x3_f32(const qv2x_f32conv_desc* desc /* host */, const float* in, const float* w, const float* bias, float* out, void* stream);
+int qv2x_deconv_f32(const qv2x_f32conv_desc* desc /* host */, const float* in, const float* w, const float* bias, float* out, void* stream);
+/* a1 + a2 in fp32: Linear(10 -> 64) with folded BN, ReLU, max over the points, scattered into the zero-filled fp32 canvas
+ * [N][ny+2][nx+2][64].  w [64][10], b [64], vox / off [3]: HOST arrays (passed by value to the kernel). */
+int qv2x_pfn_scatter_f32(const float* voxel_features, const int32_t* voxel_coords, const int32_t* voxel_num_points, int M, int max_points,
+                         const float* w, const float* b, const float* vox, const float* off, float* canvas, int N, int ny, int nx, void* stream);
+/* a6 on fp32 rows: qv2x_codebook_encode_f32 with the shared feature given as fp32 [N][h+2][w+2][256] (in_zx / in_delta unused) */
+int qv2x_codebook_encode_f32in(const qv2x_encode_desc* desc /* host */, const float* in, const float* const* level_weights /* host array */,
+                               uint8_t* codes, void* stream);
+
 /* ---- the V2X link: one agent per GPU --------------------------------------------------------------------
  * The reference simulates the link in-process: all agents are rows of one batch (heter_model_baseline.py:216) and
  * fusion_in_one.py:131-151 regroups them; get_pairwise_transformation (utils/transformation_utils.py:21-66) builds the

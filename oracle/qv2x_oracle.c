@@ -284,3 +284,78 @@ ORC_API void orc_heads(const float* x, int R, int K, const float* wdeq, const fl
 #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < (size_t)R * Cout; ++i) out[i] = (q_code(out[i], da, za) - za) * da;
 }
+
+/* =============================================================================================
+ * The UN-QUANTIZED model (fp32 mode of the product, quantv2x_amd/csrc/fp32_path.hip): the reference's plain fp32 forward
+ * (pillar_vfe.py:105-155, base_bev_backbone.py:96-119, downsample_conv.py:26-51) with BatchNorm folded, every dot product ONE
+ * fmaf chain in the order the f32 MFMA kernel walks K: groups of 8 consecutive k, inside a group k0, k4, k1, k5, k2, k6, k3, k7.
+ * ============================================================================================= */
+static const int ORC_K8[8] = {0, 4, 1, 5, 2, 6, 3, 7};
+
+/* a1 + a2 in fp32: pillars -> [M][64] features (Linear 10 -> 64 with folded BN, ReLU, max over the P slots; zero-masked slots
+ * contribute relu(bias)) */
+ORC_API void orc_pfn_f32(const float* vf, const int32_t* coords, const int32_t* npts, int M, int P, const float* w, const float* b,
+                         const float* vox, const float* off, float* out) {
+#pragma omp parallel for schedule(static)
+    for (int m = 0; m < M; ++m) {
+        const float* pts = vf + (size_t)m * P * 4;
+        const int real = npts[m] < P ? npts[m] : P;
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int p = 0; p < real; ++p) { sx += pts[p * 4 + 0]; sy += pts[p * 4 + 1]; sz += pts[p * 4 + 2]; }
+        const float n = (float)npts[m];
+        const float mx = sx / n, my = sy / n, mz = sz / n;
+        const float cx = (float)coords[m * 4 + 3] * vox[0] + off[0];
+        const float cy = (float)coords[m * 4 + 2] * vox[1] + off[1];
+        const float cz = (float)coords[m * 4 + 1] * vox[2] + off[2];
+        for (int c = 0; c < 64; ++c) {
+            float best = -INFINITY;
+            for (int p = 0; p < real; ++p) {
+                const float x = pts[p * 4 + 0], y = pts[p * 4 + 1], z = pts[p * 4 + 2], it = pts[p * 4 + 3];
+                const float f[10] = {x, y, z, it, x - mx, y - my, z - mz, x - cx, y - cy, z - cz};
+                float acc = 0.0f;
+                for (int k = 0; k < 10; ++k) acc = fmaf(f[k], w[c * 10 + k], acc);
+                best = fmaxf(best, acc + b[c]);
+            }
+            if (real < P) best = fmaxf(best, b[c]);
+            out[(size_t)m * 64 + c] = fmaxf(best, 0.0f);
+        }
+    }
+}
+
+/* 3x3 convolution, zero padding 1, stride 1 | 2 (deconv == 0), or ConvTranspose2d with kernel == stride == s (deconv == 1).
+ * in [N][H][W][cin_total] (window [cin0, cin0 + cin)), w [cols][K] row-major with K = 9 * cin (k = tap * cin + ci) or cin,
+ * cols = cout or (i*s + j)*cout + co; out [N][Ho][Wo][out_ct] at channel offset out_c0. */
+ORC_API void orc_gemm_f32(const float* in, int N, int H, int W, int cin_total, int cin0, int cin, int stride, int cout, int deconv,
+                          const float* w, const float* bias, int relu, float* out, int out_ct, int out_c0) {
+    const int taps = deconv ? 1 : 9, K = taps * cin;
+    const int Ho = deconv ? H * stride : (H + 2 - 3) / stride + 1, Wo = deconv ? W * stride : (W + 2 - 3) / stride + 1;
+    const int rows = deconv ? N * H * W : N * Ho * Wo;
+#pragma omp parallel
+    {
+        float* xk = (float*)malloc((size_t)K * sizeof(float));
+#pragma omp for schedule(static)
+        for (int m = 0; m < rows; ++m) {
+            const int per = deconv ? H * W : Ho * Wo, rw = deconv ? W : Wo;
+            const int img = m / per, rem = m % per, ry = rem / rw, rx = rem % rw;
+            for (int t = 0; t < taps; ++t) {
+                const int yy = deconv ? ry : ry * stride + t / 3 - 1, xx = deconv ? rx : rx * stride + t % 3 - 1;
+                const int inside = yy >= 0 && yy < H && xx >= 0 && xx < W;
+                const float* px = in + ((size_t)(img * H + (inside ? yy : 0)) * W + (inside ? xx : 0)) * cin_total + cin0;
+                for (int c = 0; c < cin; ++c) xk[t * cin + c] = inside ? px[c] : 0.0f;
+            }
+            const int ncols = deconv ? stride * stride * cout : cout;
+            for (int col = 0; col < ncols; ++col) {
+                const float* wr = w + (size_t)col * K;
+                float acc = 0.0f;
+                for (int g = 0; g < K; g += 8)
+                    for (int e = 0; e < 8; ++e) acc = fmaf(xk[g + ORC_K8[e]], wr[g + ORC_K8[e]], acc);
+                int co = col, oy = ry, ox = rx;
+                if (deconv) { const int ij = col / cout; co = col % cout; oy = ry * stride + ij / stride; ox = rx * stride + ij % stride; }
+                float y = acc + bias[co];
+                if (relu) y = fmaxf(y, 0.0f);
+                out[((size_t)(img * Ho + oy) * Wo + ox) * out_ct + out_c0 + co] = y;
+            }
+        }
+        free(xk);
+    }
+}

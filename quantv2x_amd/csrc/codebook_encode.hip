@@ -32,7 +32,7 @@ constexpr int D = 256;
 constexpr int ENC_SMEM_FLOATS = 2 * ER * LDF + ER + 4 * ER + 8 * ER + ER;
 
 struct EncArgs {
-    const int8_t* in; uint8_t* codes;
+    const int8_t* in; const float* in_f32; uint8_t* codes;      // in_f32 != null: the rows come as fp32 (un-quantized model)
     const float* lvl[4];
     int n, h, w, levels, kc, ax, M;
     float dx;
@@ -148,7 +148,17 @@ __global__ __launch_bounds__(512, 4) void codebook_encode_kernel(const EncArgs a
         m = m < a.M ? m : a.M - 1;
         const int img = m / (a.h * a.w), rem = m - img * (a.h * a.w);
         const int y = rem / a.w, x = rem - y * a.w;
-        const int8_t* src = a.in + ((size_t)(img * (a.h + 2) + y + 1) * (a.w + 2) + x + 1) * D + part * CPT;
+        const size_t pixel = (size_t)(img * (a.h + 2) + y + 1) * (a.w + 2) + x + 1;
+        const int8_t* src = a.in + pixel * D + part * CPT;
+        if (a.in_f32) {
+            const float* sf = a.in_f32 + pixel * D + part * CPT;
+#pragma unroll
+            for (int c = 0; c < CPT / 4; ++c) {
+                const v4f v = *(const v4f*)(sf + c * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bufA[row * LDF + kpos(part * CPT + c * 4 + e)] = v[e];
+            }
+        } else
 #pragma unroll
         for (int c = 0; c < CPT / 16; ++c) {
             const v4i raw = *(const v4i*)(src + c * 16);
@@ -308,15 +318,27 @@ extern "C" int qv2x_codebook_c2_f32(const float* codebook, int kc, float* c2, vo
 
 extern "C" int64_t qv2x_codebook_level_floats(int kc) { return qv2x::level_floats(kc); }
 
+static int encode_launch(const qv2x_encode_desc* d, const int8_t* in, const float* in_f32, const float* const* level_weights, uint8_t* codes, void* stream);
+
 extern "C" int qv2x_codebook_encode_f32(const qv2x_encode_desc* d, const int8_t* in, const float* const* level_weights,
                                         uint8_t* codes, void* stream) {
+    return encode_launch(d, in, nullptr, level_weights, codes, stream);
+}
+
+extern "C" int qv2x_codebook_encode_f32in(const qv2x_encode_desc* d, const float* in, const float* const* level_weights,
+                                          uint8_t* codes, void* stream) {
+    if (!in) return qv2x::fail(QV2X_EINVAL, "qv2x_codebook_encode_f32in: null pointer");
+    return encode_launch(d, (const int8_t*)in, in, level_weights, codes, stream);
+}
+
+static int encode_launch(const qv2x_encode_desc* d, const int8_t* in, const float* in_f32, const float* const* level_weights, uint8_t* codes, void* stream) {
     using namespace qv2x;
     if (!d || !in || !level_weights || !codes) return fail(QV2X_EINVAL, "qv2x_codebook_encode_f32: null pointer");
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->levels < 1 || d->levels > 4) return fail(QV2X_EINVAL, "qv2x_codebook_encode_f32: bad shape");
     if (d->kc < 32 || d->kc > 128 || d->kc % 32) return fail(QV2X_EINVAL, "qv2x_codebook_encode_f32: dict_size must be 32, 64, 96 or 128 (got %d)", d->kc);
     if ((uintptr_t)in & 15) return fail(QV2X_EALIGN, "qv2x_codebook_encode_f32: in must be 16-byte aligned");
     EncArgs a;
-    a.in = in; a.codes = codes; a.n = d->n; a.h = d->h; a.w = d->w; a.levels = d->levels; a.kc = d->kc;
+    a.in = in; a.in_f32 = in_f32; a.codes = codes; a.n = d->n; a.h = d->h; a.w = d->w; a.levels = d->levels; a.kc = d->kc;
     a.ax = 128 - d->in_zx; a.dx = d->in_delta; a.M = d->n * d->h * d->w;
     for (int l = 0; l < 4; ++l) {
         a.lvl[l] = l < d->levels ? level_weights[l] : nullptr;

@@ -583,6 +583,14 @@ class DeployedModel(nn.Module):
         c, r, _ = self.heads_single.splits
         return {"cls_preds_single": sp[:, :c], "reg_preds_single": sp[:, c:c + r], "dir_preds_single": sp[:, c + r:]}
 
+    def _shared_features(self, shrinker_out, n_total: int):
+        """no codebook: the fp32 shared feature [n, H*W, 256] is the dequantized shrinker output"""
+        q = self.shrink1.out_q
+        feats = self._workspace(n_total)["feats"]
+        L.check(self.lib.qv2x_dequant_i8_f32(L.ptr(shrinker_out), n_total, self.fh, self.fw, 256, int(q[1]), float(q[0]), L.ptr(feats),
+                                             L.current_stream()), "qv2x_dequant_i8_f32")
+        return feats
+
     # ---- the reference's model contract ----------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, data_dict: dict, taps: Optional[dict] = None) -> dict:
@@ -604,13 +612,7 @@ class DeployedModel(nn.Module):
         enc = self.encode_agents(data_dict["inputs_m1"], n_total, taps)
         hw = self.fh * self.fw
         bufs = self._workspace(n_total)
-        feats = None
-        if not self.has_codebook:
-            # no codebook: the fp32 shared feature is the dequantized shrinker output
-            q = self.shrink1.out_q
-            feats = bufs["feats"]
-            L.check(self.lib.qv2x_dequant_i8_f32(L.ptr(enc), n_total, self.fh, self.fw, 256, int(q[1]), float(q[0]), L.ptr(feats),
-                                                 L.current_stream()), "qv2x_dequant_i8_f32")
+        feats = None if self.has_codebook else self._shared_features(enc, n_total)
         fused = torch.empty((nb, hw, 256), dtype=torch.float32, device=self.dev)
         start = 0
         for bi, n in enumerate(lens):
@@ -669,7 +671,17 @@ class DeployedModel(nn.Module):
 
 def deploy(qt_model=None, state: Optional[Dict[str, np.ndarray]] = None, path: Optional[str] = None,
            device="cuda", **kw) -> DeployedModel:
-    """Freeze a calibrated ``QuantModel`` (or load a saved PTQ state) into the HIP int8 path."""
+    """Freeze a calibrated ``QuantModel`` (or load a saved PTQ state) into the HIP int8 path.  A plain, un-quantized model (what
+    ``create_model`` + ``load_saved_model`` give the reference's ``inference.py``) deploys on the fp32 HIP path instead."""
     if state is None:
-        state = load_ptq_state(path) if path is not None else export_ptq_state(qt_model)
+        if path is not None:
+            state = load_ptq_state(path)
+        elif any(hasattr(m, "weight_quantizer") for m in qt_model.modules()):
+            state = export_ptq_state(qt_model)
+        else:
+            from .engine_fp32 import export_fp32_state
+            state = export_fp32_state(qt_model)
+    if str(state.get("meta/mode", "w8a8")) == "fp32":
+        from .engine_fp32 import DeployedFp32Model
+        return DeployedFp32Model(state, device=device, **kw)
     return DeployedModel(state, device=device, **kw)

@@ -18,6 +18,7 @@ SYMBOLS = [
     "qv2x_deconv_i8", "qv2x_deconv_i8_batch", "qv2x_codebook_level_floats", "qv2x_codebook_c2_f32", "qv2x_codebook_encode_f32", "qv2x_fuse_att_f32",
     "qv2x_decode_lut_f32", "qv2x_dequant_i8_f32", "qv2x_heads_f32", "qv2x_decode_heads_f32", "qv2x_heads_pair_f32", "qv2x_voxelize_workspace_bytes", "qv2x_voxelize_f32",
     "qv2x_postprocess_workspace_bytes", "qv2x_postprocess_f32",
+    "qv2x_conv3x3_f32", "qv2x_deconv_f32", "qv2x_pfn_scatter_f32", "qv2x_codebook_encode_f32in",
     "qv2x_comm_unique_id", "qv2x_comm_init", "qv2x_comm_destroy", "qv2x_allgather_codes", "qv2x_pairwise_from_poses_f64",
 ]
 COMM_ID_BYTES = 128
@@ -49,6 +50,11 @@ class DeconvDesc(C.Structure):
                 ("s", C.c_int32), ("in_zx", C.c_int32), ("in_delta", C.c_float),
                 ("out_ctotal", C.c_int32), ("out_c0", C.c_int32), ("relu", C.c_int32),
                 ("out_delta", C.c_float), ("out_zp", C.c_float), ("out_h", C.c_int32), ("out_w", C.c_int32)]
+
+
+class F32ConvDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cin_total", C.c_int32), ("cin0", C.c_int32), ("cin", C.c_int32),
+                ("stride", C.c_int32), ("cout", C.c_int32), ("out_ctotal", C.c_int32), ("out_c0", C.c_int32), ("relu", C.c_int32)]
 
 
 class EncodeDesc(C.Structure):
@@ -119,6 +125,11 @@ def load() -> C.CDLL:
     lib.qv2x_postprocess_workspace_bytes.argtypes = [C.POINTER(PostprocessDesc)]
     lib.qv2x_postprocess_workspace_bytes.restype = C.c_int64
     lib.qv2x_postprocess_f32.argtypes = [C.POINTER(PostprocessDesc), vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp]
+    lib.qv2x_conv3x3_f32.argtypes = [C.POINTER(F32ConvDesc), vp, vp, vp, vp, vp]
+    lib.qv2x_deconv_f32.argtypes = [C.POINTER(F32ConvDesc), vp, vp, vp, vp, vp]
+    lib.qv2x_pfn_scatter_f32.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                         C.POINTER(C.c_float), vp, C.c_int, C.c_int, C.c_int, vp]
+    lib.qv2x_codebook_encode_f32in.argtypes = [C.POINTER(EncodeDesc), vp, C.POINTER(vp), vp, vp]
     lib.qv2x_comm_unique_id.argtypes = [vp]
     lib.qv2x_comm_init.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
     lib.qv2x_comm_destroy.argtypes = [vp]
