@@ -278,6 +278,15 @@ int qv2x_pfn_scatter_f32(const float* voxel_features, const int32_t* voxel_coord
 int qv2x_codebook_encode_f32in(const qv2x_encode_desc* desc /* host */, const float* in, const float* const* level_weights /* host array */,
                                uint8_t* codes, void* stream);
 
+/* f3, first kernel (the HEAL Pyramid fusion model).  weighted_fuse of one scale of one scene
+ * (opencood/models/fuse_modules/pyramid_fuse.py:17-62): every agent's feature map and occupancy score map warped into the ego frame
+ * (warp_affine_simple, as qv2x_fuse_att_f32), warped scores that are exactly 0 masked to -inf, softmax over the agents (NaN -> 0),
+ * score-weighted sum of the warped features.  The descriptor's agents / h / w / max_cav / ego / metres fields are used.
+ *   feats f32 [agents][h*w][channels] (channels last), score f32 [agents][h*w] (sigmoid(occupancy) + 1e-4, camera crop mask applied),
+ *   pairwise f64 [max_cav][max_cav][4][4];  out f32 [h*w][channels]. */
+int qv2x_pyramid_weighted_fuse_f32(const qv2x_fuse_desc* desc /* host */, int channels, const float* feats, const float* score,
+                                   const double* pairwise, float* out, void* stream);
+
 /* ---- the V2X link: one agent per GPU --------------------------------------------------------------------
  * The reference simulates the link in-process: all agents are rows of one batch (heter_model_baseline.py:216) and
  * fusion_in_one.py:131-151 regroups them; get_pairwise_transformation (utils/transformation_utils.py:21-66) builds the

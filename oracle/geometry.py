@@ -109,3 +109,28 @@ def pairwise_from_poses(poses, max_cav):
             if i != j:
                 t[i, j] = solve4(poses[j], poses[i])
     return t
+
+
+# ---- HEAL Pyramid fusion, one scale ----------------------------------------------------------------
+
+def weighted_fuse(x, score, affine_b, n):
+    """``pyramid_fuse.weighted_fuse`` (opencood/models/fuse_modules/pyramid_fuse.py:17-62) for one scene and one scale:
+    x [n, h, w, c], score [n, h, w, 1] -> [h, w, c].  Features and scores warped into agent 0's frame; warped scores equal to 0
+    masked to -inf; softmax over the agents with NaN (every agent masked) -> 0; score-weighted sum in agent order."""
+    theta = affine_b[:n, :n][0]
+    grid = affine_grid(theta, x.shape[1], x.shape[2]).astype(np.float32)
+    fx = grid_sample_bilinear_zeros(np.ascontiguousarray(x, dtype=np.float32), grid)
+    sx = grid_sample_bilinear_zeros(np.ascontiguousarray(score, dtype=np.float32), grid)
+    s = np.where(sx == 0, -np.inf, sx).astype(np.float32)
+    with np.errstate(invalid="ignore"):
+        m = s.max(axis=0, keepdims=True)
+        e = np.exp(s - m)
+        den = np.zeros_like(e[0])
+        for j in range(n):
+            den = den + e[j]
+        p = e / den
+    p = np.where(np.isnan(p), np.float32(0), p).astype(np.float32)
+    out = np.zeros(fx.shape[1:], np.float32)
+    for j in range(n):
+        out = out + fx[j] * p[j]
+    return out

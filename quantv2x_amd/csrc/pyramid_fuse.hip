@@ -1,0 +1,84 @@
+// f3 (first kernel of the Pyramid fusion row): weighted_fuse of the HEAL Pyramid model
+// (opencood/models/fuse_modules/pyramid_fuse.py:17-62) for ONE scale of one scene:
+//     warp every agent's feature map AND its occupancy score map into the ego frame (warp_affine_simple: affine_grid + bilinear
+//     grid_sample, zeros outside, align_corners = False), set warped scores that are exactly 0 to -inf, softmax over the agents,
+//     NaN (every agent masked) -> 0, out = sum_j p_j * feature_j.
+// One wavefront per ego cell; lane handles channels lane, lane + 64, ...; the sampling grid is the float64 -> fp32 grid of
+// fuse_att.h.  Agent order in the sums = agent index, as torch.sum(dim=0) on the stacked tensor.
+#include "fuse_att.h"
+
+namespace qv2x {
+namespace {
+
+struct PyrArgs {
+    const float* feats; const float* score; const double* pairwise; float* out;
+    int agents, h, w, c, hw, L, ego;
+    double hm, wm, ratio;
+};
+
+__global__ __launch_bounds__(256) void pyramid_weighted_fuse_kernel(const PyrArgs a) {
+    const int lane = threadIdx.x & 63;
+    int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
+    cell = __builtin_amdgcn_readfirstlane(cell);
+    if (cell >= a.hw) return;
+    const int cy = cell / a.w, cx = cell - cy * a.w;
+    const double xn = (2.0 * cx + 1.0) / a.w - 1.0, yn = (2.0 * cy + 1.0) / a.h - 1.0;
+
+    int tcell[MAXA][4];
+    float twt[MAXA][4], sc[MAXA];
+    float smax = -INFINITY;
+    for (int ag = 0; ag < a.agents; ++ag) {
+        const double* T = a.pairwise + ((size_t)a.ego * a.L + ag) * 16;
+        const double t00 = T[0], t01 = T[1] * a.hm / a.wm, t02 = T[3] / (a.ratio * a.wm) * 2.0;
+        const double t10 = T[4] * a.wm / a.hm, t11 = T[5], t12 = T[7] / (a.ratio * a.hm) * 2.0;
+        const float gx = (float)(t00 * xn + t01 * yn + t02), gy = (float)(t10 * xn + t11 * yn + t12);
+        const float ix = ((gx + 1.0f) * (float)a.w - 1.0f) / 2.0f, iy = ((gy + 1.0f) * (float)a.h - 1.0f) / 2.0f;
+        const float x0 = floorf(ix), y0 = floorf(iy), x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+        const float wt[4] = {(x1 - ix) * (y1 - iy), (ix - x0) * (y1 - iy), (x1 - ix) * (iy - y0), (ix - x0) * (iy - y0)};
+        const float tx[4] = {x0, x1, x0, x1}, ty[4] = {y0, y0, y1, y1};
+        float s = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool in = tx[t] >= 0.0f && tx[t] < (float)a.w && ty[t] >= 0.0f && ty[t] < (float)a.h;
+            tcell[ag][t] = in ? (int)ty[t] * a.w + (int)tx[t] : -1;
+            twt[ag][t] = wt[t];
+            if (in) s += a.score[(size_t)ag * a.hw + tcell[ag][t]] * wt[t];          // taps in (nw, ne, sw, se) order, as grid_sample sums them
+        }
+        sc[ag] = s == 0.0f ? -INFINITY : s;                                          // masked_fill_(scores == 0, -inf)
+        smax = fmaxf(smax, sc[ag]);
+    }
+    float den = 0.0f;
+    for (int ag = 0; ag < a.agents; ++ag) { sc[ag] = expf(sc[ag] - smax); den += sc[ag]; }   // all masked: exp(nan) -> nan, replaced below
+    for (int ch = lane; ch < a.c; ch += 64) {
+        float o = 0.0f;
+        for (int ag = 0; ag < a.agents; ++ag) {
+            float p = sc[ag] / den;
+            p = (p != p) ? 0.0f : p;                                                 // torch.where(isnan, 0, .)
+            float f = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (tcell[ag][t] >= 0) f += a.feats[((size_t)ag * a.hw + tcell[ag][t]) * a.c + ch] * twt[ag][t];
+            o += f * p;
+        }
+        a.out[(size_t)cell * a.c + ch] = o;
+    }
+}
+
+}  // namespace
+}  // namespace qv2x
+
+extern "C" int qv2x_pyramid_weighted_fuse_f32(const qv2x_fuse_desc* d, int channels, const float* feats, const float* score, const double* pairwise,
+                                              float* out, void* stream) {
+    using namespace qv2x;
+    if (!d || !feats || !score || !pairwise || !out) return fail(QV2X_EINVAL, "qv2x_pyramid_weighted_fuse_f32: null pointer");
+    if (d->agents < 1 || d->agents > MAXA || d->max_cav < d->agents || d->ego < 0 || d->ego >= d->agents)
+        return fail(QV2X_EINVAL, "qv2x_pyramid_weighted_fuse_f32: 1..%d agents, ego inside, max_cav >= agents", MAXA);
+    if (d->h <= 0 || d->w <= 0 || channels <= 0) return fail(QV2X_EINVAL, "qv2x_pyramid_weighted_fuse_f32: bad sizes");
+    if (!(d->h_metres > 0) || !(d->w_metres > 0) || !(d->discrete_ratio > 0)) return fail(QV2X_EINVAL, "qv2x_pyramid_weighted_fuse_f32: map extent must be positive");
+    PyrArgs a;
+    a.feats = feats; a.score = score; a.pairwise = pairwise; a.out = out;
+    a.agents = d->agents; a.h = d->h; a.w = d->w; a.c = channels; a.hw = d->h * d->w; a.L = d->max_cav; a.ego = d->ego;
+    a.hm = d->h_metres; a.wm = d->w_metres; a.ratio = d->discrete_ratio;
+    pyramid_weighted_fuse_kernel<<<(a.hw + 3) / 4, 256, 0, (hipStream_t)stream>>>(a);
+    return hip_check(hipGetLastError(), "qv2x_pyramid_weighted_fuse_f32 launch");
+}

@@ -19,6 +19,7 @@ SYMBOLS = [
     "qv2x_decode_lut_f32", "qv2x_dequant_i8_f32", "qv2x_heads_f32", "qv2x_decode_heads_f32", "qv2x_heads_pair_f32", "qv2x_voxelize_workspace_bytes", "qv2x_voxelize_f32",
     "qv2x_postprocess_workspace_bytes", "qv2x_postprocess_f32",
     "qv2x_conv3x3_f32", "qv2x_deconv_f32", "qv2x_pfn_scatter_f32", "qv2x_codebook_encode_f32in",
+    "qv2x_pyramid_weighted_fuse_f32",
     "qv2x_comm_unique_id", "qv2x_comm_init", "qv2x_comm_destroy", "qv2x_allgather_codes", "qv2x_pairwise_from_poses_f64",
 ]
 COMM_ID_BYTES = 128
@@ -130,6 +131,7 @@ def load() -> C.CDLL:
     lib.qv2x_pfn_scatter_f32.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                          C.POINTER(C.c_float), vp, C.c_int, C.c_int, C.c_int, vp]
     lib.qv2x_codebook_encode_f32in.argtypes = [C.POINTER(EncodeDesc), vp, C.POINTER(vp), vp, vp]
+    lib.qv2x_pyramid_weighted_fuse_f32.argtypes = [C.POINTER(FuseDesc), C.c_int, vp, vp, vp, vp, vp]
     lib.qv2x_comm_unique_id.argtypes = [vp]
     lib.qv2x_comm_init.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
     lib.qv2x_comm_destroy.argtypes = [vp]

@@ -505,8 +505,35 @@ def gen_recon():
     print("recon_units.npz", {k: getattr(v, "shape", v) for k, v in out.items()})
 
 
+def gen_pyramid():
+    """pyramid_fuse.weighted_fuse (the occupancy-weighted fusion of the HEAL Pyramid model) on seeded
+    inputs: three agents, rotations + translations incl. partly and fully out-of-view agents, a zero score plane, two scales."""
+    from opencood.models.fuse_modules.pyramid_fuse import weighted_fuse
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    poses = synth.agent_poses(3, "ring")
+    pw = torch.from_numpy(synth.pairwise_t_matrix(poses, 5)[None])
+    far = pw.clone()
+    far[0, 0, 2, 0, 3] += 500.0                                    # agent 2 lands completely outside agent 0's view
+    out['pairwise'], out['pairwise_far'] = pw.numpy(), far.numpy()
+    for tag, (h, w, c) in {"l0": (16, 32, 64), "l1": (8, 16, 128)}.items():
+        x = torch.randn(3, c, h, w, generator=g)
+        score = torch.sigmoid(torch.randn(3, 1, h, w, generator=g)) + 1e-4
+        score[1, :, : h // 2] = 0.0                                # a cropped (camera-style) agent: zero score over half its map
+        out[f'{tag}/x'], out[f'{tag}/score'] = x.numpy(), score.numpy()
+        for name, t in (("near", pw), ("far", far)):
+            aff = normalize_pairwise_tfm(t.clone(), 12.8, 25.6, 1)
+            with torch.no_grad():
+                y = weighted_fuse(x, score.clone(), torch.tensor([3]), aff, False)
+                y2 = weighted_fuse(x[:2], score[:2].clone(), torch.tensor([2]), aff, False)
+                y1 = weighted_fuse(x[:1], score[:1].clone(), torch.tensor([1]), aff, False)
+            out[f'{tag}/{name}_n3'], out[f'{tag}/{name}_n2'], out[f'{tag}/{name}_n1'] = y.numpy(), y2.numpy(), y1.numpy()
+    np.savez_compressed(os.path.join(HERE, "pyramid_fuse.npz"), **out)
+    print("pyramid_fuse.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["fp32", "w8a8", "uaq", "geometry", "codebook", "postprocess", "postprocess_mc", "recon"]
+    which = sys.argv[1:] or ["fp32", "w8a8", "uaq", "geometry", "codebook", "postprocess", "postprocess_mc", "recon", "pyramid"]
     with torch.no_grad():
         pass
     if "fp32" in which: gen_fp32()
@@ -517,3 +544,4 @@ if __name__ == "__main__":
     if "postprocess" in which: gen_postprocess()
     if "postprocess_mc" in which: gen_postprocess_mc()
     if "recon" in which: gen_recon()
+    if "pyramid" in which: gen_pyramid()
