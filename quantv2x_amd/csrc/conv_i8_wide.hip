@@ -384,7 +384,10 @@ extern "C" int qv2x_conv3x3_i8_wide_ok(const qv2x_conv_desc* d) {
         if (d->group_c[g] <= 0 || d->group_c[g] % 64 || d->group_c0[g] % 16) return 0;
         chunks += d->group_c[g] / 64;
     }
-    return chunks <= qv2x::MAX_CHUNKS && (long long)d->n * d->h * d->w >= 16384;
+    // enough 5 x 32 patches to fill the chip: a 25 x 88 map is 15 patches per image, and a batch of eight of them (120 workgroups
+    // walking K = 2304) ran 5x slower here than 64 x 64 tiles of qv2x_conv3x3_i8 (profiles/r02_bench_n1_kernel_stats_by_grid.csv)
+    const long long patches = (long long)d->n * ((d->h + qv2x::TH - 1) / qv2x::TH) * ((d->w + qv2x::TW - 1) / qv2x::TW);
+    return chunks <= qv2x::MAX_CHUNKS && (long long)d->n * d->h * d->w >= 16384 && patches >= 192;
 }
 
 extern "C" int qv2x_conv3x3_i8_pack_wide(const qv2x_conv_desc* d, const int8_t* w, int8_t* w_wide, void* stream) {
