@@ -2,15 +2,19 @@
 ``opencood/quant/quant_block.py``: ``BaseQuantBlock :45-65``, ``QuantBaseBEVBackbone :243-335``,
 ``QuantDoubleConv / QuantDownsampleConv :552-586``, ``QuantPFNLayer :589-629`` (extra activation
 quantizer after the ReLU, before the max), ``QuantPillarVFE :632-715``, ``QuantPointPillar :718-741``,
-``QuantNaiveCompressor :1543-1570``; registries ``opencood_specials :1581-1591``,
+``QuantNaiveCompressor :1543-1570``; the Pyramid model's blocks ``QuantBasicBlock :68-97``, ``QuantBottleneck :100-131``,
+``QuantResNetModified :338-395``, ``QuantResNetBEVBackbone :398-459``, ``QuantPyramidFusion :462-549``; registries ``opencood_specials :1581-1591``,
 ``specials_unquantized_names :1599-1615``.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..models.fuse_modules.pyramid_fuse import PyramidFusion, weighted_fuse
 from ..models.heter_encoders import PointPillar
 from ..models.sub_modules.base_bev_backbone import BaseBEVBackbone
+from ..models.sub_modules.base_bev_backbone_resnet import ResNetBEVBackbone
+from ..models.sub_modules.resblock import BasicBlock, Bottleneck, ResNetModified
 from ..models.sub_modules.downsample_conv import DoubleConv, DownsampleConv
 from ..models.sub_modules.naive_compress import NaiveCompressor
 from ..models.sub_modules.pillar_vfe import PFNLayer, PillarVFE
@@ -184,10 +188,140 @@ class QuantNaiveCompressor(BaseQuantBlock):
     def forward(self, x):
         return self.decoder(self.encoder(x))
 
+class _QuantResidual(BaseQuantBlock):
+    """conv branch (last conv without output quantizer) + shortcut -> add in fp32 -> ReLU -> the block's own quantizer."""
 
-specials = {}
+    def _shortcut(self, block, wq, aq):
+        if block.downsample is None:
+            return None
+        q = QuantModule(block.downsample[0], wq, aq, disable_act_quant=True)
+        q.norm_function = block.downsample[1]
+        return q
+
+    def _finish(self, out, x):
+        out += x if self.downsample is None else self.downsample(x)
+        out = self.activation_function(out)
+        return self.act_quantizer(out) if self.use_act_quant else out
+
+
+class QuantBasicBlock(_QuantResidual):
+    def __init__(self, basic_block: BasicBlock, weight_quant_params: dict = {}, act_quant_params: dict = {}):
+        super().__init__()
+        wq, aq = weight_quant_params, act_quant_params
+        self.conv1 = _wrap(basic_block.conv1, basic_block.bn1, basic_block.relu, wq, aq)
+        self.conv2 = QuantModule(basic_block.conv2, wq, aq, disable_act_quant=True)
+        self.conv2.norm_function = basic_block.bn2
+        self.downsample = self._shortcut(basic_block, wq, aq)
+        self.activation_function = basic_block.relu
+        self.act_quantizer = UniformAffineQuantizer(**aq)
+
+    def forward(self, x):
+        return self._finish(self.conv2(self.conv1(x)), x)
+
+
+class QuantBottleneck(_QuantResidual):
+    def __init__(self, bottleneck: Bottleneck, weight_quant_params: dict = {}, act_quant_params: dict = {}):
+        super().__init__()
+        wq, aq = weight_quant_params, act_quant_params
+        self.conv1 = _wrap(bottleneck.conv1, bottleneck.bn1, bottleneck.relu, wq, aq)
+        self.conv2 = _wrap(bottleneck.conv2, bottleneck.bn2, bottleneck.relu, wq, aq)
+        self.conv3 = QuantModule(bottleneck.conv3, wq, aq, disable_act_quant=True)
+        self.conv3.norm_function = bottleneck.bn3
+        self.downsample = self._shortcut(bottleneck, wq, aq)
+        self.activation_function = bottleneck.relu
+        self.act_quantizer = UniformAffineQuantizer(**aq)
+
+    def forward(self, x):
+        return self._finish(self.conv3(self.conv2(self.conv1(x))), x)
+
+
+class QuantResNetModified(BaseQuantBlock):
+    _TWINS = {BasicBlock: QuantBasicBlock, Bottleneck: QuantBottleneck}
+
+    def __init__(self, resnet_modified: ResNetModified, weight_quant_params={}, act_quant_params={}):
+        super().__init__()
+        self._norm_layer, self.layernum, self.block = resnet_modified._norm_layer, resnet_modified.layernum, resnet_modified.block
+        if self.block not in self._TWINS:
+            raise ValueError(f"Unsupported block type: {self.block}. Please add it to block_mapping.")
+        twin = self._TWINS[self.block]
+        for i in range(self.layernum):
+            seq = [twin(b, weight_quant_params, act_quant_params) if isinstance(b, self.block) else b
+                   for b in getattr(resnet_modified, f"layer{i}")]
+            setattr(self, f"layer{i}", nn.Sequential(*seq))
+
+    def forward(self, x):
+        feats = []
+        for i in range(self.layernum):
+            x = getattr(self, f"layer{i}")(x)
+            feats.append(x)
+        return feats
+
+
+class QuantResNetBEVBackbone(BaseQuantBlock):
+    def __init__(self, resnet_bev_backbone: ResNetBEVBackbone, weight_quant_params={}, act_quant_params={}):
+        super().__init__()
+        src = resnet_bev_backbone
+        self.model_cfg, self.num_levels, self.num_bev_features = src.model_cfg, src.num_levels, src.num_bev_features
+        self.resnet = QuantResNetModified(src.resnet, weight_quant_params, act_quant_params)
+        self.deblocks = nn.ModuleList(nn.Sequential(_wrap(de[0], de[1], de[2], weight_quant_params, act_quant_params))
+                                      for de in src.deblocks)
+
+    def get_multiscale_feature(self, spatial_features):
+        return self.resnet(spatial_features)
+
+    def decode_multiscale_feature(self, x):
+        ups = [self.deblocks[i](x[i]) if len(self.deblocks) > 0 else x[i] for i in range(self.num_levels)]
+        x = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
+        if len(self.deblocks) > self.num_levels:
+            x = self.deblocks[-1](x)
+        return x
+
+    def forward(self, spatial_features):
+        return self.decode_multiscale_feature(self.resnet(spatial_features))
+
+    def get_layer_i_feature(self, spatial_features, layer_i):
+        return getattr(self.resnet, f"layer{layer_i}")(spatial_features)
+
+
+class QuantPyramidFusion(QuantResNetBEVBackbone):
+    """The occupancy heads are plain ``QuantModule``s (their own output quantizer stays on); the fused maps that feed the
+    deblocks are fp32 (``weighted_fuse`` of fake-quantized features with softmax weights)."""
+
+    def __init__(self, pyramid_fusion: PyramidFusion, weight_quant_params={}, act_quant_params={}):
+        super().__init__(pyramid_fusion, weight_quant_params, act_quant_params)
+        self.stage, self.align_corners = pyramid_fusion.stage, pyramid_fusion.align_corners
+        for i in range(self.num_levels):
+            setattr(self, f"single_head_{i}", QuantModule(getattr(pyramid_fusion, f"single_head_{i}"), weight_quant_params, act_quant_params))
+
+    def forward_single(self, spatial_features):
+        feats = self.get_multiscale_feature(spatial_features)
+        occ = [getattr(self, f"single_head_{i}")(feats[i]) for i in range(self.num_levels)]
+        return self.decode_multiscale_feature(feats), occ
+
+    def forward_collab(self, spatial_features, record_len, affine_matrix, agent_modality_list=None, cam_crop_info=None):
+        if cam_crop_info:
+            raise NotImplementedError("camera crop masks: LiDAR modalities only on this path")
+        feats = self.get_multiscale_feature(spatial_features)
+        fused, occ = [], []
+        for i in range(self.num_levels):
+            o = getattr(self, f"single_head_{i}")(feats[i])
+            occ.append(o)
+            fused.append(weighted_fuse(feats[i], torch.sigmoid(o) + 1e-4, record_len, affine_matrix, self.align_corners))
+        return self.decode_multiscale_feature(fused), occ
+
+    def forward(self, spatial_features, record_len=None, affine_matrix=None, agent_modality_list=None, cam_crop_info=None):
+        if self.stage == "single":
+            return self.forward_single(spatial_features)
+        if record_len is None or affine_matrix is None:
+            raise ValueError("record_len and affine_matrix are required for forward_collab()")
+        return self.forward_collab(spatial_features, record_len, affine_matrix, agent_modality_list, cam_crop_info)
+
+
+specials = {BasicBlock: QuantBasicBlock, Bottleneck: QuantBottleneck}
 
 opencood_specials = {
+    PyramidFusion: QuantPyramidFusion,
+    ResNetBEVBackbone: QuantResNetBEVBackbone,
     BaseBEVBackbone: QuantBaseBEVBackbone,
     DownsampleConv: QuantDownsampleConv,
     PointPillar: QuantPointPillar,

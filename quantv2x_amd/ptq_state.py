@@ -48,14 +48,39 @@ def weight_codes(qm) -> np.ndarray:
     return _np(torch.clamp(code + zp, 0, wq.n_levels - 1)).astype(np.uint8)
 
 
+def _is_pyramid(model) -> bool:
+    return hasattr(model, "pyramid_backbone")
+
+
+def _residual_blocks(model):
+    """(name, block) of every quantized residual block (QuantBasicBlock / QuantBottleneck, quant_block.py:68-131)."""
+    return [(n, m) for n, m in model.named_modules() if type(m).__name__ in ("QuantBasicBlock", "QuantBottleneck")]
+
+
 def _check_structure(model) -> None:
-    """The deployed engine hard-wires one network shape.  Anything else the plugin / the reference can
+    """The deployed engines hard-wire two network shapes.  Anything else the plugin / the reference can
     build must be refused here, not silently run as a different network."""
-    fusion = getattr(model, "fusion_net", None)
-    if type(fusion).__name__ != "AttFusion":
-        raise NotImplementedError(f"deployed path: fusion_net must be AttFusion (fusion_method 'att'), got {type(fusion).__name__}")
-    if getattr(model, "shrink_flag", False):
-        raise NotImplementedError("deployed path: a post-fusion shrink_conv ('shrink_header' in the model args) is not built")
+    pyramid = _is_pyramid(model)
+    if pyramid:
+        pb = model.pyramid_backbone
+        if type(pb).__name__ != "QuantPyramidFusion" or pb.stage != "collab" or not pb.model_cfg.get("resnext", False):
+            raise NotImplementedError("deployed Pyramid path: a quantized PyramidFusion with resnext: true, stage: collab")
+        if pb.align_corners:
+            raise NotImplementedError("deployed Pyramid path: align_corners false")
+        if not getattr(model, "shrink_flag", False):
+            raise NotImplementedError("deployed Pyramid path: the post-fusion shrink_conv ('shrink_header') is part of the network")
+        if len(model.backbone_m1.deblocks) != 0 or model.backbone_m1.num_levels != 1:
+            raise NotImplementedError("deployed Pyramid path: a one-level per-agent ResNet backbone without deblocks")
+        if type(model.aligner_m1.channel_align).__name__ != "Identity":
+            raise NotImplementedError("deployed Pyramid path: aligner core_method identity")
+        if getattr(model, "codebook", None) is None:
+            raise NotImplementedError("deployed Pyramid path: the codebook model (heter_pyramid_collab_codebook_mc[_encdec])")
+    else:
+        fusion = getattr(model, "fusion_net", None)
+        if type(fusion).__name__ != "AttFusion":
+            raise NotImplementedError(f"deployed path: fusion_net must be AttFusion (fusion_method 'att'), got {type(fusion).__name__}")
+        if getattr(model, "shrink_flag", False):
+            raise NotImplementedError("deployed path: a post-fusion shrink_conv ('shrink_header' in the model args) is not built")
     if getattr(model, "compress", False):
         raise NotImplementedError("deployed path: the NaiveCompressor ('compressor' in the model args) is not built")
     for name, m in model.named_modules():
@@ -64,20 +89,28 @@ def _check_structure(model) -> None:
         if type(getattr(m, "norm_function", None)).__name__ != "StraightThrough":
             raise NotImplementedError(f"{name}: an unfolded norm_function ({type(m.norm_function).__name__}); build the QuantModel "
                                       "with is_fusing=True (BN folded into the convolution)")
-        head = name.split(".")[-1].replace("_single", "") in _HEADS
-        if m.disable_act_quant and not head:
-            raise NotImplementedError(f"{name}: disable_act_quant is only supported on the output heads")
+        leaf = name.split(".")[-1]
+        head = leaf.replace("_single", "") in _HEADS
+        # the last convolution of a residual branch and the 1x1 shortcut feed the fp32 add (quant_block.py:76-84, :108-117)
+        branch_end = pyramid and ".resnet." in name and (leaf in ("conv3", "downsample") or (leaf == "conv2" and name.startswith("backbone_m")))
+        if bool(m.disable_act_quant) != branch_end and not head:
+            raise NotImplementedError(f"{name}: disable_act_quant = {bool(m.disable_act_quant)} does not match the deployed network")
         act = type(getattr(m, "activation_function", None)).__name__
-        if act not in (("StraightThrough",) if (head or name.endswith("pfn_layers.0.linear")) else ("ReLU",)):
-            raise NotImplementedError(f"{name}: activation {act} (the deployed path has ReLU on every conv / deconv, none on the heads "
-                                      "and the PFN linear)")
+        bare = head or branch_end or name.endswith("pfn_layers.0.linear") or leaf.startswith("single_head_")
+        if act != ("StraightThrough" if bare else "ReLU"):
+            raise NotImplementedError(f"{name}: activation {act} does not match the deployed network (ReLU on every conv / deconv "
+                                      "but the heads, the PFN linear and the ends of residual branches)")
+    for name, b in _residual_blocks(model):
+        if type(b.activation_function).__name__ != "ReLU" or not b.act_quantizer.inited or b.act_quantizer.n_bits != 8:
+            raise NotImplementedError(f"{name}: residual blocks end in ReLU + a frozen 8-bit quantizer on the deployed path")
 
 
 def export_ptq_state(qt_model) -> Dict[str, np.ndarray]:
     model = qt_model.model if hasattr(qt_model, "model") and not _is_quant_module(qt_model) else qt_model
     _check_structure(model)
     out: Dict[str, np.ndarray] = {}
-    out["meta/fusion_method"] = np.array("att")
+    pyramid = _is_pyramid(model)
+    out["meta/fusion_method"] = np.array("pyramid" if pyramid else "att")
     names = []
     for name, m in model.named_modules():
         if not _is_quant_module(m):
@@ -113,11 +146,24 @@ def export_ptq_state(qt_model) -> Dict[str, np.ndarray]:
     out["meta/HW_metres"] = np.array([model.H, model.W], dtype=np.float64)
     out["meta/discrete_ratio"] = np.float64(model.fake_voxel_size)
 
-    bb = model.backbone_m1
-    out["meta/layer_nums"] = np.array([len(b) - 2 for b in bb.blocks], dtype=np.int64)
-    out["meta/layer_strides"] = np.array([int(b[1].fwd_kwargs["stride"][0]) for b in bb.blocks], dtype=np.int64)
-    out["meta/upsample_strides"] = np.array([int(d[0].fwd_kwargs["stride"][0]) for d in bb.deblocks], dtype=np.int64)
-    out["meta/supervise_single"] = np.bool_(bool(getattr(model, "supervise_single", False)))
+    if pyramid:
+        for name, b in _residual_blocks(model):       # the quantizer after the fp32 add + ReLU (quant_block.py:92-96, :126-130)
+            out[name + "/a_delta"] = np.float32(_np(torch.as_tensor(b.act_quantizer.delta)).reshape(-1)[0])
+            out[name + "/a_zp"] = np.float32(_np(torch.as_tensor(b.act_quantizer.zero_point)).reshape(-1)[0])
+        out["meta/block_names"] = np.array([n for n, _ in _residual_blocks(model)])
+        cfg_a, cfg_p = model.backbone_m1.model_cfg, model.pyramid_backbone.model_cfg
+        out["meta/layer_nums"] = np.array(cfg_a["layer_nums"], dtype=np.int64)
+        out["meta/layer_strides"] = np.array(cfg_a["layer_strides"], dtype=np.int64)
+        out["meta/pyramid_layer_nums"] = np.array(cfg_p["layer_nums"], dtype=np.int64)
+        out["meta/pyramid_layer_strides"] = np.array(cfg_p["layer_strides"], dtype=np.int64)
+        out["meta/upsample_strides"] = np.array(cfg_p["upsample_strides"], dtype=np.int64)
+        out["meta/supervise_single"] = np.bool_(False)
+    else:
+        bb = model.backbone_m1
+        out["meta/layer_nums"] = np.array([len(b) - 2 for b in bb.blocks], dtype=np.int64)
+        out["meta/layer_strides"] = np.array([int(b[1].fwd_kwargs["stride"][0]) for b in bb.blocks], dtype=np.int64)
+        out["meta/upsample_strides"] = np.array([int(d[0].fwd_kwargs["stride"][0]) for d in bb.deblocks], dtype=np.int64)
+        out["meta/supervise_single"] = np.bool_(bool(getattr(model, "supervise_single", False)))
 
     cb = getattr(model, "codebook", None)
     out["meta/has_codebook"] = np.bool_(cb is not None)

@@ -95,6 +95,52 @@ def make_hypes(shape: str = "v2xreal", multiclass: bool = True, codebook: bool =
     }
 
 
+def make_pyramid_hypes(shape: str = "v2xreal", codebook: bool = True, dict_size: int = 128, seg_num: int = 1,
+                       encdec: bool = True) -> dict:
+    """The ``model`` section of ``hypes_yaml/v2x_real/Codebook/Pyramid/lidar_pyramid_stage3.yaml:110-157`` (HEAL Pyramid fusion,
+    ResNeXt levels, 64-channel codebook) at one of ``SHAPES``; ``hard_eval`` as in ``make_hypes``' codebook models."""
+    lidar_range, voxel_size, max_voxels, max_cav = SHAPES[shape]
+    args = {
+        "num_class": 3,
+        "lidar_range": list(lidar_range),
+        "supervise_single": True,
+        "m1": {
+            "core_method": "point_pillar",
+            "sensor_type": "lidar",
+            "encoder_args": {
+                "voxel_size": list(voxel_size),
+                "lidar_range": list(lidar_range),
+                "pillar_vfe": {"use_norm": True, "with_distance": False, "use_absolute_xyz": True, "num_filters": [64]},
+                "point_pillar_scatter": {"num_features": 64},
+            },
+            "backbone_args": {"layer_nums": [3], "layer_strides": [2], "num_filters": [64]},
+            "aligner_args": {"core_method": "identity"},
+        },
+        "fusion_backbone": {
+            "resnext": True, "stage": "collab", "layer_nums": [3, 5, 8], "layer_strides": [1, 2, 2],
+            "num_filters": [64, 128, 256], "upsample_strides": [1, 2, 4], "num_upsample_filter": [128, 128, 128],
+            "anchor_number": 2,
+        },
+        "shrink_header": {"kernal_size": [3], "stride": [1], "padding": [1], "dim": [256], "input_dim": 384},
+        "fusion_method": "pyramid",
+        "in_head": 256,
+        "anchor_number": 2,
+        "dir_args": {"dir_offset": 0.7853, "num_bins": 2, "anchor_yaw": [0, 90]},
+    }
+    core = "heter_pyramid_collab_mc"
+    if codebook:
+        args["codebook"] = {"seg_num": seg_num, "dict_size": dict_size, "hard_eval": True}
+        args["use_codebook"] = True
+        core = "heter_pyramid_collab_codebook_mc" + ("_encdec" if encdec else "")
+    return {
+        "name": f"synthetic_pyramid_{shape}",
+        "model": {"core_method": core, "args": args},
+        "preprocess": {"args": {"voxel_size": list(voxel_size), "max_points_per_voxel": 32, "max_voxel_test": max_voxels},
+                       "cav_lidar_range": list(lidar_range)},
+        "train_params": {"max_cav": max_cav},
+    }
+
+
 # --------------------------------------------------------------------------- weights
 
 def _rng(seed: int, tag: str) -> np.random.Generator:
@@ -131,6 +177,9 @@ def make_state_dict(template: Dict[str, "object"], seed: int = 0) -> Dict[str, n
             out[key] = np.ones(shape, dtype=np.float32)
         elif key.startswith("codebook._freqEMA") or "._freqEMA." in key:
             out[key] = np.full(shape, 1.0 / shape[-1], dtype=np.float32)
+        elif leaf == "weight" and len(shape) == 1 and ".resnet." in key and (
+                ".bn3." in key or (".bn2." in key and key.startswith("backbone_m"))):
+            out[key] = g.uniform(0.2, 0.4, shape).astype(np.float32)   # last BN of a residual branch: keeps 16 stacked blocks O(1)
         elif leaf == "weight" and len(shape) == 1:  # BatchNorm gamma
             out[key] = g.uniform(0.8, 1.2, shape).astype(np.float32)
         elif leaf == "bias":

@@ -17,6 +17,19 @@ def build_plugin(shape="tiny", **kw):
     return model
 
 
+def build_pyramid_plugin(shape="tiny", **kw):
+    hy = synth.make_pyramid_hypes(shape, **kw)
+    model = train_utils.create_model(copy.deepcopy(hy)).eval()
+    synth.load_state_dict_numpy(model, synth.make_state_dict(model.state_dict(), seed=SEED_W))
+    return model
+
+
+def calibrated_pyramid_plugin(shape="tiny", n_agents=2, n_points=N_POINTS, **kw):
+    """The ``pyramid_tiny.npz`` recipe: W8A8 min-max, one EMA pass through the hard (encode -> decode) path, frozen."""
+    from quantv2x_amd.plugin.tools.inference_quant import calibrate_minmax
+    return calibrate_minmax(quant_wrap(build_pyramid_plugin(shape, **kw)), [scene(n_agents, shape, n_points=n_points)])
+
+
 def scene_np(n_agents, shape="tiny", seed=SEED_SCENE, n_points=N_POINTS):
     return synth.make_scene(shape, n_agents=n_agents, seed=seed, n_points=n_points)
 

@@ -532,8 +532,99 @@ def gen_pyramid():
     print("pyramid_fuse.npz", {k: v.shape for k, v in out.items()})
 
 
+def build_ref_pyramid(shape="tiny"):
+    hy = synth.make_pyramid_hypes(shape)
+    model = ref_tu.create_model(copy.deepcopy(hy)).eval()
+    synth.load_state_dict_numpy(model, synth.make_state_dict(model.state_dict(), seed=SEED_W))
+    return model
+
+
+def gen_pyramid_model():
+    """pyramid_tiny.npz: the reference's HeterPyramidCollabCodebookMCEncDec (tiny shape, N = 2) in fp32 and under the reference's
+    QuantModel (W8A8, min-max, one EMA pass, frozen): every (delta, zero_point), weight-code checksums, the output codes of every
+    residual block / deblock / occupancy head, the wire codes and the predictions."""
+    out = {}
+    model = build_ref_pyramid()
+    out['state_dict_keys'] = np.array(list(model.state_dict().keys()))
+    dd = scene(2)
+    with torch.no_grad():
+        o = model.forward_with_encdec(dd)
+        out['fp32/preds_tensor'] = np32(o['preds_tensor'])
+        for i, occ in enumerate(o['occ_single_list']):
+            out[f'fp32/occ{i}'] = np32(occ)
+        codes, _, info = model.encode_features(dd)
+        out['fp32/codes'] = np32(torch.stack([c[:, 0] for c in codes])).astype(np.uint8)
+        out['fp32/affine'] = np32(info['affine_matrix'])
+        torch.manual_seed(0)
+        out['fp32/soft_preds_tensor_seed0'] = np32(model(dd)['preds_tensor'])
+        out['fp32/preds_tensor_n1'] = np32(model.forward_with_encdec(scene(1))['preds_tensor'])
+    qt = quant_wrap(build_ref_pyramid())
+    out['quant_state_dict_keys'] = np.array(list(qt.state_dict().keys()))
+    for a in act_quantizers(qt):
+        a.set_inited(False)
+    qt.set_quant_state(True, True)
+    with torch.no_grad():
+        qt.model.forward_with_encdec(dd)
+    for a in act_quantizers(qt):
+        a.set_inited(True)
+    model = qt.model
+    outs, hooks, names, blocks = {}, [], [], []
+    for name, m in model.named_modules():
+        if isinstance(m, QuantModule):
+            names.append(name)
+        elif type(m).__name__ in ("QuantBasicBlock", "QuantBottleneck"):
+            blocks.append(name)
+        else:
+            continue
+        hooks.append(m.register_forward_hook(lambda mod, i, o, name=name: outs.__setitem__(name, o)))
+    with torch.no_grad():
+        codes, _, info = model.encode_features(dd)
+        o = model.decode_features(codes, info)
+    for h in hooks:
+        h.remove()
+    out['module_names'], out['block_names'] = np.array(names), np.array(blocks)
+    mods = dict(model.named_modules())
+
+    def code_of(t, aq):
+        code = torch.round(t / aq.delta + aq.zero_point)
+        assert float((((code - aq.zero_point) * aq.delta) - t).abs().max()) < 1e-4 * max(1.0, float(t.abs().max()))
+        return np32(code).astype(np.uint8)
+    for name in names:
+        m, key = mods[name], name.replace('.', '/')
+        wqz, aqz = m.weight_quantizer, m.act_quantizer
+        out[key + '/w_delta'] = np32(wqz.delta).reshape(-1)
+        out[key + '/w_zp'] = np32(wqz.zero_point).reshape(-1)
+        wcode = np32(torch.clamp(torch.round(m.weight / wqz.delta) + wqz.zero_point, 0, 255)).astype(np.uint8)
+        out[key + '/w_code_checksum'] = weight_checksums(wcode)
+        out[key + '/a_delta'], out[key + '/a_zp'] = np.float32(aqz.delta), np.float32(aqz.zero_point)
+        out[key + '/a_off'] = np.bool_(m.disable_act_quant)
+        keep = ('.0.conv1' in name or '.0.conv2' in name or 'deblocks' in name or 'single_head' in name or 'shrink_conv' in name)
+        if keep and not m.disable_act_quant and 'pfn_layers' not in name:
+            out[key + '/out_code'] = code_of(outs[name], aqz)
+        if name.endswith('.0.downsample') or name.endswith('layer0.0.conv3') or name.endswith('layer0.0.conv2') and m.disable_act_quant:
+            out[key + '/out_f32'] = np32(outs[name])[:, ::4]
+    for name in blocks:
+        aqz, key = mods[name].act_quantizer, name.replace('.', '/')
+        out[key + '/a_delta'], out[key + '/a_zp'] = np.float32(aqz.delta), np.float32(aqz.zero_point)
+        out[key + '/out_code'] = code_of(outs[name], aqz)
+    out['w8a8/codes'] = np32(torch.stack([c[:, 0] for c in codes])).astype(np.uint8)
+    out['w8a8/preds_tensor'] = np32(o['preds_tensor'])
+    for i, occ in enumerate(o['occ_single_list']):
+        out[f'w8a8/occ{i}'] = np32(occ)
+    with torch.no_grad():
+        out['w8a8/preds_tensor_n1'] = np32(model.forward_with_encdec(scene(1))['preds_tensor'])
+        out['w8a8/preds_tensor_n3'] = np32(model.forward_with_encdec(scene(3))['preds_tensor'])
+    from quantv2x_amd.ptq_state import export_ptq_state
+    st = export_ptq_state(qt)
+    keys = sorted(k for k in st if not k.startswith("meta/"))
+    out['ptq_export/keys'] = np.array(keys)
+    out['ptq_export/checksum'] = np.array([float(np.asarray(st[k], dtype=np.float64).sum()) for k in keys])
+    np.savez_compressed(os.path.join(HERE, "pyramid_tiny.npz"), **out)
+    print("pyramid_tiny.npz: %d arrays, %d modules, %d blocks" % (len(out), len(names), len(blocks)))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["fp32", "w8a8", "uaq", "geometry", "codebook", "postprocess", "postprocess_mc", "recon", "pyramid"]
+    which = sys.argv[1:] or ["fp32", "w8a8", "uaq", "geometry", "codebook", "postprocess", "postprocess_mc", "recon", "pyramid", "pyramid_model"]
     with torch.no_grad():
         pass
     if "fp32" in which: gen_fp32()
@@ -545,3 +636,4 @@ if __name__ == "__main__":
     if "postprocess_mc" in which: gen_postprocess_mc()
     if "recon" in which: gen_recon()
     if "pyramid" in which: gen_pyramid()
+    if "pyramid_model" in which: gen_pyramid_model()
