@@ -214,6 +214,14 @@ ORC_API void orc_codebook_c2(const float* codebook, int Kc, float* c2) {
     for (int k = 0; k < Kc; ++k) c2[k] = sumsq256(codebook + (size_t)k * 256);
 }
 
+/* D = 64 (the Pyramid model's codebook, heter_pyramid_collab_codebook_mc.py:28): one 64-wide ascending chain */
+static float sumsq_d(const float* v, int D) {
+    if (D == 256) return sumsq256(v);
+    float a = 0.0f;
+    for (int i = 0; i < D; ++i) a = fmaf(v[i], v[i], a);
+    return a;
+}
+
 /* ---------------------------------------------------------------------------------------------
  * a6: residual multi-codebook encode of R rows of D = 256 floats (m = 1), L levels, Kc codes/level.
  * Per level: z = stage(x); q = qhead(z); d_k = (|q|^2 + |C_k|^2) - 2 * (q . C_k); code = first argmin;
@@ -221,13 +229,13 @@ ORC_API void orc_codebook_c2(const float* codebook, int Kc, float* c2) {
  * weights: per level pointers packed by the caller:  stage_w/b, qhead_w/b, lhead_w/b ([256][256] / [256]),
  *          codebook [Kc][256].
  * ------------------------------------------------------------------------------------------- */
-ORC_API void orc_codebook_encode(const float* x_in, int R, int L, int Kc,
+ORC_API void orc_codebook_encode_d(const float* x_in, int R, int L, int Kc, int D,
                                  const float* const* stage_w, const float* const* stage_b,
                                  const float* const* qhead_w, const float* const* qhead_b,
                                  const float* const* lhead_w, const float* const* lhead_b,
                                  const float* const* codebook, uint8_t* codes /* [L][R] */,
                                  float* gap_out /* [L][R] top-2 gap or NULL */) {
-    const int D = 256;
+    if (D != 256 && D != 64) return;
     float* x = (float*)malloc((size_t)R * D * sizeof(float));
     float* z = (float*)malloc((size_t)R * D * sizeof(float));
     float* q = (float*)malloc((size_t)R * D * sizeof(float));
@@ -238,10 +246,10 @@ ORC_API void orc_codebook_encode(const float* x_in, int R, int L, int Kc,
         linear_rows(x, R, D, stage_w[l], stage_b[l], D, z);
         linear_rows(z, R, D, qhead_w[l], qhead_b[l], D, q);
         linear_rows(q, R, D, codebook[l], NULL, Kc, inter);
-        orc_codebook_c2(codebook[l], Kc, c2);
+        for (int k = 0; k < Kc; ++k) c2[k] = sumsq_d(codebook[l] + (size_t)k * D, D);
 #pragma omp parallel for schedule(static)
         for (int r = 0; r < R; ++r) {
-            const float x2 = sumsq256(q + (size_t)r * D);
+            const float x2 = sumsq_d(q + (size_t)r * D, D);
             float best = INFINITY, second = INFINITY; int arg = 0;
             for (int k = 0; k < Kc; ++k) {
                 const float d = (x2 + c2[k]) - 2.0f * inter[(size_t)r * Kc + k];
@@ -264,6 +272,14 @@ ORC_API void orc_codebook_encode(const float* x_in, int R, int L, int Kc,
     free(x); free(z); free(q); free(inter); free(c2);
 }
 
+ORC_API void orc_codebook_encode(const float* x_in, int R, int L, int Kc,
+                                 const float* const* stage_w, const float* const* stage_b,
+                                 const float* const* qhead_w, const float* const* qhead_b,
+                                 const float* const* lhead_w, const float* const* lhead_b,
+                                 const float* const* codebook, uint8_t* codes, float* gap_out) {
+    orc_codebook_encode_d(x_in, R, L, Kc, 256, stage_w, stage_b, qhead_w, qhead_b, lhead_w, lhead_b, codebook, codes, gap_out);
+}
+
 /* a7 as a table sum: out[r] = ((bias + T0[c0]) + T1[c1]) + T2[c2]; lut [L][Kc][256] */
 ORC_API void orc_decode_lut(const uint8_t* codes, int R, int L, int Kc, const float* lut, const float* bias, float* out) {
 #pragma omp parallel for schedule(static)
@@ -272,6 +288,16 @@ ORC_API void orc_decode_lut(const uint8_t* codes, int R, int L, int Kc, const fl
             float v = bias[j];
             for (int l = 0; l < L; ++l) v = v + lut[((size_t)l * Kc + codes[(size_t)l * R + r]) * 256 + j];
             out[(size_t)r * 256 + j] = v;
+        }
+}
+
+ORC_API void orc_decode_lut_d(const uint8_t* codes, int R, int L, int Kc, int D, const float* lut, const float* bias, float* out) {
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < R; ++r)
+        for (int j = 0; j < D; ++j) {
+            float v = bias[j];
+            for (int l = 0; l < L; ++l) v = v + lut[((size_t)l * Kc + codes[(size_t)l * R + r]) * D + j];
+            out[(size_t)r * D + j] = v;
         }
 }
 
@@ -358,4 +384,71 @@ ORC_API void orc_gemm_f32(const float* in, int N, int H, int W, int cin_total, i
         }
         free(xk);
     }
+}
+
+/* =============================================================================================
+ * f3: the layers the HEAL Pyramid model adds (quant_block.py:68-131 QuantBasicBlock / QuantBottleneck, :462-549 QuantPyramidFusion).
+ * ============================================================================================= */
+
+/* k x k convolution (k = 1 | 3, zero padding k / 2, stride 1 | 2, `groups` channel groups as torch's Conv2d) on uint8 codes with
+ * ONE input quantizer (dx implied by scale, zx):   T = sum (x - zx) * (w - zw[co])  exact;   y = bias[co] + float(T) * scale[co].
+ *   mode 0: out_u8 = q_code(relu ? max(y, 0) : y)      (QuantModule with its output quantizer, quant_layer.py:391-410)
+ *   mode 1: out_f32 = y                                (disable_act_quant: the end of a residual branch, the 1x1 shortcut)
+ * in [N][H][W][Cin]; wq [Cout][Cin/groups][k][k] u8 codes; outputs [N][Ho][Wo][Cout]. */
+ORC_API void orc_convg(const uint8_t* in, int N, int H, int W, int Cin, int zx, int k, int stride, int groups,
+                       const uint8_t* wq, const int32_t* zw, int Cout, const float* scale, const float* bias,
+                       int mode, int relu, float da, float za, uint8_t* out_u8, float* out_f32) {
+    const int pad = k / 2, Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    const int cg = Cin / groups, og = Cout / groups;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int n = 0; n < N; ++n)
+        for (int yo = 0; yo < Ho; ++yo)
+            for (int xo = 0; xo < Wo; ++xo)
+                for (int co = 0; co < Cout; ++co) {
+                    const int g = co / og;
+                    int32_t T = 0;
+                    for (int i = 0; i < k; ++i)
+                        for (int j = 0; j < k; ++j) {
+                            const int yi = yo * stride + i - pad, xi = xo * stride + j - pad;
+                            if (yi < 0 || yi >= H || xi < 0 || xi >= W) continue;       /* zero padding: (zx - zx) * w */
+                            const uint8_t* src = in + (((size_t)n * H + yi) * W + xi) * Cin + g * cg;
+                            const uint8_t* wr = wq + (((size_t)co * cg) * k + i) * k + j;
+                            for (int c = 0; c < cg; ++c) T += ((int)src[c] - zx) * ((int)wr[(size_t)c * k * k] - zw[co]);
+                        }
+                    float y = bias[co] + (float)T * scale[co];
+                    const size_t o = (((size_t)n * Ho + yo) * Wo + xo) * Cout + co;
+                    if (mode == 1) { out_f32[o] = y; continue; }
+                    if (relu) y = fmaxf(y, 0.0f);
+                    out_u8[o] = (uint8_t)q_code(y, da, za);
+                }
+}
+
+/* ConvTranspose2d(kernel == stride == s) or (s == 1) a 1x1 convolution on fp32 rows with fake-quantized weights:
+ *   acc = 0; ci ascending: acc = fmaf(x[ci], wdeq[ci][co][i][j], acc);  y = acc + bias[co];  out = q_code(relu(y))
+ * xf [N*H*W][Cin] f32 (the decoded feature, or a fused map -- neither sits on a quantizer grid); out as orc_deconv. */
+ORC_API void orc_deconv_f32in(const float* xf, int N, int H, int W, int Cin, const float* wdeq, const float* bias, int Cout, int s,
+                              int relu, float da, float za, uint8_t* out, int out_ct, int out_c0) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int n = 0; n < N; ++n)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                const float* src = xf + (((size_t)n * H + y) * W + x) * Cin;
+                for (int i = 0; i < s; ++i)
+                    for (int j = 0; j < s; ++j) {
+                        uint8_t* o = out + (((size_t)n * H * s + (y * s + i)) * (W * s) + (x * s + j)) * out_ct + out_c0;
+                        for (int co = 0; co < Cout; ++co) {
+                            float acc = 0.0f;
+                            for (int c = 0; c < Cin; ++c) acc = fmaf(src[c], wdeq[(((size_t)c * Cout + co) * s + i) * s + j], acc);
+                            float yv = acc + bias[co];
+                            if (relu) yv = fmaxf(yv, 0.0f);
+                            o[co] = (uint8_t)q_code(yv, da, za);
+                        }
+                    }
+            }
+}
+
+/* the end of a residual block: code = q_code(max(y + res, 0))   (out += residual; ReLU; act_quantizer) */
+ORC_API void orc_add_relu_quant(const float* y, const float* res, size_t n, float da, float za, uint8_t* out) {
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) out[i] = (uint8_t)q_code(fmaxf(y[i] + res[i], 0.0f), da, za);
 }
