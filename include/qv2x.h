@@ -287,6 +287,81 @@ int qv2x_codebook_encode_f32in(const qv2x_encode_desc* desc /* host */, const fl
 int qv2x_pyramid_weighted_fuse_f32(const qv2x_fuse_desc* desc /* host */, int channels, const float* feats, const float* score,
                                    const double* pairwise, float* out, void* stream);
 
+/* ---- f3, the rest of the HEAL Pyramid path (heter_pyramid_collab_codebook_mc_encdec.py:33-181 under QuantModel) -----------------
+ * Maps of activation CODES are padded i8 BEV tensors as everywhere else; maps that are not on a quantizer grid (the decoded
+ * feature, the 1x1 shortcut branch, the fused levels) are plain fp32 rows [N*H*W][C]. */
+
+/* A 1x1 convolution (stride 1 | 2, no padding) on codes: conv1 / conv3 / the shortcut of QuantBottleneck and QuantBasicBlock
+ * (quant_block.py:68-131; QuantModule quant_layer.py:391-410):
+ *     T = sum_ci (x - zx) * (w - zw[co])  exact (MFMA i8);   y = bias[co] + float(T) * scale[co]
+ *   mode 0: out = quant(relu ? max(y, 0) : y)                         -> padded i8 BEV [N][Ho+2][Wo+2][out_ctotal] at out_c0
+ *   mode 1: out = y                  (disable_act_quant)              -> f32 [N*Ho*Wo][cout]
+ *   mode 2: out = quant(max(y + res, 0)),  res f32 [N*Ho*Wo][cout]     (the block's fp32 shortcut: `out += residual`, ReLU, the block's
+ *   mode 3: out = quant(max(y + (r - res_zx) * res_delta, 0)),         quantizer) -- res i8 = the block INPUT codes, padded i8 BEV
+ *                                                                      [N][Ho+2][Wo+2][cout]
+ *   in  : padded i8 BEV [N][H+2][W+2][cin];  Ho = (H - 1) / stride + 1
+ *   w_frag: i8 (code - 128), the A fragments of v_mfma_i32_32x32x32_i8 in load order: [cout/32][cin/32][lane 0..63][16 B] with
+ *           lane = 32 * ((ci / 16) & 1) + co % 32, bytes = ci % 16
+ *   scale f32 [cout] = delta_x * delta_w[co]; corr i32 [cout] = ax * sum_ci ws + cin * ax * aw[co]; aw i32 [cout]; bias f32 [cout]
+ *   (ax = 128 - zx, aw[co] = 128 - zw[co], ws = w code - 128: as qv2x_conv3x3_i8). */
+typedef struct {
+    int32_t n, h, w, cin, cout, stride;
+    int32_t mode, relu;
+    int32_t out_ctotal, out_c0;
+    float out_delta, out_zp;
+    int32_t res_zx;
+    float res_delta;
+} qv2x_conv1x1_desc;
+int qv2x_conv1x1_i8(const qv2x_conv1x1_desc* desc /* host */, const int8_t* in, const int8_t* w_frag, const float* scale,
+                    const int32_t* corr, const int32_t* aw, const float* bias, const void* res, void* out, void* stream);
+
+/* The grouped 3x3 convolution of QuantBottleneck (ResNeXt: groups of cg = 4 | 8 | 16 channels, c inputs = c outputs; zero padding 1,
+ * stride 1 | 2) + bias + ReLU + output quantizer; the same integer arithmetic, on the VALU's v_dot4_i32_i8.
+ *   in padded i8 BEV [N][H+2][W+2][c] -> out padded i8 BEV [N][Ho+2][Wo+2][c]
+ *   w_chunk: i8 (code - 128) [c][9 taps][cg] (output channel major; tap = 3 * kh + kw; the group's input channels innermost)
+ *   scale / corr / aw / bias as above with K = 9 * cg. */
+typedef struct {
+    int32_t n, h, w, c, cg, stride, relu;
+    float out_delta, out_zp;
+} qv2x_gconv_desc;
+int qv2x_gconv3x3_i8(const qv2x_gconv_desc* desc /* host */, const int8_t* in, const int8_t* w_chunk, const float* scale,
+                     const int32_t* corr, const int32_t* aw, const float* bias, int8_t* out, void* stream);
+
+/* qv2x_conv3x3_i8 with a fused residual end (conv2 of QuantBasicBlock, quant_block.py:76-96): one input group, cout = 64;
+ *   res_mode 2: res f32 [N*Ho*Wo][cout];  res_mode 3: res = padded i8 BEV [N][Ho+2][Wo+2][cout] with (res_zx, res_delta);
+ *   out = quant(max(y + shortcut, 0)) with the BLOCK's quantizer (desc->out_delta / out_zp). */
+int qv2x_conv3x3_i8_res(const qv2x_conv_desc* desc /* host */, const int8_t* in, const int8_t* w, const float* scale, const int32_t* corr,
+                        const int32_t* aw, const float* bias, int res_mode, const void* res, int res_zx, float res_delta,
+                        int8_t* out, void* stream);
+
+/* qv2x_deconv_i8 on an fp32 map (QuantPyramidFusion's deblocks take the fused levels, quant_block.py:444-459; with s = 1 and the
+ * weight transposed it is also conv1 of the first pyramid block, whose input is the decoded feature):  in f32 [N*H*W][cin]; the
+ * descriptor's in_zx / in_delta are ignored; everything else as qv2x_deconv_i8. */
+int qv2x_deconv_f32in(const qv2x_deconv_desc* desc /* host */, const float* in, const float* w, const float* bias, int8_t* out, void* stream);
+
+/* UMGMQuantizer.decode (codebook.py:339-343) as table look-ups for any codebook width d (% 4): row r = (agent, cell),
+ *   out[r][:] = ((bias + lut[0][c0]) + lut[1][c1]) + ...,  c_l = codes[agent * agent_stride + l * level_stride + cell]
+ *   lut f32 [levels][kc][d], bias f32 [d], out f32 [agents * hw][d]. */
+int qv2x_codebook_decode_f32(const uint8_t* codes, int64_t agent_stride, int64_t level_stride, int agents, int hw, int levels,
+                             int kc, int d, const float* lut, const float* bias, float* out, void* stream);
+
+/* One level's 1x1 occupancy head (QuantModule c -> 1 with its output quantizer, quant_block.py:475-479, :507-509):
+ *     T exact;  y = bias + float(T) * scale;  code = quant(y);  score = score_lut[code]
+ *   (score_lut[k] = sigmoid((k - out_zp) * out_delta) + 1e-4, built once by the caller);  in padded i8 BEV [N][H+2][W+2][c],
+ *   w i8 (code - 128) [c];  aw = 128 - zw, corr = ax * sum ws + c * ax * aw;  score f32 [N*H*W]; occ_code u8 [N*H*W] or NULL. */
+typedef struct {
+    int32_t n, h, w, c;
+    int32_t aw, corr;
+    float scale, bias, out_delta, out_zp;
+} qv2x_occ_desc;
+int qv2x_occ_score_i8(const qv2x_occ_desc* desc /* host */, const int8_t* in, const int8_t* w, const float* score_lut, float* score,
+                      uint8_t* occ_code, void* stream);
+
+/* qv2x_pyramid_weighted_fuse_f32 with the features as activation codes: feats padded i8 BEV [agents][h+2][w+2][channels] with
+ * (in_zx, in_delta), dequantized at the taps. */
+int qv2x_pyramid_weighted_fuse_i8(const qv2x_fuse_desc* desc /* host */, int channels, const int8_t* feats, int in_zx, float in_delta,
+                                  const float* score, const double* pairwise, float* out, void* stream);
+
 /* ---- the V2X link: one agent per GPU --------------------------------------------------------------------
  * The reference simulates the link in-process: all agents are rows of one batch (heter_model_baseline.py:216) and
  * fusion_in_one.py:131-151 regroups them; get_pairwise_transformation (utils/transformation_utils.py:21-66) builds the

@@ -29,6 +29,7 @@ struct ConvArgs {
     int ho, wo, M, ktot;
     int out_ctotal, out_c0, relu;
     float out_delta, out_zp;
+    const void* res; int res_ax; float res_delta;            // EPI 2 | 3: the shortcut of a residual block (qv2x_conv3x3_i8_res)
 };
 
 // LDS rows are BK bytes = CH 16-byte chunks; chunk c of row r is stored at c ^ f(r) so that the 16 lanes of a
@@ -48,7 +49,9 @@ __device__ __forceinline__ int swz(int row, int chunk) {
 // The DMA writes LDS lane-linearly (wave-uniform base + lane*16), so the XOR swizzle is applied to the per-lane SOURCE
 // address and again on the fragment reads (cdna guide rule 21).  All LDS is one array (a second __shared__ object makes
 // hipcc drain vmcnt before every ds_read).
-template <int BM, int BN, int WM, int WN, int BK, bool MULTI, int S, int MINW>
+// EPI (single group only): 0 = quantize; 2 = + fp32 shortcut [M][cout], 3 = + dequantized shortcut codes (padded i8 BEV [..][cout]),
+// then ReLU and the block's quantizer (the end of QuantBasicBlock, quant_block.py:88-96)
+template <int BM, int BN, int WM, int WN, int BK, bool MULTI, int S, int MINW, int EPI = 0>
 __global__ __launch_bounds__(256, MINW) void conv3x3_i8_dma_kernel(const ConvArgs a) {
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MT = TM / 32, NT = TN / 32;
@@ -252,12 +255,30 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_i8_dma_kernel(const ConvArg
             for (int i = 0; i < MT; ++i) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    float y[4];
+                    float y[4], rs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (EPI == 2) {
+                        const int mrow = m0 + wm * TM + i * 32 + l31;
+                        if (mrow < a.M) {
+                            const v4f rv = *(const v4f*)((const float*)a.res + (size_t)mrow * a.cout + n0 + wn * TN + j * 32 + 8 * g + 4 * half);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) rs[e] = rv[e];
+                        }
+                    }
+                    if (EPI == 3) {
+                        const int off = rowoff[wm * TM + i * 32 + l31];
+                        if (off >= 0) {
+                            const int rw = *(const int*)((const int8_t*)a.res + (size_t)off * a.cout + n0 + wn * TN + j * 32 + 8 * g + 4 * half);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) rs[e] = (float)(((rw << (24 - 8 * e)) >> 24) + a.res_ax) * a.res_delta;
+                        }
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int r = 4 * g + e;
                         const int T = acc[i][j][r] + __mul24(c_aw[r], tot[i]) + c_cr[r];
-                        y[e] = fmaxf(c_bs[r] + (float)T * c_sc[r], lo);
+                        float yv = c_bs[r] + (float)T * c_sc[r];
+                        if (EPI != 0) yv = yv + rs[e];
+                        y[e] = fmaxf(yv, lo);
                     }
                     *(int*)(stage + (i * 32 + l31) * SP + j * 32 + 8 * g + 4 * half) = q_pack4(y[0], y[1], y[2], y[3], a.out_delta, rd, a.out_zp);
                 }
@@ -310,17 +331,17 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_i8_dma_kernel(const ConvArg
     }
 }
 
-template <int BM, int BN, int WM, int WN, int BK, bool MULTI, int S, int MINW>
+template <int BM, int BN, int WM, int WN, int BK, bool MULTI, int S, int MINW, int EPI = 0>
 static int launch_dma(const ConvArgs& a, hipStream_t st) {
     dim3 grid((a.M + BM - 1) / BM, a.cout / BN);
-    conv3x3_i8_dma_kernel<BM, BN, WM, WN, BK, MULTI, S, MINW><<<grid, 256, 0, st>>>(a);
+    conv3x3_i8_dma_kernel<BM, BN, WM, WN, BK, MULTI, S, MINW, EPI><<<grid, 256, 0, st>>>(a);
     return hip_check(hipGetLastError(), "qv2x_conv3x3_i8 launch");
 }
 
 }  // namespace qv2x
 
-extern "C" int qv2x_conv3x3_i8(const qv2x_conv_desc* d, const int8_t* in, const int8_t* w, const float* scale,
-                               const int32_t* corr, const int32_t* aw, const float* bias, int8_t* out, void* stream) {
+static int conv3x3_entry(const qv2x_conv_desc* d, const int8_t* in, const int8_t* w, const float* scale, const int32_t* corr, const int32_t* aw,
+                         const float* bias, int res_mode, const void* res, int res_zx, float res_delta, int8_t* out, void* stream) {
     using namespace qv2x;
     if (!d || !in || !w || !scale || !corr || !aw || !bias || !out) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8: null pointer");
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || (d->stride != 1 && d->stride != 2))
@@ -331,6 +352,7 @@ extern "C" int qv2x_conv3x3_i8(const qv2x_conv_desc* d, const int8_t* in, const 
     if (((uintptr_t)in & 15) || ((uintptr_t)w & 15) || ((uintptr_t)out & 15)) return fail(QV2X_EALIGN, "qv2x_conv3x3_i8: in / w / out must be 16-byte aligned");
     if (d->out_ctotal % 16 || d->out_c0 % 16) return fail(QV2X_EALIGN, "qv2x_conv3x3_i8: out_ctotal and out_c0 must be multiples of 16");
     ConvArgs a;
+    a.res = res; a.res_ax = 128 - res_zx; a.res_delta = res_delta;
     a.in = in; a.w = w; a.scale = scale; a.corr = corr; a.aw = aw; a.bias = bias; a.out = out;
     a.n = d->n; a.hp = d->h + 2; a.wp = d->w + 2; a.cin_total = d->cin_total; a.stride = d->stride; a.cout = d->cout;
     a.ngroups = d->ngroups;
@@ -354,6 +376,11 @@ extern "C" int qv2x_conv3x3_i8(const qv2x_conv_desc* d, const int8_t* in, const 
     bool k128 = true;
     for (int g = 0; g < a.ngroups; ++g) k128 = k128 && (a.gc[g] % 128 == 0);
     const bool multi = a.ngroups > 1;
+    if (res_mode) {
+        if (multi || a.cout != 64 || a.gc[0] != 64 || !res || ((uintptr_t)res & 15) || (res_mode != 2 && res_mode != 3))
+            return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_res: one input group of 64 channels, cout 64, res_mode 2 | 3, aligned shortcut");
+        return res_mode == 2 ? launch_dma<64, 64, 2, 2, 64, false, 4, 4, 2>(a, st) : launch_dma<64, 64, 2, 2, 64, false, 4, 4, 3>(a, st);
+    }
 #ifndef QV2X_CONV_FORCE
 #define QV2X_CONV_FORCE 0     // dev builds: 1 never the 128 x 128 variant, 2 also BK = 128 instead of 256, 3 only BK = 128 instead of 256
 #endif
@@ -369,4 +396,16 @@ extern "C" int qv2x_conv3x3_i8(const qv2x_conv_desc* d, const int8_t* in, const 
     const long long wgs64 = (long long)((a.M + 63) / 64) * (a.cout / 64);
     if (a.gc[0] % 256 == 0 && (QV2X_CONV_FORCE ? QV2X_CONV_FORCE < 2 : wgs64 <= 256)) return launch_dma<64, 64, 2, 2, 256, false, 3, 1>(a, st);
     return k128 ? launch_dma<64, 64, 2, 2, 128, false, 4, 2>(a, st) : launch_dma<64, 64, 2, 2, 64, false, 4, 4>(a, st);
+}
+
+extern "C" int qv2x_conv3x3_i8(const qv2x_conv_desc* d, const int8_t* in, const int8_t* w, const float* scale,
+                               const int32_t* corr, const int32_t* aw, const float* bias, int8_t* out, void* stream) {
+    return conv3x3_entry(d, in, w, scale, corr, aw, bias, 0, nullptr, 128, 0.0f, out, stream);
+}
+
+extern "C" int qv2x_conv3x3_i8_res(const qv2x_conv_desc* d, const int8_t* in, const int8_t* w, const float* scale, const int32_t* corr,
+                                   const int32_t* aw, const float* bias, int res_mode, const void* res, int res_zx, float res_delta,
+                                   int8_t* out, void* stream) {
+    if (res_mode != 2 && res_mode != 3) return qv2x::fail(QV2X_EINVAL, "qv2x_conv3x3_i8_res: res_mode 2 (fp32 shortcut) or 3 (shortcut codes)");
+    return conv3x3_entry(d, in, w, scale, corr, aw, bias, res_mode, res, res_zx, res_delta, out, stream);
 }

@@ -23,7 +23,8 @@ struct DeconvArgs {
 // one wave tile (`tile` is wave-uniform); stagebuf: this wave's 32 x 48 bytes of LDS
 constexpr int DSP = 48;                       // staging pitch per pixel: 32 channel bytes + 16 (2-way bank spread of the dword writes)
 
-template <int NT>
+// F32IN: the input is an fp32 map [M][cin] (a fused pyramid level, the decoded feature) instead of codes
+template <int NT, bool F32IN = false>
 __device__ __forceinline__ void deconv_tile(const DeconvArgs& a, const int tile, int8_t (*stagebuf)[32 * DSP]) {
     const int lane = threadIdx.x & 63;
     const int tiles_n = a.ncols / (32 * NT);
@@ -37,6 +38,7 @@ __device__ __forceinline__ void deconv_tile(const DeconvArgs& a, const int tile,
     const int img = m / (a.h * a.wd), rem = m - img * (a.h * a.wd);
     const int y = rem / a.wd, x = rem - y * a.wd;
     const int8_t* src = a.in + ((size_t)(img * (a.h + 2) + y + 1) * (a.wd + 2) + x + 1) * a.cin;
+    const float* srcf = (const float*)a.in + (size_t)m * a.cin;
     // padded output pixel index of this lane's pixel at sub-position (i = 0, j = 0); -1 past the end
     const int pixbase = (tm * 32 + (lane & 31)) < a.M ? (img * (a.h * a.s + 2) + y * a.s + 1) * (a.wd * a.s + 2) + x * a.s + 1 : -1;
     const int col0 = tn * (32 * NT) + (lane & 31);
@@ -51,7 +53,17 @@ __device__ __forceinline__ void deconv_tile(const DeconvArgs& a, const int tile,
 
     // one step = 16 input channels = 8 MFMA k-steps x 2 column tiles; the next step's operands are requested before the
     // MFMA block of the current one (register double buffer, pinned with sched_barrier: hipcc sinks loads otherwise)
-    auto loadA = [&](int k0) { return *(const v4i*)(src + k0); };
+    struct Raw { v4i q; v4f f[4]; };
+    auto loadA = [&](int k0) {
+        Raw r;
+        if (F32IN) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r.f[q] = *(const v4f*)(srcf + k0 + 4 * q);
+        } else {
+            r.q = *(const v4i*)(src + k0);
+        }
+        return r;
+    };
     auto loadB = [&](float2 (&dst)[4][NT], int k0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -59,12 +71,17 @@ __device__ __forceinline__ void deconv_tile(const DeconvArgs& a, const int tile,
             for (int t = 0; t < NT; ++t) dst[q][t] = wq[((size_t)((k0 >> 2) + q) * a.ncols + t * 32) * 2];
     };
     const int sh = par * 8;
-    auto step = [&](const v4i raw, const float2 (&b)[4][NT]) {
+    auto step = [&](const Raw& raw, const float2 (&b)[4][NT]) {
         float av[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {              // MFMA k-step j: k = k0 + 2j + par  ->  byte 2*(j&1) + par of word j>>1
-            const int xs = (raw[j >> 1] << (24 - ((j & 1) * 16 + sh))) >> 24;
-            av[j] = (float)(xs + a.ax) * a.dx;
+            if (F32IN) {
+                const float e0 = raw.f[j >> 1][2 * (j & 1)], e1 = raw.f[j >> 1][2 * (j & 1) + 1];
+                av[j] = par ? e1 : e0;
+            } else {
+                const int xs = (raw.q[j >> 1] << (24 - ((j & 1) * 16 + sh))) >> 24;
+                av[j] = (float)(xs + a.ax) * a.dx;
+            }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
@@ -72,7 +89,7 @@ __device__ __forceinline__ void deconv_tile(const DeconvArgs& a, const int tile,
             for (int t = 0; t < NT; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32((j & 1) ? b[j >> 1][t].y : b[j >> 1][t].x, av[j], acc[t], 0, 0, 0);
     };
-    v4i r0 = loadA(0), r1;
+    Raw r0 = loadA(0), r1;
     float2 b0[4][NT], b1[4][NT];
     loadB(b0, 0);
     for (int k0 = 0; k0 < a.cin; k0 += 32) {
@@ -118,10 +135,10 @@ __device__ __forceinline__ void deconv_tile(const DeconvArgs& a, const int tile,
     }
 }
 
-template <int NT>
+template <int NT, bool F32IN = false>
 __global__ __launch_bounds__(256) void deconv_f32_kernel(const DeconvArgs a) {
     __shared__ __attribute__((aligned(16))) int8_t stagebuf[4][32 * DSP];     // per wave: [32 pixels][32 channels] of one tile
-    deconv_tile<NT>(a, __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))), stagebuf);
+    deconv_tile<NT, F32IN>(a, __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))), stagebuf);
 }
 
 // Several deblocks in one launch (they only feed the concat, so all of them can run once the last block is done): one pool
@@ -200,4 +217,13 @@ extern "C" int qv2x_deconv_i8_batch(const qv2x_deconv_desc* descs, int n, const 
     b.n = n;
     deconv_f32_batch_kernel<<<(total + 3) / 4, 256, 0, (hipStream_t)stream>>>(b);
     return hip_check(hipGetLastError(), "qv2x_deconv_i8_batch launch");
+}
+
+extern "C" int qv2x_deconv_f32in(const qv2x_deconv_desc* d, const float* in, const float* w, const float* bias, int8_t* out, void* stream) {
+    using namespace qv2x;
+    DeconvArgs a;
+    if (int rc = deconv_args(d, (const int8_t*)in, w, bias, out, "qv2x_deconv_f32in", a)) return rc;
+    const int tiles = ((a.M + 31) / 32) * (a.ncols / 32);
+    deconv_f32_kernel<1, true><<<(tiles + 3) / 4, 256, 0, (hipStream_t)stream>>>(a);
+    return hip_check(hipGetLastError(), "qv2x_deconv_f32in launch");
 }

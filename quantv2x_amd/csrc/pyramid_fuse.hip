@@ -12,10 +12,14 @@ namespace {
 
 struct PyrArgs {
     const float* feats; const float* score; const double* pairwise; float* out;
+    const int8_t* feats_i8; int ax; float dx;            // I8: padded i8 BEV [agents][h+2][w+2][c] and its quantizer
     int agents, h, w, c, hw, L, ego;
     double hm, wm, ratio;
 };
 
+// I8: the features are the level's activation codes, dequantized at the four taps ((code - zp) * delta, the value the reference's
+// fake-quantized map holds)
+template <bool I8>
 __global__ __launch_bounds__(256) void pyramid_weighted_fuse_kernel(const PyrArgs a) {
     const int lane = threadIdx.x & 63;
     int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -57,7 +61,16 @@ __global__ __launch_bounds__(256) void pyramid_weighted_fuse_kernel(const PyrArg
             float f = 0.0f;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                if (tcell[ag][t] >= 0) f += a.feats[((size_t)ag * a.hw + tcell[ag][t]) * a.c + ch] * twt[ag][t];
+                if (tcell[ag][t] >= 0) {
+                    float v;
+                    if (I8) {
+                        const int cy2 = tcell[ag][t] / a.w, cx2 = tcell[ag][t] - cy2 * a.w;
+                        v = (float)((int)a.feats_i8[((size_t)(ag * (a.h + 2) + cy2 + 1) * (a.w + 2) + cx2 + 1) * a.c + ch] + a.ax) * a.dx;
+                    } else {
+                        v = a.feats[((size_t)ag * a.hw + tcell[ag][t]) * a.c + ch];
+                    }
+                    f += v * twt[ag][t];
+                }
             o += f * p;
         }
         a.out[(size_t)cell * a.c + ch] = o;
@@ -76,9 +89,25 @@ extern "C" int qv2x_pyramid_weighted_fuse_f32(const qv2x_fuse_desc* d, int chann
     if (d->h <= 0 || d->w <= 0 || channels <= 0) return fail(QV2X_EINVAL, "qv2x_pyramid_weighted_fuse_f32: bad sizes");
     if (!(d->h_metres > 0) || !(d->w_metres > 0) || !(d->discrete_ratio > 0)) return fail(QV2X_EINVAL, "qv2x_pyramid_weighted_fuse_f32: map extent must be positive");
     PyrArgs a;
-    a.feats = feats; a.score = score; a.pairwise = pairwise; a.out = out;
+    a.feats = feats; a.score = score; a.pairwise = pairwise; a.out = out; a.feats_i8 = nullptr; a.ax = 0; a.dx = 0.0f;
     a.agents = d->agents; a.h = d->h; a.w = d->w; a.c = channels; a.hw = d->h * d->w; a.L = d->max_cav; a.ego = d->ego;
     a.hm = d->h_metres; a.wm = d->w_metres; a.ratio = d->discrete_ratio;
-    pyramid_weighted_fuse_kernel<<<(a.hw + 3) / 4, 256, 0, (hipStream_t)stream>>>(a);
+    pyramid_weighted_fuse_kernel<false><<<(a.hw + 3) / 4, 256, 0, (hipStream_t)stream>>>(a);
     return hip_check(hipGetLastError(), "qv2x_pyramid_weighted_fuse_f32 launch");
+}
+
+extern "C" int qv2x_pyramid_weighted_fuse_i8(const qv2x_fuse_desc* d, int channels, const int8_t* feats, int in_zx, float in_delta,
+                                             const float* score, const double* pairwise, float* out, void* stream) {
+    using namespace qv2x;
+    if (!d || !feats || !score || !pairwise || !out) return fail(QV2X_EINVAL, "qv2x_pyramid_weighted_fuse_i8: null pointer");
+    if (d->agents < 1 || d->agents > MAXA || d->max_cav < d->agents || d->ego < 0 || d->ego >= d->agents)
+        return fail(QV2X_EINVAL, "qv2x_pyramid_weighted_fuse_i8: 1..%d agents, ego inside, max_cav >= agents", MAXA);
+    if (d->h <= 0 || d->w <= 0 || channels <= 0) return fail(QV2X_EINVAL, "qv2x_pyramid_weighted_fuse_i8: bad sizes");
+    if (!(d->h_metres > 0) || !(d->w_metres > 0) || !(d->discrete_ratio > 0)) return fail(QV2X_EINVAL, "qv2x_pyramid_weighted_fuse_i8: map extent must be positive");
+    PyrArgs a;
+    a.feats = nullptr; a.score = score; a.pairwise = pairwise; a.out = out; a.feats_i8 = feats; a.ax = 128 - in_zx; a.dx = in_delta;
+    a.agents = d->agents; a.h = d->h; a.w = d->w; a.c = channels; a.hw = d->h * d->w; a.L = d->max_cav; a.ego = d->ego;
+    a.hm = d->h_metres; a.wm = d->w_metres; a.ratio = d->discrete_ratio;
+    pyramid_weighted_fuse_kernel<true><<<(a.hw + 3) / 4, 256, 0, (hipStream_t)stream>>>(a);
+    return hip_check(hipGetLastError(), "qv2x_pyramid_weighted_fuse_i8 launch");
 }

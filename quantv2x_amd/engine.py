@@ -42,11 +42,11 @@ def _pack_k4(w: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(w.T.reshape(k // 4, 4, j).transpose(0, 2, 1), dtype=np.float32)
 
 
-def decode_tables(state: Dict[str, np.ndarray], levels: int):
+def decode_tables(state: Dict[str, np.ndarray], levels: int, width: int = 256):
     """UMGMQuantizer.decode (codebook.py:339-343, 263-269) collapsed: every head is affine, so
-    decode(c_0..c_{L-1}) = bias + sum_l T_l[c_l].  float64 algebra, fp32 tables ``[L][kc][256]``."""
+    decode(c_0..c_{L-1}) = bias + sum_l T_l[c_l].  float64 algebra, fp32 tables ``[L][kc][width]``."""
     g = lambda l, n: state[f"codebook/{l}/{n}"].astype(np.float64)
-    tables, const, chain = [], np.zeros(256), np.eye(256)
+    tables, const, chain = [], np.zeros(width), np.eye(width)
     for l in range(levels):
         front = chain @ g(l, "restore_w")
         tables.append((front @ g(l, "dqhead_w") @ g(l, "codebook").T).T)
@@ -684,4 +684,7 @@ def deploy(qt_model=None, state: Optional[Dict[str, np.ndarray]] = None, path: O
     if str(state.get("meta/mode", "w8a8")) == "fp32":
         from .engine_fp32 import DeployedFp32Model
         return DeployedFp32Model(state, device=device, **kw)
+    if str(state.get("meta/fusion_method", "att")) == "pyramid":
+        from .engine_pyramid import DeployedPyramidModel
+        return DeployedPyramidModel(state, device=device, **kw)
     return DeployedModel(state, device=device, **kw)

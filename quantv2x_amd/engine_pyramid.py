@@ -1,0 +1,536 @@
+"""Deployed W8A8 HEAL Pyramid-fusion path on MI355X: host side of ``libqv2x.so`` for
+``heter_pyramid_collab_codebook_mc[_encdec]`` under ``QuantModel``.
+
+What an agent runs before the link (``encode_features``, the reference's heter_pyramid_collab_codebook_mc_encdec.py:33-121):
+    pillars -> PFN + scatter (a1, a2) -> ResNet BasicBlocks (QuantBasicBlock x 3, stride 2) -> codebook.encode (D = 64)
+What the ego runs on the received indices (``decode_features``, :123-181):
+    codebook.decode -> ResNeXt levels (QuantBottleneck x 3 / 5 / 8) on EVERY agent's map -> per level: occupancy head, score,
+    weighted_fuse into the ego frame -> deblocks on the fused fp32 levels -> concat -> shrink_conv -> 1x1 heads
+
+Activation CODES live in padded i8 BEV tensors, maps that are not on a quantizer grid (decoded feature, strided shortcut branch, fused
+levels) are fp32 rows.  Every residual block is 3 launches (4 with a strided shortcut): conv1, conv2, [shortcut], conv3 with the
+``+ shortcut -> ReLU -> block quantizer`` end fused into its epilogue.  There is no CPU / eager fallback."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import lib as L
+from .engine import _ConvLayer, _DeconvLayer, _Heads, _dev, _pack_k4p, decode_tables
+
+
+def _q(state, name):
+    return float(np.float32(state[name + "/a_delta"])), int(state[name + "/a_zp"])
+
+
+class _Conv1x1:
+    """One 1x1 QuantModule convolution on codes: the A fragments of v_mfma_i32_32x32x32_i8 + the epilogue constants."""
+
+    def __init__(self, state, name, in_q, stride, dev):
+        code = state[name + "/w_code"]
+        cout, cin = code.shape[0], code.shape[1]
+        if code.shape[2:] != (1, 1) or cout % 64 or cin % 32:
+            raise NotImplementedError(f"{name}: a 1x1 convolution with cout % 64 == 0 and cin % 32 == 0")
+        ws = code.reshape(cout, cin).astype(np.int64) - 128
+        aw = 128 - state[name + "/w_zp"].astype(np.int64)
+        ax = 128 - int(in_q[1])
+        frag = ws.astype(np.int8).reshape(cout // 32, 32, cin // 32, 2, 16).transpose(0, 2, 3, 1, 4)   # [co/32][ci/32][half][co%32][16]
+        self.w = _dev(frag, dev)
+        self.scale = _dev((np.float32(in_q[0]) * state[name + "/w_delta"].astype(np.float32)).astype(np.float32), dev)
+        corr = ax * ws.sum(axis=1) + cin * ax * aw
+        assert np.abs(corr).max() < 2 ** 31
+        self.corr, self.aw = _dev(corr.astype(np.int32), dev), _dev(aw.astype(np.int32), dev)
+        self.bias = _dev(state[name + "/bias"].astype(np.float32), dev)
+        self.name, self.cin, self.cout, self.stride = name, cin, cout, stride
+        self.a_off = bool(state[name + "/a_off"])
+        self.out_q = None if self.a_off else _q(state, name)
+
+
+class _GConv:
+    """The grouped 3x3 convolution of a bottleneck: weights [c][9 taps][cg]."""
+
+    def __init__(self, state, name, in_q, stride, dev):
+        code = state[name + "/w_code"]                                   # [c, cg, 3, 3]
+        c, cg = code.shape[0], code.shape[1]
+        if cg not in (4, 8, 16) or c % 16:
+            raise NotImplementedError(f"{name}: grouped convolution with 4 / 8 / 16 channels per group")
+        ws = code.astype(np.int64) - 128
+        aw = 128 - state[name + "/w_zp"].astype(np.int64)
+        ax = 128 - int(in_q[1])
+        self.w = _dev(ws.transpose(0, 2, 3, 1).reshape(c, 9, cg).astype(np.int8), dev)
+        self.scale = _dev((np.float32(in_q[0]) * state[name + "/w_delta"].astype(np.float32)).astype(np.float32), dev)
+        corr = ax * ws.reshape(c, -1).sum(axis=1) + 9 * cg * ax * aw
+        self.corr, self.aw = _dev(corr.astype(np.int32), dev), _dev(aw.astype(np.int32), dev)
+        self.bias = _dev(state[name + "/bias"].astype(np.float32), dev)
+        self.name, self.c, self.cg, self.stride = name, c, cg, stride
+        self.out_q = _q(state, name)
+
+
+class _DenseF32In(_DeconvLayer):
+    """A QuantModule on an fp32 map: a deblock (ConvTranspose2d, k = s), or -- ``conv=True`` -- a 1x1 Conv2d whose [Cout, Cin, 1, 1]
+    weight (scales per Cout) is laid out as the [Cin, Cout, 1, 1] deconvolution the kernel takes."""
+
+    def __init__(self, state, name, dev, conv=False):
+        if not conv:
+            super().__init__(state, name, (1.0, 0), dev)
+            return
+        code = state[name + "/w_code"].astype(np.float32)
+        dw = state[name + "/w_delta"].astype(np.float32).reshape(-1, 1, 1, 1)
+        zw = state[name + "/w_zp"].astype(np.float32).reshape(-1, 1, 1, 1)
+        wdeq = ((code - zw) * dw).astype(np.float32)                     # [Cout, Cin, 1, 1]
+        cout, cin = wdeq.shape[:2]
+        self.w = _dev(_pack_k4p(wdeq.reshape(cout, cin)), dev)           # rows = columns of the GEMM = cout
+        self.bias = _dev(state[name + "/bias"].astype(np.float32), dev)
+        self.name, self.cin, self.cout, self.s, self.in_q = name, cin, cout, 1, (1.0, 0)
+        self.out_q = _q(state, name)
+
+
+class _Occ:
+    def __init__(self, state, name, in_q, dev):
+        code = state[name + "/w_code"]
+        if code.shape[0] != 1 or code.shape[2:] != (1, 1):
+            raise NotImplementedError(f"{name}: a 1x1 convolution to ONE occupancy channel")
+        ws = code.reshape(-1).astype(np.int64) - 128
+        self.aw = int(128 - int(state[name + "/w_zp"][0]))
+        ax = 128 - int(in_q[1])
+        self.corr = int(ax * ws.sum() + ws.size * ax * self.aw)
+        self.w = _dev(ws.astype(np.int8), dev)
+        self.scale = float(np.float32(in_q[0]) * np.float32(state[name + "/w_delta"][0]))
+        self.bias = float(np.float32(state[name + "/bias"][0]))
+        self.name, self.c, self.out_q = name, ws.size, _q(state, name)
+        da, za = np.float32(self.out_q[0]), np.float32(self.out_q[1])
+        self.occ_values = ((np.arange(256, dtype=np.float32) - za) * da).astype(np.float32)          # fp32 occupancy of every code
+        sig = (1.0 / (1.0 + np.exp(-self.occ_values.astype(np.float64)))).astype(np.float32)
+        self.lut = _dev((sig + np.float32(1e-4)).astype(np.float32), dev)                               # sigmoid(occ) + 1e-4
+        self.occ_lut = _dev(self.occ_values, dev)
+
+
+class _Block:
+    """One residual block: its convolutions, optional strided shortcut, and the quantizer after the add."""
+
+    def __init__(self, state, name, in_q, stride, bottleneck, dev, f32_input=False):
+        self.name, self.stride, self.bottleneck, self.f32_input = name, stride, bottleneck, f32_input
+        if bottleneck:
+            self.conv1 = _DenseF32In(state, name + ".conv1", dev, conv=True) if f32_input else _Conv1x1(state, name + ".conv1", in_q, 1, dev)
+            self.conv2 = _GConv(state, name + ".conv2", self.conv1.out_q, stride, dev)
+            self.conv3 = _Conv1x1(state, name + ".conv3", self.conv2.out_q, 1, dev)
+            self.cout = self.conv3.cout
+        else:
+            self.conv1 = _ConvLayer(state, name + ".conv1", [(0, 64, in_q[0], in_q[1])], stride, dev)
+            self.conv2 = _ConvLayer(state, name + ".conv2", [(0, self.conv1.cout, *self.conv1.out_q)], 1, dev)
+            self.cout = self.conv2.cout
+        self.down = None
+        if (name + ".downsample/w_code") in state:
+            if f32_input:
+                raise NotImplementedError(f"{name}: a 1x1 shortcut on an fp32 input")
+            self.down = _Conv1x1(state, name + ".downsample", in_q, stride, dev)
+        self.in_q, self.out_q = in_q, _q(state, name)
+
+
+class DeployedPyramidModel(nn.Module):
+    """Same call contract as the reference's model: ``out = model(data_dict)`` (the hard ``encode -> decode`` path of
+    ``forward_with_encdec``), plus ``encode_features`` / ``decode_features`` as the reference's encdec class exposes them."""
+
+    def __init__(self, state: Dict[str, np.ndarray], device="cuda"):
+        super().__init__()
+        self.lib = L.load()
+        if not torch.cuda.is_available():
+            raise L.Qv2xError("DeployedPyramidModel needs an MI355X (torch.cuda.is_available() is False)")
+        if str(state.get("meta/fusion_method", "att")) != "pyramid":
+            raise NotImplementedError("DeployedPyramidModel: a PTQ state exported from the Pyramid model")
+        self.state, self.dev = state, torch.device(device)
+        s, dev = state, self.dev
+        self.nx, self.ny, _ = (int(v) for v in s["meta/grid"])
+        self.hm, self.wm = (float(v) for v in s["meta/HW_metres"])
+        self.ratio = float(s["meta/discrete_ratio"])
+        self.has_codebook = True
+
+        n = "encoder_m1.pillar_vfe.pfn_layers.0.linear"
+        wq = ((s[n + "/w_code"].astype(np.float32) - s[n + "/w_zp"].astype(np.float32)[:, None]) * s[n + "/w_delta"].astype(np.float32)[:, None]).astype(np.float32)
+        if wq.shape != (64, 10):
+            raise NotImplementedError("deployed PFN expects Linear(10 -> 64)")
+        p = L.PfnParams()
+        p.w[:] = wq.reshape(-1).tolist()
+        p.b[:] = s[n + "/bias"].astype(np.float32).tolist()
+        p.d1, p.z1 = float(np.float32(s[n + "/a_delta"])), float(s[n + "/a_zp"])
+        p.d2, p.z2 = float(np.float32(s["pfn/a2_delta"])), float(s["pfn/a2_zp"])
+        p.vox[:] = [float(np.float32(v)) for v in s["meta/voxel"]]
+        p.off[:] = [float(np.float32(v)) for v in s["meta/offset"]]
+        self.pfn = p
+        q = (p.d2, int(p.z2))
+
+        # ---- the agent's ResNet level ------------------------------------------------------------------------------------------
+        nums, strides = [int(v) for v in s["meta/layer_nums"]], [int(v) for v in s["meta/layer_strides"]]
+        self.agent_stride = strides[0]
+        self.agent_blocks: List[_Block] = []
+        for b in range(nums[0]):
+            blk = _Block(s, f"backbone_m1.resnet.layer0.{b}", q, strides[0] if b == 0 else 1, False, dev)
+            self.agent_blocks.append(blk)
+            q = blk.out_q
+        self.agent_q = q
+        # ---- codebook (D = 64): the encode kernel is the 256-wide one on zero-padded heads (bit-identical sums, see _level_blob) --
+        self.levels = int(s["meta/codebook_levels"])
+        self.kc, self.D = (int(v) for v in s["codebook/0/codebook"].shape)
+        if self.D > 256 or self.D % 4 or self.agent_blocks[-1].cout != self.D:
+            raise NotImplementedError("deployed Pyramid codebook: width <= 256 equal to the agent feature's channels")
+        lut, lut_bias = decode_tables(s, self.levels, self.D)
+        self.lut, self.lut_bias = _dev(lut, dev), _dev(lut_bias, dev)
+        self.level_blobs = [self._level_blob(l) for l in range(self.levels)]
+        self.level_ptrs = (C.c_void_p * self.levels)(*[b.data_ptr() for b in self.level_blobs])
+        # ---- the pyramid: ResNeXt levels, occupancy heads, deblocks -------------------------------------------------------------------
+        p_nums, p_strides = [int(v) for v in s["meta/pyramid_layer_nums"]], [int(v) for v in s["meta/pyramid_layer_strides"]]
+        self.ups = [int(v) for v in s["meta/upsample_strides"]]
+        self.p_strides = p_strides
+        self.pyr_blocks: List[List[_Block]] = []
+        self.occ: List[_Occ] = []
+        self.deblocks: List[_DenseF32In] = []
+        q, cat_groups, c0 = None, [], 0
+        for lvl in range(len(p_nums)):
+            blocks = []
+            for b in range(p_nums[lvl]):
+                blk = _Block(s, f"pyramid_backbone.resnet.layer{lvl}.{b}", q, p_strides[lvl] if b == 0 else 1, True, dev, f32_input=q is None)
+                blocks.append(blk)
+                q = blk.out_q
+            self.pyr_blocks.append(blocks)
+            self.occ.append(_Occ(s, f"pyramid_backbone.single_head_{lvl}", q, dev))
+            de = _DenseF32In(s, f"pyramid_backbone.deblocks.{lvl}.0", dev)
+            self.deblocks.append(de)
+            cat_groups.append((c0, de.cout, de.out_q[0], de.out_q[1]))
+            c0 += de.cout
+        self.cat_channels = c0
+        self.shrink0 = _ConvLayer(s, "shrink_conv.layers.0.double_conv.0", cat_groups, 1, dev)
+        self.shrink1 = _ConvLayer(s, "shrink_conv.layers.0.double_conv.1", [(0, self.shrink0.cout, *self.shrink0.out_q)], 1, dev)
+        if self.shrink1.cout != 256:
+            raise NotImplementedError("deployed path expects a 256-channel map in front of the heads")
+        self.heads = _Heads(s, "", dev)
+        self._bufs: Dict[tuple, dict] = {}
+
+    # ------------------------------------------------------------------------------------------------------------------------------
+    def _level_blob(self, l: int) -> torch.Tensor:
+        """The level's heads zero-padded to the 256-wide layout of qv2x_codebook_encode_f32: every extra term of every fma chain is
+        0 * 0, the padded |.|^2 chains are exactly 0, so codes equal a native D-wide evaluation bit for bit."""
+        s, kc, D = self.state, self.kc, self.D
+        g = lambda n: s[f"codebook/{l}/{n}"].astype(np.float32)
+
+        def pw(w):
+            out = np.zeros((256, 256), np.float32); out[:D, :D] = w; return _pack_k4p(out)
+
+        def pb(b):
+            out = np.zeros(256, np.float32); out[:D] = b; return out
+        last = f"codebook/{l}/lhead_w" not in s
+        cb = np.zeros((kc, 256), np.float32); cb[:, :D] = g("codebook")
+        parts = [pw(g("stage_w")), pb(g("stage_b")), pw(g("qhead_w")), pb(g("qhead_b")),
+                 np.zeros((64, 256, 4), np.float32) if last else pw(g("lhead_w")), np.zeros(256, np.float32) if last else pb(g("lhead_b")),
+                 _pack_k4p(cb), cb, np.zeros(kc, np.float32)]
+        flat = np.concatenate([p.reshape(-1) for p in parts])
+        assert flat.size == self.lib.qv2x_codebook_level_floats(kc)
+        blob = _dev(flat, self.dev)
+        cb_off = flat.size - kc - kc * 256
+        L.check(self.lib.qv2x_codebook_c2_f32(C.c_void_p(blob.data_ptr() + 4 * cb_off), kc, C.c_void_p(blob.data_ptr() + 4 * (flat.size - kc)),
+                                              L.current_stream()), "qv2x_codebook_c2_f32")
+        return blob
+
+    def _padded(self, n, h, w, c, zp):
+        t = torch.empty((n, h + 2, w + 2, c), dtype=torch.int8, device=self.dev)
+        t.fill_(int(zp) - 128)
+        return t
+
+    @staticmethod
+    def _same_zp(qs, what):
+        zps = {int(q[1]) for q in qs}
+        if len(zps) != 1:
+            raise NotImplementedError(f"{what}: the layers sharing this buffer must share a zero point (post-ReLU quantizers: 0)")
+        return zps.pop()
+
+    def _agent_ws(self, n: int) -> dict:
+        key = ("agent", n)
+        if key in self._bufs:
+            return self._bufs[key]
+        b = {}
+        h, w, st = self.ny, self.nx, self.agent_stride
+        self.fh, self.fw = (h - 1) // st + 1, (w - 1) // st + 1
+        fh, fw = self.fh, self.fw
+        b["canvas"] = self._padded(n, h, w, 64, self.pfn.z2)
+        b["c1"] = self._padded(n, fh, fw, 64, self._same_zp([blk.conv1.out_q for blk in self.agent_blocks], "agent conv1"))
+        zp = self._same_zp([blk.out_q for blk in self.agent_blocks], "agent blocks")
+        b["x"] = [self._padded(n, fh, fw, 64, zp) for _ in range(2)]
+        b["enc_in"] = self._padded(n, fh, fw, 256, zp)                      # the last block writes channels [0, D); the rest stay "0.0"
+        b["ds"] = torch.empty((n * fh * fw, 64), dtype=torch.float32, device=self.dev)
+        b["codes"] = torch.empty((self.levels, n, fh * fw), dtype=torch.uint8, device=self.dev)
+        self._bufs[key] = b
+        return b
+
+    def _ego_ws(self, n: int, nb: int) -> dict:
+        key = ("ego", n, nb)
+        if key in self._bufs:
+            return self._bufs[key]
+        self._agent_ws(1)
+        b = {"feats": torch.empty((n * self.fh * self.fw, self.D), dtype=torch.float32, device=self.dev), "lvl": []}
+        h, w = self.fh, self.fw
+        for lvl, blocks in enumerate(self.pyr_blocks):
+            hi, wi = h, w
+            st = self.p_strides[lvl]
+            h, w = (h - 1) // st + 1, (w - 1) // st + 1
+            width, planes = blocks[0].conv2.c, blocks[0].cout
+            lv = {"h": h, "w": w, "hi": hi, "wi": wi}
+            z1 = self._same_zp([blk.conv1.out_q for blk in blocks], f"level {lvl} conv1")
+            lv["t1_in"] = self._padded(n, hi, wi, width, z1)                # conv1 of the first block runs at the input resolution
+            lv["t1"] = self._padded(n, h, w, width, z1)
+            lv["t2"] = self._padded(n, h, w, width, self._same_zp([blk.conv2.out_q for blk in blocks], f"level {lvl} conv2"))
+            zx = self._same_zp([blk.out_q for blk in blocks], f"level {lvl} blocks")
+            lv["x"] = [self._padded(n, h, w, planes, zx) for _ in range(2)]
+            lv["ds"] = torch.empty((n * h * w, planes), dtype=torch.float32, device=self.dev)
+            lv["score"] = torch.empty((n, h * w), dtype=torch.float32, device=self.dev)
+            lv["occ_code"] = torch.empty((n, h * w), dtype=torch.uint8, device=self.dev)
+            lv["fused"] = torch.empty((nb, h * w, planes), dtype=torch.float32, device=self.dev)
+            b["lvl"].append(lv)
+        fh, fw = b["lvl"][0]["h"] * self.ups[0], b["lvl"][0]["w"] * self.ups[0]
+        for lvl, lv in enumerate(b["lvl"]):
+            if (lv["h"] * self.ups[lvl], lv["w"] * self.ups[lvl]) != (fh, fw):
+                raise ValueError(f"deblock {lvl} gives {lv['h'] * self.ups[lvl]}x{lv['w'] * self.ups[lvl]}, level 0 gives {fh}x{fw}: the grid does not "
+                                 "line up across pyramid levels (the reference's torch.cat raises here)")
+        self.oh, self.ow = fh, fw
+        cat = torch.empty((nb, fh + 2, fw + 2, self.cat_channels), dtype=torch.int8, device=self.dev)
+        c0 = 0
+        for de in self.deblocks:
+            cat[..., c0:c0 + de.cout] = int(de.out_q[1]) - 128
+            c0 += de.cout
+        b["cat"] = cat
+        b["s0"] = self._padded(nb, fh, fw, self.shrink0.cout, self.shrink0.out_q[1])
+        b["s1"] = self._padded(nb, fh, fw, self.shrink1.cout, self.shrink1.out_q[1])
+        b["rows"] = torch.empty((nb * fh * fw, 256), dtype=torch.float32, device=self.dev)
+        self._bufs[key] = b
+        return b
+
+    # ---- launch helpers ------------------------------------------------------------------------------------------------------------
+    def _conv3x3(self, layer: _ConvLayer, x, n, h, w, out, out_q, res_mode=0, res=None, res_q=(0.0, 128)):
+        d = L.ConvDesc()
+        d.n, d.h, d.w, d.cin_total, d.stride, d.cout = n, h, w, x.shape[-1], layer.stride, layer.cout
+        d.ngroups = len(layer.groups)
+        for i, (c0, c, zx) in enumerate(layer.groups):
+            d.group_c0[i], d.group_c[i], d.group_zx[i] = c0, c, zx
+        d.out_ctotal, d.out_c0, d.relu = out.shape[-1], 0, 1
+        d.out_delta, d.out_zp = out_q[0], float(out_q[1])
+        st = L.current_stream()
+        if res_mode:
+            L.check(self.lib.qv2x_conv3x3_i8_res(C.byref(d), L.ptr(x), L.ptr(layer.w), L.ptr(layer.scale), L.ptr(layer.corr), L.ptr(layer.aw),
+                                                 L.ptr(layer.bias), res_mode, L.ptr(res), int(res_q[1]), float(res_q[0]), L.ptr(out), st), layer.name)
+            return
+        if self.lib.qv2x_conv3x3_i8_wide_ok(C.byref(d)):
+            if layer.w_wide is None:
+                layer.w_wide = torch.empty_like(layer.w)
+                L.check(self.lib.qv2x_conv3x3_i8_pack_wide(C.byref(d), L.ptr(layer.w), L.ptr(layer.w_wide), st), layer.name)
+            L.check(self.lib.qv2x_conv3x3_i8_wide(C.byref(d), L.ptr(x), L.ptr(layer.w_wide), L.ptr(layer.scale), L.ptr(layer.corr), L.ptr(layer.aw),
+                                                  L.ptr(layer.bias), L.ptr(out), st), layer.name)
+            return
+        L.check(self.lib.qv2x_conv3x3_i8(C.byref(d), L.ptr(x), L.ptr(layer.w), L.ptr(layer.scale), L.ptr(layer.corr), L.ptr(layer.aw),
+                                         L.ptr(layer.bias), L.ptr(out), st), layer.name)
+
+    def _conv1x1(self, layer: _Conv1x1, x, n, h, w, out, mode, out_q=None, res=None, res_q=(0.0, 128)):
+        d = L.Conv1x1Desc()
+        d.n, d.h, d.w, d.cin, d.cout, d.stride = n, h, w, layer.cin, layer.cout, layer.stride
+        d.mode, d.relu = mode, 1
+        if mode != 1:
+            d.out_ctotal, d.out_c0 = out.shape[-1], 0
+            d.out_delta, d.out_zp = out_q[0], float(out_q[1])
+        d.res_zx, d.res_delta = int(res_q[1]), float(res_q[0])
+        L.check(self.lib.qv2x_conv1x1_i8(C.byref(d), L.ptr(x), L.ptr(layer.w), L.ptr(layer.scale), L.ptr(layer.corr), L.ptr(layer.aw), L.ptr(layer.bias),
+                                         L.ptr(res), L.ptr(out), L.current_stream()), layer.name)
+
+    def _gconv(self, layer: _GConv, x, n, h, w, out):
+        d = L.GconvDesc()
+        d.n, d.h, d.w, d.c, d.cg, d.stride, d.relu = n, h, w, layer.c, layer.cg, layer.stride, 1
+        d.out_delta, d.out_zp = layer.out_q[0], float(layer.out_q[1])
+        L.check(self.lib.qv2x_gconv3x3_i8(C.byref(d), L.ptr(x), L.ptr(layer.w), L.ptr(layer.scale), L.ptr(layer.corr), L.ptr(layer.aw), L.ptr(layer.bias),
+                                          L.ptr(out), L.current_stream()), layer.name)
+
+    def _dense_f32in(self, de: _DenseF32In, x, n, h, w, out, out_c0=0):
+        d = L.DeconvDesc()
+        d.n, d.h, d.w, d.cin, d.cout, d.s = n, h, w, de.cin, de.cout, de.s
+        d.in_zx, d.in_delta = 0, 1.0
+        d.out_ctotal, d.out_c0, d.relu = out.shape[-1], out_c0, 1
+        d.out_delta, d.out_zp = de.out_q[0], float(de.out_q[1])
+        d.out_h, d.out_w = out.shape[1] - 2, out.shape[2] - 2
+        L.check(self.lib.qv2x_deconv_f32in(C.byref(d), L.ptr(x), L.ptr(de.w), L.ptr(de.bias), L.ptr(out), L.current_stream()), de.name)
+
+    # ---- what an agent runs before the link ---------------------------------------------------------------------------------------------
+    def pillars_to_canvas(self, inputs: dict, n: int):
+        b = self._agent_ws(n)
+        st = L.current_stream()
+        vf = inputs["voxel_features"].contiguous()
+        co = inputs["voxel_coords"].to(torch.int32).contiguous()
+        npnt = inputs["voxel_num_points"].to(torch.int32).contiguous()
+        if vf.dtype != torch.float32 or vf.dim() != 3 or tuple(vf.shape[1:]) != (32, 4):
+            raise ValueError("voxel_features must be float32 [M, 32, 4]")
+        canvas = b["canvas"]
+        L.check(self.lib.qv2x_fill_i8(L.ptr(canvas), canvas.numel(), int(self.pfn.z2) - 128, st), "qv2x_fill_i8")
+        L.check(self.lib.qv2x_pfn_scatter_i8(L.ptr(vf), L.ptr(co), L.ptr(npnt), vf.shape[0], 32, C.byref(self.pfn), L.ptr(canvas), n, self.ny, self.nx, st),
+                "qv2x_pfn_scatter_i8")
+        return canvas
+
+    def agent_backbone(self, n: int, taps: Optional[dict] = None):
+        b = self._agent_ws(n)
+        x, h, w, xq = b["canvas"], self.ny, self.nx, (self.pfn.d2, int(self.pfn.z2))
+        for i, blk in enumerate(self.agent_blocks):
+            last = i == len(self.agent_blocks) - 1
+            out = b["enc_in"] if last else b["x"][i % 2]
+            self._conv3x3(blk.conv1, x, n, h, w, b["c1"], blk.conv1.out_q)
+            if blk.down is not None:
+                self._conv1x1(blk.down, x, n, h, w, b["ds"], 1)
+                self._conv3x3(blk.conv2, b["c1"], n, self.fh, self.fw, out, blk.out_q, 2, b["ds"])
+            else:
+                self._conv3x3(blk.conv2, b["c1"], n, self.fh, self.fw, out, blk.out_q, 3, x, xq)
+            if taps is not None:
+                taps[blk.name + ".conv1"], taps[blk.name] = b["c1"].clone(), out[..., :blk.cout].clone()
+            x, h, w, xq = out, self.fh, self.fw, blk.out_q
+        return x
+
+    def encode_codes(self, n: int, out: Optional[torch.Tensor] = None):
+        b = self._agent_ws(n)
+        codes = b["codes"] if out is None else out
+        if codes.dtype != torch.uint8 or not codes.is_contiguous() or codes.numel() != self.levels * n * self.fh * self.fw:
+            raise ValueError("encode_codes: out must be a contiguous uint8 tensor [levels, n_agents, H*W]")
+        d = L.EncodeDesc()
+        d.n, d.h, d.w, d.levels, d.kc = n, self.fh, self.fw, self.levels, self.kc
+        d.in_zx, d.in_delta = int(self.agent_q[1]), float(self.agent_q[0])
+        L.check(self.lib.qv2x_codebook_encode_f32(C.byref(d), L.ptr(b["enc_in"]), self.level_ptrs, L.ptr(codes), L.current_stream()), "qv2x_codebook_encode_f32")
+        return codes
+
+    @torch.no_grad()
+    def encode_features(self, inputs: dict, n: int, taps: Optional[dict] = None, out: Optional[torch.Tensor] = None):
+        """codes u8 [levels, n, H*W] of ``n`` agents (heter_pyramid_collab_codebook_mc_encdec.py:33-121)."""
+        canvas = self.pillars_to_canvas(inputs, n)
+        if taps is not None:
+            taps["canvas"] = canvas
+        self.agent_backbone(n, taps)
+        return self.encode_codes(n, out)
+
+    # ---- what the ego runs on the received codes ------------------------------------------------------------------------------------------
+    def _block(self, blk: _Block, x, xq, n, h, w, lv, out, feats_f32=None):
+        """One bottleneck: ``x`` codes at (h, w) (or the fp32 decoded map), result codes in ``out`` at the level's resolution."""
+        ho, wo = lv["h"], lv["w"]
+        t1 = lv["t1_in"] if (h, w) != (ho, wo) else lv["t1"]
+        if blk.f32_input:
+            self._dense_f32in(blk.conv1, feats_f32, n, h, w, t1)
+        else:
+            self._conv1x1(blk.conv1, x, n, h, w, t1, 0, blk.conv1.out_q)
+        self._gconv(blk.conv2, t1, n, h, w, lv["t2"])
+        if blk.down is not None:
+            self._conv1x1(blk.down, x, n, h, w, lv["ds"], 1)
+            self._conv1x1(blk.conv3, lv["t2"], n, ho, wo, out, 2, blk.out_q, lv["ds"])
+        elif blk.f32_input:
+            self._conv1x1(blk.conv3, lv["t2"], n, ho, wo, out, 2, blk.out_q, feats_f32)
+        else:
+            self._conv1x1(blk.conv3, lv["t2"], n, ho, wo, out, 3, blk.out_q, x, xq)
+
+    def _fuse_desc(self, n, h, w, max_cav, ego):
+        d = L.FuseDesc()
+        d.agents, d.h, d.w, d.levels, d.kc = n, h, w, 1, 1
+        d.max_cav, d.ego = max_cav, ego
+        d.h_metres, d.w_metres, d.discrete_ratio = self.hm, self.wm, self.ratio
+        return d
+
+    @torch.no_grad()
+    def decode_features(self, codes, agent_stride: int, level_stride: int, lens: List[int], pairwise: torch.Tensor, ego: int = 0,
+                        taps: Optional[dict] = None) -> dict:
+        """``codes``: pointer / tensor of u8 planes, agent a's level-l plane at ``a * agent_stride + l * level_stride``; ``lens`` agents per
+        scene; ``pairwise`` f64 [B, L, L, 4, 4] (heter_pyramid_collab_codebook_mc_encdec.py:123-181)."""
+        n, nb = sum(lens), len(lens)
+        b = self._ego_ws(n, nb)
+        hw = self.fh * self.fw
+        st = L.current_stream
+        cptr = codes if isinstance(codes, C.c_void_p) else L.ptr(codes)
+        L.check(self.lib.qv2x_codebook_decode_f32(cptr, agent_stride, level_stride, n, hw, self.levels, self.kc, self.D, L.ptr(self.lut), L.ptr(self.lut_bias),
+                                                  L.ptr(b["feats"]), st()), "qv2x_codebook_decode_f32")
+        x, xq, h, w = None, None, self.fh, self.fw
+        occ_maps, c0 = [], 0
+        for lvl, blocks in enumerate(self.pyr_blocks):
+            lv = b["lvl"][lvl]
+            for i, blk in enumerate(blocks):
+                out = lv["x"][i % 2]
+                self._block(blk, x, xq, n, h, w, lv, out, b["feats"])
+                x, xq, h, w = out, blk.out_q, lv["h"], lv["w"]
+                if taps is not None:
+                    taps[blk.name] = out.clone()
+            oc = self.occ[lvl]
+            d = L.OccDesc()
+            d.n, d.h, d.w, d.c, d.aw, d.corr = n, h, w, oc.c, oc.aw, oc.corr
+            d.scale, d.bias, d.out_delta, d.out_zp = oc.scale, oc.bias, oc.out_q[0], float(oc.out_q[1])
+            L.check(self.lib.qv2x_occ_score_i8(C.byref(d), L.ptr(x), L.ptr(oc.w), L.ptr(oc.lut), L.ptr(lv["score"]), L.ptr(lv["occ_code"]), st()), oc.name)
+            occ_maps.append(oc.occ_lut[lv["occ_code"].long()].view(n, 1, h, w))
+            start = 0
+            for bi, na in enumerate(lens):
+                fd = self._fuse_desc(na, h, w, pairwise.shape[1], ego)
+                L.check(self.lib.qv2x_pyramid_weighted_fuse_i8(C.byref(fd), blocks[-1].cout, L.ptr(x[start:start + na]), int(xq[1]), float(xq[0]),
+                                                               L.ptr(lv["score"][start:start + na]), L.ptr(pairwise[bi]), L.ptr(lv["fused"][bi]), st()),
+                        "qv2x_pyramid_weighted_fuse_i8")
+                start += na
+            de = self.deblocks[lvl]
+            self._dense_f32in(de, lv["fused"], nb, h, w, b["cat"], c0)
+            c0 += de.cout
+            if taps is not None:
+                taps[f"occ_code{lvl}"], taps[f"score{lvl}"], taps[f"fused{lvl}"] = lv["occ_code"].clone(), lv["score"].clone(), lv["fused"].clone()
+        oh, ow = self.oh, self.ow
+        self._conv3x3(self.shrink0, b["cat"], nb, oh, ow, b["s0"], self.shrink0.out_q)
+        self._conv3x3(self.shrink1, b["s0"], nb, oh, ow, b["s1"], self.shrink1.out_q)
+        q = self.shrink1.out_q
+        L.check(self.lib.qv2x_dequant_i8_f32(L.ptr(b["s1"]), nb, oh, ow, 256, int(q[1]), float(q[0]), L.ptr(b["rows"]), st()), "qv2x_dequant_i8_f32")
+        hd = self.heads
+        preds = torch.empty((nb, hd.cout, oh, ow), dtype=torch.float32, device=self.dev)
+        L.check(self.lib.qv2x_heads_f32(L.ptr(b["rows"]), nb * oh * ow, oh * ow, hd.cout, hd.cout_pad, L.ptr(hd.w), L.ptr(hd.bias), L.ptr(hd.da), L.ptr(hd.za),
+                                        L.ptr(preds), st()), "qv2x_heads_f32")
+        if taps is not None:
+            taps["cat"], taps[self.shrink0.name], taps[self.shrink1.name], taps["features"] = b["cat"], b["s0"], b["s1"], b["feats"]
+        c, r, _ = hd.splits
+        return {"pyramid": "collab", "cls_preds": preds[:, :c], "reg_preds": preds[:, c:c + r], "dir_preds": preds[:, c + r:], "preds_tensor": preds,
+                "occ_single_list": occ_maps}
+
+    # ---- the reference's model contract ------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, data_dict: dict, taps: Optional[dict] = None) -> dict:
+        agents = data_dict["agent_modality_list"]
+        n_total = len(agents)
+        if any(str(a) != "m1" for a in agents):
+            raise NotImplementedError("deployed path: every agent is the LiDAR modality 'm1'")
+        pairwise = data_dict["pairwise_t_matrix"]
+        if pairwise.dtype != torch.float64 or not pairwise.is_contiguous():
+            pairwise = pairwise.to(torch.float64).contiguous()
+        if pairwise.shape[0] == 1:
+            lens = [n_total]
+        else:
+            rl = data_dict["record_len"]
+            if isinstance(rl, torch.Tensor) and rl.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise ValueError("record_len on the GPU cannot be read during HIP-graph capture: pass a CPU tensor")
+            lens = [int(v) for v in (rl.tolist() if isinstance(rl, torch.Tensor) else rl)]
+        codes = self.encode_features(data_dict["inputs_m1"], n_total, taps)
+        hw = self.fh * self.fw
+        if taps is not None:
+            taps["codes"] = codes
+        return self.decode_features(codes, hw, n_total * hw, lens, pairwise, 0, taps)
+
+    forward_with_encdec = forward
+
+    def capture(self, data_dict: dict):
+        """One frame as a HIP graph (see ``DeployedModel.capture``: fixed pillar count, CPU ``record_len``)."""
+        rl = data_dict.get("record_len")
+        if data_dict["pairwise_t_matrix"].shape[0] > 1 and isinstance(rl, torch.Tensor) and rl.is_cuda:
+            data_dict = dict(data_dict, record_len=rl.cpu())
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self.forward(data_dict)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self.forward(data_dict)
+
+        def replay():
+            graph.replay()
+            return out
+        replay.graph = graph
+        return replay

@@ -19,7 +19,8 @@ SYMBOLS = [
     "qv2x_decode_lut_f32", "qv2x_dequant_i8_f32", "qv2x_heads_f32", "qv2x_decode_heads_f32", "qv2x_heads_pair_f32", "qv2x_voxelize_workspace_bytes", "qv2x_voxelize_f32",
     "qv2x_postprocess_workspace_bytes", "qv2x_postprocess_f32",
     "qv2x_conv3x3_f32", "qv2x_deconv_f32", "qv2x_pfn_scatter_f32", "qv2x_codebook_encode_f32in",
-    "qv2x_pyramid_weighted_fuse_f32",
+    "qv2x_pyramid_weighted_fuse_f32", "qv2x_pyramid_weighted_fuse_i8", "qv2x_conv1x1_i8", "qv2x_gconv3x3_i8", "qv2x_conv3x3_i8_res",
+    "qv2x_deconv_f32in", "qv2x_codebook_decode_f32", "qv2x_occ_score_i8",
     "qv2x_comm_unique_id", "qv2x_comm_init", "qv2x_comm_destroy", "qv2x_allgather_codes", "qv2x_pairwise_from_poses_f64",
 ]
 COMM_ID_BYTES = 128
@@ -56,6 +57,22 @@ class DeconvDesc(C.Structure):
 class F32ConvDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cin_total", C.c_int32), ("cin0", C.c_int32), ("cin", C.c_int32),
                 ("stride", C.c_int32), ("cout", C.c_int32), ("out_ctotal", C.c_int32), ("out_c0", C.c_int32), ("relu", C.c_int32)]
+
+
+class Conv1x1Desc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("stride", C.c_int32),
+                ("mode", C.c_int32), ("relu", C.c_int32), ("out_ctotal", C.c_int32), ("out_c0", C.c_int32),
+                ("out_delta", C.c_float), ("out_zp", C.c_float), ("res_zx", C.c_int32), ("res_delta", C.c_float)]
+
+
+class GconvDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32), ("cg", C.c_int32), ("stride", C.c_int32),
+                ("relu", C.c_int32), ("out_delta", C.c_float), ("out_zp", C.c_float)]
+
+
+class OccDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32), ("aw", C.c_int32), ("corr", C.c_int32),
+                ("scale", C.c_float), ("bias", C.c_float), ("out_delta", C.c_float), ("out_zp", C.c_float)]
 
 
 class EncodeDesc(C.Structure):
@@ -132,6 +149,13 @@ def load() -> C.CDLL:
                                          C.POINTER(C.c_float), vp, C.c_int, C.c_int, C.c_int, vp]
     lib.qv2x_codebook_encode_f32in.argtypes = [C.POINTER(EncodeDesc), vp, C.POINTER(vp), vp, vp]
     lib.qv2x_pyramid_weighted_fuse_f32.argtypes = [C.POINTER(FuseDesc), C.c_int, vp, vp, vp, vp, vp]
+    lib.qv2x_pyramid_weighted_fuse_i8.argtypes = [C.POINTER(FuseDesc), C.c_int, vp, C.c_int, C.c_float, vp, vp, vp, vp]
+    lib.qv2x_conv1x1_i8.argtypes = [C.POINTER(Conv1x1Desc), vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.qv2x_gconv3x3_i8.argtypes = [C.POINTER(GconvDesc), vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.qv2x_conv3x3_i8_res.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_float, vp, vp]
+    lib.qv2x_deconv_f32in.argtypes = [C.POINTER(DeconvDesc), vp, vp, vp, vp, vp]
+    lib.qv2x_codebook_decode_f32.argtypes = [vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
+    lib.qv2x_occ_score_i8.argtypes = [C.POINTER(OccDesc), vp, vp, vp, vp, vp, vp]
     lib.qv2x_comm_unique_id.argtypes = [vp]
     lib.qv2x_comm_init.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
     lib.qv2x_comm_destroy.argtypes = [vp]
