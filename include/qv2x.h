@@ -345,6 +345,16 @@ int qv2x_deconv_f32in(const qv2x_deconv_desc* desc /* host */, const float* in, 
 int qv2x_codebook_decode_f32(const uint8_t* codes, int64_t agent_stride, int64_t level_stride, int agents, int hw, int levels,
                              int kc, int d, const float* lut, const float* bias, float* out, void* stream);
 
+/* qv2x_codebook_encode_f32 for the Pyramid model's 64-wide codebook (heter_pyramid_collab_codebook_mc.py:25-51): D = 64, the first 64
+ * channels of a padded i8 BEV with cin_total channels.  One f32 blob per level:
+ *       stage [16][64][4] | stage_b [64] | qhead [16][64][4] | qhead_b [64] | lhead [16][64][4] | lhead_b [64]
+ *       | cb_packed [16][Kc][4] | cb [Kc][64] | c2 [Kc]          (qv2x_codebook64_level_floats(Kc) floats; layouts as the D = 256 entry)
+ * c2 = |C_k|^2 as ONE 64-wide ascending fma chain (qv2x_codebook64_c2_f32). */
+int64_t qv2x_codebook64_level_floats(int kc);
+int qv2x_codebook64_c2_f32(const float* codebook, int kc, float* c2, void* stream);
+int qv2x_codebook_encode64_f32(const qv2x_encode_desc* desc /* host */, int cin_total, const int8_t* in,
+                               const float* const* level_weights /* host array of device pointers */, uint8_t* codes, void* stream);
+
 /* One level's 1x1 occupancy head (QuantModule c -> 1 with its output quantizer, quant_block.py:475-479, :507-509):
  *     T exact;  y = bias + float(T) * scale;  code = quant(y);  score = score_lut[code]
  *   (score_lut[k] = sigmoid((k - out_zp) * out_delta) + 1e-4, built once by the caller);  in padded i8 BEV [N][H+2][W+2][c],

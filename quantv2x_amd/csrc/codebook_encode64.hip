@@ -1,0 +1,235 @@
+// f3: UMGMQuantizer.encode for the Pyramid model's 64-wide codebook (heter_pyramid_collab_codebook_mc.py:25-51, codebook.py:330-337),
+// m = 1, fused over the residual levels on v_mfma_f32_32x32x2_f32 -- the D = 64 sibling of codebook_encode.hip (same op order, same
+// ascending-k fma chains with acc0 = bias, bit-exact against oracle/qv2x_oracle.c:orc_codebook_encode_d).
+//
+// 11x fewer MACs per row than D = 256 and every matrix is 16 KB, so the shape changes: a workgroup of FOUR waves owns 64 BEV cells;
+// each wave owns one 32 x 32 tile of the 64 x 64 GEMM outputs (row tile = wave >> 1, column tile = wave & 1) and two 32 x 32
+// (rows x codes) tiles of the distance GEMM.  x / z / q live in two LDS buffers (row stride 66 floats), the weights stream from L2
+// as [K/4][col][k0, k2, k1, k3] with the next four k-quads requested ahead of the current MFMAs; 34 KB of LDS: four workgroups per CU.
+#include "common.h"
+
+namespace qv2x {
+namespace {
+
+constexpr int D = 64, ER = 64, LDF = 66;
+__device__ __forceinline__ int kpos(int c) { return (c & ~3) | ((c & 1) << 1) | ((c >> 1) & 1); }
+
+struct Enc64Args {
+    const int8_t* in; uint8_t* codes;
+    const float* lvl[4];
+    int n, h, w, cin_total, levels, kc, ax, M;
+    float dx;
+};
+
+// this wave's 32 x 32 tile of in[64][64] . W^T (+ bias): rows [32 rt, +32), columns [32 ctile, +32)
+__device__ __forceinline__ void gemm_tile(const float* __restrict__ src, const float2* __restrict__ wp, const float* __restrict__ bias,
+                                          int rt, int ctile, int lane, v16f& acc) {
+    const int par = lane >> 5, col = ctile * 32 + (lane & 31);
+    const float b = bias[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = b;
+    const float2* wl = wp + (size_t)col * 2 + par;
+    const float* al = src + (rt * 32 + (lane & 31)) * LDF + 2 * par;
+    float2 s[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)                       // all 16 k-quads of this column: 16 float2 per lane, requested up front
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s[g][t] = wl[(size_t)(g * 4 + t) * D * 2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float2 av[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) av[t] = *(const float2*)(al + (g * 4 + t) * 4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].x, s[g][t].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].y, s[g][t].y, acc, 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ unsigned long long dist_key(float d, int code) {
+    unsigned b = __builtin_bit_cast(unsigned, d);
+    b ^= (unsigned)((int)b >> 31) | 0x80000000u;
+    return ((unsigned long long)b << 32) | (unsigned)code;
+}
+
+template <int CTRL>
+__device__ __forceinline__ void keymin_dpp(unsigned long long& k) {
+    const int lo = (int)(unsigned)k, hi = (int)(unsigned)(k >> 32);
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+    k = o < k ? o : k;
+}
+
+__device__ __forceinline__ void store_tile(float* __restrict__ dst, int rt, int ctile, int lane, const v16f& acc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[(rt * 32 + mfma32_row(r, lane)) * LDF + kpos(ctile * 32 + (lane & 31))] = acc[r];
+}
+
+__global__ __launch_bounds__(256, 4) void codebook_encode64_kernel(const Enc64Args a) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * ER * LDF + ER + 8 * ER + ER];
+    float* bufA = smem;                       // x, then q, then next x
+    float* bufB = smem + ER * LDF;            // z
+    float* x2 = smem + 2 * ER * LDF;          // [ER]
+    unsigned long long* pkey = (unsigned long long*)(x2 + ER);      // [4 code tiles][ER]
+    int* code_s = (int*)(pkey + 4 * ER);      // [ER]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rt = wave >> 1, ctile = wave & 1;
+    const int m0 = blockIdx.x * ER;
+    {   // 64 rows x 64 channels from the i8 BEV, dequantized: four threads per row, 16 channels each
+        const int row = tid >> 2, part = tid & 3;
+        int m = m0 + row;
+        m = m < a.M ? m : a.M - 1;
+        const int img = m / (a.h * a.w), rem = m - img * (a.h * a.w);
+        const int y = rem / a.w, x = rem - y * a.w;
+        const v4i raw = *(const v4i*)(a.in + ((size_t)(img * (a.h + 2) + y + 1) * (a.w + 2) + x + 1) * a.cin_total + part * 16);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int xs = (raw[e >> 2] << (24 - (e & 3) * 8)) >> 24;
+            bufA[row * LDF + kpos(part * 16 + e)] = (float)(xs + a.ax) * a.dx;
+        }
+    }
+    __syncthreads();
+
+    v16f acc;
+    for (int l = 0; l < a.levels; ++l) {
+        const float* W = a.lvl[l];
+        const float* stage_w = W;
+        const float* stage_b = stage_w + D * D;
+        const float* qhead_w = stage_b + D;
+        const float* qhead_b = qhead_w + D * D;
+        const float* lhead_w = qhead_b + D;
+        const float* lhead_b = lhead_w + D * D;
+        const float* cbp = lhead_b + D;                       // [16][kc][4]
+        const float* cb = cbp + (size_t)D * a.kc;             // [kc][64]
+        const float* c2 = cb + (size_t)a.kc * D;              // [kc]
+
+        gemm_tile(bufA, (const float2*)stage_w, stage_b, rt, ctile, lane, acc);       // z = stage(x)
+        store_tile(bufB, rt, ctile, lane, acc);
+        __syncthreads();
+        gemm_tile(bufB, (const float2*)qhead_w, qhead_b, rt, ctile, lane, acc);       // q = qhead(z)
+        store_tile(bufA, rt, ctile, lane, acc);
+        __syncthreads();
+        if (tid < ER) {      // |q|^2: one 64-wide ascending fma chain per row
+            const float2* qr = (const float2*)(bufA + tid * LDF);
+            float s = 0.0f;
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) {
+                const float2 e = qr[2 * j], o = qr[2 * j + 1];
+                s = fmaf(e.x, e.x, s); s = fmaf(o.x, o.x, s); s = fmaf(e.y, e.y, s); s = fmaf(o.y, o.y, s);
+            }
+            x2[tid] = s;
+        }
+        __syncthreads();
+
+        // ---- distances: this wave's row tile against code tiles 2 (wave & 1), 2 (wave & 1) + 1 ---------------------------------------
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int ct = 2 * ctile + c;
+            if (ct * 32 < a.kc) {
+                const int par = lane >> 5, code = ct * 32 + (lane & 31);
+                v16f dacc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dacc[r] = 0.0f;
+                const float2* cl = (const float2*)cbp + (size_t)code * 2 + par;
+                const float* al = bufA + (rt * 32 + (lane & 31)) * LDF + 2 * par;
+                float2 s[4][4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) s[g][t] = cl[(size_t)(g * 4 + t) * a.kc * 2];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float2 av[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) av[t] = *(const float2*)(al + (g * 4 + t) * 4);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        dacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].x, s[g][t].x, dacc, 0, 0, 0);
+                        dacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].y, s[g][t].y, dacc, 0, 0, 0);
+                    }
+                }
+                const float c2v = c2[code];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rt * 32 + mfma32_row(r, lane);
+                    unsigned long long key = dist_key((x2[row] + c2v) - 2.0f * dacc[r], code);
+                    keymin_dpp<0x108>(key); keymin_dpp<0x104>(key); keymin_dpp<0x102>(key); keymin_dpp<0x101>(key);
+                    const int klo = (int)(unsigned)key, khi = (int)(unsigned)(key >> 32);
+                    const unsigned lo16 = (unsigned)__builtin_amdgcn_readlane(klo, 16), hi16 = (unsigned)__builtin_amdgcn_readlane(khi, 16);
+                    const unsigned lo48 = (unsigned)__builtin_amdgcn_readlane(klo, 48), hi48 = (unsigned)__builtin_amdgcn_readlane(khi, 48);
+                    const unsigned long long o = lane < 32 ? (((unsigned long long)hi16 << 32) | lo16) : (((unsigned long long)hi48 << 32) | lo48);
+                    key = o < key ? o : key;
+                    if ((lane & 31) == 0) pkey[ct * ER + row] = key;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < ER) {
+            unsigned long long bk = pkey[tid];
+            for (int wv = 1; wv * 32 < a.kc; ++wv) {
+                const unsigned long long ok = pkey[wv * ER + tid];
+                bk = ok < bk ? ok : bk;                                // code tiles ascend: ties go to the lower code
+            }
+            const int bi = (int)(unsigned)bk;
+            code_s[tid] = bi;
+            if (m0 + tid < a.M) a.codes[(size_t)l * a.M + m0 + tid] = (uint8_t)bi;
+        }
+        __syncthreads();
+
+        if (l + 1 < a.levels) {      // x <- lhead(z) - C[code]
+            gemm_tile(bufB, (const float2*)lhead_w, lhead_b, rt, ctile, lane, acc);
+            const int col = ctile * 32 + (lane & 31);
+            int cd[16];
+            float cv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cd[r] = code_s[rt * 32 + mfma32_row(r, lane)];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cv[r] = cb[(size_t)cd[r] * D + col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bufA[(rt * 32 + mfma32_row(r, lane)) * LDF + kpos(col)] = acc[r] - cv[r];
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void codebook64_c2_kernel(const float* __restrict__ cb, int kc, float* __restrict__ c2) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= kc) return;
+    float acc = 0.0f;
+    for (int i = 0; i < D; ++i) { const float v = cb[(size_t)k * D + i]; acc = fmaf(v, v, acc); }
+    c2[k] = acc;
+}
+
+}  // namespace
+}  // namespace qv2x
+
+extern "C" int64_t qv2x_codebook64_level_floats(int kc) { return 3LL * (64 * 64 + 64) + 2LL * 64 * kc + kc; }
+
+extern "C" int qv2x_codebook64_c2_f32(const float* codebook, int kc, float* c2, void* stream) {
+    using namespace qv2x;
+    if (!codebook || !c2 || kc <= 0) return fail(QV2X_EINVAL, "qv2x_codebook64_c2_f32: bad arguments");
+    codebook64_c2_kernel<<<(kc + 63) / 64, 64, 0, (hipStream_t)stream>>>(codebook, kc, c2);
+    return hip_check(hipGetLastError(), "qv2x_codebook64_c2_f32 launch");
+}
+
+extern "C" int qv2x_codebook_encode64_f32(const qv2x_encode_desc* d, int cin_total, const int8_t* in, const float* const* level_weights,
+                                          uint8_t* codes, void* stream) {
+    using namespace qv2x;
+    if (!d || !in || !level_weights || !codes) return fail(QV2X_EINVAL, "qv2x_codebook_encode64_f32: null pointer");
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->levels < 1 || d->levels > 4) return fail(QV2X_EINVAL, "qv2x_codebook_encode64_f32: bad shape");
+    if (d->kc < 32 || d->kc > 128 || d->kc % 32) return fail(QV2X_EINVAL, "qv2x_codebook_encode64_f32: dict_size must be 32, 64, 96 or 128 (got %d)", d->kc);
+    if (cin_total < 64 || cin_total % 16 || ((uintptr_t)in & 15)) return fail(QV2X_EALIGN, "qv2x_codebook_encode64_f32: >= 64 channels (%% 16), 16-byte aligned map");
+    Enc64Args a;
+    a.in = in; a.codes = codes; a.n = d->n; a.h = d->h; a.w = d->w; a.cin_total = cin_total; a.levels = d->levels; a.kc = d->kc;
+    a.ax = 128 - d->in_zx; a.dx = d->in_delta; a.M = d->n * d->h * d->w;
+    for (int l = 0; l < 4; ++l) {
+        a.lvl[l] = l < d->levels ? level_weights[l] : nullptr;
+        if (l < d->levels && (!a.lvl[l] || ((uintptr_t)a.lvl[l] & 15))) return fail(QV2X_EALIGN, "qv2x_codebook_encode64_f32: level %d weights null or unaligned", l);
+    }
+    codebook_encode64_kernel<<<(a.M + ER - 1) / ER, 256, 0, (hipStream_t)stream>>>(a);
+    return hip_check(hipGetLastError(), "qv2x_codebook_encode64_f32 launch");
+}

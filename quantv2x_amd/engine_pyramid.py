@@ -172,11 +172,12 @@ class DeployedPyramidModel(nn.Module):
             self.agent_blocks.append(blk)
             q = blk.out_q
         self.agent_q = q
-        # ---- codebook (D = 64): the encode kernel is the 256-wide one on zero-padded heads (bit-identical sums, see _level_blob) --
+        # ---- codebook (D = 64: its own encode kernel; other widths run the 256-wide one on zero-padded heads, see _level_blob) --
         self.levels = int(s["meta/codebook_levels"])
         self.kc, self.D = (int(v) for v in s["codebook/0/codebook"].shape)
         if self.D > 256 or self.D % 4 or self.agent_blocks[-1].cout != self.D:
             raise NotImplementedError("deployed Pyramid codebook: width <= 256 equal to the agent feature's channels")
+        self.native64 = self.D == 64
         lut, lut_bias = decode_tables(s, self.levels, self.D)
         self.lut, self.lut_bias = _dev(lut, dev), _dev(lut_bias, dev)
         self.level_blobs = [self._level_blob(l) for l in range(self.levels)]
@@ -211,27 +212,30 @@ class DeployedPyramidModel(nn.Module):
 
     # ------------------------------------------------------------------------------------------------------------------------------
     def _level_blob(self, l: int) -> torch.Tensor:
-        """The level's heads zero-padded to the 256-wide layout of qv2x_codebook_encode_f32: every extra term of every fma chain is
-        0 * 0, the padded |.|^2 chains are exactly 0, so codes equal a native D-wide evaluation bit for bit."""
+        """One level's heads in the layout of the encode kernel: the native 64-wide one (qv2x_codebook_encode64_f32), or -- other widths
+        -- zero-padded to the 256-wide kernel's (every extra term of every fma chain is 0 * 0 and the padded |.|^2 chains are exactly 0,
+        so the codes equal a native evaluation bit for bit)."""
         s, kc, D = self.state, self.kc, self.D
         g = lambda n: s[f"codebook/{l}/{n}"].astype(np.float32)
+        W = 64 if self.native64 else 256
 
         def pw(w):
-            out = np.zeros((256, 256), np.float32); out[:D, :D] = w; return _pack_k4p(out)
+            out = np.zeros((W, W), np.float32); out[:D, :D] = w; return _pack_k4p(out)
 
         def pb(b):
-            out = np.zeros(256, np.float32); out[:D] = b; return out
+            out = np.zeros(W, np.float32); out[:D] = b; return out
         last = f"codebook/{l}/lhead_w" not in s
-        cb = np.zeros((kc, 256), np.float32); cb[:, :D] = g("codebook")
+        cb = np.zeros((kc, W), np.float32); cb[:, :D] = g("codebook")
         parts = [pw(g("stage_w")), pb(g("stage_b")), pw(g("qhead_w")), pb(g("qhead_b")),
-                 np.zeros((64, 256, 4), np.float32) if last else pw(g("lhead_w")), np.zeros(256, np.float32) if last else pb(g("lhead_b")),
+                 np.zeros((W // 4, W, 4), np.float32) if last else pw(g("lhead_w")), np.zeros(W, np.float32) if last else pb(g("lhead_b")),
                  _pack_k4p(cb), cb, np.zeros(kc, np.float32)]
         flat = np.concatenate([p.reshape(-1) for p in parts])
-        assert flat.size == self.lib.qv2x_codebook_level_floats(kc)
+        floats, c2fn = ((self.lib.qv2x_codebook64_level_floats, self.lib.qv2x_codebook64_c2_f32) if self.native64
+                        else (self.lib.qv2x_codebook_level_floats, self.lib.qv2x_codebook_c2_f32))
+        assert flat.size == floats(kc)
         blob = _dev(flat, self.dev)
-        cb_off = flat.size - kc - kc * 256
-        L.check(self.lib.qv2x_codebook_c2_f32(C.c_void_p(blob.data_ptr() + 4 * cb_off), kc, C.c_void_p(blob.data_ptr() + 4 * (flat.size - kc)),
-                                              L.current_stream()), "qv2x_codebook_c2_f32")
+        cb_off = flat.size - kc - kc * W
+        L.check(c2fn(C.c_void_p(blob.data_ptr() + 4 * cb_off), kc, C.c_void_p(blob.data_ptr() + 4 * (flat.size - kc)), L.current_stream()), "codebook c2")
         return blob
 
     def _padded(self, n, h, w, c, zp):
@@ -258,7 +262,8 @@ class DeployedPyramidModel(nn.Module):
         b["c1"] = self._padded(n, fh, fw, 64, self._same_zp([blk.conv1.out_q for blk in self.agent_blocks], "agent conv1"))
         zp = self._same_zp([blk.out_q for blk in self.agent_blocks], "agent blocks")
         b["x"] = [self._padded(n, fh, fw, 64, zp) for _ in range(2)]
-        b["enc_in"] = self._padded(n, fh, fw, 256, zp)                      # the last block writes channels [0, D); the rest stay "0.0"
+        # the last block writes channels [0, D); with the 256-wide encode kernel the rest stay at the code of 0.0
+        b["enc_in"] = self._padded(n, fh, fw, 64 if self.native64 else 256, zp)
         b["ds"] = torch.empty((n * fh * fw, 64), dtype=torch.float32, device=self.dev)
         b["codes"] = torch.empty((self.levels, n, fh * fw), dtype=torch.uint8, device=self.dev)
         self._bufs[key] = b
@@ -397,7 +402,12 @@ class DeployedPyramidModel(nn.Module):
         d = L.EncodeDesc()
         d.n, d.h, d.w, d.levels, d.kc = n, self.fh, self.fw, self.levels, self.kc
         d.in_zx, d.in_delta = int(self.agent_q[1]), float(self.agent_q[0])
-        L.check(self.lib.qv2x_codebook_encode_f32(C.byref(d), L.ptr(b["enc_in"]), self.level_ptrs, L.ptr(codes), L.current_stream()), "qv2x_codebook_encode_f32")
+        if self.native64:
+            L.check(self.lib.qv2x_codebook_encode64_f32(C.byref(d), b["enc_in"].shape[-1], L.ptr(b["enc_in"]), self.level_ptrs, L.ptr(codes),
+                                                        L.current_stream()), "qv2x_codebook_encode64_f32")
+        else:
+            L.check(self.lib.qv2x_codebook_encode_f32(C.byref(d), L.ptr(b["enc_in"]), self.level_ptrs, L.ptr(codes), L.current_stream()),
+                    "qv2x_codebook_encode_f32")
         return codes
 
     @torch.no_grad()

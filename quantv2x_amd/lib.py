@@ -21,6 +21,7 @@ SYMBOLS = [
     "qv2x_conv3x3_f32", "qv2x_deconv_f32", "qv2x_pfn_scatter_f32", "qv2x_codebook_encode_f32in",
     "qv2x_pyramid_weighted_fuse_f32", "qv2x_pyramid_weighted_fuse_i8", "qv2x_conv1x1_i8", "qv2x_gconv3x3_i8", "qv2x_conv3x3_i8_res",
     "qv2x_deconv_f32in", "qv2x_codebook_decode_f32", "qv2x_occ_score_i8",
+    "qv2x_codebook64_level_floats", "qv2x_codebook64_c2_f32", "qv2x_codebook_encode64_f32",
     "qv2x_comm_unique_id", "qv2x_comm_init", "qv2x_comm_destroy", "qv2x_allgather_codes", "qv2x_pairwise_from_poses_f64",
 ]
 COMM_ID_BYTES = 128
@@ -156,13 +157,17 @@ def load() -> C.CDLL:
     lib.qv2x_deconv_f32in.argtypes = [C.POINTER(DeconvDesc), vp, vp, vp, vp, vp]
     lib.qv2x_codebook_decode_f32.argtypes = [vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.qv2x_occ_score_i8.argtypes = [C.POINTER(OccDesc), vp, vp, vp, vp, vp, vp]
+    lib.qv2x_codebook64_level_floats.argtypes = [C.c_int]
+    lib.qv2x_codebook64_level_floats.restype = C.c_int64
+    lib.qv2x_codebook64_c2_f32.argtypes = [vp, C.c_int, vp, vp]
+    lib.qv2x_codebook_encode64_f32.argtypes = [C.POINTER(EncodeDesc), C.c_int, vp, C.POINTER(vp), vp, vp]
     lib.qv2x_comm_unique_id.argtypes = [vp]
     lib.qv2x_comm_init.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
     lib.qv2x_comm_destroy.argtypes = [vp]
     lib.qv2x_allgather_codes.argtypes = [vp, vp, vp, C.c_int64, vp]
     lib.qv2x_pairwise_from_poses_f64.argtypes = [vp, C.c_int, C.c_int64, C.c_int64, C.c_int, vp, vp]
     for s in SYMBOLS:
-        if s not in ("qv2x_last_error", "qv2x_codebook_level_floats", "qv2x_voxelize_workspace_bytes", "qv2x_postprocess_workspace_bytes"):
+        if s not in ("qv2x_last_error", "qv2x_codebook_level_floats", "qv2x_codebook64_level_floats", "qv2x_voxelize_workspace_bytes", "qv2x_postprocess_workspace_bytes"):
             getattr(lib, s).restype = C.c_int
     _lib = lib
     return lib

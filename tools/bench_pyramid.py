@@ -1,0 +1,79 @@
+"""Time the deployed Pyramid path at the V2X-Real grid (704 x 200 pillars -> 352 x 100 maps): whole frame as a HIP graph, then the agent
+side (encode_features) and the ego side (decode_features) separately.  ``python tools/bench_pyramid.py [n_agents] [iters]``."""
+import json
+import sys
+import time
+
+import numpy as np
+import torch
+
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from quantv2x_amd import synth  # noqa: E402
+
+
+def main():
+    n_agents = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    iters = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+    shape = sys.argv[3] if len(sys.argv) > 3 else "v2xreal"
+    import copy
+    from quantv2x_amd.engine import deploy
+    from quantv2x_amd.plugin.tools import train_utils
+    from quantv2x_amd.plugin.tools.inference_quant import calibrate_minmax, wrap
+    from quantv2x_amd.ptq_state import export_ptq_state
+    torch.set_num_threads(32)
+    hy = synth.make_pyramid_hypes(shape)
+    model = train_utils.create_model(copy.deepcopy(hy)).eval()
+    synth.load_state_dict_numpy(model, synth.make_state_dict(model.state_dict(), seed=1))
+    t0 = time.time()
+    calib = synth.scene_to_torch(synth.make_scene("small", n_agents=2, seed=3, n_points=8000))
+    # calibrate on the small grid (same weights; the quantizer ranges only need to be sane for timing)
+    hy_s = synth.make_pyramid_hypes("small")
+    ms = train_utils.create_model(copy.deepcopy(hy_s)).eval()
+    synth.load_state_dict_numpy(ms, synth.make_state_dict(ms.state_dict(), seed=1))
+    qt = calibrate_minmax(wrap(ms), [calib])
+    st = export_ptq_state(qt)
+    big = export_ptq_state.__globals__  # noqa: F841
+    # geometry of the full grid
+    for k in ("meta/grid", "meta/HW_metres", "meta/offset", "meta/voxel"):
+        pass
+    lidar_range, voxel_size, _, _ = synth.SHAPES[shape]
+    gx, gy, gz = synth.grid_size(lidar_range, voxel_size)
+    st["meta/grid"] = np.array([gx, gy, gz], dtype=np.int64)
+    st["meta/HW_metres"] = np.array([lidar_range[4] - lidar_range[1], lidar_range[3] - lidar_range[0]], dtype=np.float64)
+    st["meta/offset"] = np.array([voxel_size[i] / 2 + lidar_range[i] for i in range(3)], dtype=np.float64)
+    print("calibration s", round(time.time() - t0, 1), flush=True)
+    eng = deploy(state=st)
+    sc = synth.make_scene(shape, n_agents=n_agents, seed=0)
+    dd = synth.scene_to_torch(sc, "cuda")
+    out = eng(dd)
+    torch.cuda.synchronize()
+    hw = eng.fh * eng.fw
+    pw = dd["pairwise_t_matrix"].to(torch.float64).contiguous()
+
+    def timeit(fn, k=iters):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(k):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / k
+
+    res = {"n_agents": n_agents, "pillars": int(dd["inputs_m1"]["voxel_features"].shape[0]), "map": [eng.fh, eng.fw]}
+    replay = eng.capture(dd)
+    res["frame_graph_ms"] = timeit(replay)
+    res["frame_eager_ms"] = timeit(lambda: eng(dd))
+    codes = eng.encode_features(dd["inputs_m1"], n_agents).clone()
+    res["encode_features_ms"] = timeit(lambda: eng.encode_features(dd["inputs_m1"], n_agents))
+    res["decode_features_ms"] = timeit(lambda: eng.decode_features(codes, hw, n_agents * hw, [n_agents], pw))
+    res["agent_backbone_ms"] = timeit(lambda: eng.agent_backbone(n_agents))
+    res["codebook_encode_ms"] = timeit(lambda: eng.encode_codes(n_agents))
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
