@@ -499,6 +499,32 @@ class DeployedPyramidModel(nn.Module):
         return {"pyramid": "collab", "cls_preds": preds[:, :c], "reg_preds": preds[:, c:c + r], "dir_preds": preds[:, c + r:], "preds_tensor": preds,
                 "occ_single_list": occ_maps}
 
+    # ---- stage interface of the multi-GPU driver (quantv2x_amd/dist.py): one agent per rank, code planes + pose over the link ----------
+    def wire_shape(self):
+        self._agent_ws(1)
+        return self.levels, self.fh * self.fw
+
+    def encode_into(self, inputs: dict, frames: int, codes_out: torch.Tensor):
+        """``encode_features`` for ``frames`` frames of ONE agent (batch index = frame) into ``codes_out`` u8 [levels, frames, H*W]."""
+        return self.encode_features(inputs, frames, out=codes_out)
+
+    def pairwise_from_poses(self, gathered: torch.Tensor, world: int, agent_stride: int, pose_offset: int, max_cav: int, out: torch.Tensor):
+        L.check(self.lib.qv2x_pairwise_from_poses_f64(L.ptr(gathered), world, agent_stride, pose_offset, max_cav, L.ptr(out), L.current_stream()),
+                "qv2x_pairwise_from_poses_f64")
+
+    def fuse_frames_and_heads(self, gathered: torch.Tensor, agent_stride: int, level_stride: int, frame_stride: int, pairwise: torch.Tensor,
+                              n_agents: int, ego: int, own_codes: Optional[torch.Tensor], frames: int) -> dict:
+        """``decode_features`` for ``frames`` scenes whose agents' code planes lie ``agent_stride`` bytes apart in ``gathered`` (frame f at
+        ``+ f * frame_stride``); ``pairwise`` f64 [frames, L, L, 4, 4]; this rank's agent is ``ego``."""
+        outs = [self.decode_features(C.c_void_p(gathered.data_ptr() + f * frame_stride), agent_stride, level_stride, [n_agents],
+                                     pairwise[f:f + 1], ego) for f in range(frames)]
+        if frames == 1:
+            return outs[0]
+        preds = torch.cat([o["preds_tensor"] for o in outs])
+        c, r, _ = self.heads.splits
+        return {"pyramid": "collab", "cls_preds": preds[:, :c], "reg_preds": preds[:, c:c + r], "dir_preds": preds[:, c + r:], "preds_tensor": preds,
+                "occ_single_list": [torch.cat([o["occ_single_list"][l] for o in outs]) for l in range(len(self.occ))]}
+
     # ---- the reference's model contract ------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, data_dict: dict, taps: Optional[dict] = None) -> dict:

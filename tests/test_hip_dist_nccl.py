@@ -87,6 +87,33 @@ def test_sharded_driver_world1_equals_forward(nccl_world1, link, frames, graphs)
     model.close()
 
 
+@pytest.mark.parametrize("link,frames", [("torch", 1), ("rccl", 2)])
+def test_sharded_driver_world1_pyramid_model(nccl_world1, link, frames):
+    """The same driver over the Pyramid engine: the payload is the 64-wide codebook's planes, the ego side is decode_features."""
+    from _common import calibrated_pyramid_plugin
+    from quantv2x_amd import synth
+    from quantv2x_amd.dist import AgentShardedModel
+    from quantv2x_amd.engine import deploy
+    from quantv2x_amd.ptq_state import export_ptq_state
+    eng = deploy(state=export_ptq_state(calibrated_pyramid_plugin()))
+    parts = []
+    for f in range(frames):
+        part = {k: v.copy() for k, v in scene_np(1, seed=3 + f)["inputs_m1"].items()}
+        part["voxel_coords"][:, 0] = f
+        parts.append(part)
+    inp = {k: torch.from_numpy(np.concatenate([p[k] for p in parts])).cuda() for k in parts[0]}
+    pose = torch.from_numpy(synth.pose_matrix(3.0, -1.0, 0.2)).cuda()
+    model = AgentShardedModel(eng, frames=frames, link=link, graphs=True, max_cav=5)
+    first = model.forward(inp, pose)["preds_tensor"].clone()
+    again = model.forward(inp, pose)["preds_tensor"]
+    dd = {"inputs_m1": inp, "agent_modality_list": ["m1"] * frames, "record_len": torch.ones(frames, dtype=torch.int64),
+          "pairwise_t_matrix": torch.eye(4, dtype=torch.float64).expand(frames, 5, 5, 4, 4).contiguous().cuda()}
+    want = eng(dd)["preds_tensor"]
+    torch.cuda.synchronize()
+    assert torch.equal(first, want) and torch.equal(again, want)
+    model.close()
+
+
 def test_two_processes_over_rccl():
     if torch.cuda.device_count() < 2:
         pytest.skip("one GPU on this box: the 2-rank RCCL exchange needs two")

