@@ -5,6 +5,6 @@ from .quant_layer import QuantModule, StraightThrough, UniformAffineQuantizer
 from .quant_model import QuantModel
 from .set_act_quantize_params import set_act_quantize_params
 from .set_weight_quantize_params import save_quantized_weight, set_weight_quantize_params
-from .block_recon import block_reconstruction
+from .block_recon import block_reconstruction, pyramid_reconstruction
 from .encoder_recon import encoder_reconstruction
 from .layer_recon import layer_reconstruction

@@ -90,7 +90,23 @@ class GetLayerInpOut:
         kept = self.data_saver.input_store
         if kept is None or len(kept) == 0:
             return None
+        self.extras = tuple(kept[1:])        # a multi-input block (PyramidFusion: record_len, affine_matrix, modalities, crop info)
         return kept[0] if isinstance(kept[0], dict) else kept[0].detach()
+
+
+def first_output(out):
+    """the tensor a block is reconstructed on: ``PyramidFusion`` returns ``(fused_feature, occupancy maps)``"""
+    return out[0] if isinstance(out, (tuple, list)) else out
+
+
+def save_block_extras(model: QuantModel, block, cali_data: list):
+    """per calibration batch, the positional inputs of ``block`` after the first (``pyramid_recon_utils.get_pyramid_input``)"""
+    grab = GetLayerInpOut(model, block, device=_device_of(model))
+    out = []
+    for batch in cali_data:
+        if grab(batch) is not None:
+            out.append(grab.extras)
+    return out
 
 
 def save_inp_oup_data(model: QuantModel, block, cali_data: list, batch_size: int = 1, keep_gpu: bool = True, input_prob: bool = False):
@@ -144,6 +160,7 @@ class GetDcFpLayerInpOut:
         if output_fp is None or kept is None or len(kept) == 0:
             return None
         input_sym = kept[0] if isinstance(kept[0], dict) else kept[0].detach()
+        extras = tuple(kept[1:])
         if isinstance(input_sym, dict):
             raise NotImplementedError("distribution correction of a dict-valued block input")
         para_input = input_sym.data.clone().to(self.device)
@@ -157,7 +174,7 @@ class GetDcFpLayerInpOut:
                 self.layer.zero_grad()
                 opt.zero_grad()
                 seen.clear()
-                self.layer(para_input)
+                self.layer(para_input, *extras)
                 mean_loss, std_loss = 0, 0
                 for k, (bn_mean, bn_std) in enumerate(self.bn_stats):
                     inp = seen.get(k)
@@ -174,7 +191,7 @@ class GetDcFpLayerInpOut:
             for h in hooks:
                 h.remove()
         with torch.no_grad():
-            out_fp = self.layer(para_input)
+            out_fp = first_output(self.layer(para_input, *extras))
         out_fp = out_fp.unsqueeze(0)
         if self.input_prob:
             return out_fp.detach(), output_fp.detach(), para_input.unsqueeze(0).detach()

@@ -20,7 +20,7 @@ import torch
 import torch.nn.functional as F
 
 from .adaptive_rounding import AdaRoundQuantizer
-from .data_utils import get_dc_fp_init, get_init
+from .data_utils import first_output, get_dc_fp_init, get_init, save_block_extras
 from .quant_block import BaseQuantBlock
 from .quant_layer import QuantModule, lp_loss
 from .set_act_quantize_params import set_act_quantize_params
@@ -95,6 +95,13 @@ def forward_from_shrinker(model, feature: torch.Tensor):
     return torch.cat(parts, dim=1) if len(parts) >= 2 else parts[0]
 
 
+def forward_from_fusion(model, fused_feature: torch.Tensor):
+    """the rest of the Pyramid model after ``pyramid_backbone``: ``shrink_conv`` and the heads (``pyramid_recon.py:61-84``)"""
+    if getattr(model, "shrink_flag", False):
+        fused_feature = model.shrink_conv(fused_feature)
+    return forward_from_shrinker(model, fused_feature)
+
+
 def _pick(store, idx):
     return store[idx] if isinstance(store, torch.Tensor) else store[int(idx)]
 
@@ -102,7 +109,11 @@ def _pick(store, idx):
 def reconstruct(model, fp_model, block, fp_block, cali_data: list, batch_size: int = 1, iters: int = 20000, weight: float = 0.01,
                 opt_mode: str = 'mse', b_range: tuple = (20, 2), warmup: float = 0.0, p: float = 2.0, lr: float = 4e-5,
                 input_prob: float = 1.0, keep_gpu: bool = True, lamb_r: float = 0.2, T: float = 7.0, bn_lr: float = 1e-3, lamb_c=0.02,
-                prediction_loss: bool = False, dc_iters: int = 500, verbose: bool = True, seed=None):
+                prediction_loss: bool = False, dc_iters: int = 500, verbose: bool = True, seed=None, multi_input: bool = False,
+                prediction_fn=None):
+    """``multi_input``: the block takes further positional inputs that are passed through unchanged (``QuantPyramidFusion``: record_len,
+    affine_matrix, agent_modality_list, cam_crop_info) and may return a tuple whose first element is reconstructed;
+    ``prediction_fn(model, block_output)``: the model's tail for the prediction-level loss (default ``forward_from_shrinker``)."""
     device = next(model.parameters()).device
     gen = torch.Generator(device="cpu")
     if seed is not None:
@@ -112,8 +123,10 @@ def reconstruct(model, fp_model, block, fp_block, cali_data: list, batch_size: i
     cached_outs, cached_output, cur_syms = get_dc_fp_init(fp_model, fp_block, cali_data, batch_size=batch_size, input_prob=True,
                                                          keep_gpu=keep_gpu, bn_lr=bn_lr, lamb=lamb_c, dc_iters=dc_iters)
     sz = cached_inps.size(0) if isinstance(cached_inps, torch.Tensor) else len(cached_inps)
+    extras = save_block_extras(model, block, cali_data) if multi_input else None
+    prediction_fn = prediction_fn or forward_from_shrinker
     # 2. activation quantizers
-    set_act_quantize_params(block, cached_inps=cached_inps[:min(256, sz)])
+    set_act_quantize_params(block, cached_inps=cached_inps[:min(256, sz)], extras=extras)
     block.set_quant_state(True, True)
     for para in model.parameters():
         para.requires_grad = False
@@ -148,10 +161,10 @@ def reconstruct(model, fp_model, block, fp_block, cali_data: list, batch_size: i
             w_opt.zero_grad()
         if a_opt:
             a_opt.zero_grad()
-        out_drop = block(drop_inp)
+        out_drop = first_output(block(drop_inp, *(extras[idx] if extras is not None else ())))
         output_qt = None
         if prediction_loss:
-            output_qt = forward_from_shrinker(model.model, out_drop)
+            output_qt = prediction_fn(model.model, out_drop)
             want = output_fp if output_fp.dim() == output_qt.dim() else output_fp.unsqueeze(0) if output_qt is not None else None
             if output_qt is not None and want is not None and output_qt.shape == want.shape:
                 output_fp = want

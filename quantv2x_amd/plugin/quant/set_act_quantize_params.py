@@ -26,7 +26,8 @@ def _move(x, dev):
 
 
 def set_act_quantize_params(module: Union[QuantModel, QuantModule, BaseQuantBlock],
-                            cached_inps: Union[list, torch.Tensor], channel_sizes: list = None, batch_size: int = 8):
+                            cached_inps: Union[list, torch.Tensor], channel_sizes: list = None, batch_size: int = 8, extras: list = None):
+    """``extras``: per cached input, the block's further positional inputs (``pyramid_recon.set_act_quantize_params :104-121``)."""
     module.set_quant_state(True, True)
     holders = [t for t in module.modules()
                if isinstance(t, (QuantModule, BaseQuantBlock)) and hasattr(t, 'act_quantizer')]
@@ -36,7 +37,7 @@ def set_act_quantize_params(module: Union[QuantModel, QuantModule, BaseQuantBloc
     n = cached_inps.size(0) if isinstance(cached_inps, torch.Tensor) else min(len(cached_inps), batch_size)
     with torch.no_grad():
         for i in range(n):
-            module(_move(cached_inps[i], dev))
+            module(_move(cached_inps[i], dev), *(_move(tuple(extras[i]), dev) if extras is not None else ()))
     if torch.cuda.is_available():
         torch.cuda.empty_cache()
     for t in holders:

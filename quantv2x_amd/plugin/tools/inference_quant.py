@@ -68,10 +68,11 @@ def recon_kwargs(cali_data, iters_w=5000, weight=0.01, b_start=20, b_end=2, warm
 def recon_model(qt_model, fp_model, kwargs, log=print):
     """Walk the two module trees in step and reconstruct every quantized unit in forward order (``recon_model``, ``:286-317``):
     a bare ``QuantModule`` -> layer, a backbone / shrinker / compressor block -> block, the pillar feature net -> encoder."""
-    from ..quant.block_recon import block_reconstruction
+    from ..quant.block_recon import block_reconstruction, pyramid_reconstruction
     from ..quant.encoder_recon import encoder_reconstruction
     from ..quant.layer_recon import layer_reconstruction
-    from ..quant.quant_block import QuantBaseBEVBackbone, QuantDownsampleConv, QuantNaiveCompressor, QuantPFNLayer
+    from ..quant.quant_block import (QuantBaseBEVBackbone, QuantDownsampleConv, QuantNaiveCompressor, QuantPFNLayer, QuantPyramidFusion,
+                                     QuantResNetBEVBackbone)
     from ..quant.quant_layer import QuantModule
 
     def walk(qt, fp):
@@ -79,7 +80,10 @@ def recon_model(qt_model, fp_model, kwargs, log=print):
             if isinstance(module, QuantModule):
                 log('Reconstruction for layer {}'.format(name))
                 layer_reconstruction(qt_model, fp_model, module, fp_module, **kwargs)
-            elif isinstance(module, (QuantDownsampleConv, QuantBaseBEVBackbone, QuantNaiveCompressor)):
+            elif isinstance(module, QuantPyramidFusion):          # a QuantResNetBEVBackbone subclass: test it first, as the reference does
+                log('Reconstruction for pyramid fusion block {}'.format(name))
+                pyramid_reconstruction(qt_model, fp_model, module, fp_module, **kwargs)
+            elif isinstance(module, (QuantResNetBEVBackbone, QuantDownsampleConv, QuantBaseBEVBackbone, QuantNaiveCompressor)):
                 log('Reconstruction for block {}'.format(name))
                 block_reconstruction(qt_model, fp_model, module, fp_module, **kwargs)
             elif isinstance(module, QuantPFNLayer):

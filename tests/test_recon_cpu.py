@@ -115,3 +115,28 @@ def test_whole_model_recon_walks_every_unit_in_forward_order():
     mods = [m for m in qt.modules() if isinstance(m, QuantModule)]
     assert len(mods) == 31 and all(isinstance(m.weight_quantizer, AdaRoundQuantizer) and m.trained for m in mods)
     assert all(m.act_quantizer.inited for m in mods)
+
+
+def test_pyramid_model_recon_walk_and_export():
+    """The driver walk over the HEAL Pyramid model: PFN -> the agent's ResNet backbone as a block -> ``QuantPyramidFusion`` as ONE unit
+    (``pyramid_reconstruction``: record_len / affine_matrix passed through, prediction loss through shrink_conv + heads) -> shrink_conv ->
+    heads; the frozen result exports and runs on the Pyramid oracle."""
+    from _common import build_pyramid_plugin
+    from quantv2x_amd import synth
+    from quantv2x_amd.plugin.quant import AdaRoundQuantizer, QuantModule
+    from quantv2x_amd.plugin.tools import inference_quant as IQ
+    from quantv2x_amd.ptq_state import export_ptq_state
+    from oracle.spec_pyramid import OraclePyramid
+    fp, qt = IQ.wrap_pair(build_pyramid_plugin("tiny"))
+    cali = [scene(2, seed=3 + i) for i in range(2)]
+    seen = []
+    IQ.recon_model(qt, fp, IQ.recon_kwargs(cali, iters_w=3, dc_iters=1, verbose=False, seed=1, input_prob=0.5), log=seen.append)
+    assert [s.split()[-1] for s in seen] == ["0", "backbone_m1", "pyramid_backbone", "shrink_conv", "cls_head", "reg_head", "dir_head"]
+    assert "pyramid fusion block" in seen[2]
+    mods = [m for m in qt.modules() if isinstance(m, QuantModule)]
+    assert len(mods) == 69 and all(isinstance(m.weight_quantizer, AdaRoundQuantizer) and m.trained for m in mods)
+    blocks = [m for m in qt.modules() if type(m).__name__ in ("QuantBasicBlock", "QuantBottleneck")]
+    assert len(blocks) == 19 and all(b.trained and b.act_quantizer.inited for b in blocks)
+    st = export_ptq_state(qt)
+    out = OraclePyramid(st).forward(synth.make_scene("tiny", n_agents=2, seed=3, n_points=3000))
+    assert np.isfinite(out["preds_tensor"]).all() and out["preds_tensor"].shape == (1, 72, 16, 32)
