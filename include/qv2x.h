@@ -315,16 +315,18 @@ typedef struct {
 int qv2x_conv1x1_i8(const qv2x_conv1x1_desc* desc /* host */, const int8_t* in, const int8_t* w_frag, const float* scale,
                     const int32_t* corr, const int32_t* aw, const float* bias, const void* res, void* out, void* stream);
 
-/* The grouped 3x3 convolution of QuantBottleneck (ResNeXt: groups of cg = 4 | 8 | 16 channels, c inputs = c outputs; zero padding 1,
- * stride 1 | 2) + bias + ReLU + output quantizer; the same integer arithmetic, on the VALU's v_dot4_i32_i8.
+/* The grouped 3x3 convolution of QuantBottleneck (ResNeXt: groups of cg = 4 | 8 | 16 channels, c inputs = c outputs, c % 32 == 0; zero
+ * padding 1, stride 1 | 2) + bias + ReLU + output quantizer; the same integer arithmetic.  Every 32-channel slab runs as a dense 32 -> 32
+ * convolution with a block-diagonal weight matrix on the MFMA (structural zeros add exactly 0).
  *   in padded i8 BEV [N][H+2][W+2][c] -> out padded i8 BEV [N][Ho+2][Wo+2][c]
- *   w_chunk: i8 (code - 128) [c][9 taps][cg] (output channel major; tap = 3 * kh + kw; the group's input channels innermost)
- *   scale / corr / aw / bias as above with K = 9 * cg. */
+ *   w_frag: i8 (code - 128, 0 outside the group) [c/32 slabs][9 taps][lane 0..63][16 B] = the A fragments of v_mfma_i32_32x32x32_i8:
+ *           lane = 32 * ((ci / 16) & 1) + co % 32, bytes = ci % 16 (ci, co inside the slab; tap = 3 * kh + kw)
+ *   scale / corr / aw / bias as above with K = 9 * cg (corr over the group's taps only). */
 typedef struct {
     int32_t n, h, w, c, cg, stride, relu;
     float out_delta, out_zp;
 } qv2x_gconv_desc;
-int qv2x_gconv3x3_i8(const qv2x_gconv_desc* desc /* host */, const int8_t* in, const int8_t* w_chunk, const float* scale,
+int qv2x_gconv3x3_i8(const qv2x_gconv_desc* desc /* host */, const int8_t* in, const int8_t* w_frag, const float* scale,
                      const int32_t* corr, const int32_t* aw, const float* bias, int8_t* out, void* stream);
 
 /* qv2x_conv3x3_i8 with a fused residual end (conv2 of QuantBasicBlock, quant_block.py:76-96): one input group, cout = 64;

@@ -51,17 +51,23 @@ class _Conv1x1:
 
 
 class _GConv:
-    """The grouped 3x3 convolution of a bottleneck: weights [c][9 taps][cg]."""
+    """The grouped 3x3 convolution of a bottleneck as block-diagonal 32 x 32 MFMA A fragments: [c/32][9 taps][lane][16 B]."""
 
     def __init__(self, state, name, in_q, stride, dev):
         code = state[name + "/w_code"]                                   # [c, cg, 3, 3]
         c, cg = code.shape[0], code.shape[1]
-        if cg not in (4, 8, 16) or c % 16:
-            raise NotImplementedError(f"{name}: grouped convolution with 4 / 8 / 16 channels per group")
+        if cg not in (4, 8, 16) or c % 32:
+            raise NotImplementedError(f"{name}: grouped convolution with 4 / 8 / 16 channels per group, channels % 32 == 0")
         ws = code.astype(np.int64) - 128
         aw = 128 - state[name + "/w_zp"].astype(np.int64)
         ax = 128 - int(in_q[1])
-        self.w = _dev(ws.transpose(0, 2, 3, 1).reshape(c, 9, cg).astype(np.int8), dev)
+        dense = np.zeros((c // 32, 9, 32, 32), np.int8)                 # [slab][tap][co][ci], zero outside the group
+        taps = ws.reshape(c, cg, 9)
+        for co in range(c):
+            g0 = (co % 32) // cg * cg
+            dense[co // 32, :, co % 32, g0:g0 + cg] = taps[co].T
+        frag = dense.reshape(c // 32, 9, 32, 2, 16).transpose(0, 1, 3, 2, 4)      # [slab][tap][half][co][16]: lane = 32 * half + co
+        self.w = _dev(frag, dev)
         self.scale = _dev((np.float32(in_q[0]) * state[name + "/w_delta"].astype(np.float32)).astype(np.float32), dev)
         corr = ax * ws.reshape(c, -1).sum(axis=1) + 9 * cg * ax * aw
         self.corr, self.aw = _dev(corr.astype(np.int32), dev), _dev(aw.astype(np.int32), dev)

@@ -72,6 +72,21 @@ def main():
     res["decode_features_ms"] = timeit(lambda: eng.decode_features(codes, hw, n_agents * hw, [n_agents], pw))
     res["agent_backbone_ms"] = timeit(lambda: eng.agent_backbone(n_agents))
     res["codebook_encode_ms"] = timeit(lambda: eng.encode_codes(n_agents))
+    # throughput: batches of `frames` scenes (n_agents each) per call, one HIP graph per batch
+    for frames in (2, 4):
+        scenes = [synth.make_scene(shape, n_agents=n_agents, seed=3 + f) for f in range(frames)]
+        parts = []
+        for f, s in enumerate(scenes):
+            part = {k: v.copy() for k, v in s["inputs_m1"].items()}
+            part["voxel_coords"][:, 0] += f * n_agents
+            parts.append(part)
+        batch = {"inputs_m1": {k: torch.from_numpy(np.concatenate([p[k] for p in parts])).cuda() for k in parts[0]},
+                 "agent_modality_list": ["m1"] * (n_agents * frames), "record_len": torch.full((frames,), n_agents, dtype=torch.int64),
+                 "pairwise_t_matrix": torch.from_numpy(np.concatenate([s["pairwise_t_matrix"] for s in scenes])).cuda()}
+        rep = eng.capture(batch)
+        ms = timeit(rep, max(10, iters // frames))
+        res[f"batch{frames}_ms_per_frame"] = ms / frames
+        res[f"batch{frames}_frames_per_s"] = 1000.0 * frames / ms
     print(json.dumps(res))
 
 
