@@ -168,6 +168,42 @@ def rooflines(eng, full, frames, iters):
     return roof, stages
 
 
+def pyramid_model_line(device):
+    """SURVEY.md §8(f) rank 3, reported beside the headline: the HEAL Pyramid-fusion model (2 agents per scene, V2X-Real grid) on its
+    own engine -- one frame as a HIP graph, and batches of 4 scenes."""
+    import copy
+    import numpy as np
+    import torch
+    from quantv2x_amd import synth
+    from quantv2x_amd.engine import deploy
+    from quantv2x_amd.plugin.tools import inference_quant, train_utils
+    from quantv2x_amd.ptq_state import export_ptq_state
+    model = train_utils.create_model(copy.deepcopy(synth.make_pyramid_hypes(SHAPE))).eval()
+    synth.load_state_dict_numpy(model, synth.make_state_dict(model.state_dict(), seed=1))
+    calib = synth.scene_to_torch(synth.make_scene(SHAPE, n_agents=1, seed=3, n_points=N_POINTS))
+    eng = deploy(state=export_ptq_state(inference_quant.calibrate_minmax(inference_quant.wrap(model), [calib])), device=device)
+
+    def batch(frames, agents=2):
+        scenes = [synth.make_scene(SHAPE, n_agents=agents, seed=3 + f, n_points=N_POINTS) for f in range(frames)]
+        parts = []
+        for f, sc in enumerate(scenes):
+            part = {k: v.copy() for k, v in sc["inputs_m1"].items()}
+            part["voxel_coords"][:, 0] += f * agents
+            parts.append(part)
+        return {"inputs_m1": {k: torch.from_numpy(np.concatenate([p[k] for p in parts])).to(device) for k in parts[0]},
+                "agent_modality_list": ["m1"] * (agents * frames), "record_len": torch.full((frames,), agents, dtype=torch.int64),
+                "pairwise_t_matrix": torch.from_numpy(np.concatenate([sc["pairwise_t_matrix"] for sc in scenes])).to(device)}
+    out = {}
+    for frames in (1, 4):
+        rep = eng.capture(batch(frames))
+        us = event_time_us(rep, 30)
+        out["ms_per_frame" if frames == 1 else f"ms_per_frame_batch{frames}"] = round(us / frames / 1e3, 4)
+    out["frames_per_s_batch4"] = round(1e3 / out["ms_per_frame_batch4"], 1)
+    out["note"] = ("heter_pyramid_collab_codebook_mc_encdec under W8A8, 2 agents per scene: agent side (3 ResNet blocks, 64-wide codebook "
+                   "encode) + ego side (decode, 16 ResNeXt bottlenecks per agent, occupancy-weighted fusion, deblocks, shrink, heads)")
+    return out
+
+
 def cpu_baseline(state, sc_np, budget_s=12.0, max_frames=6):
     """The CPU oracle (checker) on the same workload, on the host cores of this box."""
     from oracle.spec import Oracle
@@ -353,6 +389,7 @@ def main():
             line["fp32_hip_path"] = {"ms_per_frame": round(ms32, 3), "frames_per_s": round(1e3 / ms32, 1),
                                      "note": "un-quantized model, one frame at a time, f32-MFMA convolutions; compare value_one_frame_at_a_time"}
             del e32, r32
+            line["pyramid_model"] = pyramid_model_line(device)
         if not args.no_cpu_baseline and world == 1:       # reported on rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(state, frame_batch(1, 0, 1, "cpu")[0])
             line["cpu_baseline_torch"] = cpu_baseline_torch(fp_model, qt, frame_batch(1, 0, 1, "cpu")[0], cores)
