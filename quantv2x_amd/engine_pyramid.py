@@ -215,6 +215,10 @@ class DeployedPyramidModel(nn.Module):
             raise NotImplementedError("deployed path expects a 256-channel map in front of the heads")
         self.heads = _Heads(s, "", dev)
         self._bufs: Dict[tuple, dict] = {}
+        # a level's occupancy head, fusion and deblock only feed the concat: they run on a side stream while the next level's blocks
+        # run on the caller's (the ego side is ~70 launches on small maps; inside a captured HIP graph this is a fork / join)
+        self.overlap_levels = True
+        self._side = None
 
     # ------------------------------------------------------------------------------------------------------------------------------
     def _level_blob(self, l: int) -> torch.Tensor:
@@ -443,6 +447,25 @@ class DeployedPyramidModel(nn.Module):
         else:
             self._conv1x1(blk.conv3, lv["t2"], n, ho, wo, out, 3, blk.out_q, x, xq)
 
+    def _fuse_level(self, lvl, lv, x, xq, n, h, w, lens, pairwise, ego, cat, c0):
+        """occupancy head + score, weighted_fuse of every scene, the level's deblock into the concat; returns the fp32 occupancy maps"""
+        st = L.current_stream
+        oc = self.occ[lvl]
+        d = L.OccDesc()
+        d.n, d.h, d.w, d.c, d.aw, d.corr = n, h, w, oc.c, oc.aw, oc.corr
+        d.scale, d.bias, d.out_delta, d.out_zp = oc.scale, oc.bias, oc.out_q[0], float(oc.out_q[1])
+        L.check(self.lib.qv2x_occ_score_i8(C.byref(d), L.ptr(x), L.ptr(oc.w), L.ptr(oc.lut), L.ptr(lv["score"]), L.ptr(lv["occ_code"]), st()), oc.name)
+        occ = oc.occ_lut[lv["occ_code"].long()].view(n, 1, h, w)
+        start = 0
+        for bi, na in enumerate(lens):
+            fd = self._fuse_desc(na, h, w, pairwise.shape[1], ego)
+            L.check(self.lib.qv2x_pyramid_weighted_fuse_i8(C.byref(fd), self.pyr_blocks[lvl][-1].cout, L.ptr(x[start:start + na]), int(xq[1]), float(xq[0]),
+                                                           L.ptr(lv["score"][start:start + na]), L.ptr(pairwise[bi]), L.ptr(lv["fused"][bi]), st()),
+                    "qv2x_pyramid_weighted_fuse_i8")
+            start += na
+        self._dense_f32in(self.deblocks[lvl], lv["fused"], len(lens), h, w, cat, c0)
+        return occ
+
     def _fuse_desc(self, n, h, w, max_cav, ego):
         d = L.FuseDesc()
         d.agents, d.h, d.w, d.levels, d.kc = n, h, w, 1, 1
@@ -472,24 +495,21 @@ class DeployedPyramidModel(nn.Module):
                 x, xq, h, w = out, blk.out_q, lv["h"], lv["w"]
                 if taps is not None:
                     taps[blk.name] = out.clone()
-            oc = self.occ[lvl]
-            d = L.OccDesc()
-            d.n, d.h, d.w, d.c, d.aw, d.corr = n, h, w, oc.c, oc.aw, oc.corr
-            d.scale, d.bias, d.out_delta, d.out_zp = oc.scale, oc.bias, oc.out_q[0], float(oc.out_q[1])
-            L.check(self.lib.qv2x_occ_score_i8(C.byref(d), L.ptr(x), L.ptr(oc.w), L.ptr(oc.lut), L.ptr(lv["score"]), L.ptr(lv["occ_code"]), st()), oc.name)
-            occ_maps.append(oc.occ_lut[lv["occ_code"].long()].view(n, 1, h, w))
-            start = 0
-            for bi, na in enumerate(lens):
-                fd = self._fuse_desc(na, h, w, pairwise.shape[1], ego)
-                L.check(self.lib.qv2x_pyramid_weighted_fuse_i8(C.byref(fd), blocks[-1].cout, L.ptr(x[start:start + na]), int(xq[1]), float(xq[0]),
-                                                               L.ptr(lv["score"][start:start + na]), L.ptr(pairwise[bi]), L.ptr(lv["fused"][bi]), st()),
-                        "qv2x_pyramid_weighted_fuse_i8")
-                start += na
-            de = self.deblocks[lvl]
-            self._dense_f32in(de, lv["fused"], nb, h, w, b["cat"], c0)
-            c0 += de.cout
+            if self.overlap_levels:
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=self.dev)
+                main = torch.cuda.current_stream()
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    occ_maps.append(self._fuse_level(lvl, lv, x, xq, n, h, w, lens, pairwise, ego, b["cat"], c0))
+            else:
+                occ_maps.append(self._fuse_level(lvl, lv, x, xq, n, h, w, lens, pairwise, ego, b["cat"], c0))
+            c0 += self.deblocks[lvl].cout
             if taps is not None:
+                torch.cuda.current_stream().wait_stream(self._side) if self.overlap_levels else None
                 taps[f"occ_code{lvl}"], taps[f"score{lvl}"], taps[f"fused{lvl}"] = lv["occ_code"].clone(), lv["score"].clone(), lv["fused"].clone()
+        if self.overlap_levels:
+            torch.cuda.current_stream().wait_stream(self._side)
         oh, ow = self.oh, self.ow
         self._conv3x3(self.shrink0, b["cat"], nb, oh, ow, b["s0"], self.shrink0.out_q)
         self._conv3x3(self.shrink1, b["s0"], nb, oh, ow, b["s1"], self.shrink1.out_q)
