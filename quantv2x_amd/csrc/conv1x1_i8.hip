@@ -41,19 +41,31 @@ __global__ __launch_bounds__(256) void conv1x1_i8_kernel(const C1Args a) {
     }
     int8_t* stage = smem + 2 * KS * 1024 + wave * (32 * SP);
     const float rd = 1.0f / a.out_delta, lo = a.relu ? 0.0f : -3.0e38f;
+    // pixel fragments of a tile: requested ahead -- the first tile's before the barrier that publishes the weight slice, the next
+    // tile's before the current one's MFMAs
+    auto tile_of = [&](int it) { return __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 4 + wave) * a.tpw + it)); };
+    auto fetch = [&](int tile, v4i (&dst)[KS]) {
+        const int mm = min(tile * 32 + l31, a.M - 1);
+        const int img = mm / (a.ho * a.wo), rem = mm - img * (a.ho * a.wo);
+        const int yo = rem / a.wo, xo = rem - yo * a.wo;
+        const int8_t* src = a.in + ((size_t)(img * (a.h + 2) + yo * a.stride + 1) * (a.wd + 2) + xo * a.stride + 1) * a.cin + 16 * half;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) dst[ks] = *(const v4i*)(src + 32 * ks);
+    };
+    v4i fb[KS], fbn[KS];
+    fetch(tile_of(0), fbn);
     __syncthreads();
     for (int it = 0; it < a.tpw; ++it) {
-        const int tile = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 4 + wave) * a.tpw + it));
+        const int tile = tile_of(it);
         if (tile * 32 >= a.M) break;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) fb[ks] = fbn[ks];
+        if (it + 1 < a.tpw) fetch(tile_of(it + 1), fbn);
         const int m = tile * 32 + l31;
         const bool valid = m < a.M;
         const int mm = valid ? m : a.M - 1;
         const int img = mm / (a.ho * a.wo), rem = mm - img * (a.ho * a.wo);
         const int yo = rem / a.wo, xo = rem - yo * a.wo;
-        const int8_t* src = a.in + ((size_t)(img * (a.h + 2) + yo * a.stride + 1) * (a.wd + 2) + xo * a.stride + 1) * a.cin + 16 * half;
-        v4i fb[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) fb[ks] = *(const v4i*)(src + 32 * ks);
         const int opix = (img * (a.ho + 2) + yo + 1) * (a.wo + 2) + xo + 1;       // padded output pixel
         v4f rf[2][4];                                               // the shortcut, requested ahead of the MFMAs
         int rw[2][4];
