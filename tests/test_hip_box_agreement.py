@@ -40,8 +40,10 @@ def _match(ca, la, cb, lb, thr=0.7):
     return best >= thr, arg, best
 
 
-@pytest.mark.parametrize("shape,n_agents,n_points", [("tiny", 2, 3000), ("v2xreal", 2, 60000)])
-def test_detections_agree_with_the_fake_quant_mirror(shape, n_agents, n_points):
+@pytest.mark.parametrize("model,shape,n_agents,n_points", [("attfuse", "tiny", 2, 3000), ("attfuse", "v2xreal", 2, 60000),
+                                                          ("pyramid", "tiny", 2, 3000), ("pyramid", "v2xreal", 2, 60000)])
+def test_detections_agree_with_the_fake_quant_mirror(model, shape, n_agents, n_points):
+    from _common import calibrated_pyramid_plugin
     from oracle import postprocess as P
     from test_postprocess_oracle import MC_CFGS, interleave, mc_params
     from quantv2x_amd import synth
@@ -49,7 +51,7 @@ def test_detections_agree_with_the_fake_quant_mirror(shape, n_agents, n_points):
     from quantv2x_amd.plugin.data_utils.post_processor import build_postprocessor
     from quantv2x_amd.ptq_state import export_ptq_state
     torch.set_num_threads(min(32, os.cpu_count() or 8))
-    qt = calibrated_plugin(shape, n_agents=n_agents, n_points=n_points)
+    qt = (calibrated_plugin if model == "attfuse" else calibrated_pyramid_plugin)(shape, n_agents=n_agents, n_points=n_points)
     qt.model.hard_eval = True                                     # deterministic codebook pair (the wire format) in the mirror too
     sc = scene_np(n_agents, shape, n_points=n_points)
     with torch.no_grad():
@@ -78,7 +80,7 @@ def test_detections_agree_with_the_fake_quant_mirror(shape, n_agents, n_points):
     dp = np.abs(out["preds_tensor"].cpu().numpy() - ref["preds_tensor"].numpy())
     top = min(50, len(gs), len(rs))
     m_top, _, _ = _match(gb[:top], gl[:top], rb, rl)
-    report = {"shape": shape, "agents": n_agents, "boxes_mirror": int(len(rs)), "boxes_deployed": int(len(gs)),
+    report = {"model": model, "shape": shape, "agents": n_agents, "boxes_mirror": int(len(rs)), "boxes_deployed": int(len(gs)),
               "deployed_matched_in_mirror_iou0.7": round(float(m_g.mean()), 4), "mirror_matched_in_deployed_iou0.7": round(float(m_r.mean()), 4),
               f"top{top}_deployed_matched": round(float(m_top.mean()), 4),
               "score_abs_diff_matched_mean": round(float(ds.mean()), 5) if len(ds) else None,
@@ -89,7 +91,7 @@ def test_detections_agree_with_the_fake_quant_mirror(shape, n_agents, n_points):
     print(json.dumps(report))
     outdir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(outdir):
-        with open(os.path.join(outdir, f"box_agreement_{shape}.json"), "w") as f:
+        with open(os.path.join(outdir, f"box_agreement_{shape}.json" if model == "attfuse" else f"box_agreement_{model}_{shape}.json"), "w") as f:
             json.dump(report, f, indent=1)
     # the bar: the two detection sets are the same objects
     assert report["deployed_matched_in_mirror_iou0.7"] >= 0.6 and report["mirror_matched_in_deployed_iou0.7"] >= 0.6, report
