@@ -126,7 +126,8 @@ def rooflines(eng, full, frames, iters):
           f"{pillars} pillars x 532 B read + {n} x 9.0 MB u8 canvas written (SURVEY 8(d) a1+a2)")
     stage("backbone_convs_i8", lambda: eng.run_plan(n, only=lambda k, l: k in ("conv", "chain") and l.name.startswith("backbone")), "mfma-i8",
           sum(2.0 * p[7] for p in bb), "TOP/s", INT8_MFMA_PEAK_TOPS, len(bb),
-          f"{sum(2.0 * p[7] for p in bb) / 1e9:.1f} GOP: 19 conv layers (level 0 = one fused launch)")
+          f"{sum(2.0 * p[7] for p in bb) / 1e9:.1f} GOP: 19 conv layers in {len(bb)} launches"
+          + (" (level 0 = one fused launch)" if any(p[0] == "chain" for p in bb) else " (one per layer: the level-0 fusion only pays for a single agent-frame)"))
     stage("backbone_deconvs_f32", lambda: eng.run_plan(n, only=lambda k, l: k == "deconv"), "mfma-f32",
           sum(2.0 * p[7] for p in de), "TFLOP/s", F32_MFMA_PEAK_TFLOPS, 1, f"{sum(2.0 * p[7] for p in de) / 1e9:.2f} GFLOP: 3 deblocks, one launch")
     stage("shrinker_convs_i8", lambda: eng.run_plan(n, only=lambda k, l: k == "conv" and l.name.startswith("shrinker")), "mfma-i8",

@@ -389,6 +389,8 @@ static int conv3x3_entry(const qv2x_conv_desc* d, const int8_t* in, const int8_t
         if (a.cout % 128) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8: multi-group input needs cout %% 128 == 0");
         return launch_dma<128, 128, 2, 2, 64, true, 4, 2>(a, st);
     }
+    // (128-byte K chunks for the 128 x 128 tile -- 96 KB ring, one workgroup per CU -- are slower: 36 vs 25-27 us on the 128 / 256-channel
+    //  levels at a batch of 8)
     if (large) return launch_dma<128, 128, 2, 2, 64, false, 3, 3>(a, st);
     // 256-byte K chunks (fewest barriers, 98 KB of LDS: one workgroup per CU) while the grid fits the chip in one round; beyond
     // that two resident workgroups per CU with 128-byte chunks win (25 x 88 x 256 layers: 10.0 vs 10.9 us for one frame, 27.0 vs

@@ -239,6 +239,7 @@ class DeployedModel(nn.Module):
         self._bufs: Dict[int, dict] = {}
         # launch-plan switches for the ablation tools (tools/bench_*_abl.py); the defaults are the shipped configuration
         self.use_wide_conv, self.batch_deconvs, self.use_chains = True, True, True
+        self.chain_max_agents = 1
 
     # ------------------------------------------------------------------------------------------------------
     def _level_blob(self, l: int) -> torch.Tensor:
@@ -368,7 +369,11 @@ class DeployedModel(nn.Module):
     def conv_plan(self, n_agents: int):
         """Static launch list of a3 + a4 for ``n_agents`` agents: ``(kind, layer, x, h, w, out, out_c0, macs)``."""
         b = self._workspace(n_agents)
-        key = ("plan", self.use_chains)
+        # one launch per backbone level (conv3x3_i8_chain64) pays while launches are latency-bound, i.e. for ONE agent-frame (29.6 us
+        # against four launches of ~10); from two on the per-layer kernels are as fast or faster (V2X-Real level 0: 2 agent-frames
+        # 509 vs 501 us for the whole stack, 8: 203 us fused against 144 us in four launches)
+        use_chains = self.use_chains and n_agents <= self.chain_max_agents
+        key = ("plan", use_chains)
         if key in b:
             return b[key]
         plan = []
@@ -376,7 +381,7 @@ class DeployedModel(nn.Module):
         for lvl, convs in enumerate(self.blocks):
             pair, ho, wo = b["lvl"][lvl]
             macs = [n_agents * ho * wo * layer.cout * layer.w.shape[1] for layer in convs]
-            if self.use_chains and self.chains[lvl] is not None:
+            if use_chains and self.chains[lvl] is not None:
                 out = pair[(len(convs) - 1) % 2]
                 plan.append(("chain", self.chains[lvl], x, h, w, out, 0, sum(macs)))
                 x, h, w = out, ho, wo
