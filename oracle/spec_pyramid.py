@@ -51,10 +51,11 @@ class OraclePyramid(Oracle):
         self.p_nums = [int(v) for v in state["meta/pyramid_layer_nums"]]
         self.p_strides = [int(v) for v in state["meta/pyramid_layer_strides"]]
         self.ups = [int(v) for v in state["meta/upsample_strides"]]
-        self.levels = int(state["meta/codebook_levels"])
-        self.D = int(state["codebook/0/codebook"].shape[1])
-        self.lut, self.lut_bias = decode_tables_d(state, self.levels, self.D)
-        self.has_codebook = True
+        self.has_codebook = bool(state["meta/has_codebook"])          # heter_pyramid_collab_mc (LiDAROnly/lidar_pyramid.yaml): no codebook
+        if self.has_codebook:
+            self.levels = int(state["meta/codebook_levels"])
+            self.D = int(state["codebook/0/codebook"].shape[1])
+            self.lut, self.lut_bias = decode_tables_d(state, self.levels, self.D)
 
     # ---- layers -----------------------------------------------------------------------------------------------------------
     def convg(self, name, x, xq, stride=1, f32_out=False, relu=True):
@@ -170,11 +171,12 @@ class OraclePyramid(Oracle):
         lut, occ = sigmoid_lut(*oq)
         return code, occ[code], lut[code]
 
-    def pyramid(self, feats, pairwise_t, record_len, taps=None):
-        """feats f32 [sum_N, h, w, D] (decoded) -> concat of the deblocks' codes [B, h, w, 384] with its three quantizers."""
+    def pyramid(self, feats, pairwise_t, record_len, taps=None, codes_in=None):
+        """feats f32 [sum_N, h, w, D] (decoded) -- or, without a codebook, ``codes_in = (x, xq)``: the agents' activation codes --
+        -> concat of the deblocks' codes [B, h, w, 384] with its three quantizers."""
         H, W = (float(v) for v in self.s["meta/HW_metres"])
         affine = geometry.normalize_pairwise_tfm(np.asarray(pairwise_t), H, W, float(self.s["meta/discrete_ratio"]))
-        x, xq, x_f32 = None, None, feats
+        x, xq, x_f32 = (None, None, feats) if codes_in is None else (codes_in[0], codes_in[1], None)
         cat, cat_q, c0, occs = None, [], 0, []
         total = sum(self.s[f"pyramid_backbone.deblocks.{l}.0/w_code"].shape[1] for l in range(len(self.ups)))
         for lvl in range(len(self.p_nums)):
@@ -237,5 +239,16 @@ class OraclePyramid(Oracle):
                 "occ_single_list": occs}
 
     def forward(self, scene, taps=None):
-        codes, shape = self.encode_features(scene, taps)
-        return self.decode_features(codes, shape, scene, taps)
+        if self.has_codebook:
+            codes, shape = self.encode_features(scene, taps)
+            return self.decode_features(codes, shape, scene, taps)
+        taps = {} if taps is None else taps
+        pcodes, canvas, cq = self.pfn_scatter(scene, len(scene["agent_modality_list"]))
+        taps["pillar_code"], taps["canvas"] = pcodes, canvas
+        x, xq = self.agent_backbone(canvas, cq, taps)
+        cat, cat_q, occs = self.pyramid(None, scene["pairwise_t_matrix"], scene["record_len"], taps, codes_in=(x, xq))
+        taps["cat"] = cat
+        shr, shr_q = self.shrink(cat, cat_q, taps)
+        cls, reg, dr = self.heads(self.dequant(shr, shr_q))
+        return {"cls_preds": cls, "reg_preds": reg, "dir_preds": dr, "preds_tensor": np.concatenate([cls, reg, dr], axis=1),
+                "occ_single_list": occs}

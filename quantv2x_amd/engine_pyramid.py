@@ -153,7 +153,7 @@ class DeployedPyramidModel(nn.Module):
         self.nx, self.ny, _ = (int(v) for v in s["meta/grid"])
         self.hm, self.wm = (float(v) for v in s["meta/HW_metres"])
         self.ratio = float(s["meta/discrete_ratio"])
-        self.has_codebook = True
+        self.has_codebook = bool(s["meta/has_codebook"])            # heter_pyramid_collab_mc (LiDAROnly/lidar_pyramid.yaml): no codebook
 
         n = "encoder_m1.pillar_vfe.pfn_layers.0.linear"
         wq = ((s[n + "/w_code"].astype(np.float32) - s[n + "/w_zp"].astype(np.float32)[:, None]) * s[n + "/w_delta"].astype(np.float32)[:, None]).astype(np.float32)
@@ -179,15 +179,17 @@ class DeployedPyramidModel(nn.Module):
             q = blk.out_q
         self.agent_q = q
         # ---- codebook (D = 64: its own encode kernel; other widths run the 256-wide one on zero-padded heads, see _level_blob) --
-        self.levels = int(s["meta/codebook_levels"])
-        self.kc, self.D = (int(v) for v in s["codebook/0/codebook"].shape)
-        if self.D > 256 or self.D % 4 or self.agent_blocks[-1].cout != self.D:
-            raise NotImplementedError("deployed Pyramid codebook: width <= 256 equal to the agent feature's channels")
-        self.native64 = self.D == 64
-        lut, lut_bias = decode_tables(s, self.levels, self.D)
-        self.lut, self.lut_bias = _dev(lut, dev), _dev(lut_bias, dev)
-        self.level_blobs = [self._level_blob(l) for l in range(self.levels)]
-        self.level_ptrs = (C.c_void_p * self.levels)(*[b.data_ptr() for b in self.level_blobs])
+        self.native64 = True
+        if self.has_codebook:
+            self.levels = int(s["meta/codebook_levels"])
+            self.kc, self.D = (int(v) for v in s["codebook/0/codebook"].shape)
+            if self.D > 256 or self.D % 4 or self.agent_blocks[-1].cout != self.D:
+                raise NotImplementedError("deployed Pyramid codebook: width <= 256 equal to the agent feature's channels")
+            self.native64 = self.D == 64
+            lut, lut_bias = decode_tables(s, self.levels, self.D)
+            self.lut, self.lut_bias = _dev(lut, dev), _dev(lut_bias, dev)
+            self.level_blobs = [self._level_blob(l) for l in range(self.levels)]
+            self.level_ptrs = (C.c_void_p * self.levels)(*[b.data_ptr() for b in self.level_blobs])
         # ---- the pyramid: ResNeXt levels, occupancy heads, deblocks -------------------------------------------------------------------
         p_nums, p_strides = [int(v) for v in s["meta/pyramid_layer_nums"]], [int(v) for v in s["meta/pyramid_layer_strides"]]
         self.ups = [int(v) for v in s["meta/upsample_strides"]]
@@ -195,7 +197,7 @@ class DeployedPyramidModel(nn.Module):
         self.pyr_blocks: List[List[_Block]] = []
         self.occ: List[_Occ] = []
         self.deblocks: List[_DenseF32In] = []
-        q, cat_groups, c0 = None, [], 0
+        q, cat_groups, c0 = (None if self.has_codebook else self.agent_q), [], 0
         for lvl in range(len(p_nums)):
             blocks = []
             for b in range(p_nums[lvl]):
@@ -275,7 +277,8 @@ class DeployedPyramidModel(nn.Module):
         # the last block writes channels [0, D); with the 256-wide encode kernel the rest stay at the code of 0.0
         b["enc_in"] = self._padded(n, fh, fw, 64 if self.native64 else 256, zp)
         b["ds"] = torch.empty((n * fh * fw, 64), dtype=torch.float32, device=self.dev)
-        b["codes"] = torch.empty((self.levels, n, fh * fw), dtype=torch.uint8, device=self.dev)
+        if self.has_codebook:
+            b["codes"] = torch.empty((self.levels, n, fh * fw), dtype=torch.uint8, device=self.dev)
         self._bufs[key] = b
         return b
 
@@ -284,7 +287,9 @@ class DeployedPyramidModel(nn.Module):
         if key in self._bufs:
             return self._bufs[key]
         self._agent_ws(1)
-        b = {"feats": torch.empty((n * self.fh * self.fw, self.D), dtype=torch.float32, device=self.dev), "lvl": []}
+        b = {"lvl": []}
+        if self.has_codebook:
+            b["feats"] = torch.empty((n * self.fh * self.fw, self.D), dtype=torch.float32, device=self.dev)
         h, w = self.fh, self.fw
         for lvl, blocks in enumerate(self.pyr_blocks):
             hi, wi = h, w
@@ -423,6 +428,8 @@ class DeployedPyramidModel(nn.Module):
     @torch.no_grad()
     def encode_features(self, inputs: dict, n: int, taps: Optional[dict] = None, out: Optional[torch.Tensor] = None):
         """codes u8 [levels, n, H*W] of ``n`` agents (heter_pyramid_collab_codebook_mc_encdec.py:33-121)."""
+        if not self.has_codebook:
+            raise L.Qv2xError("encode_features: this model has no codebook (no wire format); call forward")
         canvas = self.pillars_to_canvas(inputs, n)
         if taps is not None:
             taps["canvas"] = canvas
@@ -478,20 +485,29 @@ class DeployedPyramidModel(nn.Module):
                         taps: Optional[dict] = None) -> dict:
         """``codes``: pointer / tensor of u8 planes, agent a's level-l plane at ``a * agent_stride + l * level_stride``; ``lens`` agents per
         scene; ``pairwise`` f64 [B, L, L, 4, 4] (heter_pyramid_collab_codebook_mc_encdec.py:123-181)."""
+        if not self.has_codebook:
+            raise L.Qv2xError("decode_features: this model has no codebook (no wire format); call forward")
         n, nb = sum(lens), len(lens)
         b = self._ego_ws(n, nb)
         hw = self.fh * self.fw
-        st = L.current_stream
         cptr = codes if isinstance(codes, C.c_void_p) else L.ptr(codes)
         L.check(self.lib.qv2x_codebook_decode_f32(cptr, agent_stride, level_stride, n, hw, self.levels, self.kc, self.D, L.ptr(self.lut), L.ptr(self.lut_bias),
-                                                  L.ptr(b["feats"]), st()), "qv2x_codebook_decode_f32")
-        x, xq, h, w = None, None, self.fh, self.fw
+                                                  L.ptr(b["feats"]), L.current_stream()), "qv2x_codebook_decode_f32")
+        return self._pyramid_and_heads(None, None, b["feats"], lens, pairwise, ego, taps)
+
+    def _pyramid_and_heads(self, x, xq, feats_f32, lens: List[int], pairwise: torch.Tensor, ego: int, taps: Optional[dict]) -> dict:
+        """The ResNeXt levels on every agent's map -- codes ``x`` with quantizer ``xq``, or the decoded fp32 map -- fusion, deblocks,
+        shrink_conv and the heads."""
+        n, nb = sum(lens), len(lens)
+        b = self._ego_ws(n, nb)
+        st = L.current_stream
+        h, w = self.fh, self.fw
         occ_maps, c0 = [], 0
         for lvl, blocks in enumerate(self.pyr_blocks):
             lv = b["lvl"][lvl]
             for i, blk in enumerate(blocks):
                 out = lv["x"][i % 2]
-                self._block(blk, x, xq, n, h, w, lv, out, b["feats"])
+                self._block(blk, x, xq, n, h, w, lv, out, feats_f32)
                 x, xq, h, w = out, blk.out_q, lv["h"], lv["w"]
                 if taps is not None:
                     taps[blk.name] = out.clone()
@@ -520,7 +536,7 @@ class DeployedPyramidModel(nn.Module):
         L.check(self.lib.qv2x_heads_f32(L.ptr(b["rows"]), nb * oh * ow, oh * ow, hd.cout, hd.cout_pad, L.ptr(hd.w), L.ptr(hd.bias), L.ptr(hd.da), L.ptr(hd.za),
                                         L.ptr(preds), st()), "qv2x_heads_f32")
         if taps is not None:
-            taps["cat"], taps[self.shrink0.name], taps[self.shrink1.name], taps["features"] = b["cat"], b["s0"], b["s1"], b["feats"]
+            taps["cat"], taps[self.shrink0.name], taps[self.shrink1.name], taps["features"] = b["cat"], b["s0"], b["s1"], feats_f32
         c, r, _ = hd.splits
         return {"pyramid": "collab", "cls_preds": preds[:, :c], "reg_preds": preds[:, c:c + r], "dir_preds": preds[:, c + r:], "preds_tensor": preds,
                 "occ_single_list": occ_maps}
@@ -568,6 +584,12 @@ class DeployedPyramidModel(nn.Module):
             if isinstance(rl, torch.Tensor) and rl.is_cuda and torch.cuda.is_current_stream_capturing():
                 raise ValueError("record_len on the GPU cannot be read during HIP-graph capture: pass a CPU tensor")
             lens = [int(v) for v in (rl.tolist() if isinstance(rl, torch.Tensor) else rl)]
+        if not self.has_codebook:                                    # heter_pyramid_collab_mc: the agents' codes go straight into the pyramid
+            canvas = self.pillars_to_canvas(data_dict["inputs_m1"], n_total)
+            if taps is not None:
+                taps["canvas"] = canvas
+            x = self.agent_backbone(n_total, taps)
+            return self._pyramid_and_heads(x, self.agent_q, None, lens, pairwise, 0, taps)
         codes = self.encode_features(data_dict["inputs_m1"], n_total, taps)
         hw = self.fh * self.fw
         if taps is not None:

@@ -73,8 +73,6 @@ def _check_structure(model) -> None:
             raise NotImplementedError("deployed Pyramid path: a one-level per-agent ResNet backbone without deblocks")
         if type(model.aligner_m1.channel_align).__name__ != "Identity":
             raise NotImplementedError("deployed Pyramid path: aligner core_method identity")
-        if getattr(model, "codebook", None) is None:
-            raise NotImplementedError("deployed Pyramid path: the codebook model (heter_pyramid_collab_codebook_mc[_encdec])")
     else:
         fusion = getattr(model, "fusion_net", None)
         if type(fusion).__name__ != "AttFusion":

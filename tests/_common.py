@@ -25,7 +25,8 @@ def build_pyramid_plugin(shape="tiny", **kw):
 
 
 def calibrated_pyramid_plugin(shape="tiny", n_agents=2, n_points=N_POINTS, **kw):
-    """The ``pyramid_tiny.npz`` recipe: W8A8 min-max, one EMA pass through the hard (encode -> decode) path, frozen."""
+    """The ``pyramid_tiny.npz`` recipe: W8A8 min-max, one EMA pass through the hard (encode -> decode) path, frozen.
+    ``codebook=False``: ``heter_pyramid_collab_mc`` (LiDAROnly/lidar_pyramid.yaml), the same network without the compressor."""
     from quantv2x_amd.plugin.tools.inference_quant import calibrate_minmax
     return calibrate_minmax(quant_wrap(build_pyramid_plugin(shape, **kw)), [scene(n_agents, shape, n_points=n_points)])
 

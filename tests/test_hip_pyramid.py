@@ -37,8 +37,9 @@ def compare_pyramid_frame(orc, eng, sc, st):
             np.testing.assert_array_equal(interior_u8(gtaps[name]), arr, err_msg=name)
             checked += 1
     assert checked >= 3 * 2 + 16
-    np.testing.assert_array_equal(gtaps["codes"].cpu().numpy().reshape(otaps["codes"].shape), otaps["codes"], err_msg="wire indices")
-    np.testing.assert_array_equal(gtaps["features"].cpu().numpy().reshape(otaps["features"].shape), otaps["features"], err_msg="decoded map")
+    if orc.has_codebook:
+        np.testing.assert_array_equal(gtaps["codes"].cpu().numpy().reshape(otaps["codes"].shape), otaps["codes"], err_msg="wire indices")
+        np.testing.assert_array_equal(gtaps["features"].cpu().numpy().reshape(otaps["features"].shape), otaps["features"], err_msg="decoded map")
     H, W = (float(v) for v in st["meta/HW_metres"])
     affine = geometry.normalize_pairwise_tfm(np.asarray(sc["pairwise_t_matrix"]), H, W, float(st["meta/discrete_ratio"]))
     lens = [int(v) for v in sc["record_len"]]
@@ -86,6 +87,25 @@ def test_small_frame_every_stage():
     from oracle.spec_pyramid import OraclePyramid
     st = export_ptq_state(calibrated_pyramid_plugin("small", n_points=8000))
     compare_pyramid_frame(OraclePyramid(st), deploy(state=st), scene_np(2, "small", n_points=8000), st)
+
+
+def test_model_without_codebook():
+    """``heter_pyramid_collab_mc`` (hypes_yaml/v2x_real/LiDAROnly/lidar_pyramid.yaml): the agents' activation codes go straight into
+    the pyramid -- every stage against the oracle; there is no wire format, so the multi-GPU driver and the encdec entry points refuse."""
+    from quantv2x_amd import lib as L
+    from quantv2x_amd.dist import AgentShardedModel
+    from quantv2x_amd.engine import deploy
+    from quantv2x_amd.ptq_state import export_ptq_state
+    from oracle.spec_pyramid import OraclePyramid
+    st = export_ptq_state(calibrated_pyramid_plugin(codebook=False))
+    assert not bool(st["meta/has_codebook"])
+    eng = deploy(state=st)
+    for n in (1, 2):
+        compare_pyramid_frame(OraclePyramid(st), eng, scene_np(n), st)
+    with pytest.raises(L.Qv2xError):
+        eng.encode_features({}, 1)
+    with pytest.raises(NotImplementedError):
+        AgentShardedModel(eng)
 
 
 def test_encdec_split_and_reference_model_contract(tiny):
