@@ -69,6 +69,13 @@ class UniformAffineQuantizer(nn.Module):
     def forward(self, x: torch.Tensor):
         if self.inited is False:
             self.delta, self.zero_point = self.init_quantization_scale(x.clone().detach(), self.channel_wise)
+        else:
+            # (delta, zero_point) are plain attributes, not buffers: ``model.cuda()`` after the weight ranges were taken on the CPU
+            # leaves them behind (the reference builds on the GPU from the start and never meets this)
+            for name in ("delta", "zero_point"):
+                t = getattr(self, name)
+                if isinstance(t, torch.Tensor) and not isinstance(t, torch.nn.Parameter) and t.device != x.device:
+                    setattr(self, name, t.to(x.device))
         code = torch.clamp(round_ste(x / self.delta) + self.zero_point, 0, self.n_levels - 1)
         deq = (code - self.zero_point) * self.delta
         if self.is_training and self.prob < 1.0:

@@ -44,7 +44,11 @@ def test_tiny_layer_by_layer_launches(tiny, n_agents):
     state, orc, eng = tiny
     sc = scene_np(n_agents)
     assert eng.use_chains and eng.chains[0] is not None
-    _, fused_taps, _, fused_out = compare_frame(orc, eng, sc, state)
+    keep, eng.chain_max_agents = eng.chain_max_agents, 8           # (the engine itself fuses for one agent-frame only)
+    try:
+        _, fused_taps, _, fused_out = compare_frame(orc, eng, sc, state)
+    finally:
+        eng.chain_max_agents = keep
     fused_out = {k: v.clone() for k, v in fused_out.items()}
     eng.use_chains = False
     try:
