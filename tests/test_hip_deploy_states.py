@@ -60,3 +60,25 @@ def test_reconstruction_on_the_gpu_then_deploy():
     state, orc, eng = _deploy(qt)
     for n_agents in (1, 2):
         compare_frame(orc, eng, scene_np(n_agents), state)
+
+
+def test_pyramid_reconstruction_on_the_gpu_then_deploy():
+    """The same for the HEAL Pyramid model: PFN -> agent ResNet block -> ``QuantPyramidFusion`` as one unit (``pyramid_reconstruction``)
+    -> shrink_conv -> heads reconstructed on the GPU, exported, deployed on the Pyramid engine, every stage bit-exact vs its oracle."""
+    from _common import build_pyramid_plugin, scene
+    from test_hip_pyramid import compare_pyramid_frame
+    from oracle.spec_pyramid import OraclePyramid
+    from quantv2x_amd.engine import deploy
+    from quantv2x_amd.plugin.quant import AdaRoundQuantizer, QuantModule
+    from quantv2x_amd.plugin.tools import inference_quant as IQ
+    from quantv2x_amd.ptq_state import export_ptq_state
+    fp, qt = IQ.wrap_pair(build_pyramid_plugin("tiny"))
+    fp.cuda(); qt.cuda()
+    cali = [scene(2, seed=3 + i, device="cuda") for i in range(2)]
+    seen = []
+    IQ.recon_model(qt, fp, IQ.recon_kwargs(cali, iters_w=10, dc_iters=2, verbose=False, seed=0), log=seen.append)
+    assert [s.split()[-1] for s in seen] == ["0", "backbone_m1", "pyramid_backbone", "shrink_conv", "cls_head", "reg_head", "dir_head"]
+    assert all(isinstance(m.weight_quantizer, AdaRoundQuantizer) and m.weight_quantizer.alpha.is_cuda for m in qt.modules() if isinstance(m, QuantModule))
+    st = export_ptq_state(qt)
+    eng = deploy(state=st)
+    compare_pyramid_frame(OraclePyramid(st), eng, scene_np(2), st)
