@@ -185,6 +185,8 @@ typedef struct {
     int32_t max_cav, ego;
     int64_t code_agent_stride, code_level_stride;
     double h_metres, w_metres, discrete_ratio;
+    int32_t fusion;            /* 0 = AttFusion (per-cell attention, ego row; fusion_in_one.py:126-151), 1 = MaxFusion (F-Cooper:
+                                * elementwise max over the warped agents, fusion_in_one.py:87-123) */
 } qv2x_fuse_desc;
 int qv2x_fuse_att_f32(const qv2x_fuse_desc* desc /* host */, const uint8_t* codes, const float* lut, const float* lut_bias,
                       const float* feats, const double* pairwise, float* fused, void* stream);

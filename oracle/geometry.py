@@ -69,6 +69,11 @@ def att_fuse(warped):
 
 # ---- pairwise transforms from the gathered world poses (the multi-GPU link carries poses, not the pairwise matrix) ----------
 
+def max_fuse(warped):
+    """``MaxFusion`` (fusion_in_one.py:118-121): elementwise max over the warped agents (an out-of-view agent is a map of zeros)"""
+    return warped.max(axis=0)
+
+
 def solve4(a, b):
     """X with ``a @ X = b`` for 4 x 4 float64 matrices: Gaussian elimination with partial pivoting (first largest pivot), every
     update a separate multiply and subtract, then back substitution -- the fixed operation order ``qv2x_pairwise_from_poses_f64``

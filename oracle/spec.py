@@ -211,7 +211,8 @@ class Oracle:
         affine = geometry.normalize_pairwise_tfm(np.asarray(pairwise_t), H, W, float(self.s["meta/discrete_ratio"]))
         out, start = [], 0
         for b, n in enumerate(int(v) for v in record_len):
-            out.append(geometry.att_fuse(geometry.warp_to_ego(feats[start:start + n], affine[b], n)))
+            warped = geometry.warp_to_ego(feats[start:start + n], affine[b], n)
+            out.append(geometry.max_fuse(warped) if str(self.s.get("meta/fusion_method", "att")) == "max" else geometry.att_fuse(warped))
             start += n
         return np.stack(out)
 

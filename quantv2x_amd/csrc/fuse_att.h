@@ -11,6 +11,7 @@ struct FuseArgs {
     const uint8_t* codes; const float4* lut; const float4* lut_bias; const float4* feats; float4* fused;
     const double* pairwise;          // device, [L][L][4][4]; row `ego` is used: T[ego][j] = T_j^-1 T_ego
     int agents, h, w, levels, kc, hw, L, ego;
+    int fusion;                      // 0 = AttFusion, 1 = MaxFusion
     long long code_agent_stride, code_level_stride;
     double hm, wm, ratio;            // metres covered by the map (H, W) and discrete_ratio of normalize_pairwise_tfm
 };
@@ -68,6 +69,13 @@ __device__ __forceinline__ float4 fuse_cell_n(const FuseArgs& a, int cell, int l
                 }
             }
         }
+    }
+    if (a.fusion == 1) {              // MaxFusion (fusion_in_one.py:118-121): torch.max over the warped agents, out-of-view agents are zeros
+        float4 o = f[0];
+#pragma unroll
+        for (int ag = 1; ag < NA; ++ag)
+            if (ag < a.agents) { o.x = fmaxf(o.x, f[ag].x); o.y = fmaxf(o.y, f[ag].y); o.z = fmaxf(o.z, f[ag].z); o.w = fmaxf(o.w, f[ag].w); }
+        return o;
     }
     float4 fq = f[0];                 // the ego's own feature is the query
 #pragma unroll

@@ -33,6 +33,8 @@ int fuse_args_from_desc(const qv2x_fuse_desc* d, const uint8_t* codes, const flo
     a.agents = d->agents; a.h = d->h; a.w = d->w; a.levels = d->levels; a.kc = d->kc; a.hw = d->h * d->w; a.L = d->max_cav; a.ego = d->ego;
     a.code_agent_stride = d->code_agent_stride; a.code_level_stride = d->code_level_stride;
     a.hm = d->h_metres; a.wm = d->w_metres; a.ratio = d->discrete_ratio;
+    if (d->fusion != 0 && d->fusion != 1) return fail(QV2X_EINVAL, "%s: fusion 0 (attention) or 1 (max)", who);
+    a.fusion = d->fusion;
     return QV2X_OK;
 }
 

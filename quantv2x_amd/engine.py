@@ -170,8 +170,9 @@ class DeployedModel(nn.Module):
         self.state = state
         self.dev = torch.device(device)
         s = state
-        if str(s.get("meta/fusion_method", "att")) != "att":
-            raise NotImplementedError(f"deployed path: fusion_method {s['meta/fusion_method']!r} (only 'att' = AttFusion is built)")
+        if str(s.get("meta/fusion_method", "att")) not in ("att", "max"):
+            raise NotImplementedError(f"deployed path: fusion_method {s['meta/fusion_method']!r} ('att' = AttFusion and 'max' = MaxFusion are built here)")
+        self.fusion = 1 if str(s.get("meta/fusion_method", "att")) == "max" else 0
         self.nx, self.ny, _ = (int(v) for v in s["meta/grid"])
         self.hm, self.wm = (float(v) for v in s["meta/HW_metres"])
         self.ratio = float(s["meta/discrete_ratio"])
@@ -519,6 +520,7 @@ class DeployedModel(nn.Module):
         d.max_cav, d.ego = pairwise_b.shape[0], ego
         d.code_agent_stride, d.code_level_stride = agent_stride, level_stride
         d.h_metres, d.w_metres, d.discrete_ratio = self.hm, self.wm, self.ratio
+        d.fusion = self.fusion
         return d
 
     def fuse(self, codes_ptr, agent_stride, level_stride, feats, pairwise_b, n, out, ego=0):

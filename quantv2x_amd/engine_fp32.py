@@ -40,9 +40,10 @@ def _fold(w: np.ndarray, b: Optional[np.ndarray], bn, out_axis: int):
 
 def export_fp32_state(model) -> Dict[str, np.ndarray]:
     """Plain (un-quantized) ``HeterModelBaseline`` / ``HeterBaselineCollabCodebook`` (``_mc``) -> numpy state of the fp32 HIP path."""
-    if type(getattr(model, "fusion_net", None)).__name__ != "AttFusion" or getattr(model, "shrink_flag", False) or getattr(model, "compress", False):
-        raise NotImplementedError("deployed path: AttFusion, no post-fusion shrink_conv, no compressor")
-    out: Dict[str, np.ndarray] = {"meta/mode": np.array("fp32"), "meta/fusion_method": np.array("att")}
+    fusion = type(getattr(model, "fusion_net", None)).__name__
+    if fusion not in ("AttFusion", "MaxFusion") or getattr(model, "shrink_flag", False) or getattr(model, "compress", False):
+        raise NotImplementedError("deployed path: AttFusion or MaxFusion, no post-fusion shrink_conv, no compressor")
+    out: Dict[str, np.ndarray] = {"meta/mode": np.array("fp32"), "meta/fusion_method": np.array("max" if fusion == "MaxFusion" else "att")}
     enc = model.encoder_m1
     vfe = enc.pillar_vfe
     if len(vfe.pfn_layers) != 1 or vfe.with_distance or not vfe.use_absolute_xyz:
@@ -163,6 +164,7 @@ class DeployedFp32Model(DeployedModel):
         self.strides = [int(v) for v in s["meta/layer_strides"]]
         self.ups = [int(v) for v in s["meta/upsample_strides"]]
         self.has_codebook = bool(s["meta/has_codebook"])
+        self.fusion = 1 if str(s.get("meta/fusion_method", "att")) == "max" else 0
         self.emit_single = bool(s["meta/supervise_single"]) if emit_single_preds is None else bool(emit_single_preds)
         f32a = lambda a: (C.c_float * len(a))(*[float(np.float32(v)) for v in a])
         self.pfn_w, self.pfn_b = f32a(s["pfn/w"].reshape(-1)), f32a(s["pfn/bias"])

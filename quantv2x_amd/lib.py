@@ -85,7 +85,7 @@ class FuseDesc(C.Structure):
     _fields_ = [("agents", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("levels", C.c_int32), ("kc", C.c_int32),
                 ("max_cav", C.c_int32), ("ego", C.c_int32),
                 ("code_agent_stride", C.c_int64), ("code_level_stride", C.c_int64),
-                ("h_metres", C.c_double), ("w_metres", C.c_double), ("discrete_ratio", C.c_double)]
+                ("h_metres", C.c_double), ("w_metres", C.c_double), ("discrete_ratio", C.c_double), ("fusion", C.c_int32)]
 
 
 class PostprocessDesc(C.Structure):

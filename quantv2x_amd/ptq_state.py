@@ -75,8 +75,8 @@ def _check_structure(model) -> None:
             raise NotImplementedError("deployed Pyramid path: aligner core_method identity")
     else:
         fusion = getattr(model, "fusion_net", None)
-        if type(fusion).__name__ != "AttFusion":
-            raise NotImplementedError(f"deployed path: fusion_net must be AttFusion (fusion_method 'att'), got {type(fusion).__name__}")
+        if type(fusion).__name__ not in ("AttFusion", "MaxFusion"):
+            raise NotImplementedError(f"deployed path: fusion_net must be AttFusion or MaxFusion (fusion_method 'att' / 'max'), got {type(fusion).__name__}")
         if getattr(model, "shrink_flag", False):
             raise NotImplementedError("deployed path: a post-fusion shrink_conv ('shrink_header' in the model args) is not built")
     if getattr(model, "compress", False):
@@ -108,7 +108,7 @@ def export_ptq_state(qt_model) -> Dict[str, np.ndarray]:
     _check_structure(model)
     out: Dict[str, np.ndarray] = {}
     pyramid = _is_pyramid(model)
-    out["meta/fusion_method"] = np.array("pyramid" if pyramid else "att")
+    out["meta/fusion_method"] = np.array("pyramid" if pyramid else ("max" if type(getattr(model, "fusion_net", None)).__name__ == "MaxFusion" else "att"))
     names = []
     for name, m in model.named_modules():
         if not _is_quant_module(m):

@@ -46,7 +46,7 @@ def grid_size(lidar_range: Sequence[float], voxel_size: Sequence[float]) -> Tupl
 
 
 def make_hypes(shape: str = "v2xreal", multiclass: bool = True, codebook: bool = True,
-               supervise_single: bool = True, dict_size: int = 128, seg_num: int = 1) -> dict:
+               supervise_single: bool = True, dict_size: int = 128, seg_num: int = 1, fusion: str = "att") -> dict:
     """Return a ``hypes`` dict with the ``model`` section the reference's yaml would give."""
     lidar_range, voxel_size, max_voxels, max_cav = SHAPES[shape]
     args = {
@@ -73,7 +73,7 @@ def make_hypes(shape: str = "v2xreal", multiclass: bool = True, codebook: bool =
             "shrink_header": {"kernal_size": [3], "stride": [1], "padding": [1],
                               "dim": [256], "input_dim": 384},
         },
-        "fusion_method": "att",
+        "fusion_method": fusion,              # "att" (AttFusion) | "max" (F-Cooper's MaxFusion, hypes_yaml/v2x_real/Codebook/Fcooper)
         "att": {"feat_dim": 256},
         "in_head": 256,
         "anchor_number": 2,

@@ -316,6 +316,26 @@ def gen_geometry():
     print("geometry.npz", {k: v.shape for k, v in out.items()})
 
 
+def gen_maxfuse():
+    """maxfuse.npz: the reference's MaxFusion (F-Cooper, fusion_in_one.py:87-123) on the inputs of geometry.npz, and the tiny model with
+    ``fusion_method: max`` (hypes_yaml/v2x_real/Codebook/Fcooper) through the hard codebook path."""
+    from opencood.models.fuse_modules.fusion_in_one import MaxFusion
+    geo = np.load(os.path.join(HERE, "geometry.npz"))
+    src, aff64 = torch.from_numpy(geo['src']), torch.from_numpy(geo['affine_f64'])
+    out = {}
+    with torch.no_grad():
+        mf = MaxFusion()
+        out['max_fused'] = np32(mf(src, torch.tensor([4]), aff64))
+        out['max_fused_n1'] = np32(mf(src[:1], torch.tensor([1]), aff64))
+        out['max_fused_b2'] = np32(mf(src, torch.tensor([1, 3]), torch.cat([aff64, aff64])))
+        model = build_ref(fusion="max")
+        out['state_dict_keys'] = np.array(list(model.state_dict().keys()))
+        for n in (1, 2, 3):
+            out[f'preds_tensor_n{n}'] = np32(hard_forward(model, scene(n)))
+    np.savez_compressed(os.path.join(HERE, "maxfuse.npz"), **out)
+    print("maxfuse.npz", {k: v.shape for k, v in out.items() if k != 'state_dict_keys'})
+
+
 def gen_codebook():
     out = {}
     model = build_ref()
@@ -624,7 +644,7 @@ def gen_pyramid_model():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["fp32", "w8a8", "uaq", "geometry", "codebook", "postprocess", "postprocess_mc", "recon", "pyramid", "pyramid_model"]
+    which = sys.argv[1:] or ["fp32", "w8a8", "uaq", "geometry", "codebook", "postprocess", "postprocess_mc", "recon", "pyramid", "pyramid_model", "maxfuse"]
     with torch.no_grad():
         pass
     if "fp32" in which: gen_fp32()
@@ -637,3 +657,4 @@ if __name__ == "__main__":
     if "recon" in which: gen_recon()
     if "pyramid" in which: gen_pyramid()
     if "pyramid_model" in which: gen_pyramid_model()
+    if "maxfuse" in which: gen_maxfuse()

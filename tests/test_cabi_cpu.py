@@ -33,7 +33,8 @@ def test_struct_layouts_match_header():
     assert C.sizeof(lib.ConvDesc) == (7 + 3 * 4 + 3) * 4 + 8
     assert C.sizeof(lib.DeconvDesc) == 15 * 4
     assert C.sizeof(lib.EncodeDesc) == 7 * 4
-    assert C.sizeof(lib.FuseDesc) == 7 * 4 + 4 + 2 * 8 + 3 * 8      # 4 bytes of padding before the int64 fields
+    assert C.sizeof(lib.FuseDesc) == 7 * 4 + 4 + 2 * 8 + 3 * 8 + 4 + 4    # 4 bytes of padding before the int64 fields, `fusion` + tail padding
+    assert C.sizeof(lib.Conv1x1Desc) == 14 * 4 and C.sizeof(lib.GconvDesc) == 9 * 4 and C.sizeof(lib.OccDesc) == 10 * 4
 
 
 def test_argument_errors_without_gpu():
@@ -124,10 +125,11 @@ def test_export_refuses_networks_the_engine_does_not_build():
         synth.load_state_dict_numpy(m, synth.make_state_dict(m.state_dict(), seed=1))
         return m
 
-    # max fusion
+    # max fusion (F-Cooper) is built since round 2: it exports, tagged; any other fusion the plugin cannot even construct
     qt = calibrate_minmax(quant_wrap(plugin(lambda a: a.update(fusion_method="max"))), [scene(2)])
-    with pytest.raises(NotImplementedError, match="AttFusion"):
-        export_ptq_state(qt)
+    assert str(export_ptq_state(qt)["meta/fusion_method"]) == "max"
+    with pytest.raises(NotImplementedError):
+        plugin(lambda a: a.update(fusion_method="v2xvit"))
     # post-fusion shrink_conv
     sh = {"kernal_size": [3], "stride": [1], "padding": [1], "dim": [256], "input_dim": 256}
     qt = calibrate_minmax(quant_wrap(plugin(lambda a: a.update(shrink_header=sh))), [scene(2)])
