@@ -245,6 +245,10 @@ class Oracle:
             taps["codes"] = codes.reshape(-1, n, h, w)
             feats = self.decode(codes).reshape(n, h, w, c)
         else:
+            if bool(self.s.get("meta/compress", False)):          # NaiveCompressor (naive_compress.py:5-35 under quant_block.py:1543-1570)
+                for name in ("compressor.encoder.0", "compressor.decoder.0", "compressor.decoder.1"):
+                    shr, shr_q = self.conv(name, shr, [(0, shr.shape[3], shr_q[0], shr_q[1])])
+                    taps[name] = shr
             feats = (shr.astype(np.float32) - np.float32(shr_q[1])) * np.float32(shr_q[0])
         taps["features"] = feats
         fused = self.fuse(feats, scene["pairwise_t_matrix"], scene["record_len"])

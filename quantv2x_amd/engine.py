@@ -66,10 +66,22 @@ def _pack_k4p(w: np.ndarray) -> np.ndarray:
 class _ConvLayer:
     """Device-side constants of one 3x3 QuantModule convolution."""
 
-    def __init__(self, state, name, in_groups, stride, dev):
+    def __init__(self, state, name, in_groups, stride, dev, pad_cin=0, pad_cout=0):
+        """``pad_cin`` / ``pad_cout``: widen a narrow layer (the 16-channel NaiveCompressor bottleneck) to the kernels' 64-channel
+        granularity.  Extra input channels get the weight code zw[co] (so (w - zw) = 0 whatever they hold), extra output channels
+        a zero filter with zero bias (they quantize to the code of 0.0 and are never read with a non-zero weight)."""
         code = state[name + "/w_code"]                              # [Cout, Cin, 3, 3] uint8
         dw = state[name + "/w_delta"].astype(np.float32)
         zw = state[name + "/w_zp"].astype(np.int64)
+        bias_np = state[name + "/bias"].astype(np.float32)
+        if pad_cin > code.shape[1]:
+            fill = np.broadcast_to(np.clip(zw, 0, 255).astype(np.uint8)[:, None, None, None], (code.shape[0], pad_cin - code.shape[1], 3, 3))
+            code = np.concatenate([code, fill], axis=1)
+        if pad_cout > code.shape[0]:
+            extra = pad_cout - code.shape[0]
+            code = np.concatenate([code, np.full((extra,) + code.shape[1:], 128, np.uint8)])
+            dw, zw = np.concatenate([dw, np.ones(extra, np.float32)]), np.concatenate([zw, np.full(extra, 128, np.int64)])
+            bias_np = np.concatenate([bias_np, np.zeros(extra, np.float32)])
         cout = code.shape[0]
         ws = code.astype(np.int64) - 128
         aw = 128 - zw
@@ -87,7 +99,7 @@ class _ConvLayer:
         self.scale = _dev(np.stack(scale).astype(np.float32), dev)
         self.corr = _dev(np.stack(corr).astype(np.int32), dev)
         self.aw = _dev(aw.astype(np.int32), dev)
-        self.bias = _dev(state[name + "/bias"].astype(np.float32), dev)
+        self.bias = _dev(bias_np, dev)
         self.out_q = (float(np.float32(state[name + "/a_delta"])), int(state[name + "/a_zp"]))
         assert np.abs(np.stack(corr)).max() < 2 ** 31
 
@@ -225,6 +237,19 @@ class DeployedModel(nn.Module):
                                   [(0, self.shrink0.cout, *self.shrink0.out_q)], 1, dev)
         if self.shrink1.cout != 256:
             raise NotImplementedError("deployed path expects a 256-channel shared feature")
+        # ---- NaiveCompressor (models without the codebook): 256 -> 256 / r -> 256 -> 256, the bottleneck padded to 64 channels ----
+        self.compress = bool(s.get("meta/compress", False))
+        self.final = self.shrink1                                      # the layer whose output is the shared feature
+        if self.compress:
+            if self.has_codebook:
+                raise NotImplementedError("deployed path: compressor and codebook together")
+            narrow = int(s["compressor.encoder.0/w_code"].shape[0])
+            pad = (narrow + 63) // 64 * 64
+            self.comp = [_ConvLayer(s, "compressor.encoder.0", [(0, 256, *self.shrink1.out_q)], 1, dev, pad_cout=pad)]
+            self.comp.append(_ConvLayer(s, "compressor.decoder.0", [(0, pad, *self.comp[0].out_q)], 1, dev, pad_cin=pad))
+            self.comp.append(_ConvLayer(s, "compressor.decoder.1", [(0, 256, *self.comp[1].out_q)], 1, dev))
+            self.comp_channels = narrow                                # what would travel: narrow x H x W bytes per agent
+            self.final = self.comp[-1]
         # ---- a6 / a7: codebook -----------------------------------------------------------------------------
         if self.has_codebook:
             self.levels = int(s["meta/codebook_levels"])
@@ -299,6 +324,8 @@ class DeployedModel(nn.Module):
         b["cat"] = cat
         b["s0"] = self._padded(n, self.fh, self.fw, self.shrink0.cout, self.shrink0.out_q)
         b["s1"] = self._padded(n, self.fh, self.fw, self.shrink1.cout, self.shrink1.out_q)
+        if self.compress:
+            b["comp"] = [self._padded(n, self.fh, self.fw, c.cout, c.out_q) for c in self.comp]
         hw = self.fh * self.fw
         if self.has_codebook:
             b["codes"] = torch.empty((self.levels, n, hw), dtype=torch.uint8, device=self.dev)
@@ -397,6 +424,11 @@ class DeployedModel(nn.Module):
         hw = n_agents * self.fh * self.fw
         plan.append(("conv", self.shrink0, b["cat"], self.fh, self.fw, b["s0"], 0, hw * self.shrink0.cout * self.shrink0.w.shape[1]))
         plan.append(("conv", self.shrink1, b["s0"], self.fh, self.fw, b["s1"], 0, hw * self.shrink1.cout * self.shrink1.w.shape[1]))
+        if self.compress:
+            x = b["s1"]
+            for c, out in zip(self.comp, b["comp"]):
+                plan.append(("conv", c, x, self.fh, self.fw, out, 0, hw * c.cout * c.w.shape[1]))
+                x = out
         b[key] = plan
         return plan
 
@@ -504,7 +536,10 @@ class DeployedModel(nn.Module):
         if taps is not None:
             taps["canvas"], taps["cat"] = canvas, b["cat"]
             taps[self.shrink0.name], taps[self.shrink1.name] = b["s0"], b["s1"]
-        return self.encode_codes(n_agents) if self.has_codebook else b["s1"]
+        if taps is not None and self.compress:
+            for c, out in zip(self.comp, b["comp"]):
+                taps[c.name] = out
+        return self.encode_codes(n_agents) if self.has_codebook else (b["comp"][-1] if self.compress else b["s1"])
 
     def decode_rows(self, codes, n_rows_total):
         """codes u8 [levels, R] -> fp32 [R, 256] (only needed for the *_single heads)."""
@@ -592,7 +627,7 @@ class DeployedModel(nn.Module):
 
     def _shared_features(self, shrinker_out, n_total: int):
         """no codebook: the fp32 shared feature [n, H*W, 256] is the dequantized shrinker output"""
-        q = self.shrink1.out_q
+        q = self.final.out_q
         feats = self._workspace(n_total)["feats"]
         L.check(self.lib.qv2x_dequant_i8_f32(L.ptr(shrinker_out), n_total, self.fh, self.fw, 256, int(q[1]), float(q[0]), L.ptr(feats),
                                              L.current_stream()), "qv2x_dequant_i8_f32")

@@ -164,6 +164,7 @@ class DeployedFp32Model(DeployedModel):
         self.strides = [int(v) for v in s["meta/layer_strides"]]
         self.ups = [int(v) for v in s["meta/upsample_strides"]]
         self.has_codebook = bool(s["meta/has_codebook"])
+        self.compress = False
         self.fusion = 1 if str(s.get("meta/fusion_method", "att")) == "max" else 0
         self.emit_single = bool(s["meta/supervise_single"]) if emit_single_preds is None else bool(emit_single_preds)
         f32a = lambda a: (C.c_float * len(a))(*[float(np.float32(v)) for v in a])

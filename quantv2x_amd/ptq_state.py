@@ -79,8 +79,9 @@ def _check_structure(model) -> None:
             raise NotImplementedError(f"deployed path: fusion_net must be AttFusion or MaxFusion (fusion_method 'att' / 'max'), got {type(fusion).__name__}")
         if getattr(model, "shrink_flag", False):
             raise NotImplementedError("deployed path: a post-fusion shrink_conv ('shrink_header' in the model args) is not built")
-    if getattr(model, "compress", False):
-        raise NotImplementedError("deployed path: the NaiveCompressor ('compressor' in the model args) is not built")
+    if getattr(model, "compress", False) and (pyramid or getattr(model, "codebook", None) is not None):
+        raise NotImplementedError("deployed path: the NaiveCompressor ('compressor' in the model args) is built for the baseline models "
+                                  "without a codebook (the codebook models never call it, heter_baseline_collab_codebook.py:119-132)")
     for name, m in model.named_modules():
         if not _is_quant_module(m):
             continue
@@ -163,6 +164,7 @@ def export_ptq_state(qt_model) -> Dict[str, np.ndarray]:
         out["meta/upsample_strides"] = np.array([int(d[0].fwd_kwargs["stride"][0]) for d in bb.deblocks], dtype=np.int64)
         out["meta/supervise_single"] = np.bool_(bool(getattr(model, "supervise_single", False)))
 
+    out["meta/compress"] = np.bool_(bool(getattr(model, "compress", False)))
     cb = getattr(model, "codebook", None)
     out["meta/has_codebook"] = np.bool_(cb is not None)
     if cb is not None:

@@ -46,7 +46,7 @@ def grid_size(lidar_range: Sequence[float], voxel_size: Sequence[float]) -> Tupl
 
 
 def make_hypes(shape: str = "v2xreal", multiclass: bool = True, codebook: bool = True,
-               supervise_single: bool = True, dict_size: int = 128, seg_num: int = 1, fusion: str = "att") -> dict:
+               supervise_single: bool = True, dict_size: int = 128, seg_num: int = 1, fusion: str = "att", compress_ratio: int = 0) -> dict:
     """Return a ``hypes`` dict with the ``model`` section the reference's yaml would give."""
     lidar_range, voxel_size, max_voxels, max_cav = SHAPES[shape]
     args = {
@@ -82,6 +82,8 @@ def make_hypes(shape: str = "v2xreal", multiclass: bool = True, codebook: bool =
     if codebook:
         args["codebook"] = {"seg_num": seg_num, "dict_size": dict_size}
         args["use_codebook"] = True
+    if compress_ratio:                                # hypes_yaml/v2x_real/Naive_Compressor/*: `compressor: {input_dim: 256, compress_ratio: 16}`
+        args["compressor"] = {"input_dim": 256, "compress_ratio": int(compress_ratio)}
     core = "heter_baseline_collab_codebook" if codebook else "heter_model_baseline"
     if multiclass:
         core += "_mc"

@@ -332,6 +332,10 @@ def gen_maxfuse():
         out['state_dict_keys'] = np.array(list(model.state_dict().keys()))
         for n in (1, 2, 3):
             out[f'preds_tensor_n{n}'] = np32(hard_forward(model, scene(n)))
+        # the NaiveCompressor baseline (hypes_yaml/v2x_real/Naive_Compressor/Attfuse): plain forward, no codebook
+        comp = build_ref(codebook=False, compress_ratio=16)
+        out['compress/state_dict_keys'] = np.array(list(comp.state_dict().keys()))
+        out['compress/preds_tensor_n2'] = np32(comp(scene(2))['preds_tensor'])
     np.savez_compressed(os.path.join(HERE, "maxfuse.npz"), **out)
     print("maxfuse.npz", {k: v.shape for k, v in out.items() if k != 'state_dict_keys'})
 

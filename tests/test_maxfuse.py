@@ -59,3 +59,31 @@ def test_hip_fp32_engine_max_fusion():
     want = OracleFp32(st).forward(sc)
     got = eng(synth.scene_to_torch(sc, "cuda"))
     np.testing.assert_allclose(got["preds_tensor"].cpu().numpy(), want["preds_tensor"], rtol=2e-4, atol=2e-4)
+
+
+def test_compressor_model_mirror_matches_the_reference():
+    """``NaiveCompressor`` baseline (hypes_yaml/v2x_real/Naive_Compressor/Attfuse: 256 -> 16 -> 256 -> 256 around the link)"""
+    torch.set_num_threads(1)
+    model = build_plugin(codebook=False, compress_ratio=16)
+    assert list(model.state_dict().keys()) == [str(k) for k in G["compress/state_dict_keys"]]
+    with torch.no_grad():
+        np.testing.assert_allclose(model(scene(2))["preds_tensor"].numpy(), G["compress/preds_tensor_n2"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fusion", ["att", "max"])
+def test_hip_engine_compressor_vs_oracle(fusion):
+    """the compressor's three convolutions on the int8 kernels (the 16-channel bottleneck padded to 64): every code bit-exact"""
+    from _common import interior_u8
+    from oracle.spec import Oracle
+    from quantv2x_amd.engine import deploy
+    from quantv2x_amd.ptq_state import export_ptq_state
+    state = export_ptq_state(calibrated_plugin(fusion=fusion, codebook=False, compress_ratio=16))
+    assert bool(state["meta/compress"])
+    eng, orc = deploy(state=state), Oracle(state)
+    for n in (1, 2):
+        otaps, gtaps, _, _ = compare_frame(orc, eng, scene_np(n), state)
+        for name in ("compressor.encoder.0", "compressor.decoder.0", "compressor.decoder.1"):
+            want = otaps[name]
+            np.testing.assert_array_equal(interior_u8(gtaps[name])[..., :want.shape[-1]], want, err_msg=name)
+    assert eng.comp_channels == 16
