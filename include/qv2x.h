@@ -251,6 +251,17 @@ int qv2x_postprocess_f32(const qv2x_postprocess_desc* desc /* host */, const flo
                          const float* anchors, void* workspace, int64_t workspace_bytes, float* out_corners,
                          float* out_scores, int32_t* out_labels, int32_t* out_count, void* stream);
 
+/* Late fusion (hypes_yaml/v2x_real/LiDAROnly/lidar_late_mc_fusion.yaml): the same pipeline over `ncav` (1..8) CAVs -- the loop over
+ * `cav_content` of the reference's post_process (voxel_postprocessor.py:272-345, voxel_postprocessor_3heads.py:345-420): every CAV's head
+ * maps decoded against ITS anchors and projected by ITS matrix, candidates concatenated in CAV order, then one filter / sort / NMS /
+ * range mask over the union.  Host arrays of `ncav` device pointers; transforms = HOST float [ncav][16] (desc->transform is ignored);
+ * workspace: qv2x_postprocess_late_workspace_bytes(desc, ncav). */
+int64_t qv2x_postprocess_late_workspace_bytes(const qv2x_postprocess_desc* desc /* host */, int ncav);
+int qv2x_postprocess_late_f32(const qv2x_postprocess_desc* desc /* host */, int ncav, const float* const* cls, const float* const* reg,
+                              const float* const* dir, const float* const* anchors, const float* transforms /* host */, void* workspace,
+                              int64_t workspace_bytes, float* out_corners, float* out_scores, int32_t* out_labels, int32_t* out_count,
+                              void* stream);
+
 /* ---- the un-quantized model (SURVEY.md §8(b) "fp32 fall-backs for un-quantized mode") ------------------------------------------
  * What the reference's plain opencood/tools/inference.py:106-170 flow runs in fp32 -- PillarVFE (pillar_vfe.py:105-155) +
  * PointPillarScatter, BaseBEVBackbone (base_bev_backbone.py:96-119), DownsampleConv (downsample_conv.py:26-51) -- as f32-MFMA

@@ -175,14 +175,8 @@ def nms_rotated(corners, scores, thresh, top=1000):
     return np.array(pick, dtype=np.int64)
 
 
-def post_process(cls, reg, dirp, anchors, t, lidar_range, score_threshold=0.2, nms_thresh=0.15, dir_offset=0.7853,
-                 num_bins=2, nms=True, num_classes=1, max_extent=6.0, z_lim=(-3.0, 1.0), range_xy_only=False, return_labels=False):
-    """-> (corners f32 [K, 8, 3], scores f32 [K]) in descending score order; ``nms=False`` keeps every filtered box.
-
-    ``num_classes > 1`` is VoxelPostprocessor3Heads.post_process (voxel_postprocessor_3heads.py:318-478): ``anchors`` is
-    then [H, W, A_all, 7] with the anchor sets already interleaved per cell ((h, w, class set, rotation) order, :354-358),
-    the score the largest class probability, no direction fix; box_utils_mc's limits are ``max_extent=100``,
-    ``z_lim=(-100, 100)``, ``range_xy_only=True`` with ``lidar_range`` = GT_RANGE."""
+def _candidates(cls, reg, dirp, anchors, t, score_threshold, dir_offset, num_bins, num_classes):
+    """one CAV: thresholded, decoded, direction-fixed boxes as corners projected by ``t`` (+ scores, labels), reference order"""
     if num_classes == 1:
         prob = sigmoid(np.transpose(cls, (0, 2, 3, 1))).reshape(-1)
         labels = np.ones(prob.shape, np.int64)
@@ -192,9 +186,8 @@ def post_process(cls, reg, dirp, anchors, t, lidar_range, score_threshold=0.2, n
     boxes = delta_to_boxes3d(reg, anchors)
     mask = prob > F(score_threshold)
     boxes, scores, labels = boxes[mask], prob[mask], labels[mask]
-    empty = (np.zeros((0, 8, 3), F), np.zeros((0,), F)) + ((np.zeros((0,), np.int64),) if return_labels else ())
     if boxes.shape[0] == 0:
-        return empty
+        return np.zeros((0, 8, 3), F), np.zeros((0,), F), np.zeros((0,), np.int64)
     if dirp is not None:
         dm = np.transpose(dirp, (0, 2, 3, 1)).reshape(-1, num_bins)[mask]
         dl = np.argmax(dm, axis=-1).astype(F)
@@ -202,7 +195,18 @@ def post_process(cls, reg, dirp, anchors, t, lidar_range, score_threshold=0.2, n
         rot = limit_period(boxes[:, 6] - F(dir_offset), 0.0, period)
         boxes[:, 6] = rot + F(dir_offset) + F(period) * dl
         boxes[:, 6] = limit_period(boxes[:, 6], 0.5, 2 * np.pi)
-    corners = project_box3d(boxes_to_corners_3d(boxes), t)
+    return project_box3d(boxes_to_corners_3d(boxes), t), scores, labels
+
+
+def post_process_late(cavs, lidar_range, score_threshold=0.2, nms_thresh=0.15, dir_offset=0.7853, num_bins=2, nms=True, num_classes=1,
+                      max_extent=6.0, z_lim=(-3.0, 1.0), range_xy_only=False, return_labels=False):
+    """``cavs``: list of ``(cls, reg, dirp, anchors, t)``, one per CAV in the order of the reference's ``data_dict`` -- late fusion
+    (voxel_postprocessor.py:272-345 / voxel_postprocessor_3heads.py:345-420): candidates of every CAV concatenated, then the single-CAV
+    tail (size / z filters, NMS, range mask) over the union.  -> as ``post_process``."""
+    parts = [_candidates(c, r, d, a, t, score_threshold, dir_offset, num_bins, num_classes) for (c, r, d, a, t) in cavs]
+    corners = np.concatenate([p[0] for p in parts]); scores = np.concatenate([p[1] for p in parts]); labels = np.concatenate([p[2] for p in parts])
+    if corners.shape[0] == 0:
+        return (np.zeros((0, 8, 3), F), np.zeros((0,), F)) + ((np.zeros((0,), np.int64),) if return_labels else ())
     xl = corners[:, :, 0].max(1) - corners[:, :, 0].min(1)
     yl = corners[:, :, 1].max(1) - corners[:, :, 1].min(1)
     keep = (xl <= max_extent) & (yl <= max_extent) & (yl != 0)     # remove_large_pred_bbx, quirk kept
@@ -218,3 +222,15 @@ def post_process(cls, reg, dirp, anchors, t, lidar_range, score_threshold=0.2, n
     if return_labels:
         return corners[inside], scores[inside], labels[inside]
     return corners[inside], scores[inside]
+
+
+def post_process(cls, reg, dirp, anchors, t, lidar_range, score_threshold=0.2, nms_thresh=0.15, dir_offset=0.7853,
+                 num_bins=2, nms=True, num_classes=1, max_extent=6.0, z_lim=(-3.0, 1.0), range_xy_only=False, return_labels=False):
+    """-> (corners f32 [K, 8, 3], scores f32 [K]) in descending score order; ``nms=False`` keeps every filtered box.
+
+    ``num_classes > 1`` is VoxelPostprocessor3Heads.post_process (voxel_postprocessor_3heads.py:318-478): ``anchors`` is
+    then [H, W, A_all, 7] with the anchor sets already interleaved per cell ((h, w, class set, rotation) order, :354-358),
+    the score the largest class probability, no direction fix; box_utils_mc's limits are ``max_extent=100``,
+    ``z_lim=(-100, 100)``, ``range_xy_only=True`` with ``lidar_range`` = GT_RANGE."""
+    return post_process_late([(cls, reg, dirp, anchors, t)], lidar_range, score_threshold, nms_thresh, dir_offset, num_bins, nms, num_classes,
+                             max_extent, z_lim, range_xy_only, return_labels)

@@ -1,4 +1,6 @@
-// f2: detection-head maps -> 3-D boxes on the GPU for the anchor heads, one CAV per call:
+// f2: detection-head maps -> 3-D boxes on the GPU for the anchor heads; one CAV per call (intermediate /
+// early fusion) or several (late fusion: every CAV's candidates decoded and projected with ITS matrix, concatenated in CAV order,
+// then ONE filter / sort / NMS over the union -- the loop over `cav_content` of the reference's post_process):
 // VoxelPostprocessor.post_process (opencood/data_utils/post_processor/voxel_postprocessor.py:245-405; line numbers below)
 // and, with num_classes > 1, VoxelPostprocessor3Heads.post_process (voxel_postprocessor_3heads.py:318-478: score = largest
 // class probability + label, no direction fix, the limits of box_utils_mc.py, x-y range mask).
@@ -23,11 +25,13 @@ namespace {
 
 constexpr int TOPK_MAX = 1024;                       // bit-matrix row = 16 x u64
 
+constexpr int MAX_CAVS = 8;
+
 struct PPArgs {
-    const float* cls; const float* reg; const float* dir; const float* anchors;
-    int h, w, a, na, num_bins, topk, ncls, xy_only;
+    const float* cls[MAX_CAVS]; const float* reg[MAX_CAVS]; const float* dir[MAX_CAVS]; const float* anchors[MAX_CAVS];
+    int h, w, a, na, na1, num_bins, topk, ncls, xy_only;          // na1 anchors per CAV, na = ncav * na1 (index = cav * na1 + local)
     float thr, nms_thr, dir_offset, max_extent, z_lo, z_hi;
-    float range[6], t[16];
+    float range[6], t[MAX_CAVS][16];
     // workspace
     float* prob; int* flag; int* pos; float* cand_corners; float* cand_score; unsigned* key_in; unsigned* key_out;
     int* idx_in; int* idx_out; unsigned long long* mask;
@@ -36,16 +40,18 @@ struct PPArgs {
 };
 
 __global__ void pp_score_kernel(const PPArgs p) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // anchor index in (h, w, a) order
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // anchor index in (cav, h, w, a) order
     if (i >= p.na) return;
-    const int a = i % p.a, cell = i / p.a;
+    const int cav = i / p.na1, li = i - cav * p.na1;
+    const int a = li % p.a, cell = li / p.a;
     const size_t hw = (size_t)p.h * p.w;
+    const float* cls = p.cls[cav];
     // one score class: the anchor's logit; several (voxel_postprocessor_3heads.py:362-373): channel a * ncls + k, the score is
     // the largest class probability (first one on ties), the label its index + 1
-    float s = 1.0f / (1.0f + expf(-p.cls[(size_t)(a * p.ncls) * hw + cell]));
+    float s = 1.0f / (1.0f + expf(-cls[(size_t)(a * p.ncls) * hw + cell]));
     int lab = 1;
     for (int k = 1; k < p.ncls; ++k) {
-        const float v = 1.0f / (1.0f + expf(-p.cls[(size_t)(a * p.ncls + k) * hw + cell]));
+        const float v = 1.0f / (1.0f + expf(-cls[(size_t)(a * p.ncls + k) * hw + cell]));
         if (v > s) { s = v; lab = k + 1; }
     }
     p.label[i] = lab;
@@ -62,20 +68,25 @@ __global__ void pp_decode_kernel(const PPArgs p) {
     if (i >= p.na) return;
     if (!p.flag[i]) return;
     const int c = p.pos[i];                                        // candidate number, reference order
-    const int a = i % p.a, cell = i / p.a;
+    const int cav = i / p.na1, li = i - cav * p.na1;
+    const int a = li % p.a, cell = li / p.a;
     const size_t hw = (size_t)p.h * p.w;
+    const float* reg = p.reg[cav];
+    const float* dirm = p.dir[cav];
+    const float* anchors = p.anchors[cav];
+    const float* T = p.t[cav];
     float d[7], an[7];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) { d[k] = p.reg[(size_t)(a * 7 + k) * hw + cell]; an[k] = p.anchors[(size_t)i * 7 + k]; }
+    for (int k = 0; k < 7; ++k) { d[k] = reg[(size_t)(a * 7 + k) * hw + cell]; an[k] = anchors[(size_t)li * 7 + k]; }
     const float diag = sqrtf(an[4] * an[4] + an[5] * an[5]);
     float bx = d[0] * diag + an[0], by = d[1] * diag + an[1], bz = d[2] * an[3] + an[2];
     const float bh = expf(d[3]) * an[3], bw = expf(d[4]) * an[4], bl = expf(d[5]) * an[5];
     float yaw = d[6] + an[6];
-    if (p.dir) {
+    if (dirm) {
         int label = 0;
-        float best = p.dir[(size_t)(a * p.num_bins) * hw + cell];
+        float best = dirm[(size_t)(a * p.num_bins) * hw + cell];
         for (int b = 1; b < p.num_bins; ++b) {
-            const float v = p.dir[(size_t)(a * p.num_bins + b) * hw + cell];
+            const float v = dirm[(size_t)(a * p.num_bins + b) * hw + cell];
             if (v > best) { best = v; label = b; }                 // first maximum, as torch.max
         }
         const float period = (float)(2.0 * 3.141592653589793 / p.num_bins);
@@ -94,9 +105,9 @@ __global__ void pp_decode_kernel(const PPArgs p) {
         const float rx = cx * cosa + cy * (-sina) + bx;
         const float ry = cx * sina + cy * cosa + by;
         const float rz = cz + bz;
-        const float px = p.t[0] * rx + p.t[1] * ry + p.t[2] * rz + p.t[3];
-        const float py = p.t[4] * rx + p.t[5] * ry + p.t[6] * rz + p.t[7];
-        const float pz = p.t[8] * rx + p.t[9] * ry + p.t[10] * rz + p.t[11];
+        const float px = T[0] * rx + T[1] * ry + T[2] * rz + T[3];
+        const float py = T[4] * rx + T[5] * ry + T[6] * rz + T[7];
+        const float pz = T[8] * rx + T[9] * ry + T[10] * rz + T[11];
         out[k * 3 + 0] = px; out[k * 3 + 1] = py; out[k * 3 + 2] = pz;
         xmin = fminf(xmin, px); xmax = fmaxf(xmax, px); ymin = fminf(ymin, py); ymax = fmaxf(ymax, py);
         zmin = fminf(zmin, pz); zmax = fmaxf(zmax, pz);
@@ -274,32 +285,30 @@ int check_desc(const qv2x_postprocess_desc* d, const char* who) {
 
 }  // namespace qv2x
 
-extern "C" int64_t qv2x_postprocess_workspace_bytes(const qv2x_postprocess_desc* d) {
+static int postprocess_run(const qv2x_postprocess_desc* d, int ncav, const float* const* cls, const float* const* reg, const float* const* dir,
+                           const float* const* anchors, const float* transforms, void* workspace, int64_t workspace_bytes, float* out_corners,
+                           float* out_scores, int32_t* out_labels, int32_t* out_count, void* stream, const char* who) {
     using namespace qv2x;
-    if (check_desc(d, "qv2x_postprocess_workspace_bytes")) return -1;
-    return (int64_t)layout(d->h * d->w * d->anchors_per_cell).total;
-}
-
-extern "C" int qv2x_postprocess_f32(const qv2x_postprocess_desc* d, const float* cls, const float* reg, const float* dir,
-                                    const float* anchors, void* workspace, int64_t workspace_bytes, float* out_corners,
-                                    float* out_scores, int32_t* out_labels, int32_t* out_count, void* stream) {
-    using namespace qv2x;
-    if (int rc = check_desc(d, "qv2x_postprocess_f32")) return rc;
-    if (!cls || !reg || !anchors || !workspace || !out_corners || !out_scores || !out_count) return fail(QV2X_EINVAL, "qv2x_postprocess_f32: null pointer");
-    if (d->num_bins > 0 && !dir) return fail(QV2X_EINVAL, "qv2x_postprocess_f32: num_bins > 0 needs the direction map");
-    const int na = d->h * d->w * d->anchors_per_cell;
+    if (int rc = check_desc(d, who)) return rc;
+    if (ncav < 1 || ncav > MAX_CAVS) return fail(QV2X_EINVAL, "%s: 1..%d CAVs", who, MAX_CAVS);
+    if (!cls || !reg || !anchors || !transforms || !workspace || !out_corners || !out_scores || !out_count) return fail(QV2X_EINVAL, "%s: null pointer", who);
+    const int na1 = d->h * d->w * d->anchors_per_cell, na = na1 * ncav;
     const Layout l = layout(na);
-    if (workspace_bytes < (int64_t)l.total) return fail(QV2X_EINVAL, "qv2x_postprocess_f32: workspace of %lld bytes, need %lld", (long long)workspace_bytes, (long long)l.total);
-    if ((uintptr_t)workspace & 255) return fail(QV2X_EALIGN, "qv2x_postprocess_f32: workspace must be 256-byte aligned");
+    if (workspace_bytes < (int64_t)l.total) return fail(QV2X_EINVAL, "%s: workspace of %lld bytes, need %lld", who, (long long)workspace_bytes, (long long)l.total);
+    if ((uintptr_t)workspace & 255) return fail(QV2X_EALIGN, "%s: workspace must be 256-byte aligned", who);
     char* ws = (char*)workspace;
     PPArgs p{};
-    p.cls = cls; p.reg = reg; p.dir = d->num_bins > 0 ? dir : nullptr; p.anchors = anchors;
-    p.h = d->h; p.w = d->w; p.a = d->anchors_per_cell; p.na = na; p.num_bins = d->num_bins;
+    for (int c = 0; c < ncav; ++c) {
+        if (!cls[c] || !reg[c] || !anchors[c]) return fail(QV2X_EINVAL, "%s: null map of CAV %d", who, c);
+        if (d->num_bins > 0 && (!dir || !dir[c])) return fail(QV2X_EINVAL, "%s: num_bins > 0 needs the direction map", who);
+        p.cls[c] = cls[c]; p.reg[c] = reg[c]; p.dir[c] = d->num_bins > 0 ? dir[c] : nullptr; p.anchors[c] = anchors[c];
+        for (int i = 0; i < 16; ++i) p.t[c][i] = transforms[c * 16 + i];
+    }
+    p.h = d->h; p.w = d->w; p.a = d->anchors_per_cell; p.na = na; p.na1 = na1; p.num_bins = d->num_bins;
     p.topk = d->max_boxes < na ? d->max_boxes : na;
     p.thr = d->score_threshold; p.nms_thr = d->nms_threshold; p.dir_offset = d->dir_offset;
     p.ncls = d->num_classes; p.xy_only = d->range_xy_only; p.max_extent = d->max_extent; p.z_lo = d->z_min; p.z_hi = d->z_max;
     for (int i = 0; i < 6; ++i) p.range[i] = d->range[i];
-    for (int i = 0; i < 16; ++i) p.t[i] = d->transform[i];
     p.prob = (float*)(ws + l.prob); p.flag = (int*)(ws + l.flag); p.pos = (int*)(ws + l.pos);
     p.cand_corners = (float*)(ws + l.corners); p.cand_score = (float*)(ws + l.score);
     p.key_in = (unsigned*)(ws + l.key_in); p.key_out = (unsigned*)(ws + l.key_out);
@@ -318,5 +327,33 @@ extern "C" int qv2x_postprocess_f32(const qv2x_postprocess_desc* d, const float*
                         "postprocess sort"))) return rc;
     pp_iou_kernel<<<p.topk, 256, 0, st>>>(p);
     pp_sweep_kernel<<<1, 256, 0, st>>>(p);
-    return hip_check(hipGetLastError(), "qv2x_postprocess_f32 launch");
+    return hip_check(hipGetLastError(), who);
+}
+
+extern "C" int64_t qv2x_postprocess_workspace_bytes(const qv2x_postprocess_desc* d) {
+    using namespace qv2x;
+    if (check_desc(d, "qv2x_postprocess_workspace_bytes")) return -1;
+    return (int64_t)layout(d->h * d->w * d->anchors_per_cell).total;
+}
+
+extern "C" int64_t qv2x_postprocess_late_workspace_bytes(const qv2x_postprocess_desc* d, int ncav) {
+    using namespace qv2x;
+    if (check_desc(d, "qv2x_postprocess_late_workspace_bytes") || ncav < 1 || ncav > MAX_CAVS) return -1;
+    return (int64_t)layout(d->h * d->w * d->anchors_per_cell * ncav).total;
+}
+
+extern "C" int qv2x_postprocess_f32(const qv2x_postprocess_desc* d, const float* cls, const float* reg, const float* dir,
+                                    const float* anchors, void* workspace, int64_t workspace_bytes, float* out_corners,
+                                    float* out_scores, int32_t* out_labels, int32_t* out_count, void* stream) {
+    if (!d) return qv2x::fail(QV2X_EINVAL, "qv2x_postprocess_f32: null descriptor");
+    return postprocess_run(d, 1, &cls, &reg, &dir, &anchors, d->transform, workspace, workspace_bytes, out_corners, out_scores, out_labels,
+                           out_count, stream, "qv2x_postprocess_f32");
+}
+
+extern "C" int qv2x_postprocess_late_f32(const qv2x_postprocess_desc* d, int ncav, const float* const* cls, const float* const* reg,
+                                         const float* const* dir, const float* const* anchors, const float* transforms, void* workspace,
+                                         int64_t workspace_bytes, float* out_corners, float* out_scores, int32_t* out_labels,
+                                         int32_t* out_count, void* stream) {
+    return postprocess_run(d, ncav, cls, reg, dir, anchors, transforms, workspace, workspace_bytes, out_corners, out_scores, out_labels,
+                           out_count, stream, "qv2x_postprocess_late_f32");
 }

@@ -17,7 +17,7 @@ SYMBOLS = [
     "qv2x_conv3x3_i8_wide_ok", "qv2x_conv3x3_i8_pack_wide", "qv2x_conv3x3_i8_wide", "qv2x_conv3x3_i8_chain64",
     "qv2x_deconv_i8", "qv2x_deconv_i8_batch", "qv2x_codebook_level_floats", "qv2x_codebook_c2_f32", "qv2x_codebook_encode_f32", "qv2x_fuse_att_f32",
     "qv2x_decode_lut_f32", "qv2x_dequant_i8_f32", "qv2x_heads_f32", "qv2x_decode_heads_f32", "qv2x_heads_pair_f32", "qv2x_voxelize_workspace_bytes", "qv2x_voxelize_f32",
-    "qv2x_postprocess_workspace_bytes", "qv2x_postprocess_f32",
+    "qv2x_postprocess_workspace_bytes", "qv2x_postprocess_f32", "qv2x_postprocess_late_workspace_bytes", "qv2x_postprocess_late_f32",
     "qv2x_conv3x3_f32", "qv2x_deconv_f32", "qv2x_pfn_scatter_f32", "qv2x_codebook_encode_f32in",
     "qv2x_pyramid_weighted_fuse_f32", "qv2x_pyramid_weighted_fuse_i8", "qv2x_conv1x1_i8", "qv2x_gconv3x3_i8", "qv2x_conv3x3_i8_res",
     "qv2x_deconv_f32in", "qv2x_codebook_decode_f32", "qv2x_occ_score_i8",
@@ -144,6 +144,10 @@ def load() -> C.CDLL:
     lib.qv2x_postprocess_workspace_bytes.argtypes = [C.POINTER(PostprocessDesc)]
     lib.qv2x_postprocess_workspace_bytes.restype = C.c_int64
     lib.qv2x_postprocess_f32.argtypes = [C.POINTER(PostprocessDesc), vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp]
+    lib.qv2x_postprocess_late_workspace_bytes.argtypes = [C.POINTER(PostprocessDesc), C.c_int]
+    lib.qv2x_postprocess_late_workspace_bytes.restype = C.c_int64
+    lib.qv2x_postprocess_late_f32.argtypes = [C.POINTER(PostprocessDesc), C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                              C.POINTER(C.c_float), vp, C.c_int64, vp, vp, vp, vp, vp]
     lib.qv2x_conv3x3_f32.argtypes = [C.POINTER(F32ConvDesc), vp, vp, vp, vp, vp]
     lib.qv2x_deconv_f32.argtypes = [C.POINTER(F32ConvDesc), vp, vp, vp, vp, vp]
     lib.qv2x_pfn_scatter_f32.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
@@ -167,7 +171,8 @@ def load() -> C.CDLL:
     lib.qv2x_allgather_codes.argtypes = [vp, vp, vp, C.c_int64, vp]
     lib.qv2x_pairwise_from_poses_f64.argtypes = [vp, C.c_int, C.c_int64, C.c_int64, C.c_int, vp, vp]
     for s in SYMBOLS:
-        if s not in ("qv2x_last_error", "qv2x_codebook_level_floats", "qv2x_codebook64_level_floats", "qv2x_voxelize_workspace_bytes", "qv2x_postprocess_workspace_bytes"):
+        if s not in ("qv2x_last_error", "qv2x_codebook_level_floats", "qv2x_codebook64_level_floats", "qv2x_voxelize_workspace_bytes", "qv2x_postprocess_workspace_bytes",
+                     "qv2x_postprocess_late_workspace_bytes"):
             getattr(lib, s).restype = C.c_int
     _lib = lib
     return lib

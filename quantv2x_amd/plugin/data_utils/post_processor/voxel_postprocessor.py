@@ -3,8 +3,9 @@ constructor, ``generate_anchor_box`` (:30-83) and ``post_process(data_dict, outp
 work done by ``qv2x_postprocess_f32`` (``csrc/postprocess.hip``).  Training-side members (``generate_label``,
 ``collate_batch``, ``visualize``) are out of scope (datasets / training).
 
-``post_process`` handles what intermediate fusion produces: ``output_dict`` with the ego entry only.  The head maps
-must live on the GPU (they come from ``DeployedModel``); there is no CPU fallback.
+``post_process`` handles what intermediate / early fusion produces (``output_dict`` with the ego entry only) and late fusion (one
+entry per CAV: ``qv2x_postprocess_late_f32``, up to 8 CAVs).  The head maps must live on the GPU (they come from ``DeployedModel``);
+there is no CPU fallback.
 """
 import ctypes as C
 import math
@@ -27,26 +28,36 @@ def load_point_pillar_anchor_args(hypes: dict) -> dict:
 
 def gpu_post_process(owner, cls, reg, dirp, anchors_dev, transformation_matrix, *, anchors_per_cell, num_classes, num_bins, dir_offset,
                      rng, range_xy_only, max_extent, z_lim, max_boxes):
-    """One ``qv2x_postprocess_f32`` call; ``owner`` keeps the workspace between frames.  -> (corners [K, 8, 3], scores [K],
-    labels i32 [K]) on the GPU, or (None, None, None)."""
+    """One ``qv2x_postprocess_f32`` call (or, when ``cls`` / ``reg`` / ``dirp`` / ``anchors_dev`` / ``transformation_matrix`` are lists with
+    one entry per CAV, one ``qv2x_postprocess_late_f32`` call); ``owner`` keeps the workspace between frames.
+    -> (corners [K, 8, 3], scores [K], labels i32 [K]) on the GPU, or (None, None, None)."""
     lib = load()
-    dev = cls.device
+    many = isinstance(cls, (list, tuple))
+    cls_l, reg_l = (list(cls), list(reg)) if many else ([cls], [reg])
+    dir_l = (list(dirp) if many else [dirp]) if dirp is not None else [None] * len(cls_l)
+    anc_l = list(anchors_dev) if many else [anchors_dev]
+    t_l = list(transformation_matrix) if many else [transformation_matrix]
+    ncav = len(cls_l)
+    dev = cls_l[0].device
     d = PostprocessDesc()
-    d.h, d.w, d.anchors_per_cell, d.num_bins = int(cls.shape[2]), int(cls.shape[3]), anchors_per_cell, num_bins
+    d.h, d.w, d.anchors_per_cell, d.num_bins = int(cls_l[0].shape[2]), int(cls_l[0].shape[3]), anchors_per_cell, num_bins
     d.score_threshold = float(owner.params["target_args"]["score_threshold"])
     d.nms_threshold = float(owner.params["nms_thresh"])
     d.dir_offset = dir_offset
     for i, v in enumerate(rng):
         d.range[i] = float(v)
-    t = transformation_matrix
-    t = np.asarray(t.detach().cpu() if torch.is_tensor(t) else t, dtype=np.float32).reshape(16)
-    for i in range(16):
-        d.transform[i] = float(t[i])
+    tf = (C.c_float * (16 * ncav))()
+    for c, t in enumerate(t_l):
+        t = np.asarray(t.detach().cpu() if torch.is_tensor(t) else t, dtype=np.float32).reshape(16)
+        for i in range(16):
+            tf[c * 16 + i] = float(t[i])
+            if c == 0:
+                d.transform[i] = float(t[i])
     d.max_boxes, d.num_classes, d.range_xy_only = max_boxes, num_classes, int(range_xy_only)
     d.max_extent, d.z_min, d.z_max = max_extent, z_lim[0], z_lim[1]
-    need = lib.qv2x_postprocess_workspace_bytes(C.byref(d))
+    need = lib.qv2x_postprocess_late_workspace_bytes(C.byref(d), ncav)
     if need < 0:
-        check(-1, "qv2x_postprocess_workspace_bytes")
+        check(-1, "qv2x_postprocess_late_workspace_bytes")
     if owner._ws is None or owner._ws.numel() < need or owner._ws.device != dev:
         owner._ws = torch.empty(need, dtype=torch.uint8, device=dev)
     corners = torch.empty((max_boxes, 8, 3), dtype=torch.float32, device=dev)
@@ -54,10 +65,11 @@ def gpu_post_process(owner, cls, reg, dirp, anchors_dev, transformation_matrix, 
     labels = torch.empty((max_boxes,), dtype=torch.int32, device=dev)
     count = torch.zeros((1,), dtype=torch.int32, device=dev)
     f32 = lambda x: x.to(torch.float32).contiguous()
-    cls, reg = f32(cls), f32(reg)
-    dirp = f32(dirp) if dirp is not None and num_bins > 0 else None
-    check(lib.qv2x_postprocess_f32(C.byref(d), ptr(cls), ptr(reg), ptr(dirp), ptr(anchors_dev), ptr(owner._ws), need,
-                                   ptr(corners), ptr(scores), ptr(labels), ptr(count), current_stream()), "qv2x_postprocess_f32")
+    cls_l, reg_l = [f32(x) for x in cls_l], [f32(x) for x in reg_l]
+    dir_l = [f32(x) if (x is not None and num_bins > 0) else None for x in dir_l]
+    arr = lambda ts: (C.c_void_p * ncav)(*[(t.data_ptr() if t is not None else None) for t in ts])
+    check(lib.qv2x_postprocess_late_f32(C.byref(d), ncav, arr(cls_l), arr(reg_l), arr(dir_l), arr(anc_l), tf, ptr(owner._ws), need,
+                                        ptr(corners), ptr(scores), ptr(labels), ptr(count), current_stream()), "qv2x_postprocess_late_f32")
     k = int(count.item())                            # the one host synchronisation of the frame (the reference goes to numpy here)
     if k == 0:
         return None, None, None
@@ -100,27 +112,31 @@ class VoxelPostprocessor:
         """-> (pred_box3d_tensor [K, 8, 3], scores [K]) on the GPU, or (None, None) when nothing passes."""
         if self.params["order"] != "hwl":
             raise NotImplementedError("deployed post-process: box order 'hwl' (PointPillar)")
-        if len(output_dict) != 1:
-            raise NotImplementedError("deployed post-process: one CAV (intermediate / early fusion); late fusion is not built")
-        cav_id = next(iter(output_dict))
-        out, cav = output_dict[cav_id], data_dict[cav_id]
-        cls = out["cls_preds"] if "cls_preds" in out else out["psm"]
-        reg = out["reg_preds"] if "reg_preds" in out else out["rm"]
-        dirp = out.get("dir_preds", out.get("dm"))
-        if not cls.is_cuda:
-            raise RuntimeError("VoxelPostprocessor.post_process runs on the GPU (libqv2x): the head maps must be CUDA tensors")
-        if cls.shape[0] != 1 or cls.shape[1] != self.anchor_num:
-            raise ValueError(f"cls_preds {tuple(cls.shape)}: batch 1 and {self.anchor_num} anchors per cell expected")
-        h, w = int(cls.shape[2]), int(cls.shape[3])
-        anchors = cav["anchor_box"]
-        if self._anchors_dev is None or self._anchors_dev[0] is not anchors:
-            a32 = torch.as_tensor(np.asarray(anchors.cpu() if torch.is_tensor(anchors) else anchors)).to(torch.float32)
-            if tuple(a32.shape) != (h, w, self.anchor_num, 7):
-                raise ValueError(f"anchor_box {tuple(a32.shape)} does not match the head maps ({h}, {w}, {self.anchor_num}, 7)")
-            self._anchors_dev = (anchors, a32.reshape(-1, 7).contiguous().to(cls.device))
+        cavs = [c for c in data_dict if c in output_dict]              # late fusion: one entry per CAV, the reference's loop order
+        if not 1 <= len(cavs) <= 8:
+            raise NotImplementedError("deployed post-process: 1..8 CAVs per call")
+        cls_l, reg_l, dir_l, anc_l, t_l = [], [], [], [], []
+        for cav_id in cavs:
+            out, cav = output_dict[cav_id], data_dict[cav_id]
+            cls = out["cls_preds"] if "cls_preds" in out else out["psm"]
+            reg = out["reg_preds"] if "reg_preds" in out else out["rm"]
+            dirp = out.get("dir_preds", out.get("dm"))
+            if not cls.is_cuda:
+                raise RuntimeError("VoxelPostprocessor.post_process runs on the GPU (libqv2x): the head maps must be CUDA tensors")
+            if cls.shape[0] != 1 or cls.shape[1] != self.anchor_num:
+                raise ValueError(f"cls_preds {tuple(cls.shape)}: batch 1 and {self.anchor_num} anchors per cell expected")
+            h, w = int(cls.shape[2]), int(cls.shape[3])
+            anchors = cav["anchor_box"]
+            if self._anchors_dev is None or self._anchors_dev[0] is not anchors:
+                a32 = torch.as_tensor(np.asarray(anchors.cpu() if torch.is_tensor(anchors) else anchors)).to(torch.float32)
+                if tuple(a32.shape) != (h, w, self.anchor_num, 7):
+                    raise ValueError(f"anchor_box {tuple(a32.shape)} does not match the head maps ({h}, {w}, {self.anchor_num}, 7)")
+                self._anchors_dev = (anchors, a32.reshape(-1, 7).contiguous().to(cls.device))
+            cls_l.append(cls); reg_l.append(reg); dir_l.append(dirp); anc_l.append(self._anchors_dev[1]); t_l.append(cav["transformation_matrix"])
+        has_dir = all(x is not None for x in dir_l)
         boxes, scores, _ = gpu_post_process(
-            self, cls, reg, dirp, self._anchors_dev[1], cav["transformation_matrix"], anchors_per_cell=self.anchor_num,
-            num_classes=1, num_bins=int(self.params["dir_args"]["num_bins"]) if dirp is not None else 0,
-            dir_offset=float(self.params["dir_args"]["dir_offset"]) if dirp is not None else 0.0,
+            self, cls_l, reg_l, dir_l if has_dir else None, anc_l, t_l, anchors_per_cell=self.anchor_num,
+            num_classes=1, num_bins=int(self.params["dir_args"]["num_bins"]) if has_dir else 0,
+            dir_offset=float(self.params["dir_args"]["dir_offset"]) if has_dir else 0.0,
             rng=self.params["gt_range"], range_xy_only=False, max_extent=6.0, z_lim=(-3.0, 1.0), max_boxes=max_boxes)
         return boxes, scores

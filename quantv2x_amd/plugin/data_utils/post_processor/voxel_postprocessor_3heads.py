@@ -71,24 +71,27 @@ class VoxelPostprocessor3Heads:
             raise NotImplementedError("deployed post-process: box order 'hwl' (PointPillar)")
         if not projection:
             raise NotImplementedError("deployed post-process returns the projected boxes (projection=True)")
-        cavs = [c for c in data_dict if c in output_dict]
-        if len(cavs) != 1:
-            raise NotImplementedError("deployed post-process: one CAV (intermediate / early fusion); late fusion is not built")
-        cav, out = data_dict[cavs[0]], output_dict[cavs[0]]
-        cls, reg = out["cls_preds"], out["reg_preds"]
-        if not cls.is_cuda:
-            raise RuntimeError("VoxelPostprocessor3Heads.post_process runs on the GPU (libqv2x): the head maps must be CUDA tensors")
-        all_anchors = cav["all_anchors"]                       # (num_class, H, W, anchor_num, 7)
-        if self._anchors_dev is None or self._anchors_dev[0] is not all_anchors:
-            a = torch.as_tensor(np.asarray(all_anchors.cpu() if torch.is_tensor(all_anchors) else all_anchors)).to(torch.float32)
-            a = a.permute(1, 2, 0, 3, 4).contiguous()           # (H, W, num_class, anchor_num, 7), :354
-            self._anchors_dev = (all_anchors, a.reshape(-1, 7).to(cls.device), int(a.shape[2] * a.shape[3]), tuple(a.shape[:2]))
-        _, anchors_dev, per_cell, hw = self._anchors_dev
-        if cls.shape[0] != 1 or tuple(cls.shape[2:]) != hw or cls.shape[1] % per_cell or reg.shape[1] != per_cell * 7:
-            raise ValueError(f"cls_preds {tuple(cls.shape)} / reg_preds {tuple(reg.shape)} do not match {per_cell} anchors per cell on {hw}")
+        cavs = [c for c in data_dict if c in output_dict]              # late fusion: one entry per CAV, the reference's loop order (:345)
+        if not 1 <= len(cavs) <= 8:
+            raise NotImplementedError("deployed post-process: 1..8 CAVs per call")
+        cls_l, reg_l, anc_l, t_l = [], [], [], []
+        for cav_id in cavs:
+            cav, out = data_dict[cav_id], output_dict[cav_id]
+            cls, reg = out["cls_preds"], out["reg_preds"]
+            if not cls.is_cuda:
+                raise RuntimeError("VoxelPostprocessor3Heads.post_process runs on the GPU (libqv2x): the head maps must be CUDA tensors")
+            all_anchors = cav["all_anchors"]                       # (num_class, H, W, anchor_num, 7)
+            if self._anchors_dev is None or self._anchors_dev[0] is not all_anchors:
+                a = torch.as_tensor(np.asarray(all_anchors.cpu() if torch.is_tensor(all_anchors) else all_anchors)).to(torch.float32)
+                a = a.permute(1, 2, 0, 3, 4).contiguous()           # (H, W, num_class, anchor_num, 7), :354
+                self._anchors_dev = (all_anchors, a.reshape(-1, 7).to(cls.device), int(a.shape[2] * a.shape[3]), tuple(a.shape[:2]))
+            _, anchors_dev, per_cell, hw = self._anchors_dev
+            if cls.shape[0] != 1 or tuple(cls.shape[2:]) != hw or cls.shape[1] % per_cell or reg.shape[1] != per_cell * 7:
+                raise ValueError(f"cls_preds {tuple(cls.shape)} / reg_preds {tuple(reg.shape)} do not match {per_cell} anchors per cell on {hw}")
+            cls_l.append(cls); reg_l.append(reg); anc_l.append(anchors_dev); t_l.append(cav["transformation_matrix"])
         boxes, scores, labels = gpu_post_process(
-            self, cls, reg, None, anchors_dev, cav["transformation_matrix"], anchors_per_cell=per_cell,
-            num_classes=int(cls.shape[1] // per_cell), num_bins=0, dir_offset=0.0, rng=self.gt_range, range_xy_only=True,
+            self, cls_l, reg_l, None, anc_l, t_l, anchors_per_cell=per_cell,
+            num_classes=int(cls_l[0].shape[1] // per_cell), num_bins=0, dir_offset=0.0, rng=self.gt_range, range_xy_only=True,
             max_extent=100.0, z_lim=(-100.0, 100.0), max_boxes=max_boxes)
         if boxes is None:
             return None, None

@@ -460,6 +460,16 @@ def gen_postprocess_mc():
             od = {"ego": {"cls_preds": torch.from_numpy(cls.copy()), "reg_preds": torch.from_numpy(reg.copy())}}
             boxes, score_labels = pp.post_process(data, od)
             out[f"{tag}_boxes"], out[f"{tag}_score_labels"] = np32(boxes), np32(score_labels)
+        # late fusion: two CAVs (the ego + one at `T`), each with its own head maps, one post_process call over both
+        cls2 = rng.normal(-3.6, 1.7, size=(1, 18, h, w)).astype(np.float32)
+        reg2 = rng.normal(0.0, 0.25, size=(1, 42, h, w)).astype(np.float32)
+        out["late_cls2"], out["late_reg2"] = cls2, reg2
+        data = {"ego": {"transformation_matrix": torch.eye(4), "all_anchors": torch.from_numpy(all_anchors), "num_anchors_per_location": per_loc},
+                "cav1": {"transformation_matrix": torch.from_numpy(T), "all_anchors": torch.from_numpy(all_anchors), "num_anchors_per_location": per_loc}}
+        od = {"ego": {"cls_preds": torch.from_numpy(cls.copy()), "reg_preds": torch.from_numpy(reg.copy())},
+              "cav1": {"cls_preds": torch.from_numpy(cls2.copy()), "reg_preds": torch.from_numpy(reg2.copy())}}
+        boxes, score_labels = pp.post_process(data, od)
+        out["late_boxes"], out["late_score_labels"] = np32(boxes), np32(score_labels)
     finally:
         box_utils_mc.nms_rotated = orig
     np.savez_compressed(os.path.join(HERE, "postprocess_mc.npz"), **out)

@@ -156,6 +156,32 @@ def test_mc_golden_inputs_match_oracle(tag):
     np.testing.assert_allclose(gb, wb, **TOL)
 
 
+def test_mc_late_fusion_two_cavs_match_oracle():
+    """late fusion on the GPU (qv2x_postprocess_late_f32 behind the plugin class): two CAVs with their own head maps and matrices, NMS
+    over the union -- identical box set and order as the oracle"""
+    from test_postprocess_oracle import interleave, mc_params
+    from quantv2x_amd.plugin.data_utils.post_processor import build_postprocessor
+    with np.load(os.path.join(os.path.dirname(__file__), "golden", "postprocess_mc.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    anchors = interleave(g["all_anchors"])
+    cavs = [(g["cls"], g["reg"], None, anchors, np.eye(4, dtype=np.float32)), (g["late_cls2"], g["late_reg2"], None, anchors, g["T"])]
+    wb, ws, wl = P.post_process_late(cavs, g["gt_range"], num_classes=3, max_extent=100.0, z_lim=(-100.0, 100.0), range_xy_only=True, return_labels=True)
+    pp = build_postprocessor(mc_params(g["lidar_range"], 64, 32), train=False)
+    aa = torch.from_numpy(g["all_anchors"])
+    data = {"ego": {"transformation_matrix": torch.eye(4), "all_anchors": aa, "num_anchors_per_location": [2, 2, 2]},
+            "cav1": {"transformation_matrix": torch.from_numpy(g["T"]), "all_anchors": aa, "num_anchors_per_location": [2, 2, 2]}}
+    out = {"ego": {"cls_preds": torch.from_numpy(g["cls"]).cuda(), "reg_preds": torch.from_numpy(g["reg"]).cuda()},
+           "cav1": {"cls_preds": torch.from_numpy(g["late_cls2"]).cuda(), "reg_preds": torch.from_numpy(g["late_reg2"]).cuda()}}
+    boxes, sl = pp.post_process(data, out)
+    gb, gsl = boxes.cpu().numpy(), sl.cpu().numpy()
+    assert gb.shape == wb.shape and len(wb) > 0
+    np.testing.assert_array_equal(gsl[:, 1].astype(np.int64), wl)
+    np.testing.assert_allclose(gsl[:, 0], ws, **TOL)
+    np.testing.assert_allclose(gb, wb, **TOL)
+    single, _ = pp.post_process({"ego": data["ego"]}, {"ego": out["ego"]})          # one CAV through the same entry still works
+    assert 0 < len(single) < len(gb) + 1
+
+
 def test_mc_deployed_model_heads_to_boxes():
     """The multi-class deployed model's own head maps (tiny shape, 3 agents) through the GPU post-processor == the oracle
     post-processor on the same maps: the frame ends in boxes without leaving the GPU except for the box count."""

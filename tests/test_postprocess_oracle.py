@@ -112,3 +112,17 @@ def test_mc_flow_without_nms_matches_reference(gold_mc, tag):
     np.testing.assert_array_equal(labels, want[:, 1].astype(np.int64))
     np.testing.assert_allclose(scores, want[:, 0], **TOL)
     np.testing.assert_allclose(boxes, gold_mc[tag + "_boxes"], **TOL)
+
+
+def test_mc_late_fusion_without_nms_matches_reference(gold_mc):
+    """two CAVs in one ``post_process`` call (late fusion, voxel_postprocessor_3heads.py:345-420): the union in the reference's order"""
+    anchors = interleave(gold_mc["all_anchors"])
+    cavs = [(gold_mc["cls"], gold_mc["reg"], None, anchors, np.eye(4, dtype=np.float32)),
+            (gold_mc["late_cls2"], gold_mc["late_reg2"], None, anchors, gold_mc["T"])]
+    boxes, scores, labels = P.post_process_late(cavs, gold_mc["gt_range"], nms=False, num_classes=3, max_extent=100.0, z_lim=(-100.0, 100.0),
+                                                range_xy_only=True, return_labels=True)
+    want = gold_mc["late_score_labels"]
+    assert boxes.shape == gold_mc["late_boxes"].shape and len(boxes) > len(gold_mc["ident_boxes"])
+    np.testing.assert_array_equal(labels, want[:, 1].astype(np.int64))
+    np.testing.assert_allclose(scores, want[:, 0], **TOL)
+    np.testing.assert_allclose(boxes, gold_mc["late_boxes"], **TOL)
