@@ -370,6 +370,20 @@ int qv2x_codebook64_c2_f32(const float* codebook, int kc, float* c2, void* strea
 int qv2x_codebook_encode64_f32(const qv2x_encode_desc* desc /* host */, int cin_total, const int8_t* in,
                                const float* const* level_weights /* host array of device pointers */, uint8_t* codes, void* stream);
 
+/* The same from fp32 rows (the un-quantized Pyramid model): in f32, padded map [N][H+2][W+2][cin_total], first 64 channels. */
+int qv2x_codebook_encode64_f32in(const qv2x_encode_desc* desc /* host */, int cin_total, const float* in,
+                                 const float* const* level_weights /* host array of device pointers */, uint8_t* codes, void* stream);
+
+/* The un-quantized Pyramid model (plain opencood/tools/inference.py flow) reuses qv2x_conv3x3_f32 / qv2x_deconv_f32 (1x1 = deconv with
+ * stride 1; a grouped 3x3 = one dense launch per 64-channel slab through the cin / out windows) and adds:
+ *   qv2x_add_relu_f32     out = max(a + b, 0) over `count` floats (the end of a residual block, resblock.py:58-66, :118-128)
+ *   qv2x_occ_sigmoid_f32  channel 0 of a padded fp32 map [n][h+2][w+2][c_total] -> occ f32 [n*h*w], score = sigmoid(occ) + 1e-4
+ *   qv2x_pyramid_weighted_fuse_f32p   qv2x_pyramid_weighted_fuse_f32 with features AND output as padded maps [..][h+2][w+2][channels] */
+int qv2x_add_relu_f32(const float* a, const float* b, float* out, int64_t count, void* stream);
+int qv2x_occ_sigmoid_f32(const float* in, int n, int h, int w, int c_total, float* occ, float* score, void* stream);
+int qv2x_pyramid_weighted_fuse_f32p(const qv2x_fuse_desc* desc /* host */, int channels, const float* feats, const float* score,
+                                    const double* pairwise, float* out, void* stream);
+
 /* One level's 1x1 occupancy head (QuantModule c -> 1 with its output quantizer, quant_block.py:475-479, :507-509):
  *     T exact;  y = bias + float(T) * scale;  code = quant(y);  score = score_lut[code]
  *   (score_lut[k] = sigmoid((k - out_zp) * out_delta) + 1e-4, built once by the caller);  in padded i8 BEV [N][H+2][W+2][c],

@@ -15,7 +15,7 @@ constexpr int D = 64, ER = 64, LDF = 66;
 __device__ __forceinline__ int kpos(int c) { return (c & ~3) | ((c & 1) << 1) | ((c >> 1) & 1); }
 
 struct Enc64Args {
-    const int8_t* in; uint8_t* codes;
+    const int8_t* in; const float* in_f32; uint8_t* codes;        // in_f32 != null: the rows come as fp32 (un-quantized model)
     const float* lvl[4];
     int n, h, w, cin_total, levels, kc, ax, M;
     float dx;
@@ -85,11 +85,21 @@ __global__ __launch_bounds__(256, 4) void codebook_encode64_kernel(const Enc64Ar
         m = m < a.M ? m : a.M - 1;
         const int img = m / (a.h * a.w), rem = m - img * (a.h * a.w);
         const int y = rem / a.w, x = rem - y * a.w;
-        const v4i raw = *(const v4i*)(a.in + ((size_t)(img * (a.h + 2) + y + 1) * (a.w + 2) + x + 1) * a.cin_total + part * 16);
+        const size_t pixel = (size_t)(img * (a.h + 2) + y + 1) * (a.w + 2) + x + 1;
+        if (a.in_f32) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int xs = (raw[e >> 2] << (24 - (e & 3) * 8)) >> 24;
-            bufA[row * LDF + kpos(part * 16 + e)] = (float)(xs + a.ax) * a.dx;
+            for (int c = 0; c < 4; ++c) {
+                const v4f v = *(const v4f*)(a.in_f32 + pixel * a.cin_total + part * 16 + c * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bufA[row * LDF + kpos(part * 16 + c * 4 + e)] = v[e];
+            }
+        } else {
+            const v4i raw = *(const v4i*)(a.in + pixel * a.cin_total + part * 16);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int xs = (raw[e >> 2] << (24 - (e & 3) * 8)) >> 24;
+                bufA[row * LDF + kpos(part * 16 + e)] = (float)(xs + a.ax) * a.dx;
+            }
         }
     }
     __syncthreads();
@@ -216,15 +226,16 @@ extern "C" int qv2x_codebook64_c2_f32(const float* codebook, int kc, float* c2, 
     return hip_check(hipGetLastError(), "qv2x_codebook64_c2_f32 launch");
 }
 
-extern "C" int qv2x_codebook_encode64_f32(const qv2x_encode_desc* d, int cin_total, const int8_t* in, const float* const* level_weights,
-                                          uint8_t* codes, void* stream) {
+static int encode64_launch(const qv2x_encode_desc* d, int cin_total, const int8_t* in, const float* in_f32, const float* const* level_weights,
+                           uint8_t* codes, void* stream) {
     using namespace qv2x;
-    if (!d || !in || !level_weights || !codes) return fail(QV2X_EINVAL, "qv2x_codebook_encode64_f32: null pointer");
+    if (!d || (!in && !in_f32) || !level_weights || !codes) return fail(QV2X_EINVAL, "qv2x_codebook_encode64_f32: null pointer");
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->levels < 1 || d->levels > 4) return fail(QV2X_EINVAL, "qv2x_codebook_encode64_f32: bad shape");
     if (d->kc < 32 || d->kc > 128 || d->kc % 32) return fail(QV2X_EINVAL, "qv2x_codebook_encode64_f32: dict_size must be 32, 64, 96 or 128 (got %d)", d->kc);
-    if (cin_total < 64 || cin_total % 16 || ((uintptr_t)in & 15)) return fail(QV2X_EALIGN, "qv2x_codebook_encode64_f32: >= 64 channels (%% 16), 16-byte aligned map");
+    if (cin_total < 64 || cin_total % 16 || ((uintptr_t)in & 15) || ((uintptr_t)in_f32 & 15))
+        return fail(QV2X_EALIGN, "qv2x_codebook_encode64_f32: >= 64 channels (%% 16), 16-byte aligned map");
     Enc64Args a;
-    a.in = in; a.codes = codes; a.n = d->n; a.h = d->h; a.w = d->w; a.cin_total = cin_total; a.levels = d->levels; a.kc = d->kc;
+    a.in = in; a.in_f32 = in_f32; a.codes = codes; a.n = d->n; a.h = d->h; a.w = d->w; a.cin_total = cin_total; a.levels = d->levels; a.kc = d->kc;
     a.ax = 128 - d->in_zx; a.dx = d->in_delta; a.M = d->n * d->h * d->w;
     for (int l = 0; l < 4; ++l) {
         a.lvl[l] = l < d->levels ? level_weights[l] : nullptr;
@@ -232,4 +243,14 @@ extern "C" int qv2x_codebook_encode64_f32(const qv2x_encode_desc* d, int cin_tot
     }
     codebook_encode64_kernel<<<(a.M + ER - 1) / ER, 256, 0, (hipStream_t)stream>>>(a);
     return hip_check(hipGetLastError(), "qv2x_codebook_encode64_f32 launch");
+}
+
+extern "C" int qv2x_codebook_encode64_f32(const qv2x_encode_desc* d, int cin_total, const int8_t* in, const float* const* level_weights,
+                                          uint8_t* codes, void* stream) {
+    return encode64_launch(d, cin_total, in, nullptr, level_weights, codes, stream);
+}
+
+extern "C" int qv2x_codebook_encode64_f32in(const qv2x_encode_desc* d, int cin_total, const float* in, const float* const* level_weights,
+                                            uint8_t* codes, void* stream) {
+    return encode64_launch(d, cin_total, nullptr, in, level_weights, codes, stream);
 }

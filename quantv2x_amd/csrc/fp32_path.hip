@@ -158,8 +158,46 @@ int gemm_launch(const qv2x_f32conv_desc* d, const float* in, const float* w, con
     return hip_check(hipGetLastError(), who);
 }
 
+// the end of a residual block in fp32 (resblock.py:58-66, :118-128): out = relu(a + b), elementwise over whole (padded) maps
+__global__ __launch_bounds__(256) void add_relu_f32_kernel(const v4f* __restrict__ a, const v4f* __restrict__ b, v4f* __restrict__ out, long long n4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const v4f x = a[i], y = b[i];
+    v4f o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = fmaxf(x[e] + y[e], 0.0f);
+    out[i] = o;
+}
+
+// channel 0 of a padded fp32 map [n][h+2][w+2][ct] -> occupancy [n*h*w] and score = sigmoid(occupancy) + 1e-4 (pyramid_fuse.py:150-152)
+__global__ __launch_bounds__(256) void occ_sigmoid_f32_kernel(const float* __restrict__ in, int n, int h, int w, int ct, float* __restrict__ occ,
+                                                              float* __restrict__ score) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= n * h * w) return;
+    const int img = m / (h * w), rem = m - img * (h * w), y = rem / w, x = rem - y * w;
+    const float v = in[((size_t)(img * (h + 2) + y + 1) * (w + 2) + x + 1) * ct];
+    occ[m] = v;
+    score[m] = 1.0f / (1.0f + expf(-v)) + 1e-4f;
+}
+
 }  // namespace
 }  // namespace qv2x
+
+extern "C" int qv2x_add_relu_f32(const float* a, const float* b, float* out, int64_t count, void* stream) {
+    using namespace qv2x;
+    if (!a || !b || !out) return fail(QV2X_EINVAL, "qv2x_add_relu_f32: null pointer");
+    if (count <= 0 || count % 4 || ((uintptr_t)a & 15) || ((uintptr_t)b & 15) || ((uintptr_t)out & 15)) return fail(QV2X_EALIGN, "qv2x_add_relu_f32: count %% 4, 16-byte aligned pointers");
+    add_relu_f32_kernel<<<(unsigned)((count / 4 + 255) / 256), 256, 0, (hipStream_t)stream>>>((const v4f*)a, (const v4f*)b, (v4f*)out, count / 4);
+    return hip_check(hipGetLastError(), "qv2x_add_relu_f32 launch");
+}
+
+extern "C" int qv2x_occ_sigmoid_f32(const float* in, int n, int h, int w, int c_total, float* occ, float* score, void* stream) {
+    using namespace qv2x;
+    if (!in || !occ || !score) return fail(QV2X_EINVAL, "qv2x_occ_sigmoid_f32: null pointer");
+    if (n <= 0 || h <= 0 || w <= 0 || c_total <= 0) return fail(QV2X_EINVAL, "qv2x_occ_sigmoid_f32: bad shape");
+    occ_sigmoid_f32_kernel<<<(n * h * w + 255) / 256, 256, 0, (hipStream_t)stream>>>(in, n, h, w, c_total, occ, score);
+    return hip_check(hipGetLastError(), "qv2x_occ_sigmoid_f32 launch");
+}
 
 extern "C" int qv2x_conv3x3_f32(const qv2x_f32conv_desc* d, const float* in, const float* w, const float* bias, float* out, void* stream) {
     return qv2x::gemm_launch(d, in, w, bias, out, stream, 0, "qv2x_conv3x3_f32");

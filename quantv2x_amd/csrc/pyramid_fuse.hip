@@ -17,6 +17,7 @@ namespace {
 struct PyrArgs {
     const float* feats; const float* score; const double* pairwise; float* out;
     const int8_t* feats_i8; int ax; float dx;            // I8: padded i8 BEV [agents][h+2][w+2][c] and its quantizer
+    int pad;                                             // fp32 variant: 1 = features AND output are padded maps [..][h+2][w+2][c]
     int agents, h, w, c, hw, L, ego;
     double hm, wm, ratio;
 };
@@ -99,7 +100,9 @@ __global__ __launch_bounds__(256) void pyramid_weighted_fuse_kernel(const PyrArg
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = (float)(((wv << (24 - 8 * e)) >> 24) + a.ax) * a.dx;
                         } else {
-                            const v4f fv = *(const v4f*)(a.feats + ((size_t)ag * a.hw + tc) * a.c + ch);
+                            size_t at = (size_t)ag * a.hw + tc;
+                            if (a.pad) { const int cy2 = tc / a.w, cx2 = tc - cy2 * a.w; at = (size_t)(ag * (a.h + 2) + cy2 + 1) * (a.w + 2) + cx2 + 1; }
+                            const v4f fv = *(const v4f*)(a.feats + at * a.c + ch);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = fv[e];
                         }
@@ -112,7 +115,9 @@ __global__ __launch_bounds__(256) void pyramid_weighted_fuse_kernel(const PyrArg
                 for (int e = 0; e < 4; ++e) o[e] += f[e] * p;
             }
             v4f ov = {o[0], o[1], o[2], o[3]};
-            *(v4f*)(a.out + (size_t)cell * a.c + ch) = ov;
+            size_t oc = cell;
+            if (!I8 && a.pad) { const int cy2 = cell / a.w, cx2 = cell - cy2 * a.w; oc = (size_t)(cy2 + 1) * (a.w + 2) + cx2 + 1; }
+            *(v4f*)(a.out + oc * a.c + ch) = ov;
         }
     }
 }
@@ -120,8 +125,21 @@ __global__ __launch_bounds__(256) void pyramid_weighted_fuse_kernel(const PyrArg
 }  // namespace
 }  // namespace qv2x
 
+static int weighted_fuse_f32(const qv2x_fuse_desc* d, int channels, const float* feats, const float* score, const double* pairwise, float* out,
+                             void* stream, int padded);
+
 extern "C" int qv2x_pyramid_weighted_fuse_f32(const qv2x_fuse_desc* d, int channels, const float* feats, const float* score, const double* pairwise,
                                               float* out, void* stream) {
+    return weighted_fuse_f32(d, channels, feats, score, pairwise, out, stream, 0);
+}
+
+extern "C" int qv2x_pyramid_weighted_fuse_f32p(const qv2x_fuse_desc* d, int channels, const float* feats, const float* score, const double* pairwise,
+                                               float* out, void* stream) {
+    return weighted_fuse_f32(d, channels, feats, score, pairwise, out, stream, 1);
+}
+
+static int weighted_fuse_f32(const qv2x_fuse_desc* d, int channels, const float* feats, const float* score, const double* pairwise, float* out,
+                             void* stream, int padded) {
     using namespace qv2x;
     if (!d || !feats || !score || !pairwise || !out) return fail(QV2X_EINVAL, "qv2x_pyramid_weighted_fuse_f32: null pointer");
     if (d->agents < 1 || d->agents > MAXA || d->max_cav < d->agents || d->ego < 0 || d->ego >= d->agents)
@@ -129,7 +147,7 @@ extern "C" int qv2x_pyramid_weighted_fuse_f32(const qv2x_fuse_desc* d, int chann
     if (d->h <= 0 || d->w <= 0 || channels < 64 || channels % 64) return fail(QV2X_EINVAL, "qv2x_pyramid_weighted_fuse_f32: bad sizes (channels %% 64)");
     if (!(d->h_metres > 0) || !(d->w_metres > 0) || !(d->discrete_ratio > 0)) return fail(QV2X_EINVAL, "qv2x_pyramid_weighted_fuse_f32: map extent must be positive");
     PyrArgs a;
-    a.feats = feats; a.score = score; a.pairwise = pairwise; a.out = out; a.feats_i8 = nullptr; a.ax = 0; a.dx = 0.0f;
+    a.feats = feats; a.score = score; a.pairwise = pairwise; a.out = out; a.feats_i8 = nullptr; a.ax = 0; a.dx = 0.0f; a.pad = padded;
     a.agents = d->agents; a.h = d->h; a.w = d->w; a.c = channels; a.hw = d->h * d->w; a.L = d->max_cav; a.ego = d->ego;
     a.hm = d->h_metres; a.wm = d->w_metres; a.ratio = d->discrete_ratio;
     pyramid_weighted_fuse_kernel<false><<<(a.hw + 15) / 16, 256, 0, (hipStream_t)stream>>>(a);
@@ -145,7 +163,7 @@ extern "C" int qv2x_pyramid_weighted_fuse_i8(const qv2x_fuse_desc* d, int channe
     if (d->h <= 0 || d->w <= 0 || channels < 64 || channels % 64) return fail(QV2X_EINVAL, "qv2x_pyramid_weighted_fuse_i8: bad sizes (channels %% 64)");
     if (!(d->h_metres > 0) || !(d->w_metres > 0) || !(d->discrete_ratio > 0)) return fail(QV2X_EINVAL, "qv2x_pyramid_weighted_fuse_i8: map extent must be positive");
     PyrArgs a;
-    a.feats = nullptr; a.score = score; a.pairwise = pairwise; a.out = out; a.feats_i8 = feats; a.ax = 128 - in_zx; a.dx = in_delta;
+    a.feats = nullptr; a.score = score; a.pairwise = pairwise; a.out = out; a.feats_i8 = feats; a.ax = 128 - in_zx; a.dx = in_delta; a.pad = 0;
     a.agents = d->agents; a.h = d->h; a.w = d->w; a.c = channels; a.hw = d->h * d->w; a.L = d->max_cav; a.ego = d->ego;
     a.hm = d->h_metres; a.wm = d->w_metres; a.ratio = d->discrete_ratio;
     pyramid_weighted_fuse_kernel<true><<<(a.hw + 15) / 16, 256, 0, (hipStream_t)stream>>>(a);

@@ -720,10 +720,16 @@ def deploy(qt_model=None, state: Optional[Dict[str, np.ndarray]] = None, path: O
             state = load_ptq_state(path)
         elif any(hasattr(m, "weight_quantizer") for m in qt_model.modules()):
             state = export_ptq_state(qt_model)
+        elif hasattr(qt_model, "pyramid_backbone"):
+            from .engine_pyramid_fp32 import export_fp32_pyramid_state
+            state = export_fp32_pyramid_state(qt_model)
         else:
             from .engine_fp32 import export_fp32_state
             state = export_fp32_state(qt_model)
     if str(state.get("meta/mode", "w8a8")) == "fp32":
+        if str(state.get("meta/fusion_method", "att")) == "pyramid":
+            from .engine_pyramid_fp32 import DeployedPyramidFp32Model
+            return DeployedPyramidFp32Model(state, device=device, **kw)
         from .engine_fp32 import DeployedFp32Model
         return DeployedFp32Model(state, device=device, **kw)
     if str(state.get("meta/fusion_method", "att")) == "pyramid":

@@ -21,7 +21,8 @@ SYMBOLS = [
     "qv2x_conv3x3_f32", "qv2x_deconv_f32", "qv2x_pfn_scatter_f32", "qv2x_codebook_encode_f32in",
     "qv2x_pyramid_weighted_fuse_f32", "qv2x_pyramid_weighted_fuse_i8", "qv2x_conv1x1_i8", "qv2x_gconv3x3_i8", "qv2x_conv3x3_i8_res",
     "qv2x_deconv_f32in", "qv2x_codebook_decode_f32", "qv2x_occ_score_i8",
-    "qv2x_codebook64_level_floats", "qv2x_codebook64_c2_f32", "qv2x_codebook_encode64_f32",
+    "qv2x_codebook64_level_floats", "qv2x_codebook64_c2_f32", "qv2x_codebook_encode64_f32", "qv2x_codebook_encode64_f32in",
+    "qv2x_add_relu_f32", "qv2x_occ_sigmoid_f32", "qv2x_pyramid_weighted_fuse_f32p",
     "qv2x_comm_unique_id", "qv2x_comm_init", "qv2x_comm_destroy", "qv2x_allgather_codes", "qv2x_pairwise_from_poses_f64",
 ]
 COMM_ID_BYTES = 128
@@ -165,6 +166,10 @@ def load() -> C.CDLL:
     lib.qv2x_codebook64_level_floats.restype = C.c_int64
     lib.qv2x_codebook64_c2_f32.argtypes = [vp, C.c_int, vp, vp]
     lib.qv2x_codebook_encode64_f32.argtypes = [C.POINTER(EncodeDesc), C.c_int, vp, C.POINTER(vp), vp, vp]
+    lib.qv2x_codebook_encode64_f32in.argtypes = [C.POINTER(EncodeDesc), C.c_int, vp, C.POINTER(vp), vp, vp]
+    lib.qv2x_add_relu_f32.argtypes = [vp, vp, vp, C.c_int64, vp]
+    lib.qv2x_occ_sigmoid_f32.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
+    lib.qv2x_pyramid_weighted_fuse_f32p.argtypes = [C.POINTER(FuseDesc), C.c_int, vp, vp, vp, vp, vp]
     lib.qv2x_comm_unique_id.argtypes = [vp]
     lib.qv2x_comm_init.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
     lib.qv2x_comm_destroy.argtypes = [vp]
