@@ -52,10 +52,23 @@ __device__ __host__ __forceinline__ int64_t level_floats(int kc) { return 3LL * 
 // so the in-order vmcnt wait at a set's first use leaves the other set's loads in flight (sched_barrier pins the
 // request block ahead of the MFMA block: hipcc otherwise sinks every load to its first use).  Reads past the last
 // k-quad hit the next section of the weight blob.
-__device__ __forceinline__ void gemm_rows_x32(const float* __restrict__ src, const float2* __restrict__ wp, const float* __restrict__ bias,
+// the first four k-quads of a weight matrix + the bias of this lane's column: requested BEFORE the barrier that precedes the GEMM, so
+// the L2 round trip overlaps the previous phase's tile store and the barrier wait
+struct GemmHead { float2 s0[4]; float b; };
+__device__ __forceinline__ GemmHead gemm_head(const float2* __restrict__ wp, const float* __restrict__ bias, int wave, int lane) {
+    const int par = lane >> 5, col = wave * 32 + (lane & 31);
+    GemmHead h;
+    h.b = bias[col];
+    const float2* wl = wp + (size_t)col * 2 + par;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) h.s0[t] = wl[(size_t)t * D * 2];
+    return h;
+}
+
+__device__ __forceinline__ void gemm_rows_x32(const float* __restrict__ src, const float2* __restrict__ wp, const GemmHead& head,
                                               int wave, int lane, v16f (&acc)[ERT]) {
     const int par = lane >> 5, col = wave * 32 + (lane & 31);
-    const float b = bias[col];
+    const float b = head.b;
 #pragma unroll
     for (int i = 0; i < ERT; ++i)
 #pragma unroll
@@ -81,7 +94,8 @@ __device__ __forceinline__ void gemm_rows_x32(const float* __restrict__ src, con
         }
     };
     float2 s0[4], s1[4];
-    loadB(s0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) s0[t] = head.s0[t];
     for (int q0 = 0; q0 < 64; q0 += 8) {
         loadB(s1, q0 + 4);
         __builtin_amdgcn_sched_barrier(0);
@@ -169,6 +183,7 @@ __global__ __launch_bounds__(512, 4) void codebook_encode_kernel(const EncArgs a
             }
         }
     }
+    GemmHead head = gemm_head((const float2*)a.lvl[0], a.lvl[0] + D * D, wave, lane);      // stage_w / stage_b of level 0
     __syncthreads();
 
     v16f acc[ERT];
@@ -184,10 +199,12 @@ __global__ __launch_bounds__(512, 4) void codebook_encode_kernel(const EncArgs a
         const float* cb = cbp + (size_t)D * a.kc;             // [kc][256]
         const float* c2 = cb + (size_t)a.kc * D;              // [kc]
 
-        gemm_rows_x32(bufA, (const float2*)stage_w, stage_b, wave, lane, acc);      // z = stage(x)
+        gemm_rows_x32(bufA, (const float2*)stage_w, head, wave, lane, acc);         // z = stage(x)
+        head = gemm_head((const float2*)qhead_w, qhead_b, wave, lane);
         store_tile(bufB, wave, lane, acc);
         __syncthreads();
-        gemm_rows_x32(bufB, (const float2*)qhead_w, qhead_b, wave, lane, acc);      // q = qhead(z)
+        gemm_rows_x32(bufB, (const float2*)qhead_w, head, wave, lane, acc);         // q = qhead(z)
+        if (l + 1 < a.levels) head = gemm_head((const float2*)lhead_w, lhead_b, wave, lane);      // used after the argmin
         store_tile(bufA, wave, lane, acc);                                        // x is dead since the barrier above
         __syncthreads();
 
@@ -202,13 +219,24 @@ __global__ __launch_bounds__(512, 4) void codebook_encode_kernel(const EncArgs a
             }
             pval[part * ER + row] = s;
         }
+        // the distance tile's first codebook k-quads and |C_k|^2, requested ahead of the two barriers of the |q|^2 reduction
+        const int ct = wave & 3, rt = wave >> 2;
+        const bool has_dist = rt < ERT && ct * 32 < a.kc;
+        float2 dhead[4];
+        float c2v = 0.0f;
+        if (has_dist) {
+            const int code = ct * 32 + (lane & 31);
+            const float2* cl = (const float2*)cbp + (size_t)code * 2 + (lane >> 5);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dhead[t] = cl[(size_t)t * a.kc * 2];
+            c2v = c2[code];
+        }
         __syncthreads();
         if (tid < ER) x2[tid] = (pval[tid] + pval[ER + tid]) + (pval[2 * ER + tid] + pval[3 * ER + tid]);
         __syncthreads();
 
         // ---- distances: wave -> (row tile = wave >> 2, codes [32*(wave & 3), +32)), then the argmin ------------
-        const int ct = wave & 3, rt = wave >> 2;
-        if (rt < ERT && ct * 32 < a.kc) {
+        if (has_dist) {
             const int par = lane >> 5, code = ct * 32 + (lane & 31);
             v16f dacc;
 #pragma unroll
@@ -230,7 +258,8 @@ __global__ __launch_bounds__(512, 4) void codebook_encode_kernel(const EncArgs a
                 }
             };
             float2 s0[4], s1[4];
-            loadC(s0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) s0[t] = dhead[t];
             for (int q0 = 0; q0 < 64; q0 += 8) {
                 loadC(s1, q0 + 4);
                 __builtin_amdgcn_sched_barrier(0);
@@ -241,7 +270,6 @@ __global__ __launch_bounds__(512, 4) void codebook_encode_kernel(const EncArgs a
                 dist4(s1, q0 + 4);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const float c2v = c2[code];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rt * 32 + mfma32_row(r, lane);
@@ -271,19 +299,19 @@ __global__ __launch_bounds__(512, 4) void codebook_encode_kernel(const EncArgs a
         __syncthreads();
 
         if (l + 1 < a.levels) {      // x <- lhead(z) - C[code]
-            gemm_rows_x32(bufB, (const float2*)lhead_w, lhead_b, wave, lane, acc);
+            // the chosen codewords' entries of this lane's column: 16 gathers requested ahead of the GEMM that produces the minuend
             const int col = wave * 32 + (lane & 31);
+            float cv[ERT][16];
 #pragma unroll
-            for (int i = 0; i < ERT; ++i) {
-                int cd[16];
-                float cv[16];
+            for (int i = 0; i < ERT; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) cd[r] = code_s[i * 32 + mfma32_row(r, lane)];
+                for (int r = 0; r < 16; ++r) cv[i][r] = cb[(size_t)code_s[i * 32 + mfma32_row(r, lane)] * D + col];
+            gemm_rows_x32(bufB, (const float2*)lhead_w, head, wave, lane, acc);
+            head = gemm_head((const float2*)a.lvl[l + 1], a.lvl[l + 1] + D * D, wave, lane);     // the next level's stage
 #pragma unroll
-                for (int r = 0; r < 16; ++r) cv[r] = cb[(size_t)cd[r] * D + col];       // 16 gathers in flight
+            for (int i = 0; i < ERT; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) bufA[(i * 32 + mfma32_row(r, lane)) * LDF + kpos(col)] = acc[i][r] - cv[r];
-            }
+                for (int r = 0; r < 16; ++r) bufA[(i * 32 + mfma32_row(r, lane)) * LDF + kpos(col)] = acc[i][r] - cv[i][r];
             __syncthreads();
         }
     }
