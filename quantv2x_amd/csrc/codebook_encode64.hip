@@ -21,20 +21,27 @@ struct Enc64Args {
     float dx;
 };
 
-// this wave's 32 x 32 tile of in[64][64] . W^T (+ bias): rows [32 rt, +32), columns [32 ctile, +32)
-__device__ __forceinline__ void gemm_tile(const float* __restrict__ src, const float2* __restrict__ wp, const float* __restrict__ bias,
-                                          int rt, int ctile, int lane, v16f& acc) {
+// all 16 k-quads of this lane's weight column (16 float2) + its bias: requested BEFORE the barrier that precedes the GEMM, so the L2 round
+// trip overlaps the previous phase's tile store and the barrier wait
+struct TileW { float2 s[4][4]; float b; };
+__device__ __forceinline__ TileW tile_weights(const float2* __restrict__ wp, const float* __restrict__ bias, int ctile, int lane) {
     const int par = lane >> 5, col = ctile * 32 + (lane & 31);
-    const float b = bias[col];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = b;
+    TileW w;
+    w.b = bias[col];
     const float2* wl = wp + (size_t)col * 2 + par;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w.s[g][t] = wl[(size_t)(g * 4 + t) * D * 2];
+    return w;
+}
+
+// this wave's 32 x 32 tile of in[64][64] . W^T (+ bias): rows [32 rt, +32), columns [32 ctile, +32)
+__device__ __forceinline__ void gemm_tile(const float* __restrict__ src, const TileW& w, int rt, int lane, v16f& acc) {
+    const int par = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = w.b;
     const float* al = src + (rt * 32 + (lane & 31)) * LDF + 2 * par;
-    float2 s[4][4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g)                       // all 16 k-quads of this column: 16 float2 per lane, requested up front
-#pragma unroll
-        for (int t = 0; t < 4; ++t) s[g][t] = wl[(size_t)(g * 4 + t) * D * 2];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         float2 av[4];
@@ -42,8 +49,8 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ src, const f
         for (int t = 0; t < 4; ++t) av[t] = *(const float2*)(al + (g * 4 + t) * 4);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].x, s[g][t].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].y, s[g][t].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].x, w.s[g][t].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].y, w.s[g][t].y, acc, 0, 0, 0);
         }
     }
 }
@@ -102,6 +109,7 @@ __global__ __launch_bounds__(256, 4) void codebook_encode64_kernel(const Enc64Ar
             }
         }
     }
+    TileW tw = tile_weights((const float2*)a.lvl[0], a.lvl[0] + D * D, ctile, lane);          // stage_w / stage_b of level 0
     __syncthreads();
 
     v16f acc;
@@ -117,10 +125,12 @@ __global__ __launch_bounds__(256, 4) void codebook_encode64_kernel(const Enc64Ar
         const float* cb = cbp + (size_t)D * a.kc;             // [kc][64]
         const float* c2 = cb + (size_t)a.kc * D;              // [kc]
 
-        gemm_tile(bufA, (const float2*)stage_w, stage_b, rt, ctile, lane, acc);       // z = stage(x)
+        gemm_tile(bufA, tw, rt, lane, acc);                                          // z = stage(x)
+        tw = tile_weights((const float2*)qhead_w, qhead_b, ctile, lane);
         store_tile(bufB, rt, ctile, lane, acc);
         __syncthreads();
-        gemm_tile(bufB, (const float2*)qhead_w, qhead_b, rt, ctile, lane, acc);       // q = qhead(z)
+        gemm_tile(bufB, tw, rt, lane, acc);                                          // q = qhead(z)
+        if (l + 1 < a.levels) tw = tile_weights((const float2*)lhead_w, lhead_b, ctile, lane);   // used after the argmin
         store_tile(bufA, rt, ctile, lane, acc);
         __syncthreads();
         if (tid < ER) {      // |q|^2: one 64-wide ascending fma chain per row
@@ -191,14 +201,12 @@ __global__ __launch_bounds__(256, 4) void codebook_encode64_kernel(const Enc64Ar
         __syncthreads();
 
         if (l + 1 < a.levels) {      // x <- lhead(z) - C[code]
-            gemm_tile(bufB, (const float2*)lhead_w, lhead_b, rt, ctile, lane, acc);
             const int col = ctile * 32 + (lane & 31);
-            int cd[16];
-            float cv[16];
+            float cv[16];                                                             // the chosen codewords' entries, ahead of the GEMM
 #pragma unroll
-            for (int r = 0; r < 16; ++r) cd[r] = code_s[rt * 32 + mfma32_row(r, lane)];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) cv[r] = cb[(size_t)cd[r] * D + col];
+            for (int r = 0; r < 16; ++r) cv[r] = cb[(size_t)code_s[rt * 32 + mfma32_row(r, lane)] * D + col];
+            gemm_tile(bufB, tw, rt, lane, acc);
+            tw = tile_weights((const float2*)a.lvl[l + 1], a.lvl[l + 1] + D * D, ctile, lane);   // the next level's stage
 #pragma unroll
             for (int r = 0; r < 16; ++r) bufA[(rt * 32 + mfma32_row(r, lane)) * LDF + kpos(col)] = acc[r] - cv[r];
             __syncthreads();
