@@ -200,3 +200,44 @@ def test_adaround_mse_and_output_off_states_export():
 def calibrated_plugin_cached():
     from _common import calibrated_plugin
     return calibrated_plugin()
+
+
+def test_argument_errors_of_the_pyramid_entries_without_gpu():
+    """the f3 entry points reject bad descriptors / pointers on the host, before any launch"""
+    from quantv2x_amd import lib
+    l = _lib()
+    buf = np.zeros(4096, np.uint8)
+    p = lib.ptr(buf)
+    d = lib.Conv1x1Desc()
+    d.n, d.h, d.w, d.cin, d.cout, d.stride, d.mode, d.out_ctotal, d.out_delta = 1, 4, 4, 96, 64, 1, 0, 64, 0.1
+    assert l.qv2x_conv1x1_i8(C.byref(d), p, p, p, p, p, p, None, p, None) == -2 and b"cin 64" in l.qv2x_last_error()
+    d.cin, d.mode = 64, 2
+    assert l.qv2x_conv1x1_i8(C.byref(d), p, p, p, p, p, p, None, p, None) == -1 and b"shortcut" in l.qv2x_last_error()
+    d.mode, d.stride = 0, 3
+    assert l.qv2x_conv1x1_i8(C.byref(d), p, p, p, p, p, p, None, p, None) == -1
+    g = lib.GconvDesc()
+    g.n, g.h, g.w, g.c, g.cg, g.stride, g.out_delta = 1, 4, 4, 128, 6, 1, 0.1
+    assert l.qv2x_gconv3x3_i8(C.byref(g), p, p, p, p, p, p, p, None) == -2 and b"per group" in l.qv2x_last_error()
+    g.cg, g.out_delta = 4, 0.0
+    assert l.qv2x_gconv3x3_i8(C.byref(g), p, p, p, p, p, p, p, None) == -1 and b"out_delta" in l.qv2x_last_error()
+    o = lib.OccDesc()
+    o.n, o.h, o.w, o.c, o.out_delta = 1, 4, 4, 60, 0.1
+    assert l.qv2x_occ_score_i8(C.byref(o), p, p, p, p, None, None) == -1
+    assert l.qv2x_codebook_decode_f32(p, 16, 16, 1, 16, 3, 128, 62, p, p, p, None) == -1            # width % 4
+    assert l.qv2x_codebook_decode_f32(p, 16, 16, 1, 16, 9, 128, 64, p, p, p, None) == -1            # levels
+    e = lib.EncodeDesc()
+    e.n, e.h, e.w, e.levels, e.kc = 1, 4, 4, 3, 100
+    ptrs = (C.c_void_p * 3)()
+    assert l.qv2x_codebook_encode64_f32(C.byref(e), 64, p, ptrs, p, None) == -1 and b"dict_size" in l.qv2x_last_error()
+    e.kc = 128
+    assert l.qv2x_codebook_encode64_f32(C.byref(e), 48, p, ptrs, p, None) == -2                     # fewer than 64 channels
+    assert l.qv2x_add_relu_f32(p, p, p, 6, None) == -2                                              # count % 4
+    assert l.qv2x_codebook64_level_floats(128) == 3 * (64 * 64 + 64) + 2 * 64 * 128 + 128
+    f = lib.FuseDesc()
+    f.agents, f.h, f.w, f.max_cav, f.ego, f.h_metres, f.w_metres, f.discrete_ratio = 2, 4, 4, 5, 0, 1.0, 1.0, 1.0
+    assert l.qv2x_pyramid_weighted_fuse_i8(C.byref(f), 48, p, 0, 0.1, p, p, p, None) == -1 and b"channels" in l.qv2x_last_error()
+    f.fusion = 7
+    assert l.qv2x_fuse_att_f32(C.byref(f), None, None, None, p, p, p, None) == -1 and b"fusion" in l.qv2x_last_error()
+    pp = lib.PostprocessDesc()
+    pp.h, pp.w, pp.anchors_per_cell, pp.num_classes, pp.max_boxes, pp.score_threshold, pp.max_extent, pp.z_min, pp.z_max = 4, 4, 2, 1, 10, 0.2, 6.0, -3.0, 1.0
+    assert l.qv2x_postprocess_late_workspace_bytes(C.byref(pp), 9) == -1 and l.qv2x_postprocess_late_workspace_bytes(C.byref(pp), 2) > 0

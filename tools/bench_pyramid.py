@@ -26,22 +26,8 @@ def main():
     model = train_utils.create_model(copy.deepcopy(hy)).eval()
     synth.load_state_dict_numpy(model, synth.make_state_dict(model.state_dict(), seed=1))
     t0 = time.time()
-    calib = synth.scene_to_torch(synth.make_scene("small", n_agents=2, seed=3, n_points=8000))
-    # calibrate on the small grid (same weights; the quantizer ranges only need to be sane for timing)
-    hy_s = synth.make_pyramid_hypes("small")
-    ms = train_utils.create_model(copy.deepcopy(hy_s)).eval()
-    synth.load_state_dict_numpy(ms, synth.make_state_dict(ms.state_dict(), seed=1))
-    qt = calibrate_minmax(wrap(ms), [calib])
-    st = export_ptq_state(qt)
-    big = export_ptq_state.__globals__  # noqa: F841
-    # geometry of the full grid
-    for k in ("meta/grid", "meta/HW_metres", "meta/offset", "meta/voxel"):
-        pass
-    lidar_range, voxel_size, _, _ = synth.SHAPES[shape]
-    gx, gy, gz = synth.grid_size(lidar_range, voxel_size)
-    st["meta/grid"] = np.array([gx, gy, gz], dtype=np.int64)
-    st["meta/HW_metres"] = np.array([lidar_range[4] - lidar_range[1], lidar_range[3] - lidar_range[0]], dtype=np.float64)
-    st["meta/offset"] = np.array([voxel_size[i] / 2 + lidar_range[i] for i in range(3)], dtype=np.float64)
+    calib = synth.scene_to_torch(synth.make_scene(shape, n_agents=1, seed=3, n_points=60000))
+    st = export_ptq_state(calibrate_minmax(wrap(model), [calib]))          # the reference's min-max recipe: one observer pass, frozen
     print("calibration s", round(time.time() - t0, 1), flush=True)
     eng = deploy(state=st)
     sc = synth.make_scene(shape, n_agents=n_agents, seed=0)
