@@ -1,10 +1,11 @@
 """Deployed W8A8 hot path on MI355X: host side of ``libqv2x.so``.
 
 ``deploy(qt_model)`` takes a calibrated ``QuantModel`` (the reference's ``opencood.quant.QuantModel`` or this
-build's mirror -- only attribute names are read) of the ONE network shape this engine hard-wires -- PointPillar
-encoder, BaseBEVBackbone, shrinker, optional codebook, AttFusion, 1x1 heads, BN folded, ReLU on every conv / deconv;
-``ptq_state.export_ptq_state`` raises ``NotImplementedError`` for anything else (max fusion, post-fusion
-``shrink_header``, ``compressor``, unfolded BN, ``disable_act_quant`` off the heads) -- freezes its PTQ state and
+build's mirror -- only attribute names are read) of the network shape this engine hard-wires -- PointPillar
+encoder, BaseBEVBackbone, shrinker, optional codebook or NaiveCompressor, AttFusion or MaxFusion, 1x1 heads, BN folded, ReLU on every
+conv / deconv (the HEAL Pyramid model has its own engine, ``engine_pyramid.py``);
+``ptq_state.export_ptq_state`` raises ``NotImplementedError`` for anything else (other fusions, a post-fusion
+``shrink_header``, unfolded BN, ``disable_act_quant`` off the heads) -- freezes its PTQ state and
 returns a ``DeployedModel``: an ``nn.Module`` with the reference's model contract
 
     out = model(data_dict)      # data_dict = batch['ego'];  out: cls_preds / reg_preds / dir_preds / preds_tensor
