@@ -342,6 +342,21 @@ typedef struct {
 int qv2x_gconv3x3_i8(const qv2x_gconv_desc* desc /* host */, const int8_t* in, const int8_t* w_frag, const float* scale,
                      const int32_t* corr, const int32_t* aw, const float* bias, int8_t* out, void* stream);
 
+/* One whole QuantBottleneck (quant_block.py:100-131) in one launch, for the blocks with stride 1 and an identity shortcut:
+ *     out = quant_b(relu(conv3(quant_2(relu(gconv3x3(quant_1(relu(conv1(x))))))) + (x - in_zx) * in_delta))
+ * -- the three layers' integer arithmetic exactly as qv2x_conv1x1_i8 / qv2x_gconv3x3_i8 / qv2x_conv1x1_i8 (mode 3) compute it; the
+ * intermediate maps stay in LDS (conv1 is recomputed on the 1-pixel halo of each 2 x 32 output patch).
+ *   x, out: padded i8 BEV [N][H+2][W+2][planes];  w / scale / corr / aw / bias: HOST arrays of three device pointers (conv1, conv2, conv3)
+ *   in the layouts of the separate entry points (w[0]: [width/32][planes/32][64][16], w[1]: [width/32][9][64][16], w[2]: [planes/32][width/32][64][16]). */
+typedef struct {
+    int32_t n, h, w, planes, width, cg;
+    int32_t in_zx;
+    float in_delta;
+    float delta1, zp1, delta2, zp2, out_delta, out_zp;
+} qv2x_bottleneck_desc;
+int qv2x_bottleneck_i8(const qv2x_bottleneck_desc* desc /* host */, const int8_t* x, const int8_t* const* w, const float* const* scale,
+                       const int32_t* const* corr, const int32_t* const* aw, const float* const* bias, int8_t* out, void* stream);
+
 /* qv2x_conv3x3_i8 with a fused residual end (conv2 of QuantBasicBlock, quant_block.py:76-96): one input group, cout = 64;
  *   res_mode 2: res f32 [N*Ho*Wo][cout];  res_mode 3: res = padded i8 BEV [N][Ho+2][Wo+2][cout] with (res_zx, res_delta);
  *   out = quant(max(y + shortcut, 0)) with the BLOCK's quantizer (desc->out_delta / out_zp). */

@@ -221,6 +221,8 @@ class DeployedPyramidModel(nn.Module):
         # run on the caller's (the ego side is ~70 launches on small maps; inside a captured HIP graph this is a fork / join)
         self.overlap_levels = True
         self._side = None
+        self.fuse_blocks = True              # stride-1 bottlenecks with an identity shortcut as ONE launch (csrc/bottleneck_i8.hip)
+        self.fuse_planes = (64, 128)
 
     # ------------------------------------------------------------------------------------------------------------------------------
     def _level_blob(self, l: int) -> torch.Tensor:
@@ -437,9 +439,26 @@ class DeployedPyramidModel(nn.Module):
         return self.encode_codes(n, out)
 
     # ---- what the ego runs on the received codes ------------------------------------------------------------------------------------------
+    def _bottleneck(self, blk: _Block, x, xq, n, h, w, out):
+        """a stride-1 bottleneck with an identity shortcut: conv1 -> grouped 3x3 -> conv3 + x, one launch (qv2x_bottleneck_i8)"""
+        d = L.BottleneckDesc()
+        d.n, d.h, d.w, d.planes, d.width, d.cg = n, h, w, blk.cout, blk.conv2.c, blk.conv2.cg
+        d.in_zx, d.in_delta = int(xq[1]), float(xq[0])
+        d.delta1, d.zp1 = blk.conv1.out_q[0], float(blk.conv1.out_q[1])
+        d.delta2, d.zp2 = blk.conv2.out_q[0], float(blk.conv2.out_q[1])
+        d.out_delta, d.out_zp = blk.out_q[0], float(blk.out_q[1])
+        layers = (blk.conv1, blk.conv2, blk.conv3)
+        arr = lambda name: (C.c_void_p * 3)(*[getattr(l, name).data_ptr() for l in layers])
+        L.check(self.lib.qv2x_bottleneck_i8(C.byref(d), L.ptr(x), arr("w"), arr("scale"), arr("corr"), arr("aw"), arr("bias"), L.ptr(out),
+                                            L.current_stream()), blk.name)
+
     def _block(self, blk: _Block, x, xq, n, h, w, lv, out, feats_f32=None):
         """One bottleneck: ``x`` codes at (h, w) (or the fp32 decoded map), result codes in ``out`` at the level's resolution."""
         ho, wo = lv["h"], lv["w"]
+        # one launch where it pays: 31 vs 45 us (64 planes, 70 400 cells), 29 vs 32 us (128 planes); at 256 planes / 4 400 cells the fused
+        # kernel has 78 workgroups of three serial phases and loses (41 vs 27 us), so that level stays on the per-layer kernels
+        if self.fuse_blocks and blk.stride == 1 and blk.down is None and not blk.f32_input and blk.cout in self.fuse_planes and blk.conv2.c == 2 * blk.cout:
+            return self._bottleneck(blk, x, xq, n, h, w, out)
         t1 = lv["t1_in"] if (h, w) != (ho, wo) else lv["t1"]
         if blk.f32_input:
             self._dense_f32in(blk.conv1, feats_f32, n, h, w, t1)

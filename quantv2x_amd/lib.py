@@ -22,7 +22,7 @@ SYMBOLS = [
     "qv2x_pyramid_weighted_fuse_f32", "qv2x_pyramid_weighted_fuse_i8", "qv2x_conv1x1_i8", "qv2x_gconv3x3_i8", "qv2x_conv3x3_i8_res",
     "qv2x_deconv_f32in", "qv2x_codebook_decode_f32", "qv2x_occ_score_i8",
     "qv2x_codebook64_level_floats", "qv2x_codebook64_c2_f32", "qv2x_codebook_encode64_f32", "qv2x_codebook_encode64_f32in",
-    "qv2x_add_relu_f32", "qv2x_occ_sigmoid_f32", "qv2x_pyramid_weighted_fuse_f32p",
+    "qv2x_add_relu_f32", "qv2x_occ_sigmoid_f32", "qv2x_pyramid_weighted_fuse_f32p", "qv2x_bottleneck_i8",
     "qv2x_comm_unique_id", "qv2x_comm_init", "qv2x_comm_destroy", "qv2x_allgather_codes", "qv2x_pairwise_from_poses_f64",
 ]
 COMM_ID_BYTES = 128
@@ -65,6 +65,12 @@ class Conv1x1Desc(C.Structure):
     _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("stride", C.c_int32),
                 ("mode", C.c_int32), ("relu", C.c_int32), ("out_ctotal", C.c_int32), ("out_c0", C.c_int32),
                 ("out_delta", C.c_float), ("out_zp", C.c_float), ("res_zx", C.c_int32), ("res_delta", C.c_float)]
+
+
+class BottleneckDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("planes", C.c_int32), ("width", C.c_int32), ("cg", C.c_int32),
+                ("in_zx", C.c_int32), ("in_delta", C.c_float), ("delta1", C.c_float), ("zp1", C.c_float), ("delta2", C.c_float), ("zp2", C.c_float),
+                ("out_delta", C.c_float), ("out_zp", C.c_float)]
 
 
 class GconvDesc(C.Structure):
@@ -170,6 +176,7 @@ def load() -> C.CDLL:
     lib.qv2x_add_relu_f32.argtypes = [vp, vp, vp, C.c_int64, vp]
     lib.qv2x_occ_sigmoid_f32.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     lib.qv2x_pyramid_weighted_fuse_f32p.argtypes = [C.POINTER(FuseDesc), C.c_int, vp, vp, vp, vp, vp]
+    lib.qv2x_bottleneck_i8.argtypes = [C.POINTER(BottleneckDesc), vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, vp]
     lib.qv2x_comm_unique_id.argtypes = [vp]
     lib.qv2x_comm_init.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
     lib.qv2x_comm_destroy.argtypes = [vp]

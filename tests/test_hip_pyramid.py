@@ -167,3 +167,27 @@ def test_v2xreal_full_size_two_agents():
     pw = dd["pairwise_t_matrix"].to(torch.float64).contiguous()
     c = eng.decode_features(codes, hw, 2 * hw, [2], pw)["preds_tensor"]
     assert torch.equal(a, c)
+
+
+def test_fused_bottleneck_equals_the_per_layer_kernels(tiny):
+    """qv2x_bottleneck_i8 (conv1 -> grouped 3x3 -> conv3 + shortcut in one launch) at every width, against the three separate launches:
+    identical codes for every block of the frame"""
+    from quantv2x_amd import synth
+    st, orc, eng = tiny
+    dd = synth.scene_to_torch(scene_np(2), "cuda")
+    keep = (eng.fuse_blocks, eng.fuse_planes)
+    try:
+        eng.fuse_blocks, eng.fuse_planes = True, (64, 128, 256)
+        a = {}
+        pa = eng(dd, a)["preds_tensor"].clone()
+        eng.fuse_blocks = False
+        b = {}
+        pb = eng(dd, b)["preds_tensor"]
+        torch.cuda.synchronize()
+        names = [k for k in a if ".resnet.layer" in k and k.startswith("pyramid_backbone")]
+        assert len(names) == 16
+        for k in names:
+            assert torch.equal(a[k], b[k]), k
+        assert torch.equal(pa, pb)
+    finally:
+        eng.fuse_blocks, eng.fuse_planes = keep
