@@ -379,7 +379,7 @@ static int conv3x3_entry(const qv2x_conv_desc* d, const int8_t* in, const int8_t
     if (res_mode) {
         if (multi || a.cout != 64 || a.gc[0] != 64 || !res || ((uintptr_t)res & 15) || (res_mode != 2 && res_mode != 3))
             return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_res: one input group of 64 channels, cout 64, res_mode 2 | 3, aligned shortcut");
-        return res_mode == 2 ? launch_dma<64, 64, 2, 2, 64, false, 4, 4, 2>(a, st) : launch_dma<64, 64, 2, 2, 64, false, 4, 4, 3>(a, st);
+        return res_mode == 2 ? launch_dma<64, 64, 2, 2, 64, false, 3, 6, 2>(a, st) : launch_dma<64, 64, 2, 2, 64, false, 3, 6, 3>(a, st);
     }
 #ifndef QV2X_CONV_FORCE
 #define QV2X_CONV_FORCE 0     // dev builds: 1 never the 128 x 128 variant, 2 also BK = 128 instead of 256, 3 only BK = 128 instead of 256
@@ -397,7 +397,9 @@ static int conv3x3_entry(const qv2x_conv_desc* d, const int8_t* in, const int8_t
     // 21.1 us for a batch of four, profiles/r02_conv_dispatch_ablation.log)
     const long long wgs64 = (long long)((a.M + 63) / 64) * (a.cout / 64);
     if (a.gc[0] % 256 == 0 && (QV2X_CONV_FORCE ? QV2X_CONV_FORCE < 2 : wgs64 <= 256)) return launch_dma<64, 64, 2, 2, 256, false, 3, 1>(a, st);
-    return k128 ? launch_dma<64, 64, 2, 2, 128, false, 4, 2>(a, st) : launch_dma<64, 64, 2, 2, 64, false, 4, 4>(a, st);
+    // three stages rather than four: the extra resident workgroup (3 or 6 per CU) hides more latency than the fourth stage did
+    // (64->64 layer at batch 8: 38.7 -> 32.4 us; 25x88 128-channel layer at batch 4: 20.4 -> 15.7 us)
+    return k128 ? launch_dma<64, 64, 2, 2, 128, false, 3, 3>(a, st) : launch_dma<64, 64, 2, 2, 64, false, 3, 6>(a, st);
 }
 
 extern "C" int qv2x_conv3x3_i8(const qv2x_conv_desc* d, const int8_t* in, const int8_t* w, const float* scale,
