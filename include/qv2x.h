@@ -416,6 +416,50 @@ int qv2x_occ_score_i8(const qv2x_occ_desc* desc /* host */, const int8_t* in, co
 int qv2x_pyramid_weighted_fuse_i8(const qv2x_fuse_desc* desc /* host */, int channels, const int8_t* feats, int in_zx, float in_delta,
                                   const float* score, const double* pairwise, float* out, void* stream);
 
+/* ---- a13: the quantized SECOND encoder (secondary) -----------------------------------------------------
+ * SECOND.forward (opencood/models/heter_encoders.py:66-81) = MeanVFE (sub_modules/mean_vfe.py:13-32) -> VoxelBackBone8x
+ * (sub_modules/sparse_backbone_3d.py:48-153: twelve SubMConv3d / SparseConv3d + BatchNorm1d + ReLU) -> HeightCompression
+ * (sub_modules/height_compression.py:12-27), every convolution under QuantSpconvModule.forward (quant/quant_layer.py:460-490).
+ * The reference evaluates the convolutions with spconv, a pip wheel that is NOT part of the reference tree: these entry points
+ * restate its published semantics (oracle/spec_second.py; parity against spconv itself is unpinned).
+ *
+ * A sparse level on the device: coords i32 [cap][4] = (agent, z, y, x); features i8 [cap + 1][C] of (code - 128), C a multiple of 32,
+ * row `cap` = the fill row (zp - 128: the real value 0); the number of rows is a DEVICE int32 (no host round trip anywhere);
+ * a dense index volume i32 [agents][D][H][W] (-1 = no site).  A convolution is a rulebook nbr i32 [K][cap_out] (input row or the fill
+ * row `cap_in` per output site and window offset, z-major) followed by a gather-GEMM. */
+typedef struct {
+    int32_t subm;                         /* 1: SubMConv3d (outputs = the input's sites), 0: SparseConv3d */
+    int32_t k[3], s[3], p[3];             /* window, stride, padding along (z, y, x) */
+    int32_t in_shape[3], out_shape[3];    /* (D, H, W) */
+    int32_t agents, cin, cout;            /* cin / cout: PADDED channel counts of the i8 rows (the f32-in layer: cin = 4) */
+    int32_t cap_in, cap_out;              /* row capacities (the fill rows sit at index cap) */
+    float out_delta, out_zp;              /* the layer's output quantizer */
+} qv2x_spconv_desc;
+/* MeanVFE: voxel_features f32 [cap][max_points][4] (unused slots zero) -> out f32 [cap][4], summed slot by slot. */
+int qv2x_mean_vfe_f32(const float* voxel_features, const int32_t* voxel_num_points, const int32_t* n_voxels /* device */, int cap,
+                      int max_points, float* out, void* stream);
+/* set != 0: volume[coords[row]] = row for row < *n_rows;  set == 0: back to -1 (how a frame leaves the volume clean). */
+int qv2x_sp_index_scatter(const int32_t* coords, const int32_t* n_rows /* device */, int cap, int agents, int D, int H, int W,
+                          int32_t* volume, int set, void* stream);
+/* SparseConv3d's active outputs: every output position whose window holds an active input.  out_volume must be all -1 on entry and
+ * holds the new rows on return; out_coords / *n_out are written (row order is arbitrary, as spconv's is). */
+int qv2x_sp_out_sites(const qv2x_spconv_desc* desc /* host */, const int32_t* in_coords, const int32_t* n_in, int32_t* out_volume,
+                      int32_t* out_coords, int32_t* n_out, void* stream);
+int qv2x_sp_rulebook(const qv2x_spconv_desc* desc /* host */, const int32_t* out_coords, const int32_t* n_out, const int32_t* in_volume,
+                     int32_t* nbr, void* stream);
+/* conv_input (fp32 means in): w f32 [K][4][16] = (code - zp_w) * delta_w; y = acc * bn_g + bn_h -> ReLU -> quantize; out i8 [cap_out+1][32]. */
+int qv2x_sp_conv_f32in(const qv2x_spconv_desc* desc /* host */, const float* feat, const int32_t* nbr, const int32_t* n_out, const float* w,
+                       const float* bn_g, const float* bn_h, int8_t* out, void* stream);
+/* the eleven integer layers: w_frag i8 [K][cin/32][cout/32][64][16] (lane l: output channel l % 32 of the tile, input bytes
+ * 16 * (l / 32) .. + 15 of the 32-channel step; values code - 128), scale = delta_w * delta_x, aw = 128 - zp_w,
+ * corr = (128 - zp_x) * sum ws + K * cin * (128 - zp_x) * aw;  y = (T * scale) * bn_g + bn_h -> ReLU -> quantize. */
+int qv2x_sp_conv_i8(const qv2x_spconv_desc* desc /* host */, const int8_t* in, const int32_t* nbr, const int32_t* n_out, const int8_t* w_frag,
+                    const float* scale, const int32_t* corr, const int32_t* aw, const float* bn_g, const float* bn_h, int8_t* out, void* stream);
+/* HeightCompression into the padded i8 BEV layout of the 2-D path: bev i8 [agents][H+2][W+2][c*D], channel = ch * D + z, every cell
+ * without a site (and the border) = fill. */
+int qv2x_sp_to_bev_i8(const int8_t* feat, const int32_t* coords, const int32_t* n_rows /* device */, int cap, int c, int c_padded, int agents,
+                      int D, int H, int W, int fill, int8_t* bev, void* stream);
+
 /* ---- the V2X link: one agent per GPU --------------------------------------------------------------------
  * The reference simulates the link in-process: all agents are rows of one batch (heter_model_baseline.py:216) and
  * fusion_in_one.py:131-151 regroups them; get_pairwise_transformation (utils/transformation_utils.py:21-66) builds the

@@ -24,6 +24,7 @@ SYMBOLS = [
     "qv2x_codebook64_level_floats", "qv2x_codebook64_c2_f32", "qv2x_codebook_encode64_f32", "qv2x_codebook_encode64_f32in",
     "qv2x_add_relu_f32", "qv2x_occ_sigmoid_f32", "qv2x_pyramid_weighted_fuse_f32p", "qv2x_bottleneck_i8",
     "qv2x_comm_unique_id", "qv2x_comm_init", "qv2x_comm_destroy", "qv2x_allgather_codes", "qv2x_pairwise_from_poses_f64",
+    "qv2x_mean_vfe_f32", "qv2x_sp_index_scatter", "qv2x_sp_out_sites", "qv2x_sp_rulebook", "qv2x_sp_conv_f32in", "qv2x_sp_conv_i8", "qv2x_sp_to_bev_i8",
 ]
 COMM_ID_BYTES = 128
 
@@ -76,6 +77,12 @@ class BottleneckDesc(C.Structure):
 class GconvDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32), ("cg", C.c_int32), ("stride", C.c_int32),
                 ("relu", C.c_int32), ("out_delta", C.c_float), ("out_zp", C.c_float)]
+
+
+class SpconvDesc(C.Structure):
+    _fields_ = [("subm", C.c_int32), ("k", C.c_int32 * 3), ("s", C.c_int32 * 3), ("p", C.c_int32 * 3),
+                ("in_shape", C.c_int32 * 3), ("out_shape", C.c_int32 * 3), ("agents", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32),
+                ("cap_in", C.c_int32), ("cap_out", C.c_int32), ("out_delta", C.c_float), ("out_zp", C.c_float)]
 
 
 class OccDesc(C.Structure):
@@ -144,6 +151,13 @@ def load() -> C.CDLL:
     lib.qv2x_heads_pair_f32.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp,
                                         vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.qv2x_dequant_i8_f32.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]
+    lib.qv2x_mean_vfe_f32.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp]
+    lib.qv2x_sp_index_scatter.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]
+    lib.qv2x_sp_out_sites.argtypes = [C.POINTER(SpconvDesc), vp, vp, vp, vp, vp, vp]
+    lib.qv2x_sp_rulebook.argtypes = [C.POINTER(SpconvDesc), vp, vp, vp, vp, vp]
+    lib.qv2x_sp_conv_f32in.argtypes = [C.POINTER(SpconvDesc), vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.qv2x_sp_conv_i8.argtypes = [C.POINTER(SpconvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.qv2x_sp_to_bev_i8.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.qv2x_voxelize_workspace_bytes.argtypes = [C.c_int]
     lib.qv2x_voxelize_workspace_bytes.restype = C.c_int64
     lib.qv2x_voxelize_f32.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int,

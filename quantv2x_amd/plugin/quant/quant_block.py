@@ -11,14 +11,16 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..models.fuse_modules.pyramid_fuse import PyramidFusion, weighted_fuse
-from ..models.heter_encoders import PointPillar
+from ..models.heter_encoders import SECOND, PointPillar
 from ..models.sub_modules.base_bev_backbone import BaseBEVBackbone
 from ..models.sub_modules.base_bev_backbone_resnet import ResNetBEVBackbone
 from ..models.sub_modules.resblock import BasicBlock, Bottleneck, ResNetModified
 from ..models.sub_modules.downsample_conv import DoubleConv, DownsampleConv
 from ..models.sub_modules.naive_compress import NaiveCompressor
 from ..models.sub_modules.pillar_vfe import PFNLayer, PillarVFE
-from .quant_layer import QuantModule, StraightThrough, UniformAffineQuantizer
+from ..models.sub_modules.sparse_backbone_3d import VoxelBackBone8x
+from ..models.sub_modules.sparse_ops import SparseConv3d, SparseConvTensor, SparseSequential, SubMConv3d
+from .quant_layer import QuantModule, QuantSpconvModule, StraightThrough, UniformAffineQuantizer
 
 
 class BaseQuantBlock(nn.Module):
@@ -178,6 +180,67 @@ class QuantPointPillar(nn.Module):
         return self.scatter(self.pillar_vfe(batch))['spatial_features']
 
 
+class QuantVoxelBackBone8x(BaseQuantBlock):
+    """``VoxelBackBone8x`` with every sparse convolution wrapped (reference ``quant_block.py:988-1034``): a BatchNorm1d / ReLU that
+    follows a convolution inside a ``SparseSequential`` becomes that wrapper's norm / activation."""
+
+    def __init__(self, voxel_backbone: VoxelBackBone8x, weight_quant_params={}, act_quant_params={}):
+        super().__init__()
+        self.model_cfg = voxel_backbone.model_cfg
+        self.sparse_shape = voxel_backbone.sparse_shape
+        self.num_point_features = voxel_backbone.num_point_features
+        self.backbone_channels = voxel_backbone.backbone_channels
+
+        def wrap(seq):
+            out = SparseSequential()
+            last = None
+            for i, layer in enumerate(seq):
+                if isinstance(layer, (SubMConv3d, SparseConv3d)):
+                    last = QuantSpconvModule(layer, weight_quant_params, act_quant_params)
+                    out.add_module(f"quant_conv_{i}", last)
+                elif isinstance(layer, nn.BatchNorm1d) and last is not None:
+                    last.norm_function = layer
+                elif isinstance(layer, nn.ReLU) and last is not None:
+                    last.activation_function = layer
+                elif isinstance(layer, nn.Sequential):
+                    out.add_module(f"layer_{i}", wrap(layer))
+            return out
+
+        for stage in ("conv_input", "conv1", "conv2", "conv3", "conv4", "conv_out"):
+            setattr(self, stage, wrap(getattr(voxel_backbone, stage)))
+
+    def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
+        self.use_weight_quant, self.use_act_quant = weight_quant, act_quant
+        for m in self.modules():
+            if isinstance(m, QuantSpconvModule):
+                m.set_quant_state(weight_quant, act_quant)
+
+    def forward(self, x):
+        for stage in ("conv_input", "conv1", "conv2", "conv3", "conv4", "conv_out"):
+            x = getattr(self, stage)(x)
+        return x
+
+
+class QuantSECOND(nn.Module):
+    """reference ``quant_block.py:1037-1078``: the mean VFE and the height compression stay as they are."""
+
+    def __init__(self, second: SECOND, weight_quant_params={}, act_quant_params={}):
+        super().__init__()
+        self.vfe = second.vfe
+        self.map_to_bev = second.map_to_bev
+        self.spconv_block = QuantVoxelBackBone8x(second.spconv_block, weight_quant_params, act_quant_params)
+
+    def forward(self, data_dict, modality_name):
+        src = data_dict[f'inputs_{modality_name}']
+        batch = {k: src[k] for k in ('voxel_features', 'voxel_coords', 'voxel_num_points')}
+        batch['batch_size'] = int(batch['voxel_coords'][:, 0].max().item()) + 1
+        batch = self.vfe(batch)
+        x = SparseConvTensor(features=batch['voxel_features'], indices=batch['voxel_coords'].int(),
+                             spatial_shape=self.spconv_block.sparse_shape, batch_size=batch['batch_size'])
+        batch['encoded_spconv_tensor'] = self.spconv_block(x)
+        return self.map_to_bev(batch)['spatial_features']
+
+
 class QuantNaiveCompressor(BaseQuantBlock):
     def __init__(self, naive_compressor: NaiveCompressor, weight_quant_params={}, act_quant_params={}):
         super().__init__()
@@ -325,6 +388,7 @@ opencood_specials = {
     BaseBEVBackbone: QuantBaseBEVBackbone,
     DownsampleConv: QuantDownsampleConv,
     PointPillar: QuantPointPillar,
+    SECOND: QuantSECOND,
     NaiveCompressor: QuantNaiveCompressor,
 }
 

@@ -275,3 +275,46 @@ class QuantModule(nn.Module):
     def extra_repr(self):
         return 'wbit={}, abit={}, disable_act_quant={}'.format(
             self.weight_quantizer.n_bits, self.act_quantizer.n_bits, self.disable_act_quant)
+
+
+class QuantSpconvModule(nn.Module):
+    """A sparse convolution evaluated on fake-quantized weights, then its BatchNorm1d / ReLU on the feature rows, then the output
+    activation quantizer (reference ``quant_layer.py:423-497``).  BatchNorm is NOT folded here: ``fold_bn`` only absorbs into
+    ``Conv2d`` / ``Linear``, so the deployed path keeps the per-channel affine after the integer accumulation."""
+
+    def __init__(self, org_module, weight_quant_params={}, act_quant_params={}, disable_act_quant=False):
+        super().__init__()
+        from ..models.sub_modules.sparse_ops import SparseConv3d, SubMConv3d
+        assert isinstance(org_module, (SubMConv3d, SparseConv3d)), "QuantSpconvModule wraps SubMConv3d / SparseConv3d"
+        self.spconv_module = org_module
+        self.weight = org_module.weight
+        self.org_weight = org_module.weight.data.clone()
+        self.bias = org_module.bias
+        self.org_bias = None if org_module.bias is None else org_module.bias.data.clone()
+        self.use_weight_quant = False
+        self.use_act_quant = False
+        self.disable_act_quant = disable_act_quant
+        self.ignore_reconstruction = False
+        self.trained = False
+        self.weight_quantizer = UniformAffineQuantizer(**weight_quant_params)
+        self.act_quantizer = UniformAffineQuantizer(**act_quant_params)
+        self.norm_function = StraightThrough()
+        self.activation_function = StraightThrough()
+        self.is_sparse_conv = True
+
+    def forward(self, input):
+        weight = self.weight_quantizer(self.weight) if self.use_weight_quant else self.org_weight
+        bias = self.org_bias
+        dev = input.features.device
+        out = self.spconv_module(input, weight=weight.to(dev), bias=None if bias is None else bias.to(dev))
+        out = out.replace_feature(self.activation_function(self.norm_function(out.features)))
+        if self.use_act_quant and not self.disable_act_quant:
+            out = out.replace_feature(self.act_quantizer(out.features))
+        return out
+
+    def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
+        self.use_weight_quant = weight_quant
+        self.use_act_quant = act_quant
+
+    def extra_repr(self):
+        return f"wbit={self.weight_quantizer.n_bits}, abit={self.act_quantizer.n_bits}, disable_act_quant={self.disable_act_quant}"

@@ -1,13 +1,14 @@
 """Activation-quantizer initialisation; mirror of ``opencood/quant/set_act_quantize_params.py:7-32``.
 
 The reference moves each cached input with ``.cuda()``; here the input follows the module's device, so the
-routine also runs on the CPU container (on a ROCm box ``cuda`` is the HIP device either way)."""
+routine also runs on the CPU container; sparse wrappers are included as in ``second_recon.py:33-50``; the
+routine also runs without a GPU (on a ROCm box ``cuda`` is the HIP device either way)."""
 from typing import Union
 
 import torch
 
 from .quant_block import BaseQuantBlock
-from .quant_layer import QuantModule
+from .quant_layer import QuantModule, QuantSpconvModule
 from .quant_model import QuantModel
 
 
@@ -30,7 +31,7 @@ def set_act_quantize_params(module: Union[QuantModel, QuantModule, BaseQuantBloc
     """``extras``: per cached input, the block's further positional inputs (``pyramid_recon.set_act_quantize_params :104-121``)."""
     module.set_quant_state(True, True)
     holders = [t for t in module.modules()
-               if isinstance(t, (QuantModule, BaseQuantBlock)) and hasattr(t, 'act_quantizer')]
+               if isinstance(t, (QuantSpconvModule, QuantModule, BaseQuantBlock)) and hasattr(t, 'act_quantizer')]
     for t in holders:
         t.act_quantizer.set_inited(False)
     dev = _module_device(module)

@@ -190,3 +190,52 @@ def save_ptq_state(path: str, state: Dict[str, np.ndarray]) -> None:
 def load_ptq_state(path: str) -> Dict[str, np.ndarray]:
     with np.load(path, allow_pickle=False) as z:
         return {k: z[k] for k in z.files}
+
+
+def second_layers(enc):
+    """The sparse convolutions of a ``QuantSECOND`` in execution order: (name, wrapper)."""
+    block = enc.spconv_block
+    out = []
+    for stage in ("conv_input", "conv1", "conv2", "conv3", "conv4", "conv_out"):
+        for name, m in getattr(block, stage).named_modules():
+            if type(m).__name__ == "QuantSpconvModule":
+                out.append((f"spconv_block.{stage}.{name}", m))
+    return out
+
+
+def export_second_state(enc) -> Dict[str, np.ndarray]:
+    """Frozen W8A8 state of a calibrated ``QuantSECOND`` (reference ``quant_block.py:1037-1078``).
+
+    Per sparse convolution ``second/<i>/``: ``w_code`` u8 ``[K, C_in, C_out]`` (K = kz*ky*kx window offsets, z-major), ``w_delta`` /
+    ``w_zp`` f32 ``[C_out]`` (the weight is ``[C_out, kz, ky, kx, C_in]``: dim 0 = C_out), ``bn_g`` / ``bn_h`` f32 ``[C_out]`` -- the
+    BatchNorm1d that follows the accumulation, NOT folded (fold_bn.py only absorbs into Conv2d / Linear), as ``y = conv * g + h`` --
+    ``a_delta`` / ``a_zp`` of the output quantizer, and ``geom`` i64 ``[10] = (subm, kz, ky, kx, sz, sy, sx, pz, py, px)``."""
+    out: Dict[str, np.ndarray] = {}
+    layers = second_layers(enc)
+    for i, (name, m) in enumerate(layers):
+        wq, aq, conv = m.weight_quantizer, m.act_quantizer, m.spconv_module
+        if wq.n_bits != 8 or aq.n_bits != 8 or m.disable_act_quant:
+            raise ValueError(f"{name}: the deployed path is W8A8 with every output quantized")
+        if not (getattr(wq, "inited", True) and aq.inited):
+            raise ValueError(f"{name}: quantizers must be frozen before export")
+        if type(m.activation_function).__name__ != "ReLU" or type(m.norm_function).__name__ != "BatchNorm1d" or m.bias is not None:
+            raise NotImplementedError(f"{name}: deployed sparse layers are conv (no bias) + BatchNorm1d + ReLU")
+        code = weight_codes(m)                                              # [Cout, kz, ky, kx, Cin]
+        co, kz, ky, kx, ci = code.shape
+        p = f"second/{i}/"
+        out[p + "w_code"] = np.ascontiguousarray(code.reshape(co, kz * ky * kx, ci).transpose(1, 2, 0))
+        out[p + "w_delta"] = _np(torch.as_tensor(wq.delta)).reshape(-1).astype(np.float32)
+        out[p + "w_zp"] = _np(torch.as_tensor(wq.zero_point)).reshape(-1).astype(np.float32)
+        if out[p + "w_delta"].size != co:
+            raise NotImplementedError(f"{name}: channel-wise weight quantizer expected")
+        bn = m.norm_function
+        g = (_np(bn.weight).astype(np.float64) / np.sqrt(_np(bn.running_var).astype(np.float64) + bn.eps))
+        out[p + "bn_g"] = g.astype(np.float32)
+        out[p + "bn_h"] = (_np(bn.bias).astype(np.float64) - _np(bn.running_mean).astype(np.float64) * g).astype(np.float32)
+        out[p + "a_delta"] = np.float32(_np(torch.as_tensor(aq.delta)).reshape(-1)[0])
+        out[p + "a_zp"] = np.float32(_np(torch.as_tensor(aq.zero_point)).reshape(-1)[0])
+        out[p + "geom"] = np.array([int(conv.subm), *conv.kernel_size, *conv.stride, *conv.padding], dtype=np.int64)
+    out["second/n_layers"] = np.int64(len(layers))
+    out["second/sparse_shape"] = np.asarray(enc.spconv_block.sparse_shape, dtype=np.int64)      # (D, H, W) of the input volume
+    out["second/names"] = np.array([n for n, _ in layers])
+    return out

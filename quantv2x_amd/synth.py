@@ -39,6 +39,41 @@ SHAPES = {
 }
 
 
+# SECOND encoder: 0.1 m voxels, 40 height slices, <= 5 points per voxel (the HEAL / OPV2V SECOND yaml)
+SECOND_SHAPES = {
+    # name: (lidar_range, voxel_size, max_voxels)
+    "second_tiny": ([-6.4, -3.2, -3.0, 6.4, 3.2, 1.0], [0.1, 0.1, 0.1], 4096),          # 128 x 64 x 40 -> 16 x 8 BEV map
+    "second_small": ([-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], [0.1, 0.1, 0.1], 16384),    # 512 x 256 x 40 -> 64 x 32
+    "second_full": ([-140.8, -40.0, -3.0, 140.8, 40.0, 1.0], [0.1, 0.1, 0.1], 70000),   # 2816 x 800 x 40 -> 352 x 100
+}
+
+
+def make_second_args(shape: str = "second_tiny", num_features_out: int = 128) -> dict:
+    """``encoder_args`` of a ``core_method: second`` modality (reference ``heter_encoders.py:52-64``)."""
+    lidar_range, voxel_size, _ = SECOND_SHAPES[shape]
+    return {"voxel_size": list(voxel_size), "lidar_range": list(lidar_range),
+            "mean_vfe": {"num_point_features": 4},
+            "spconv": {"num_features_in": 4, "num_features_out": int(num_features_out)},
+            "map2bev": {"feature_num": 2 * int(num_features_out)}}
+
+
+def make_second_scene(shape: str = "second_tiny", n_agents: int = 1, seed: int = 0, n_points: int = 4000) -> dict:
+    """``inputs_m1`` of a SECOND modality: <= 5 points per 0.1 m voxel, ``voxel_coords`` = (agent, z, y, x)."""
+    lidar_range, voxel_size, max_voxels = SECOND_SHAPES[shape]
+    feats, coords, nump = [], [], []
+    sigma = 0.25 * (lidar_range[3] - lidar_range[0])
+    for a in range(n_agents):
+        pts = make_points(lidar_range, n_points, seed * 131 + a, sigma_m=sigma)
+        # a ground sheet and a few walls: neighbouring voxels must be occupied or every window holds a single site
+        g = np.random.Generator(np.random.PCG64([seed, a, 7]))
+        pts[: len(pts) // 2, 2] = lidar_range[2] + 0.35 + 0.15 * g.random(len(pts) // 2).astype(np.float32)
+        f, c, n = voxelize(pts, lidar_range, voxel_size, max_points=5, max_voxels=max_voxels)
+        feats.append(f)
+        coords.append(np.concatenate([np.full((len(c), 1), a, np.int32), c], axis=1))
+        nump.append(n)
+    return {"voxel_features": np.concatenate(feats), "voxel_coords": np.concatenate(coords), "voxel_num_points": np.concatenate(nump)}
+
+
 def grid_size(lidar_range: Sequence[float], voxel_size: Sequence[float]) -> Tuple[int, int, int]:
     r = np.asarray(lidar_range, dtype=np.float64)
     g = np.round((r[3:6] - r[0:3]) / np.asarray(voxel_size, dtype=np.float64)).astype(np.int64)
@@ -189,6 +224,8 @@ def make_state_dict(template: Dict[str, "object"], seed: int = 0) -> Dict[str, n
         elif leaf == "weight":
             if ".deblocks." in key and len(shape) == 4:  # ConvTranspose2d [Cin, Cout, k, k]: one tap per output
                 fan_in = shape[0]
+            elif len(shape) == 5:                        # sparse 3-D convolution [Cout, kz, ky, kx, Cin]; about a third of a window is occupied
+                fan_in = shape[1] * shape[2] * shape[3] * shape[4] // 3
             elif len(shape) == 4:
                 fan_in = shape[1] * shape[2] * shape[3]
             else:
