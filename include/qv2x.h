@@ -442,9 +442,11 @@ int qv2x_mean_vfe_f32(const float* voxel_features, const int32_t* voxel_num_poin
 int qv2x_sp_index_scatter(const int32_t* coords, const int32_t* n_rows /* device */, int cap, int agents, int D, int H, int W,
                           int32_t* volume, int set, void* stream);
 /* SparseConv3d's active outputs: every output position whose window holds an active input.  out_volume must be all -1 on entry and
- * holds the new rows on return; out_coords / *n_out are written (row order is arbitrary, as spconv's is). */
+ * holds the new rows on return; out_coords / *n_out are written, rows in raster order of (agent, z, y, x) (spconv's own order is hash
+ * order; nothing downstream depends on it).  workspace: qv2x_sp_out_sites_workspace_bytes(desc) bytes of device memory. */
+int64_t qv2x_sp_out_sites_workspace_bytes(const qv2x_spconv_desc* desc /* host */);
 int qv2x_sp_out_sites(const qv2x_spconv_desc* desc /* host */, const int32_t* in_coords, const int32_t* n_in, int32_t* out_volume,
-                      int32_t* out_coords, int32_t* n_out, void* stream);
+                      int32_t* out_coords, int32_t* n_out, void* workspace, int64_t workspace_bytes, void* stream);
 int qv2x_sp_rulebook(const qv2x_spconv_desc* desc /* host */, const int32_t* out_coords, const int32_t* n_out, const int32_t* in_volume,
                      int32_t* nbr, void* stream);
 /* conv_input (fp32 means in): w f32 [K][4][16] = (code - zp_w) * delta_w; y = acc * bn_g + bn_h -> ReLU -> quantize; out i8 [cap_out+1][32]. */

@@ -234,8 +234,16 @@ class Oracle:
     def forward(self, scene, taps=None):
         n_agents = len(scene["agent_modality_list"])
         taps = {} if taps is None else taps
-        pcodes, canvas, cq = self.pfn_scatter(scene, n_agents)
-        taps["pillar_code"], taps["canvas"] = pcodes, canvas
+        if "meta/encoder" in self.s and str(self.s["meta/encoder"]) == "second":      # a13 (oracle/spec_second.py) in front of the same 2-D path
+            from .spec_second import OracleSecond
+            sec = OracleSecond(self.s)
+            last = f"second/{sec.n_layers - 1}/"
+            canvas = np.ascontiguousarray(sec.forward(scene["inputs_m1"], batch_size=n_agents).transpose(0, 2, 3, 1))
+            cq = (np.float32(self.s[last + "a_delta"]), int(self.s[last + "a_zp"]))
+            taps["canvas"] = canvas
+        else:
+            pcodes, canvas, cq = self.pfn_scatter(scene, n_agents)
+            taps["pillar_code"], taps["canvas"] = pcodes, canvas
         cat, cat_q = self.backbone(canvas, cq, taps)
         shr, shr_q = self.shrinker(cat, cat_q, taps)
         taps["shrinker_q"] = shr_q

@@ -10,6 +10,7 @@
 //   * per level one dense i32 volume [agents][D][H][W] maps a coordinate to its row (-1: no site).  At 0.1 m over 281.6 x 80 x 4 m
 //     that is 369 MB per agent at level 1 -- 0.13 % of the HBM, against a hash probe per neighbour lookup.  It is cleared by
 //     un-scattering the rows that were set, not by a memset.
+//   * the rows of every level a SparseConv3d opens are in raster order of (agent, z, y, x) (mark -> scan -> assign over the volume).
 //   * a convolution = rulebook + gather-GEMM.  The rulebook nbr i32 [K][cap_out] holds, per output site and window offset, the input
 //     row or the fill row; sub-manifold layers that share an `indice_key` share it.  Absent neighbours read the fill row, so the
 //     GEMM is the dense gemmlowp identity of the 2-D convolutions (T = sum xs*ws + aw*sum xs + corr) with no per-site bookkeeping.
@@ -44,10 +45,11 @@ __global__ void mean_vfe_kernel(const float* __restrict__ vox, const int32_t* __
 // value >= 0: volume[coord(row)] = row;  value < 0: volume[coord(row)] = -1 (undo)
 __global__ void index_scatter_kernel(const int32_t* __restrict__ coords, const int32_t* __restrict__ n_rows, int cap, int D, int H, int W,
                                      int32_t* __restrict__ vol, int set) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= min(*n_rows, cap)) return;
-    const v4i c = *(const v4i*)(coords + (size_t)m * 4);
-    vol[lin4(c[0], c[1], c[2], c[3], D, H, W)] = set ? m : -1;
+    const int n = min(*n_rows, cap);
+    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < n; m += gridDim.x * blockDim.x) {
+        const v4i c = *(const v4i*)(coords + (size_t)m * 4);
+        vol[lin4(c[0], c[1], c[2], c[3], D, H, W)] = set ? m : -1;
+    }
 }
 
 struct Geom {
@@ -55,47 +57,130 @@ struct Geom {
     int iD, iH, iW, oD, oH, oW;
 };
 
-// Active outputs of a strided sparse convolution: every (input site, window offset) pair names at most one output position; the
-// first pair to claim it (atomicCAS on the output volume) takes the next row.  Row ORDER is therefore arbitrary (so is spconv's);
-// every row's VALUE is computed by gathering, so the dense result does not depend on it.
-__global__ void out_sites_kernel(const int32_t* __restrict__ in_coords, const int32_t* __restrict__ n_in, int cap_in, const Geom g,
-                                 int32_t* __restrict__ out_vol, int32_t* __restrict__ out_coords, int32_t* __restrict__ n_out, int cap_out) {
+// Active outputs of a strided sparse convolution, in RASTER order of (agent, z, y, x):
+//   mark    every (input site, window offset) pair names at most one output position: its cell of the output volume is set to -2
+//           (a plain idempotent store, no atomics);
+//   count   marked cells per 1024-cell block of the volume;  scan: one workgroup turns the counts into block offsets and the total;
+//   assign  every marked cell takes row = block offset + its rank inside the block, and writes its coordinates there.
+// Raster rows are what makes the gather-GEMM cache-friendly (the 32 sites of a tile are neighbours along x and share most of their
+// window), and they are deterministic -- the same order the CPU checker produces.
+constexpr int SCAN_CELLS = 1024;                                   // cells per block of the count / assign passes (256 threads x 4)
+
+__global__ void mark_sites_kernel(const int32_t* __restrict__ in_coords, const int32_t* __restrict__ n_in, int cap_in, const Geom g,
+                                  int32_t* __restrict__ out_vol) {
     const int K = g.k[0] * g.k[1] * g.k[2];
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int m = (int)(t / K), kk = (int)(t - (long long)m * K);
-    if (m >= min(*n_in, cap_in)) return;
-    const v4i c = *(const v4i*)(in_coords + (size_t)m * 4);
-    const int kz = kk / (g.k[1] * g.k[2]), ky = (kk / g.k[2]) % g.k[1], kx = kk % g.k[2];
-    const int nz = c[1] + g.p[0] - kz, ny = c[2] + g.p[1] - ky, nx = c[3] + g.p[2] - kx;
-    if (nz < 0 || ny < 0 || nx < 0 || nz % g.s[0] || ny % g.s[1] || nx % g.s[2]) return;
-    const int oz = nz / g.s[0], oy = ny / g.s[1], ox = nx / g.s[2];
-    if (oz >= g.oD || oy >= g.oH || ox >= g.oW) return;
-    int32_t* cell = out_vol + lin4(c[0], oz, oy, ox, g.oD, g.oH, g.oW);
-    if (atomicCAS(cell, -1, -2) != -1) return;
-    const int row = atomicAdd(n_out, 1);
-    if (row >= cap_out) { *cell = -1; return; }           // over capacity: dropped (the engine sizes cap_out so that it cannot happen)
-    *cell = row;
-    v4i o = {c[0], oz, oy, ox};
-    *(v4i*)(out_coords + (size_t)row * 4) = o;
+    const long long total = (long long)min(*n_in, cap_in) * K;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(t / K), kk = (int)(t - (long long)m * K);
+        const v4i c = *(const v4i*)(in_coords + (size_t)m * 4);
+        const int kz = kk / (g.k[1] * g.k[2]), ky = (kk / g.k[2]) % g.k[1], kx = kk % g.k[2];
+        const int nz = c[1] + g.p[0] - kz, ny = c[2] + g.p[1] - ky, nx = c[3] + g.p[2] - kx;
+        if (nz < 0 || ny < 0 || nx < 0 || nz % g.s[0] || ny % g.s[1] || nx % g.s[2]) continue;
+        const int oz = nz / g.s[0], oy = ny / g.s[1], ox = nx / g.s[2];
+        if (oz >= g.oD || oy >= g.oH || ox >= g.oW) continue;
+        out_vol[lin4(c[0], oz, oy, ox, g.oD, g.oH, g.oW)] = -2;
+    }
 }
 
-__global__ void clamp_count_kernel(int32_t* n, int cap) { if (*n > cap) *n = cap; }
+__device__ __forceinline__ int block_sum_256(int v, int* sh) {       // sum over the 256 threads of a block; sh: 4 ints
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const int r = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void count_marks_kernel(const int32_t* __restrict__ vol, long long cells, int32_t* __restrict__ counts) {
+    __shared__ int sh[4];
+    const long long base = (long long)blockIdx.x * SCAN_CELLS + threadIdx.x * 4;
+    int c = 0;
+    if (base + 3 < cells) {
+        const v4i v = *(const v4i*)(vol + base);
+        c = (v[0] == -2) + (v[1] == -2) + (v[2] == -2) + (v[3] == -2);
+    } else {
+        for (int e = 0; e < 4; ++e) c += (base + e < cells) && vol[base + e] == -2;
+    }
+    const int tot = block_sum_256(c, sh);
+    if (threadIdx.x == 0) counts[blockIdx.x] = tot;
+}
+
+// one workgroup: counts[nb] -> exclusive offsets in place, total -> *n_out (clamped to cap_out)
+__global__ __launch_bounds__(1024) void scan_counts_kernel(int32_t* __restrict__ counts, int nb, int32_t* __restrict__ n_out, int cap_out) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < nb; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < nb ? counts[i] : 0;
+        int inc = v;                                                // inclusive scan inside the wave
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int before = carry_s;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (i < nb) counts[i] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = before + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_out = min(carry_s, cap_out);
+}
+
+__global__ __launch_bounds__(256) void assign_rows_kernel(int32_t* __restrict__ vol, long long cells, const int32_t* __restrict__ offsets,
+                                                          int oD, int oH, int oW, int32_t* __restrict__ out_coords, int cap_out) {
+    __shared__ int wsum[4];
+    const long long base = (long long)blockIdx.x * SCAN_CELLS + threadIdx.x * 4;
+    int mk[4], c = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { mk[e] = (base + e < cells) && vol[base + e] == -2; c += mk[e]; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = c;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int row = offsets[blockIdx.x] + inc - c;
+    for (int w = 0; w < wave; ++w) row += wsum[w];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (!mk[e]) continue;
+        const long long cell = base + e;
+        if (row < cap_out) {                                        // over capacity: dropped (the engine sizes cap_out so that it cannot happen)
+            vol[cell] = row;
+            const int x = (int)(cell % oW), y = (int)((cell / oW) % oH), z = (int)((cell / ((long long)oW * oH)) % oD);
+            const int b = (int)(cell / ((long long)oW * oH * oD));
+            v4i o = {b, z, y, x};
+            *(v4i*)(out_coords + (size_t)row * 4) = o;
+        } else {
+            vol[cell] = -1;
+        }
+        ++row;
+    }
+}
 
 __global__ void rulebook_kernel(const int32_t* __restrict__ out_coords, const int32_t* __restrict__ n_out, int cap_out, const Geom g,
                                 const int32_t* __restrict__ in_vol, int fill_row, int32_t* __restrict__ nbr) {
-    const int K = g.k[0] * g.k[1] * g.k[2];
-    const int m = blockIdx.x * blockDim.x + threadIdx.x, kk = blockIdx.y;
-    if (m >= min(*n_out, cap_out)) return;
-    const v4i c = *(const v4i*)(out_coords + (size_t)m * 4);
+    const int kk = blockIdx.y;
     const int kz = kk / (g.k[1] * g.k[2]), ky = (kk / g.k[2]) % g.k[1], kx = kk % g.k[2];
-    const int z = c[1] * g.s[0] - g.p[0] + kz, y = c[2] * g.s[1] - g.p[1] + ky, x = c[3] * g.s[2] - g.p[2] + kx;
-    int row = fill_row;
-    if (z >= 0 && z < g.iD && y >= 0 && y < g.iH && x >= 0 && x < g.iW) {
-        const int r = in_vol[lin4(c[0], z, y, x, g.iD, g.iH, g.iW)];
-        if (r >= 0) row = r;
+    const int n = min(*n_out, cap_out);
+    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < n; m += gridDim.x * blockDim.x) {
+        const v4i c = *(const v4i*)(out_coords + (size_t)m * 4);
+        const int z = c[1] * g.s[0] - g.p[0] + kz, y = c[2] * g.s[1] - g.p[1] + ky, x = c[3] * g.s[2] - g.p[2] + kx;
+        int row = fill_row;
+        if (z >= 0 && z < g.iD && y >= 0 && y < g.iH && x >= 0 && x < g.iW) {
+            const int r = in_vol[lin4(c[0], z, y, x, g.iD, g.iH, g.iW)];
+            if (r >= 0) row = r;
+        }
+        nbr[(size_t)kk * cap_out + m] = row;
     }
-    nbr[(size_t)kk * cap_out + m] = row;
-    (void)K;
 }
 
 // Layer 0: fp32 voxel means (4 channels) in, 16 channels out.  One lane per site; acc = acc + x * w in window / channel order over the
@@ -268,10 +353,12 @@ static int launch_sp(const SpArgs& a, hipStream_t st) {
 
 __global__ void to_bev_kernel(const int8_t* __restrict__ feat, const int32_t* __restrict__ coords, const int32_t* __restrict__ n_rows, int cap,
                               int C, int Cp, int D, int H, int W, int8_t* __restrict__ bev) {
-    const int m = blockIdx.x, c = threadIdx.x;
-    if (m >= min(*n_rows, cap) || c >= C) return;
-    const v4i p = *(const v4i*)(coords + (size_t)m * 4);
-    bev[(((size_t)p[0] * (H + 2) + p[2] + 1) * (W + 2) + p[3] + 1) * (size_t)(C * D) + c * D + p[1]] = feat[(size_t)m * Cp + c];
+    const int n = min(*n_rows, cap), c = threadIdx.x;
+    if (c >= C) return;
+    for (int m = blockIdx.x; m < n; m += gridDim.x) {
+        const v4i p = *(const v4i*)(coords + (size_t)m * 4);
+        bev[(((size_t)p[0] * (H + 2) + p[2] + 1) * (W + 2) + p[3] + 1) * (size_t)(C * D) + c * D + p[1]] = feat[(size_t)m * Cp + c];
+    }
 }
 
 static Geom make_geom(const qv2x_spconv_desc* d) {
@@ -313,23 +400,35 @@ extern "C" int qv2x_sp_index_scatter(const int32_t* coords, const int32_t* n_row
     if (!coords || !n_rows || !volume) return fail(QV2X_EINVAL, "qv2x_sp_index_scatter: null pointer");
     if (cap <= 0 || agents <= 0 || D <= 0 || H <= 0 || W <= 0) return fail(QV2X_EINVAL, "qv2x_sp_index_scatter: bad shape");
     if ((uintptr_t)coords & 15) return fail(QV2X_EALIGN, "qv2x_sp_index_scatter: 16-byte aligned coords");
-    index_scatter_kernel<<<(cap + 255) / 256, 256, 0, (hipStream_t)stream>>>(coords, n_rows, cap, D, H, W, volume, set);
+    index_scatter_kernel<<<min((cap + 255) / 256, 2048), 256, 0, (hipStream_t)stream>>>(coords, n_rows, cap, D, H, W, volume, set);
     return hip_check(hipGetLastError(), "qv2x_sp_index_scatter launch");
 }
 
+extern "C" int64_t qv2x_sp_out_sites_workspace_bytes(const qv2x_spconv_desc* d) {
+    using namespace qv2x;
+    if (check_geom(d, "qv2x_sp_out_sites_workspace_bytes")) return -1;
+    const long long cells = (long long)d->agents * d->out_shape[0] * d->out_shape[1] * d->out_shape[2];
+    return ((cells + SCAN_CELLS - 1) / SCAN_CELLS) * 4 + 16;
+}
+
 extern "C" int qv2x_sp_out_sites(const qv2x_spconv_desc* d, const int32_t* in_coords, const int32_t* n_in, int32_t* out_volume,
-                                 int32_t* out_coords, int32_t* n_out, void* stream) {
+                                 int32_t* out_coords, int32_t* n_out, void* workspace, int64_t workspace_bytes, void* stream) {
     using namespace qv2x;
     if (int e = check_geom(d, "qv2x_sp_out_sites")) return e;
-    if (!in_coords || !n_in || !out_volume || !out_coords || !n_out) return fail(QV2X_EINVAL, "qv2x_sp_out_sites: null pointer");
+    if (!in_coords || !n_in || !out_volume || !out_coords || !n_out || !workspace) return fail(QV2X_EINVAL, "qv2x_sp_out_sites: null pointer");
     if (d->subm) return fail(QV2X_EINVAL, "qv2x_sp_out_sites: a sub-manifold layer keeps its input's sites");
-    if (((uintptr_t)in_coords & 15) || ((uintptr_t)out_coords & 15)) return fail(QV2X_EALIGN, "qv2x_sp_out_sites: 16-byte aligned coords");
+    if (((uintptr_t)in_coords & 15) || ((uintptr_t)out_coords & 15) || ((uintptr_t)out_volume & 15) || ((uintptr_t)workspace & 15))
+        return fail(QV2X_EALIGN, "qv2x_sp_out_sites: 16-byte aligned pointers");
+    if (workspace_bytes < qv2x_sp_out_sites_workspace_bytes(d)) return fail(QV2X_EINVAL, "qv2x_sp_out_sites: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    if (int e = hip_check(hipMemsetAsync(n_out, 0, 4, st), "qv2x_sp_out_sites: count reset")) return e;
     const Geom g = make_geom(d);
+    const long long cells = (long long)d->agents * g.oD * g.oH * g.oW;
+    const int nb = (int)((cells + SCAN_CELLS - 1) / SCAN_CELLS);
     const long long threads = (long long)d->cap_in * g.k[0] * g.k[1] * g.k[2];
-    out_sites_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(in_coords, n_in, d->cap_in, g, out_volume, out_coords, n_out, d->cap_out);
-    clamp_count_kernel<<<1, 1, 0, st>>>(n_out, d->cap_out);
+    mark_sites_kernel<<<(unsigned)min((threads + 255) / 256, 4096LL), 256, 0, st>>>(in_coords, n_in, d->cap_in, g, out_volume);
+    count_marks_kernel<<<nb, 256, 0, st>>>(out_volume, cells, (int32_t*)workspace);
+    scan_counts_kernel<<<1, 1024, 0, st>>>((int32_t*)workspace, nb, n_out, d->cap_out);
+    assign_rows_kernel<<<nb, 256, 0, st>>>(out_volume, cells, (const int32_t*)workspace, g.oD, g.oH, g.oW, out_coords, d->cap_out);
     return hip_check(hipGetLastError(), "qv2x_sp_out_sites launch");
 }
 
@@ -340,7 +439,7 @@ extern "C" int qv2x_sp_rulebook(const qv2x_spconv_desc* d, const int32_t* out_co
     if (!out_coords || !n_out || !in_volume || !nbr) return fail(QV2X_EINVAL, "qv2x_sp_rulebook: null pointer");
     if ((uintptr_t)out_coords & 15) return fail(QV2X_EALIGN, "qv2x_sp_rulebook: 16-byte aligned coords");
     const Geom g = make_geom(d);
-    dim3 grid((d->cap_out + 255) / 256, g.k[0] * g.k[1] * g.k[2]);
+    dim3 grid(min((d->cap_out + 255) / 256, 512), g.k[0] * g.k[1] * g.k[2]);
     rulebook_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(out_coords, n_out, d->cap_out, g, in_volume, d->cap_in, nbr);
     return hip_check(hipGetLastError(), "qv2x_sp_rulebook launch");
 }
@@ -391,6 +490,6 @@ extern "C" int qv2x_sp_to_bev_i8(const int8_t* feat, const int32_t* coords, cons
     hipStream_t st = (hipStream_t)stream;
     const size_t bytes = (size_t)agents * (H + 2) * (W + 2) * c * D;
     if (int e = hip_check(hipMemsetAsync(bev, fill & 255, bytes, st), "qv2x_sp_to_bev_i8: fill")) return e;
-    to_bev_kernel<<<cap, ((c + 63) / 64) * 64, 0, st>>>(feat, coords, n_rows, cap, c, c_padded, D, H, W, bev);
+    to_bev_kernel<<<min(cap, 8192), ((c + 63) / 64) * 64, 0, st>>>(feat, coords, n_rows, cap, c, c_padded, D, H, W, bev);
     return hip_check(hipGetLastError(), "qv2x_sp_to_bev_i8 launch");
 }

@@ -196,28 +196,37 @@ class DeployedModel(nn.Module):
         self.emit_single = bool(s["meta/supervise_single"]) if emit_single_preds is None else bool(emit_single_preds)
         dev = self.dev
 
-        # ---- a1: PFN parameters (host struct, passed by value to the kernel) ------------------------------
-        n = "encoder_m1.pillar_vfe.pfn_layers.0.linear"
-        wq = ((s[n + "/w_code"].astype(np.float32) - s[n + "/w_zp"].astype(np.float32)[:, None])
-              * s[n + "/w_delta"].astype(np.float32)[:, None]).astype(np.float32)
-        if wq.shape != (64, 10):
-            raise NotImplementedError("deployed PFN expects Linear(10 -> 64)")
-        p = L.PfnParams()
-        p.w[:] = wq.reshape(-1).tolist()
-        p.b[:] = s[n + "/bias"].astype(np.float32).tolist()
-        p.d1, p.z1 = float(np.float32(s[n + "/a_delta"])), float(s[n + "/a_zp"])
-        p.d2, p.z2 = float(np.float32(s["pfn/a2_delta"])), float(s["pfn/a2_zp"])
-        p.vox[:] = [float(np.float32(v)) for v in s["meta/voxel"]]
-        p.off[:] = [float(np.float32(v)) for v in s["meta/offset"]]
-        self.pfn = p
-        q = (p.d2, int(p.z2))                                    # quantizer of the canvas
+        # ---- a1: PFN parameters (host struct, passed by value to the kernel) -- or a13, the SECOND encoder ------------
+        self.encoder_kind = str(s["meta/encoder"]) if "meta/encoder" in s else "point_pillar"
+        if self.encoder_kind == "second":
+            last = int(s["second/n_layers"]) - 1
+            q = (float(np.float32(s[f"second/{last}/a_delta"])), int(s[f"second/{last}/a_zp"]))
+            self.canvas_c, self.canvas_q, self.pfn = int(s["meta/canvas_channels"]), q, None
+            self.second: Dict[int, object] = {}                        # per agent count: a DeployedSecondEncoder (it owns the canvas)
+            self.second_max_voxels, self.second_max_points = 70000, 5
+        else:
+            n = "encoder_m1.pillar_vfe.pfn_layers.0.linear"
+            wq = ((s[n + "/w_code"].astype(np.float32) - s[n + "/w_zp"].astype(np.float32)[:, None])
+                  * s[n + "/w_delta"].astype(np.float32)[:, None]).astype(np.float32)
+            if wq.shape != (64, 10):
+                raise NotImplementedError("deployed PFN expects Linear(10 -> 64)")
+            p = L.PfnParams()
+            p.w[:] = wq.reshape(-1).tolist()
+            p.b[:] = s[n + "/bias"].astype(np.float32).tolist()
+            p.d1, p.z1 = float(np.float32(s[n + "/a_delta"])), float(s[n + "/a_zp"])
+            p.d2, p.z2 = float(np.float32(s["pfn/a2_delta"])), float(s["pfn/a2_zp"])
+            p.vox[:] = [float(np.float32(v)) for v in s["meta/voxel"]]
+            p.off[:] = [float(np.float32(v)) for v in s["meta/offset"]]
+            self.pfn = p
+            q = (p.d2, int(p.z2))                                    # quantizer of the canvas
+            self.canvas_c, self.canvas_q = 64, q
 
         # ---- a3: backbone ----------------------------------------------------------------------------------
         self.blocks: List[List[_ConvLayer]] = []
         self.chains: List[Optional[_ChainLayers]] = []                 # per level: its conv layers as one launch, where built
         self.deblocks: List[_DeconvLayer] = []
         cat_groups, c0 = [], 0
-        cin = 64
+        cin = self.canvas_c
         for lvl in range(len(self.layer_nums)):
             convs = []
             for i in range(self.layer_nums[lvl] + 1):
@@ -298,7 +307,12 @@ class DeployedModel(nn.Module):
             return self._bufs[n]
         b = {}
         h, w = self.ny, self.nx
-        b["canvas"] = self._padded(n, h, w, 64, (self.pfn.d2, int(self.pfn.z2)))
+        if self.encoder_kind == "second":
+            from .engine_second import DeployedSecondEncoder
+            self.second[n] = DeployedSecondEncoder(self.state, self.dev, agents=n, max_voxels=self.second_max_voxels, max_points=self.second_max_points)
+            b["canvas"] = self.second[n].bev
+        else:
+            b["canvas"] = self._padded(n, h, w, 64, self.canvas_q)
         b["lvl"] = []
         for lvl, convs in enumerate(self.blocks):
             h, w = (h + 2 - 3) // self.strides[lvl] + 1, (w + 2 - 3) // self.strides[lvl] + 1
@@ -470,6 +484,8 @@ class DeployedModel(nn.Module):
         vf = inputs["voxel_features"].contiguous()
         co = inputs["voxel_coords"].to(torch.int32).contiguous()
         npnt = inputs["voxel_num_points"].to(torch.int32).contiguous()
+        if self.encoder_kind == "second":                             # a13: MeanVFE + sparse convolutions + height compression
+            return self.second[n_agents]({"voxel_features": vf, "voxel_coords": co, "voxel_num_points": npnt})
         if vf.dtype != torch.float32 or vf.dim() != 3 or tuple(vf.shape[1:]) != (32, 4):
             raise ValueError("voxel_features must be float32 [M, 32, 4]")
         canvas = b["canvas"]

@@ -77,6 +77,7 @@ class _Level:
         self.volume = torch.full((agents * self.shape[0] * self.shape[1] * self.shape[2],), -1, dtype=torch.int32, device=dev)
         self.coords = torch.zeros((self.cap, 4), dtype=torch.int32, device=dev) if own_coords else None
         self.count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.scan_ws = torch.zeros((self.volume.numel() + 1023) // 1024 * 4 + 16, dtype=torch.uint8, device=dev)      # qv2x_sp_out_sites_workspace_bytes
 
 
 class DeployedSecondEncoder:
@@ -176,8 +177,8 @@ class DeployedSecondEncoder:
             key = self._rb_key(li)
             nbr = self.nbr[key]
             if not ly.subm:
-                L.check(lib.qv2x_sp_out_sites(C.byref(d), L.ptr(src.coords), L.ptr(src.count), L.ptr(dst.volume), L.ptr(dst.coords), L.ptr(dst.count), st),
-                        f"qv2x_sp_out_sites[{li}]")
+                L.check(lib.qv2x_sp_out_sites(C.byref(d), L.ptr(src.coords), L.ptr(src.count), L.ptr(dst.volume), L.ptr(dst.coords), L.ptr(dst.count),
+                                              L.ptr(dst.scan_ws), dst.scan_ws.numel(), st), f"qv2x_sp_out_sites[{li}]")
             if key not in built:                                      # sub-manifold layers of one `indice_key` share the rulebook
                 L.check(lib.qv2x_sp_rulebook(C.byref(d), L.ptr(dst.coords), L.ptr(dst.count), L.ptr(src.volume), L.ptr(nbr), st), f"qv2x_sp_rulebook[{li}]")
                 built.add(key)

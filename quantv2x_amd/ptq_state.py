@@ -132,16 +132,28 @@ def export_ptq_state(qt_model) -> Dict[str, np.ndarray]:
     out["meta/module_names"] = np.array(names)
 
     enc = model.encoder_m1
-    vfe = enc.pillar_vfe
-    if len(vfe.pfn_layers) != 1 or vfe.with_distance or not vfe.use_absolute_xyz:
-        raise NotImplementedError("deployed PFN: one layer, use_absolute_xyz, no distance feature (the V2X-Real / OPV2V yaml)")
-    pfn = vfe.pfn_layers[0]
-    out["pfn/a2_delta"] = np.float32(_np(torch.as_tensor(pfn.act_quantizer.delta)).reshape(-1)[0])
-    out["pfn/a2_zp"] = np.float32(_np(torch.as_tensor(pfn.act_quantizer.zero_point)).reshape(-1)[0])
-    out["meta/voxel"] = np.array([vfe.voxel_x, vfe.voxel_y, vfe.voxel_z], dtype=np.float64)
-    out["meta/offset"] = np.array([vfe.x_offset, vfe.y_offset, vfe.z_offset], dtype=np.float64)
-    sc = enc.scatter
-    out["meta/grid"] = np.array([sc.nx, sc.ny, sc.nz], dtype=np.int64)
+    if type(enc).__name__ == "QuantSECOND":                       # the sparse encoder in front of the same 2-D path
+        if pyramid:
+            raise NotImplementedError("deployed Pyramid path: PointPillar agents")
+        out.update(export_second_state(enc))
+        shape = [int(v) for v in enc.spconv_block.sparse_shape]
+        for _, m in second_layers(enc):
+            shape = m.spconv_module.out_shape(shape)
+        out["meta/encoder"] = np.array("second")
+        out["meta/grid"] = np.array([shape[2], shape[1], shape[0]], dtype=np.int64)          # (W, H, D) of the BEV map the encoder hands over
+        out["meta/canvas_channels"] = np.int64(enc.spconv_block.num_point_features * shape[0])
+    else:
+        vfe = enc.pillar_vfe
+        if len(vfe.pfn_layers) != 1 or vfe.with_distance or not vfe.use_absolute_xyz:
+            raise NotImplementedError("deployed PFN: one layer, use_absolute_xyz, no distance feature (the V2X-Real / OPV2V yaml)")
+        pfn = vfe.pfn_layers[0]
+        out["pfn/a2_delta"] = np.float32(_np(torch.as_tensor(pfn.act_quantizer.delta)).reshape(-1)[0])
+        out["pfn/a2_zp"] = np.float32(_np(torch.as_tensor(pfn.act_quantizer.zero_point)).reshape(-1)[0])
+        out["meta/voxel"] = np.array([vfe.voxel_x, vfe.voxel_y, vfe.voxel_z], dtype=np.float64)
+        out["meta/offset"] = np.array([vfe.x_offset, vfe.y_offset, vfe.z_offset], dtype=np.float64)
+        sc = enc.scatter
+        out["meta/grid"] = np.array([sc.nx, sc.ny, sc.nz], dtype=np.int64)
+        out["meta/encoder"] = np.array("point_pillar")
     out["meta/HW_metres"] = np.array([model.H, model.W], dtype=np.float64)
     out["meta/discrete_ratio"] = np.float64(model.fake_voxel_size)
 

@@ -42,7 +42,7 @@ SHAPES = {
 # SECOND encoder: 0.1 m voxels, 40 height slices, <= 5 points per voxel (the HEAL / OPV2V SECOND yaml)
 SECOND_SHAPES = {
     # name: (lidar_range, voxel_size, max_voxels)
-    "second_tiny": ([-6.4, -3.2, -3.0, 6.4, 3.2, 1.0], [0.1, 0.1, 0.1], 4096),          # 128 x 64 x 40 -> 16 x 8 BEV map
+    "second_tiny": ([-12.8, -6.4, -3.0, 12.8, 6.4, 1.0], [0.1, 0.1, 0.1], 4096),        # 256 x 128 x 40 -> 32 x 16 BEV map (= "tiny")
     "second_small": ([-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], [0.1, 0.1, 0.1], 16384),    # 512 x 256 x 40 -> 64 x 32
     "second_full": ([-140.8, -40.0, -3.0, 140.8, 40.0, 1.0], [0.1, 0.1, 0.1], 70000),   # 2816 x 800 x 40 -> 352 x 100
 }
@@ -81,8 +81,11 @@ def grid_size(lidar_range: Sequence[float], voxel_size: Sequence[float]) -> Tupl
 
 
 def make_hypes(shape: str = "v2xreal", multiclass: bool = True, codebook: bool = True,
-               supervise_single: bool = True, dict_size: int = 128, seg_num: int = 1, fusion: str = "att", compress_ratio: int = 0) -> dict:
-    """Return a ``hypes`` dict with the ``model`` section the reference's yaml would give."""
+               supervise_single: bool = True, dict_size: int = 128, seg_num: int = 1, fusion: str = "att", compress_ratio: int = 0,
+               encoder: str = "point_pillar") -> dict:
+    """Return a ``hypes`` dict with the ``model`` section the reference's yaml would give.  ``encoder="second"``: the m1 modality is the
+    SECOND encoder over ``SECOND_SHAPES["second_" + shape]`` (same metric range, 0.1 m voxels); its 256-channel map is already at the
+    resolution PointPillar's first backbone level reaches, so the backbone starts with stride 1 and ``inplanes: 256``."""
     lidar_range, voxel_size, max_voxels, max_cav = SHAPES[shape]
     args = {
         "ego_modality": "m1",
@@ -119,6 +122,13 @@ def make_hypes(shape: str = "v2xreal", multiclass: bool = True, codebook: bool =
         args["use_codebook"] = True
     if compress_ratio:                                # hypes_yaml/v2x_real/Naive_Compressor/*: `compressor: {input_dim: 256, compress_ratio: 16}`
         args["compressor"] = {"input_dim": 256, "compress_ratio": int(compress_ratio)}
+    if encoder == "second":
+        sname = {"tiny": "second_tiny", "small": "second_small", "v2xreal": "second_full"}[shape]
+        args["m1"]["core_method"] = "second"
+        args["m1"]["encoder_args"] = make_second_args(sname)
+        args["m1"]["backbone_args"].update({"layer_strides": [1, 2, 2], "inplanes": 256})
+    elif encoder != "point_pillar":
+        raise ValueError(encoder)
     core = "heter_baseline_collab_codebook" if codebook else "heter_model_baseline"
     if multiclass:
         core += "_mc"
@@ -349,8 +359,9 @@ def pairwise_t_matrix(poses: Sequence[np.ndarray], max_cav: int) -> np.ndarray:
 # --------------------------------------------------------------------------- scenes
 
 def make_scene(shape: str = "v2xreal", n_agents: int = 1, seed: int = 0, n_points: int = 60000,
-               layout: str = "line", sigma_m: Optional[float] = None, max_cav: Optional[int] = None) -> dict:
-    """Build the numpy form of ``batch_data['ego']`` for one frame (batch size 1)."""
+               layout: str = "line", sigma_m: Optional[float] = None, max_cav: Optional[int] = None, encoder: str = "point_pillar") -> dict:
+    """Build the numpy form of ``batch_data['ego']`` for one frame (batch size 1).  ``encoder="second"``: ``inputs_m1`` holds the 0.1 m
+    voxels of ``make_second_scene`` over the same range."""
     lidar_range, voxel_size, max_voxels, L = SHAPES[shape]
     if max_cav is not None:
         L = max_cav
@@ -366,12 +377,12 @@ def make_scene(shape: str = "v2xreal", n_agents: int = 1, seed: int = 0, n_point
         coords.append(np.concatenate([np.full((c.shape[0], 1), a, dtype=np.int32), c], axis=1))
         nums.append(n)
     poses = agent_poses(n_agents, layout)
+    inputs = {"voxel_features": np.concatenate(feats, axis=0), "voxel_coords": np.concatenate(coords, axis=0),
+              "voxel_num_points": np.concatenate(nums, axis=0)}
+    if encoder == "second":
+        inputs = make_second_scene({"tiny": "second_tiny", "small": "second_small", "v2xreal": "second_full"}[shape], n_agents, seed, n_points)
     return {
-        "inputs_m1": {
-            "voxel_features": np.concatenate(feats, axis=0),
-            "voxel_coords": np.concatenate(coords, axis=0),
-            "voxel_num_points": np.concatenate(nums, axis=0),
-        },
+        "inputs_m1": inputs,
         "agent_modality_list": ["m1"] * n_agents,
         "record_len": np.asarray([n_agents], dtype=np.int64),
         "pairwise_t_matrix": pairwise_t_matrix(poses, L)[None].astype(np.float64),

@@ -42,3 +42,19 @@ def calibrated_second(shape="second_tiny", agents=2, n_points=4000, num_features
     set_act_quantize_params(qm, [dd])
     qm.set_quant_state(True, True)
     return qm
+
+
+def second_model_scene_np(n_agents=2, shape="tiny", n_points=4000, seed=SEED_SCENE):
+    return synth.make_scene(shape, n_agents=n_agents, seed=seed, n_points=n_points, encoder="second")
+
+
+def calibrated_second_model(shape="tiny", n_agents=2, n_points=4000, **kw):
+    """The whole collaborative model with a ``core_method: second`` modality, W8A8 min-max, frozen after one pass."""
+    import copy
+    from quantv2x_amd.plugin.tools import train_utils
+    from quantv2x_amd.plugin.tools.inference_quant import calibrate_minmax, wrap
+    hy = synth.make_hypes(shape, encoder="second", **kw)
+    model = train_utils.create_model(copy.deepcopy(hy)).eval()
+    synth.load_state_dict_numpy(model, synth.make_state_dict(model.state_dict(), seed=SEED_W))
+    sc = synth.scene_to_torch(second_model_scene_np(n_agents, shape, n_points))
+    return calibrate_minmax(wrap(model, "minmax"), [sc])

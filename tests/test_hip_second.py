@@ -40,6 +40,8 @@ def test_second_encoder_matches_the_oracle(shape, agents, n_points):
             gk, gc = _rows_by_key((f[:n, :co].to(torch.int16) + 128).cpu().numpy().astype(np.uint8), coords[:n].cpu().numpy(), gsh)
             ok, occ = _rows_by_key(oc, oi, osh)
             assert np.array_equal(gk, ok), f"layer {i}: active sites differ"
+            if i >= 2:                                                # levels a SparseConv3d opened: rows in raster order, like the checker's
+                assert np.array_equal(coords[:n].cpu().numpy(), oi), f"layer {i}: rows are not in raster order"
             assert np.array_equal(gc, occ), f"layer {i}: {(gc != occ).sum()} codes differ"
         assert np.array_equal(eng.dense_codes(bev).cpu().numpy(), want)
     for l in eng.levels:
@@ -57,7 +59,7 @@ def test_second_encoder_close_to_the_torch_mirror():
     got = eng.dequant(eng({k: torch.from_numpy(v).cuda() for k, v in sc.items()})).cpu().numpy()
     lsb = eng.out_q[0]
     d = np.abs(got - ref)
-    assert d.max() <= 2.001 * lsb and (d > 1e-4).mean() < 2e-3, (d.max() / lsb, (d > 1e-4).mean())
+    assert d.max() <= 6.001 * lsb and (d > 1e-4).mean() < 2e-2, (d.max() / lsb, (d > 1e-4).mean())     # whole path: see test_second_cpu.py
 
 
 def test_empty_and_single_voxel():
@@ -76,3 +78,19 @@ def test_empty_and_single_voxel():
     want = OracleSecond(state).forward(one, batch_size=1)
     got = eng.dense_codes(eng({k: torch.from_numpy(v).cuda() for k, v in one.items()})).cpu().numpy()
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("n_agents", [1, 2])
+def test_whole_model_with_a_second_modality(n_agents):
+    """The SECOND encoder in front of the int8 2-D path: every uint8 activation and codebook index equal to the oracle's."""
+    from _common import compare_frame
+    from _common_second import calibrated_second_model, second_model_scene_np
+    from oracle.spec import Oracle
+    from quantv2x_amd.engine import deploy
+    from quantv2x_amd.ptq_state import export_ptq_state
+    state = export_ptq_state(calibrated_second_model(n_agents=2))
+    eng = deploy(state=state, device="cuda:0")
+    eng.second_max_voxels = 4096
+    sc = second_model_scene_np(n_agents)
+    compare_frame(Oracle(state), eng, sc, state)
+    compare_frame(Oracle(state), eng, sc, state, every_layer=False)      # again: the index volumes were left clean

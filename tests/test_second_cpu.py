@@ -52,13 +52,14 @@ def test_fake_quant_stays_close_to_fp32():
     with torch.no_grad():
         ref = enc(dd, "m1")
         got = calibrated_second()(dd)
-    assert ref.shape == (2, 256, 8, 16)
+    assert ref.shape == (2, 256, 16, 32)
     assert (got - ref).abs().max() < 0.1 * ref.abs().max()
 
 
 @pytest.mark.parametrize("num_features_out", [128, 64])
 def test_oracle_agrees_with_the_mirror(num_features_out):
-    """Whole path, not teacher-forced: at most one code of the last quantizer, on a handful of cells."""
+    """Whole path, not teacher-forced: a rounding flip in an early layer propagates through up to eleven more, so the end result is
+    compared loosely here (a few codes on ~1 % of the cells); the layer-by-layer pin is the teacher-forced test below."""
     from oracle.spec_second import OracleSecond
     from quantv2x_amd.ptq_state import export_second_state
     qm = calibrated_second(num_features_out=num_features_out)
@@ -70,8 +71,8 @@ def test_oracle_agrees_with_the_mirror(num_features_out):
     got = orc.dequant(orc.forward(sc))
     lsb = float(state["second/11/a_delta"])
     d = np.abs(got - ref)
-    assert got.shape == ref.shape == (2, 2 * num_features_out, 8, 16)
-    assert d.max() <= 1.001 * lsb and (d > 1e-4).mean() < 1e-3
+    assert got.shape == ref.shape == (2, 2 * num_features_out, 16, 32)
+    assert d.max() <= 6.001 * lsb and (d > 1e-4).mean() < 2e-2, (d.max() / lsb, (d > 1e-4).mean())
 
 
 def test_oracle_layers_teacher_forced():
@@ -120,13 +121,40 @@ def test_cabi_argument_checks():
         d.k[a], d.s[a], d.p[a], d.in_shape[a], d.out_shape[a] = 3, 2, 1, 41, 21
     d.agents, d.cin, d.cout, d.cap_in, d.cap_out, d.out_delta, d.out_zp = 1, 32, 32, 64, 64, 0.1, 0.0
     one = C.c_void_p(16)
-    assert lib.qv2x_sp_out_sites(C.byref(d), None, one, one, one, one, None) == -1
+    assert lib.qv2x_sp_out_sites(C.byref(d), None, one, one, one, one, one, 1 << 20, None) == -1
+    assert lib.qv2x_sp_out_sites_workspace_bytes(C.byref(d)) == (21 * 21 * 21 + 1023) // 1024 * 4 + 16
+    assert lib.qv2x_sp_out_sites(C.byref(d), one, one, one, one, one, one, 8, None) == -1 and b"workspace" in lib.qv2x_last_error()
     d.out_shape[1] = 20
     assert lib.qv2x_sp_rulebook(C.byref(d), one, one, one, one, None) == -1 and b"out_shape" in lib.qv2x_last_error()
     d.out_shape[1] = 21
     d.cin = 48
     assert lib.qv2x_sp_conv_i8(C.byref(d), one, one, one, one, one, one, one, one, one, one, None) == -2
     d.subm = 1
-    assert lib.qv2x_sp_out_sites(C.byref(d), one, one, one, one, one, None) == -1
+    assert lib.qv2x_sp_out_sites(C.byref(d), one, one, one, one, one, one, 1 << 20, None) == -1
     assert lib.qv2x_mean_vfe_f32(one, one, one, 0, 5, one, None) == -1
     assert lib.qv2x_sp_to_bev_i8(one, one, one, 8, 128, 128, 1, 2, 8, 16, 300, one, None) == -1
+
+
+def test_whole_model_with_a_second_modality():
+    """``core_method: second`` in front of the same backbone / shrinker / codebook / fusion: QuantModel wraps it, the export carries
+    both halves, and the integer restatement tracks the mirror (the codebook argmin is discontinuous, so agreement past it is counted)."""
+    from _common import hard_forward
+    from _common_second import calibrated_second_model, second_model_scene_np
+    from oracle.spec import Oracle
+    from quantv2x_amd import synth
+    from quantv2x_amd.ptq_state import export_ptq_state
+    qt = calibrated_second_model()
+    assert type(qt.model.encoder_m1).__name__ == "QuantSECOND" and qt.model.backbone_m1.blocks[0][1].weight.shape[1] == 256
+    state = export_ptq_state(qt)
+    assert str(state["meta/encoder"]) == "second" and list(state["meta/grid"]) == [32, 16, 2] and int(state["meta/canvas_channels"]) == 256
+    assert list(state["meta/layer_strides"]) == [1, 2, 2] and "pfn/a2_delta" not in state
+    sc = second_model_scene_np()
+    ot, mt = {}, {}
+    Oracle(state).forward(sc, ot)
+    with torch.no_grad():
+        hard_forward(qt.model, synth.scene_to_torch(sc), mt)
+    lsb, zp = float(state["second/11/a_delta"]), float(state["second/11/a_zp"])
+    canvas = (ot["canvas"].astype(np.float32) - zp) * lsb
+    d = np.abs(canvas.transpose(0, 3, 1, 2) - mt["spatial_features"].numpy())
+    assert d.max() <= 2.001 * lsb and (d > 1e-4).mean() < 1e-2
+    assert (ot["codes"] == mt["codes"].numpy()).mean() > 0.85
