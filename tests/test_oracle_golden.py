@@ -142,8 +142,8 @@ def test_freeze_step_gives_the_same_state_on_the_reference_objects(golden, state
     attribute names): same keys, same contents as on the mirror -- ``quantv2x_amd.deploy`` accepts the reference's objects."""
     g = golden["tiny_w8a8"]
     keys = [str(k) for k in g["ptq_export/keys"]]
-    # meta/fusion_method and meta/compress are newer than the golden file (round 2: the export names the fusion / compressor it found)
-    assert keys == sorted(k for k in state if k not in ("meta/module_names", "meta/fusion_method", "meta/compress"))
+    # meta/fusion_method, meta/compress and meta/encoder are newer than the golden file (round 2: the export names the fusion / compressor / encoder it found)
+    assert keys == sorted(k for k in state if k not in ("meta/module_names", "meta/fusion_method", "meta/compress", "meta/encoder"))
     got_sum = np.array([float(np.asarray(state[k], dtype=np.float64).sum()) for k in keys])
     got_abs = np.array([float(np.abs(np.asarray(state[k], dtype=np.float64)).sum()) for k in keys])
     np.testing.assert_allclose(got_sum, g["ptq_export/checksum"], rtol=1e-6, atol=1e-9)
