@@ -205,6 +205,56 @@ def pyramid_model_line(device):
     return out
 
 
+def second_encoder_line(device):
+    """SURVEY.md §8 row a13, reported beside the headline: the quantized SECOND encoder (MeanVFE + 12 sparse 3-D convolutions + height
+    compression) on one full-size synthetic sweep (0.1 m voxels over the V2X-Real range), as one HIP graph."""
+    import torch
+    import torch.nn as nn
+    from quantv2x_amd import synth
+    from quantv2x_amd.engine_second import DeployedSecondEncoder
+    from quantv2x_amd.plugin.models.heter_encoders import SECOND
+    from quantv2x_amd.plugin.quant import QuantModel, set_act_quantize_params, set_weight_quantize_params
+    from quantv2x_amd.ptq_state import export_second_state
+
+    class EncoderOnly(nn.Module):
+        def __init__(self, enc):
+            super().__init__()
+            self.encoder_m1 = enc
+
+        def forward(self, dd):
+            return self.encoder_m1(dd, "m1")
+
+    shape = "second_full"
+    enc = SECOND(synth.make_second_args(shape)).eval()
+    synth.load_state_dict_numpy(enc, synth.make_state_dict(enc.state_dict(), seed=1))
+    qm = QuantModel(EncoderOnly(enc), dict(n_bits=8, channel_wise=True, scale_method="minmax"),
+                    dict(n_bits=8, channel_wise=False, scale_method="minmax", leaf_param=True)).eval()
+    calib = synth.make_second_scene(shape, 1, seed=3, n_points=15000)          # ranges from a thinner sweep: they set values, not time
+    set_weight_quantize_params(qm)
+    set_act_quantize_params(qm, [{"inputs_m1": {k: torch.from_numpy(v) for k, v in calib.items()}}])
+    eng = DeployedSecondEncoder(export_second_state(qm.model.encoder_m1), device, agents=1, max_voxels=synth.SECOND_SHAPES[shape][2])
+    sweep = synth.make_second_scene(shape, 1, seed=3, n_points=N_POINTS)
+    inp = {k: torch.from_numpy(v).to(device) for k, v in sweep.items()}
+    taps = {}
+    eng(inp, taps)
+    torch.cuda.synchronize()
+    sites = [int(taps[f"second/{i}"][2].item()) for i in range(len(eng.layers))]
+    gmac = sum(n * ly.K * ly.ci * ly.co for n, ly in zip(sites, eng.layers)) / 1e9
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        eng(inp)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            eng(inp)
+    torch.cuda.synchronize()
+    us = event_time_us(graph.replay, 30)
+    return {"ms_per_sweep": round(us / 1e3, 4), "sweeps_per_s": round(1e6 / us, 1), "voxels": int(sweep["voxel_coords"].shape[0]),
+            "active_sites_per_level": [sites[1], sites[4], sites[7], sites[10], sites[11]], "dense_window_gmac": round(gmac, 2),
+            "int8_top_s_equivalent": round(2 * gmac / us * 1e3, 1),
+            "note": "QuantSECOND under W8A8 (parity against spconv itself unpinned, DESIGN.md 1): rulebooks + gather-GEMM on int8 MFMA; "
+                    "dense_window_gmac counts every window offset of every active output, occupied or not"}
+
+
 def cpu_baseline(state, sc_np, budget_s=12.0, max_frames=6):
     """The CPU oracle (checker) on the same workload, on the host cores of this box."""
     from oracle.spec import Oracle
@@ -391,6 +441,7 @@ def main():
                                      "note": "un-quantized model, one frame at a time, f32-MFMA convolutions; compare value_one_frame_at_a_time"}
             del e32, r32
             line["pyramid_model"] = pyramid_model_line(device)
+            line["second_encoder"] = second_encoder_line(device)
         if not args.no_cpu_baseline and world == 1:       # reported on rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(state, frame_batch(1, 0, 1, "cpu")[0])
             line["cpu_baseline_torch"] = cpu_baseline_torch(fp_model, qt, frame_batch(1, 0, 1, "cpu")[0], cores)

@@ -15,13 +15,13 @@ def _rows_by_key(codes, coords, shape):
     return key[order], codes[order]
 
 
-@pytest.mark.parametrize("shape,agents,n_points", [("second_tiny", 2, 4000), ("second_small", 1, 30000)])
-def test_second_encoder_matches_the_oracle(shape, agents, n_points):
+@pytest.mark.parametrize("shape,agents,n_points,cout", [("second_tiny", 2, 4000, 128), ("second_small", 1, 30000, 128), ("second_tiny", 1, 4000, 64)])
+def test_second_encoder_matches_the_oracle(shape, agents, n_points, cout):
     from oracle.spec_second import OracleSecond
     from quantv2x_amd.engine_second import DeployedSecondEncoder
     from quantv2x_amd.ptq_state import export_second_state
     from quantv2x_amd import synth
-    qm = calibrated_second(shape, agents, n_points)
+    qm = calibrated_second(shape, agents, n_points, num_features_out=cout)
     state = export_second_state(qm.model.encoder_m1)
     sc = second_scene_np(shape, agents, n_points)
     to, tg = {}, {}
