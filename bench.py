@@ -205,6 +205,42 @@ def pyramid_model_line(device):
     return out
 
 
+def collapsed_encode_line(state, full, B, F, steps, device):
+    """NOT the headline: the same step (B frames per graph, F graphs in flight) with the OPT-IN collapsed codebook encode
+    (engine.encode_mode = "collapsed": the encoder's affine heads multiplied out on the host, one GEMM + an argmin chain per cell).  Its
+    indices differ from the exact path's in ~1 cell of 10 000, all of them cells whose two best distances tie to within fp32 rounding
+    (tools/bench_collapsed_encode.py, profiles/r02_collapsed_encode.json); the exact kernel stays the default and the parity configuration."""
+    import torch
+    from quantv2x_amd.engine import deploy
+    engines = [deploy(state=state) for _ in range(F)]
+    streams = [torch.cuda.Stream() for _ in range(F)]
+    reps = []
+    for e, st in zip(engines, streams):
+        e.encode_mode = "collapsed"
+        with torch.cuda.stream(st):
+            reps.append(e.capture(full))
+    torch.cuda.synchronize()
+    for i in range(2 * F):
+        with torch.cuda.stream(streams[i % F]):
+            reps[i % F]()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        with torch.cuda.stream(streams[i % F]):
+            reps[i % F]()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    exact = engines[0]
+    exact.encode_mode = "exact"
+    a = exact.encode_agents(full["inputs_m1"], B).clone()
+    exact.encode_mode = "collapsed"
+    b = exact.encode_agents(full["inputs_m1"], B)
+    torch.cuda.synchronize()
+    return {"frames_per_s": round(B * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4),
+            "index_mismatch_rate_vs_exact": float((a != b).float().mean().item()),
+            "note": "opt-in, not the parity configuration and not `value`: same graphs with engine.encode_mode = 'collapsed'"}
+
+
 def second_encoder_line(device):
     """SURVEY.md §8 row a13, reported beside the headline: the quantized SECOND encoder (MeanVFE + 12 sparse 3-D convolutions + height
     compression) on one full-size synthetic sweep (0.1 m voxels over the V2X-Real range), as one HIP graph."""
@@ -442,6 +478,7 @@ def main():
             del e32, r32
             line["pyramid_model"] = pyramid_model_line(device)
             line["second_encoder"] = second_encoder_line(device)
+            line["collapsed_encode_opt_in"] = collapsed_encode_line(state, full, B, F, args.steps, device)
         if not args.no_cpu_baseline and world == 1:       # reported on rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(state, frame_batch(1, 0, 1, "cpu")[0])
             line["cpu_baseline_torch"] = cpu_baseline_torch(fp_model, qt, frame_batch(1, 0, 1, "cpu")[0], cores)

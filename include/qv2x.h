@@ -169,6 +169,17 @@ int qv2x_codebook_encode_f32(const qv2x_encode_desc* desc /* host */, const int8
                              const float* const* level_weights /* host array of device pointers */,
                              uint8_t* codes, void* stream);
 
+/* OPT-IN, not the parity configuration: qv2x_codebook_encode_f32 with the encoder's affine heads collapsed on the host
+ * (quantv2x_amd/engine.py: collapse_encoder).  distance_l[k] - |q_l|^2 = G_l[k] . x + g_l[k] + sum_{j<l} T_lj[code_j][k] with x the shared
+ * feature: ONE 256 -> levels*kc GEMM per cell plus an argmin chain over the tables, 6.3x fewer flops than the reference's op order.  The
+ * argmin can differ from the reference's where the two best distances are closer than fp32 rounding error (measured: DESIGN.md §3); the
+ * exact entry above stays the shipped default.  levels <= 3, levels * kc <= 384.
+ *   g_packed f32 [levels*kc/32][128][64]: value (tile t, step i, lane l) = in_delta * G[32 t + l % 32][2 i + l / 32]
+ *   bias f32 [levels*kc] = g + in_delta * (0 - in_zx) * rowsum(G)      (the kernel multiplies by the uint8 code itself)
+ *   tables f32 [levels*(levels-1)/2][kc][kc]: table (l, j) at index l (l - 1) / 2 + j */
+int qv2x_codebook_encode_collapsed_f32(const qv2x_encode_desc* desc /* host */, const int8_t* in, const float* g_packed, const float* bias,
+                                       const float* tables, uint8_t* codes, void* stream);
+
 /* a7 + a8 + a9 + a10.  UMGMQuantizer.decode as three table look-ups (codebook.py:339-343; all heads affine),
  * warp_affine_simple (torch_transformation_utils.py:323-332: affine_grid + bilinear grid_sample, zeros,
  * align_corners=False) of every agent into the ego frame and AttFusion's per-cell scaled-dot-product

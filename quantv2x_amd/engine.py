@@ -58,6 +58,45 @@ def decode_tables(state: Dict[str, np.ndarray], levels: int, width: int = 256):
     return np.ascontiguousarray(np.stack(tables), dtype=np.float32), np.ascontiguousarray(const, dtype=np.float32)
 
 
+def collapse_encoder(state: Dict[str, np.ndarray], levels: int, in_delta: float, in_zx: int):
+    """UMGMQuantizer.encode (codebook.py:330-337 -> :231-239 -> :106-131) with its affine heads multiplied out in float64 -- the operands
+    of the OPT-IN ``qv2x_codebook_encode_collapsed_f32`` (not the parity path: the argmin may differ where the two best distances are
+    within fp32 rounding error of each other).  With z = stage(x), q = qhead(z), x' = lhead(z) - C[code]:
+
+        dist_l[k] - |q_l|^2 = |C_l[k]|^2 - 2 C_l[k] . q_l = G_l[k] . x_1 + g_l[k] + sum_{j<l} T_lj[code_j][k]
+
+    Returns (g_packed f32 [L*kc/32][128][64], bias f32 [L*kc], tables f32 [L(L-1)/2][kc][kc]); the input dequantization
+    x_1 = in_delta * (code - in_zx) is folded in: the kernel multiplies by the uint8 code itself."""
+    g = lambda l, n: state[f"codebook/{l}/{n}"].astype(np.float64)
+    kc = int(state["codebook/0/codebook"].shape[0])
+    front, shift = np.eye(256), np.zeros(256)          # x_l = front @ x_1 + shift - sum_j back[j] @ C_j[code_j]
+    back = []                                          # per earlier level j: the matrix that carries its subtracted codeword to x_l
+    G, gb, tables = [], [], {}
+    for l in range(levels):
+        Ws, bs, Wq, bq, Cb = g(l, "stage_w"), g(l, "stage_b"), g(l, "qhead_w"), g(l, "qhead_b"), g(l, "codebook")
+        Gp = -2.0 * Cb @ Wq @ Ws                       # on x_l
+        gp = (Cb * Cb).sum(1) - 2.0 * Cb @ (Wq @ bs + bq)
+        G.append(Gp @ front)
+        gb.append(Gp @ shift + gp)
+        for j, Bj in enumerate(back):
+            tables[(l, j)] = -(Gp @ Bj @ g(j, "codebook").T).T          # [kc_j][kc_l]
+        if l < levels - 1:
+            A = g(l, "lhead_w") @ Ws
+            d = g(l, "lhead_w") @ bs + g(l, "lhead_b")
+            front, shift = A @ front, A @ shift + d
+            back = [A @ Bj for Bj in back] + [np.eye(256)]
+    Gall, gall = np.concatenate(G), np.concatenate(gb)                  # [L*kc, 256], [L*kc]
+    bias = gall + in_delta * (0.0 - in_zx) * Gall.sum(1)
+    Gs = in_delta * Gall
+    nct = levels * kc // 32
+    lane = np.arange(64)
+    col = (np.arange(nct)[:, None, None] * 32 + (lane & 31)[None, None, :])             # [nct, 1, 64]
+    k = (2 * np.arange(128)[None, :, None] + (lane >> 5)[None, None, :])               # [1, 128, 64]
+    packed = Gs[col, k]
+    tab = np.stack([tables[(l, j)] for l in range(levels) for j in range(l)]) if levels > 1 else np.zeros((1, kc, kc))
+    return (np.ascontiguousarray(packed, dtype=np.float32), np.ascontiguousarray(bias, dtype=np.float32), np.ascontiguousarray(tab, dtype=np.float32))
+
+
 def _pack_k4p(w: np.ndarray) -> np.ndarray:
     """As ``_pack_k4`` but the four k of a group are stored (k0, k2, k1, k3): the half-wave feeding MFMA k-parity p
     reads one contiguous float2 = (k_p, k_{p+2}) (codebook_encode.hip)."""
@@ -276,6 +315,8 @@ class DeployedModel(nn.Module):
         # launch-plan switches for the ablation tools (tools/bench_*_abl.py); the defaults are the shipped configuration
         self.use_wide_conv, self.batch_deconvs, self.use_chains = True, True, True
         self.chain_max_agents = 1
+        # "exact": the reference's eleven chained GEMMs, bit-identical indices (the parity configuration).  "collapsed": opt-in, see collapse_encoder
+        self.encode_mode, self._collapsed = "exact", None
 
     # ------------------------------------------------------------------------------------------------------
     def _level_blob(self, l: int) -> torch.Tensor:
@@ -503,6 +544,15 @@ class DeployedModel(nn.Module):
         d = L.EncodeDesc()
         d.n, d.h, d.w, d.levels, d.kc = n_agents, self.fh, self.fw, self.levels, self.kc
         d.in_zx, d.in_delta = int(self.shrink1.out_q[1]), float(self.shrink1.out_q[0])
+        if self.encode_mode == "collapsed":                           # opt-in: one GEMM + argmin chain, indices may differ at near-ties
+            if self._collapsed is None:
+                self._collapsed = tuple(_dev(t, self.dev) for t in collapse_encoder(self.state, self.levels, d.in_delta, d.in_zx))
+            gp, bias, tab = self._collapsed
+            L.check(self.lib.qv2x_codebook_encode_collapsed_f32(C.byref(d), L.ptr(b["s1"]), L.ptr(gp), L.ptr(bias), L.ptr(tab), L.ptr(codes),
+                                                                L.current_stream()), "qv2x_codebook_encode_collapsed_f32")
+            return codes
+        if self.encode_mode != "exact":
+            raise ValueError(f"encode_mode {self.encode_mode!r}: 'exact' (the reference's op order, the default) or 'collapsed'")
         L.check(self.lib.qv2x_codebook_encode_f32(C.byref(d), L.ptr(b["s1"]), self.level_ptrs, L.ptr(codes),
                                                   L.current_stream()), "qv2x_codebook_encode_f32")
         return codes

@@ -241,3 +241,34 @@ def test_argument_errors_of_the_pyramid_entries_without_gpu():
     pp = lib.PostprocessDesc()
     pp.h, pp.w, pp.anchors_per_cell, pp.num_classes, pp.max_boxes, pp.score_threshold, pp.max_extent, pp.z_min, pp.z_max = 4, 4, 2, 1, 10, 0.2, 6.0, -3.0, 1.0
     assert l.qv2x_postprocess_late_workspace_bytes(C.byref(pp), 9) == -1 and l.qv2x_postprocess_late_workspace_bytes(C.byref(pp), 2) > 0
+
+
+def test_collapsed_encoder_algebra_matches_the_exact_checker():
+    """engine.collapse_encoder (the operands of the OPT-IN qv2x_codebook_encode_collapsed_f32) evaluated in numpy: on the tiny scene every
+    index equals the exact checker's, or differs only where the exact top-2 gap is within rounding error."""
+    import numpy as np
+    from _common import calibrated_plugin, scene_np
+    from oracle.spec import Oracle
+    from quantv2x_amd.engine import collapse_encoder
+    from quantv2x_amd.ptq_state import export_ptq_state
+    state = export_ptq_state(calibrated_plugin("tiny", n_agents=2))
+    orc, taps = Oracle(state), {}
+    orc.forward(scene_np(2), taps)
+    shr, q = taps["shrinker_m1.layers.0.double_conv.1"], taps["shrinker_q"]
+    exact, gaps = orc.encode_rows(((shr.astype(np.float32) - np.float32(q[1])) * np.float32(q[0])).reshape(-1, 256), want_gaps=True)
+    gp, bias, tab = collapse_encoder(state, 3, float(q[0]), int(q[1]))
+    assert gp.shape == (12, 128, 64) and bias.shape == (384,) and tab.shape == (3, 128, 128)
+    lane = np.arange(64)
+    G = np.zeros((384, 256), np.float32)
+    for t in range(12):
+        for i in range(128):
+            G[t * 32 + (lane & 31), 2 * i + (lane >> 5)] = gp[t, i]
+    scores = shr.reshape(-1, 256).astype(np.float32) @ G.T + bias
+    codes = np.zeros((3, scores.shape[0]), np.int64)
+    for l in range(3):
+        v = scores[:, l * 128:(l + 1) * 128].copy()
+        for j in range(l):
+            v += tab[l * (l - 1) // 2 + j][codes[j]]
+        codes[l] = v.argmin(1)
+    mm = codes != exact
+    assert mm.mean() < 2e-3 and (not mm.any() or gaps[mm].max() < 0.05)
