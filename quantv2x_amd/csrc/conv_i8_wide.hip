@@ -48,7 +48,13 @@ template <int V> struct IC { static constexpr int value = V; };
 // same two waves per SIMD -- but the two are independent workgroups, so the prologue / fold / epilogue of one overlaps the K
 // loop of the other, and every CU has work.  The two channel halves of a patch get block ids 8 apart (same XCD: the halo
 // tile they both fetch is served by one L2).
-template <int S, bool MULTI, int NW, int NT, int BN>
+//
+// DIRECT: a wave only ever reads ITS OWN 32 rows of a step's [256][64] weight tile, so staging the tile in LDS buys nothing but
+// asynchrony -- and costs 16 KB of LDS writes + 16 KB of LDS reads per step next to the 80 KB of halo-fragment reads, and a workgroup
+// barrier per K step (the ring stage is shared).  With DIRECT the weights go L2 -> registers (two 16-byte loads per lane per step, a ring
+// of three steps), LDS only holds the halo tiles, and the waves meet at a barrier once per 64-channel chunk (nine steps) instead of
+// every step.
+template <int S, bool MULTI, int NW, int NT, int BN, bool DIRECT = false>
 __global__ __launch_bounds__(NW * 64, 512 / (NW * 64)) void conv3x3_i8_wide_kernel(const WideArgs a) {
     static_assert(NW * NT * 32 == BN && WTILE % BN == 0, "wave layout");
     constexpr int BSTAGE = BN * 64, NB = WTILE / BN;
@@ -56,10 +62,11 @@ __global__ __launch_bounds__(NW * 64, 512 / (NW * 64)) void conv3x3_i8_wide_kern
     constexpr int NF = MULTI ? 16 : 1;
     static_assert(NT == 1, "the epilogue below is written for one 32-channel tile per wave");
     constexpr int NG = MULTI ? QV2X_MAX_GROUPS : 1;
-    __shared__ __attribute__((aligned(16))) int8_t lds[2 * HBUF + S * BSTAGE + NW * BM * 4 + NG * BN * 16];
+    constexpr int BRING = DIRECT ? 0 : S * BSTAGE;                     // the weight ring (none with DIRECT)
+    __shared__ __attribute__((aligned(16))) int8_t lds[2 * HBUF + BRING + NW * BM * 4 + NG * BN * 16];
     int8_t* hbuf = lds;
     int8_t* bst = lds + 2 * HBUF;
-    int* xbuf = (int*)(bst + S * BSTAGE);                              // [NW][BM] partial window sums
+    int* xbuf = (int*)(bst + BRING);                              // [NW][BM] partial window sums
     v4i* ctab = (v4i*)(xbuf + NW * BM);                                // [group][BN] {aw, corr_g, scale_g (bits), bias (bits)} per channel
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -154,6 +161,16 @@ __global__ __launch_bounds__(NW * 64, 512 / (NW * 64)) void conv3x3_i8_wide_kern
         for (int ks = 0; ks < 2; ++ks) offB[j][ks] = row * 64 + (((ks * 2 + half) ^ ((row >> 2) & 3)) << 4);
     }
 
+    // DIRECT: this lane's 2 x 16 bytes of step `st`: row = cout (wave, lane & 31), piece ks * 2 + half of the row's 64 bytes
+    const int8_t* wdir = a.wt + (size_t)(cb / NB) * total * (WTILE * 64) + (cb % NB) * BSTAGE + (wave * 32 + (lane & 31)) * 64 + half * 16;
+    v4i wr[3][2];
+    auto load_w = [&](auto slot_c, int st) __attribute__((always_inline)) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        const int8_t* p = wdir + (size_t)(st < total ? st : total - 1) * (WTILE * 64);
+        wr[SLOT][0] = *(const v4i*)p;
+        wr[SLOT][1] = *(const v4i*)(p + 32);
+    };
+
     constexpr int NSET = NT == 2 ? 2 : 1;
     v4i fa[NSET][2][MT], fb[NSET][2][NT];
     auto read_frags = [&](auto set_c, int chunk, int tap, int step) __attribute__((always_inline)) {
@@ -171,10 +188,12 @@ __global__ __launch_bounds__(NW * 64, 512 / (NW * 64)) void conv3x3_i8_wide_kern
             fa[SET][0][i] = *(const v4i*)(hb + a0);
             fa[SET][1][i] = *(const v4i*)(hb + (a0 ^ 32));
         }
+        if (!DIRECT) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            fb[SET][0][j] = *(const v4i*)(bs + offB[j][0]);
-            fb[SET][1][j] = *(const v4i*)(bs + offB[j][1]);
+            for (int j = 0; j < NT; ++j) {
+                fb[SET][0][j] = *(const v4i*)(bs + offB[j][0]);
+                fb[SET][1][j] = *(const v4i*)(bs + offB[j][1]);
+            }
         }
     };
 
@@ -220,8 +239,13 @@ __global__ __launch_bounds__(NW * 64, 512 / (NW * 64)) void conv3x3_i8_wide_kern
 
     // ---- prologue: halo of chunk 0, weight tiles of steps 0 .. S-2 ------------------------------------------------
     issue_halo(0);
+    if (DIRECT) {
+        load_w(IC<0>{}, 0);
+        load_w(IC<1>{}, 1);
+    } else {
 #pragma unroll
-    for (int p = 0; p < S - 1; ++p) issue_b();
+        for (int p = 0; p < S - 1; ++p) issue_b();
+    }
 
     // per-channel constants -> LDS table (younger than the prologue DMAs: waiting for them also lands the prologue, which the
     // first K step needs anyway)
@@ -248,10 +272,21 @@ __global__ __launch_bounds__(NW * 64, 512 / (NW * 64)) void conv3x3_i8_wide_kern
         constexpr int TAP = decltype(tap_c)::value, SET = (NSET == 2) ? (TAP & 1) : 0;
         constexpr int INFLIGHT = (S - 3) * LB + ((TAP >= 1 && TAP <= S - 2) ? LH : 0);
         const int step = chunk * 9 + TAP;
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(INFLIGHT) : "memory");
-        __builtin_amdgcn_s_barrier();
-        issue_b();
-        if (TAP == 0) issue_halo(chunk + 1);
+        if (DIRECT) {
+            static_assert(!DIRECT || (NT == 1 && NSET == 1), "DIRECT is written for one 32-channel tile per wave");
+            load_w(IC<(TAP + 2) % 3>{}, step + 2);                     // slot of step - 1, which is done
+            if (TAP == 0) {
+                // the halo of this chunk was requested nine steps ago, before every weight load still in flight (steps +0, +1, +2)
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                          // ... by every wave; and every wave is done with the other halo buffer
+                issue_halo(chunk + 1);
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(INFLIGHT) : "memory");
+            __builtin_amdgcn_s_barrier();
+            issue_b();
+            if (TAP == 0) issue_halo(chunk + 1);
+        }
         if (TAP == 0 || NSET == 1) read_frags(IC<0>{}, chunk, TAP, step);
         if (TAP < 8 && NSET == 2) read_frags(IC<(SET ^ 1) % NSET>{}, chunk, TAP + 1, step + 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -269,7 +304,7 @@ __global__ __launch_bounds__(NW * 64, 512 / (NW * 64)) void conv3x3_i8_wide_kern
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[SET][ks][j], fa[SET][ks][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(DIRECT ? wr[TAP % 3][ks] : fb[SET][ks][j], fa[SET][ks][i], acc[i][j], 0, 0, 0);
     };
     for (int chunk = 0; chunk < a.nchunks; ++chunk) {
         one_step(IC<0>{}, chunk); one_step(IC<1>{}, chunk); one_step(IC<2>{}, chunk);
@@ -421,8 +456,11 @@ extern "C" int qv2x_conv3x3_i8_wide(const qv2x_conv_desc* d, const int8_t* in, c
     else conv3x3_i8_wide_kernel<5, false, 4, 1, 128><<<grid, 256, 0, st>>>(a);
 #else
     const dim3 grid(patches8 * (a.cout / 256));
-    if (d->ngroups > 1) conv3x3_i8_wide_kernel<5, true, 8, 1, 256><<<grid, 512, 0, st>>>(a);
-    else conv3x3_i8_wide_kernel<5, false, 8, 1, 256><<<grid, 512, 0, st>>>(a);
+#ifndef QV2X_WIDE_DIRECT
+#define QV2X_WIDE_DIRECT 1
+#endif
+    if (d->ngroups > 1) conv3x3_i8_wide_kernel<5, true, 8, 1, 256, QV2X_WIDE_DIRECT != 0><<<grid, 512, 0, st>>>(a);
+    else conv3x3_i8_wide_kernel<5, false, 8, 1, 256, QV2X_WIDE_DIRECT != 0><<<grid, 512, 0, st>>>(a);
 #endif
     return hip_check(hipGetLastError(), "qv2x_conv3x3_i8_wide launch");
 }
