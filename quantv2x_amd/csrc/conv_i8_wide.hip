@@ -32,6 +32,7 @@ struct WideArgs {
     int out_ctotal, out_c0, relu;
     float out_delta, out_zp;
     int nchunks, ngroups;
+    int wtile;                        // rows of one pre-tiled weight tile: min(cout, 256)
     int cend[QV2X_MAX_GROUPS];        // first chunk index past group g
     int coff[MAX_CHUNKS];             // channel byte offset of each 64-channel chunk inside a pixel
 };
@@ -55,8 +56,9 @@ template <int V> struct IC { static constexpr int value = V; };
 // of three steps), LDS only holds the halo tiles, and the waves meet at a barrier once per 64-channel chunk (nine steps) instead of
 // every step.
 template <int S, bool MULTI, int NW, int NT, int BN, bool DIRECT = false>
-__global__ __launch_bounds__(NW * 64, 512 / (NW * 64)) void conv3x3_i8_wide_kernel(const WideArgs a) {
+__global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kernel(const WideArgs a) {
     static_assert(NW * NT * 32 == BN && WTILE % BN == 0, "wave layout");
+    static_assert(DIRECT || BN >= 128, "the LDS weight ring is only laid out for 128 / 256 output channels per workgroup");
     constexpr int BSTAGE = BN * 64, NB = WTILE / BN;
     constexpr int LH = (HBLK + NW - 1) / NW, LB = BSTAGE / 1024 / NW;  // DMA instructions per wave: halo tile, weight tile
     constexpr int NF = MULTI ? 16 : 1;
@@ -162,11 +164,12 @@ __global__ __launch_bounds__(NW * 64, 512 / (NW * 64)) void conv3x3_i8_wide_kern
     }
 
     // DIRECT: this lane's 2 x 16 bytes of step `st`: row = cout (wave, lane & 31), piece ks * 2 + half of the row's 64 bytes
-    const int8_t* wdir = a.wt + (size_t)(cb / NB) * total * (WTILE * 64) + (cb % NB) * BSTAGE + (wave * 32 + (lane & 31)) * 64 + half * 16;
+    const int wstep = a.wtile * 64;                                    // bytes of one step's weight tile
+    const int8_t* wdir = a.wt + (size_t)(n0 / a.wtile) * total * wstep + ((n0 % a.wtile) + wave * 32 + (lane & 31)) * 64 + half * 16;
     v4i wr[3][2];
     auto load_w = [&](auto slot_c, int st) __attribute__((always_inline)) {
         constexpr int SLOT = decltype(slot_c)::value;
-        const int8_t* p = wdir + (size_t)(st < total ? st : total - 1) * (WTILE * 64);
+        const int8_t* p = wdir + (size_t)(st < total ? st : total - 1) * wstep;
         wr[SLOT][0] = *(const v4i*)p;
         wr[SLOT][1] = *(const v4i*)(p + 32);
     };
@@ -207,12 +210,12 @@ __global__ __launch_bounds__(NW * 64, 512 / (NW * 64)) void conv3x3_i8_wide_kern
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (tid < BM) {
+        for (int t = tid; t < BM; t += NW * 64) {                       // (a two-wave workgroup has fewer threads than the patch has pixels)
             int v = 0;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) v += xbuf[w * BM + tid];
+            for (int w = 0; w < NW; ++w) v += xbuf[w * BM + t];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            xbuf[tid] = v;                                             // only thread tid touches column tid of row 0
+            xbuf[t] = v;                                               // only this thread touches column t of row 0
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -357,15 +360,15 @@ __global__ __launch_bounds__(NW * 64, 512 / (NW * 64)) void conv3x3_i8_wide_kern
     }
 }
 
-// [Cout][G][3][3][C_g] -> [Cout/256][chunk = (g, cc)][tap][256][64]
+// [Cout][G][3][3][C_g] -> [Cout/wtile][chunk = (g, cc)][tap][wtile][64], wtile = min(Cout, 256)
 __global__ void pack_wide_kernel(const int8_t* __restrict__ w, int8_t* __restrict__ wt, int cout, int ktot, int nchunks,
                                  WideArgs a) {
     const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one 16-byte unit each
     const long long units = (long long)cout * ktot / 16;
     if (u >= units) return;
     const int c16 = u & 3;
-    const int row = (u >> 2) & 255;
-    const long long tile = u >> 10;
+    const int row = (int)((u >> 2) % a.wtile);
+    const long long tile = u / (a.wtile * 4);
     const int step = tile % (nchunks * 9);
     const int nb = tile / (nchunks * 9);
     const int chunk = step / 9, tap = step % 9;
@@ -374,12 +377,14 @@ __global__ void pack_wide_kernel(const int8_t* __restrict__ w, int8_t* __restric
     while (chunk >= a.cend[g]) { const int gc = (a.cend[g] - cfirst) * 64; k0 += 9 * gc; cfirst = a.cend[g]; ++g; }
     const int gc = (a.cend[g] - cfirst) * 64;
     const int k = k0 + tap * gc + (chunk - cfirst) * 64 + c16 * 16;
-    *(v4i*)(wt + u * 16) = *(const v4i*)(w + (size_t)(nb * 256 + row) * ktot + k);
+    *(v4i*)(wt + u * 16) = *(const v4i*)(w + (size_t)(nb * a.wtile + row) * ktot + k);
 }
 
 int fill_args(const qv2x_conv_desc* d, WideArgs& a) {
     if (d->n <= 0 || d->h <= 0 || d->w <= 0) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_wide: bad shape n=%d h=%d w=%d", d->n, d->h, d->w);
-    if (d->stride != 1 || d->cout % 256) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_wide: stride 1 and cout %% 256 == 0 only");
+    if (d->stride != 1 || (d->cout != 64 && d->cout != 128 && d->cout % 256)) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_wide: stride 1 and cout 64 | 128 | a multiple of 256");
+    if (d->cout < 256 && d->ngroups != 1) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_wide: the 64 / 128-channel form takes one input group");
+    a.wtile = d->cout < 256 ? d->cout : 256;
     if (d->ngroups < 1 || d->ngroups > QV2X_MAX_GROUPS) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_wide: 1..%d input groups", QV2X_MAX_GROUPS);
     if (d->cin_total % 16 || d->out_ctotal % 16 || d->out_c0 % 16 || d->out_ctotal < d->out_c0 + d->cout)
         return fail(QV2X_EALIGN, "qv2x_conv3x3_i8_wide: cin_total, out_ctotal, out_c0 %% 16; out channel window");
@@ -412,17 +417,26 @@ int fill_args(const qv2x_conv_desc* d, WideArgs& a) {
 
 }  // namespace qv2x
 
+// output channels per workgroup: 256 (8 waves) while that fills the chip, else 128 (4 waves), 64 for the 64-channel layers
+static int wide_bn(const qv2x_conv_desc* d) {
+    const long long patches = (long long)d->n * ((d->h + qv2x::TH - 1) / qv2x::TH) * ((d->w + qv2x::TW - 1) / qv2x::TW);
+    if (d->cout % 256 == 0) return patches * (d->cout / 256) >= 192 ? 256 : 128;
+    return d->cout;
+}
+
 extern "C" int qv2x_conv3x3_i8_wide_ok(const qv2x_conv_desc* d) {
-    if (!d || d->stride != 1 || d->cout % 256 || d->ngroups < 1 || d->ngroups > QV2X_MAX_GROUPS) return 0;
+    if (!d || d->stride != 1 || (d->cout != 64 && d->cout != 128 && d->cout % 256) || d->ngroups < 1 || d->ngroups > QV2X_MAX_GROUPS) return 0;
+    if (d->cout < 256 && d->ngroups != 1) return 0;
     int chunks = 0;
     for (int g = 0; g < d->ngroups; ++g) {
         if (d->group_c[g] <= 0 || d->group_c[g] % 64 || d->group_c0[g] % 16) return 0;
         chunks += d->group_c[g] / 64;
     }
-    // enough 5 x 32 patches to fill the chip: a 25 x 88 map is 15 patches per image, and a batch of eight of them (120 workgroups
-    // walking K = 2304) ran 5x slower here than 64 x 64 tiles of qv2x_conv3x3_i8 (profiles/r02_bench_n1_kernel_stats_by_grid.csv)
+    // enough workgroups (a 5 x 32 patch x 64 / 128 / 256 output channels each) to fill the chip: below that the 64 x 64-tile kernel
+    // of qv2x_conv3x3_i8 spreads the layer over more CUs
     const long long patches = (long long)d->n * ((d->h + qv2x::TH - 1) / qv2x::TH) * ((d->w + qv2x::TW - 1) / qv2x::TW);
-    return chunks <= qv2x::MAX_CHUNKS && (long long)d->n * d->h * d->w >= 16384 && patches >= 192;
+    const long long wgs = patches * (d->cout / wide_bn(d));
+    return chunks <= qv2x::MAX_CHUNKS && (long long)d->n * d->h * d->w >= 16384 && wgs >= (d->cout == 64 ? 1024 : 192);
 }
 
 extern "C" int qv2x_conv3x3_i8_pack_wide(const qv2x_conv_desc* d, const int8_t* w, int8_t* w_wide, void* stream) {
@@ -447,20 +461,15 @@ extern "C" int qv2x_conv3x3_i8_wide(const qv2x_conv_desc* d, const int8_t* in, c
     a.in = in; a.wt = w_wide; a.scale = scale; a.corr = corr; a.aw = aw; a.bias = bias; a.out = out;
     hipStream_t st = (hipStream_t)stream;
     const int patches8 = (a.n * a.tiles_x * a.tiles_y + 7) / 8 * 8;   // block ids come in groups of 8 (one per XCD)
-#ifndef QV2X_WIDE_BN
-#define QV2X_WIDE_BN 256
-#endif
-#if QV2X_WIDE_BN == 128                                               // ablation build: 440 four-wave workgroups, two per CU (measured: no gain)
-    const dim3 grid(patches8 * (a.cout / 128));
-    if (d->ngroups > 1) conv3x3_i8_wide_kernel<5, true, 4, 1, 128><<<grid, 256, 0, st>>>(a);
-    else conv3x3_i8_wide_kernel<5, false, 4, 1, 128><<<grid, 256, 0, st>>>(a);
-#else
-    const dim3 grid(patches8 * (a.cout / 256));
-#ifndef QV2X_WIDE_DIRECT
-#define QV2X_WIDE_DIRECT 1
-#endif
-    if (d->ngroups > 1) conv3x3_i8_wide_kernel<5, true, 8, 1, 256, QV2X_WIDE_DIRECT != 0><<<grid, 512, 0, st>>>(a);
-    else conv3x3_i8_wide_kernel<5, false, 8, 1, 256, QV2X_WIDE_DIRECT != 0><<<grid, 512, 0, st>>>(a);
-#endif
+    const int bn = wide_bn(d);
+    const dim3 grid(patches8 * (a.cout / bn));
+    if (d->ngroups > 1) {
+        if (bn == 256) conv3x3_i8_wide_kernel<5, true, 8, 1, 256, true><<<grid, 512, 0, st>>>(a);
+        else conv3x3_i8_wide_kernel<5, true, 4, 1, 128, true><<<grid, 256, 0, st>>>(a);
+    } else {
+        if (bn == 256) conv3x3_i8_wide_kernel<5, false, 8, 1, 256, true><<<grid, 512, 0, st>>>(a);
+        else if (bn == 128) conv3x3_i8_wide_kernel<5, false, 4, 1, 128, true><<<grid, 256, 0, st>>>(a);
+        else conv3x3_i8_wide_kernel<5, false, 2, 1, 64, true><<<grid, 128, 0, st>>>(a);
+    }
     return hip_check(hipGetLastError(), "qv2x_conv3x3_i8_wide launch");
 }

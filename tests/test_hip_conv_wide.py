@@ -30,22 +30,27 @@ def _padded(x_u8, zx_per_channel):
     return (p - 128).astype(np.int8)
 
 
-@pytest.mark.parametrize("n,h,w,groups", [
-    (1, 5, 32, [(0, 64)]),
-    (1, 10, 16, [(0, 64)]),
-    (1, 20, 32, [(0, 128)]),
-    (2, 13, 37, [(0, 64), (64, 128), (192, 64)]),
-    (1, 7, 50, [(0, 128), (128, 64)]),
-    (3, 25, 16, [(0, 256)]),
+@pytest.mark.parametrize("n,h,w,groups,cout", [
+    (1, 5, 32, [(0, 64)], 256),
+    (1, 10, 16, [(0, 64)], 256),
+    (1, 20, 32, [(0, 128)], 256),
+    (2, 13, 37, [(0, 64), (64, 128), (192, 64)], 256),
+    (1, 7, 50, [(0, 128), (128, 64)], 256),
+    (3, 25, 16, [(0, 256)], 256),
+    (40, 25, 32, [(0, 256)], 256),          # 200 patches: the eight-wave, 256-channel workgroups
+    (1, 10, 16, [(0, 64)], 64),             # the backbone's 64- and 128-channel layers (two / four waves per workgroup)
+    (2, 13, 37, [(0, 64)], 64),
+    (1, 5, 32, [(0, 128)], 128),
+    (2, 13, 37, [(0, 128)], 128),
 ])
-def test_wide_matches_regular_and_oracle(n, h, w, groups):
+def test_wide_matches_regular_and_oracle(n, h, w, groups, cout):
     from oracle.spec import Oracle
     from quantv2x_amd import lib as L
     from quantv2x_amd.engine import _ConvLayer
     lib = L.load()
     dev = torch.device("cuda")
     rng = np.random.default_rng(h * 1000 + w)
-    cin, cout, name = sum(c for _, c in groups), 256, "layer"
+    cin, name = sum(c for _, c in groups), "layer"
     state = _layer_state(rng, name, cin, cout)
     in_q = [(c0, c, np.float32(0.03 + 0.02 * i), 90 + 30 * i) for i, (c0, c) in enumerate(groups)]
     layer = _ConvLayer(state, name, in_q, 1, dev)
@@ -91,9 +96,15 @@ def test_wide_rejects_unsupported():
     d.n, d.h, d.w, d.cin_total, d.stride, d.cout, d.ngroups = 1, 100, 352, 64, 2, 256, 1
     d.group_c[0], d.out_ctotal, d.out_delta = 64, 256, 0.1
     assert lib.qv2x_conv3x3_i8_wide_ok(C.byref(d)) == 0               # stride 2
-    d.stride, d.cout = 1, 128
-    assert lib.qv2x_conv3x3_i8_wide_ok(C.byref(d)) == 0               # cout % 256
-    d.cout = 256
+    d.stride, d.cout = 1, 192
+    assert lib.qv2x_conv3x3_i8_wide_ok(C.byref(d)) == 0               # cout: 64, 128 or a multiple of 256
+    d.cout = 128
+    assert lib.qv2x_conv3x3_i8_wide_ok(C.byref(d)) == 1               # 220 patches of 128 channels
+    d.cout = 64
+    assert lib.qv2x_conv3x3_i8_wide_ok(C.byref(d)) == 0               # 220 two-wave workgroups do not fill the chip ...
+    d.n = 8
+    assert lib.qv2x_conv3x3_i8_wide_ok(C.byref(d)) == 1               # ... 1760 do
+    d.n, d.cout = 1, 256
     assert lib.qv2x_conv3x3_i8_wide_ok(C.byref(d)) == 1
     x = torch.zeros(64, dtype=torch.int8, device="cuda")
     d.stride = 2

@@ -104,3 +104,31 @@ def test_v2xreal_properties_four_agents(v2xreal):
     three = eng.fuse_and_heads(rep, hw, 3 * hw, eye, 3)["preds_tensor"]
     d = (one - three).abs()
     assert float(d.max()) <= head_lsb(state) * 1.001 and float((d > 1e-5).float().mean()) < 1e-3
+
+
+def test_v2xreal_batch_of_eight_frames_exact(v2xreal):
+    """The throughput configuration of bench.py: eight single-agent frames in one batch.  At this size every stride-1 layer of the
+    backbone runs on the halo-patch kernel (64 / 128 output channels per workgroup, the 25 x 88 level split in two channel halves);
+    every uint8 activation of the encode side and every codebook index against the oracle, frame by frame."""
+    from quantv2x_amd import synth
+    state, eng, orc = v2xreal
+    scenes = [synth.make_scene("v2xreal", n_agents=1, seed=11 + f, n_points=60000) for f in range(8)]
+    parts = []
+    for f, sc in enumerate(scenes):
+        part = {k: v.copy() for k, v in sc["inputs_m1"].items()}
+        part["voxel_coords"][:, 0] += f
+        parts.append(part)
+    inputs = {k: torch.from_numpy(np.concatenate([p[k] for p in parts])).cuda() for k in parts[0]}
+    taps = {}
+    codes = eng.encode_agents(inputs, 8, taps).cpu().numpy()            # [levels, 8, H*W]
+    torch.cuda.synchronize()
+    names = [f"backbone_m1.blocks.{l}.{i + 1}" for l, n in enumerate(eng.layer_nums) for i in range(n + 1)] + \
+            ["shrinker_m1.layers.0.double_conv.0", "shrinker_m1.layers.0.double_conv.1"]
+    from _common import interior_u8
+    got = {n: interior_u8(taps[n]) for n in names}
+    for f, sc in enumerate(scenes):
+        ot = {}
+        orc.forward(sc, ot)
+        for n in names:
+            np.testing.assert_array_equal(got[n][f], ot[n][0], err_msg=f"frame {f}: {n}")
+        np.testing.assert_array_equal(codes[:, f].reshape(ot["codes"].shape[0], -1), ot["codes"].reshape(ot["codes"].shape[0], -1), err_msg=f"frame {f}: codes")
