@@ -8,9 +8,10 @@
 //     each wave a 160 x 32 register tile = 5 accumulators of v_mfma_i32_32x32x32_i8;
 //   * the input is staged as a 7 x 34 pixel HALO tile per 64-channel chunk and the nine taps read it at shifted
 //     pixel offsets: 15.2 KB fetched per nine K-steps instead of 9 x 10 KB;
-//   * the weights are pre-tiled (qv2x_conv3x3_i8_pack_wide) so that the [256][64] tile of one K-step is 16 KB
-//     contiguous: every LDS-DMA instruction reads 1 KiB of whole cache lines (64-byte row gathers run the same
-//     stream at half the rate, measured).
+//   * the weights are pre-tiled (qv2x_conv3x3_i8_pack_wide) so that the [wtile][64] tile of one K-step is contiguous, and go
+//     straight from L2 to registers: a wave only ever reads ITS OWN 32 rows of a tile, so the LDS ring of round 1 (16 KB written
+//     and 16 KB read per step, a workgroup barrier per step) bought nothing but asynchrony.  Two 16-byte loads per lane per
+//     step, a ring of three steps; LDS holds the two halo tiles only and the waves meet once per 64-channel chunk (nine steps).
 #include "common.h"
 
 #include <cstdlib>
@@ -39,36 +40,22 @@ struct WideArgs {
 
 template <int V> struct IC { static constexpr int value = V; };
 
-// NW waves, each a 160 x (NT*32) register tile, NW * NT * 32 == 256.  <8, 1> (two waves per SIMD, 1.2 fragment reads
-// per MFMA, one fragment set) is what ships: 31.5 us on the 256->256 shrinker layer against 37.5 us for <4, 2> (one wave
-// per SIMD, 0.7 reads per MFMA, fragments of step s+1 read while step s multiplies), and the multi-group layer's extra
-// fp32 fold accumulator per output (2 x 160 registers at NT = 2) only fits the register file at NT = 1.
-//
-// BN = output channels per workgroup.  BN = 256 is one workgroup per CU (110 KB of LDS, 220 workgroups at V2X-Real size: 36
-// CUs idle).  BN = 128 (<S, MULTI, 4, 1, 128>) halves the weight stage (74 KB of LDS): 440 four-wave workgroups, two per CU, the
-// same two waves per SIMD -- but the two are independent workgroups, so the prologue / fold / epilogue of one overlaps the K
-// loop of the other, and every CU has work.  The two channel halves of a patch get block ids 8 apart (same XCD: the halo
-// tile they both fetch is served by one L2).
-//
-// DIRECT: a wave only ever reads ITS OWN 32 rows of a step's [256][64] weight tile, so staging the tile in LDS buys nothing but
-// asynchrony -- and costs 16 KB of LDS writes + 16 KB of LDS reads per step next to the 80 KB of halo-fragment reads, and a workgroup
-// barrier per K step (the ring stage is shared).  With DIRECT the weights go L2 -> registers (two 16-byte loads per lane per step, a ring
-// of three steps), LDS only holds the halo tiles, and the waves meet at a barrier once per 64-channel chunk (nine steps) instead of
-// every step.
-template <int S, bool MULTI, int NW, int NT, int BN, bool DIRECT = false>
+// NW waves, each a 160 x 32 register tile (NT = 1), BN = NW * 32 output channels per workgroup:
+//   <8, 1, 256>  the shrinker: one workgroup per 5 x 32 patch (two waves per SIMD; a <4, 2> split -- one wave per SIMD, two channel
+//                tiles each -- measured slower, 37.5 vs 31.5 us, and the three-group layer's fp32 fold accumulators do not fit at NT = 2);
+//   <4, 1, 128>  the backbone's 128-channel layers, and 256-channel layers whose patches alone would leave CUs idle (25 x 88 x 8 frames =
+//                120 patches): the two channel halves of a patch get block ids 8 apart (same XCD: one L2 serves the halo they both fetch);
+//   <2, 1, 64>   the backbone's 64-channel layers.
+template <bool MULTI, int NW, int NT, int BN>
 __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kernel(const WideArgs a) {
     static_assert(NW * NT * 32 == BN && WTILE % BN == 0, "wave layout");
-    static_assert(DIRECT || BN >= 128, "the LDS weight ring is only laid out for 128 / 256 output channels per workgroup");
-    constexpr int BSTAGE = BN * 64, NB = WTILE / BN;
-    constexpr int LH = (HBLK + NW - 1) / NW, LB = BSTAGE / 1024 / NW;  // DMA instructions per wave: halo tile, weight tile
+    constexpr int LH = (HBLK + NW - 1) / NW;                           // halo DMA instructions per wave
     constexpr int NF = MULTI ? 16 : 1;
     static_assert(NT == 1, "the epilogue below is written for one 32-channel tile per wave");
     constexpr int NG = MULTI ? QV2X_MAX_GROUPS : 1;
-    constexpr int BRING = DIRECT ? 0 : S * BSTAGE;                     // the weight ring (none with DIRECT)
-    __shared__ __attribute__((aligned(16))) int8_t lds[2 * HBUF + BRING + NW * BM * 4 + NG * BN * 16];
+    __shared__ __attribute__((aligned(16))) int8_t lds[2 * HBUF + NW * BM * 4 + NG * BN * 16];
     int8_t* hbuf = lds;
-    int8_t* bst = lds + 2 * HBUF;
-    int* xbuf = (int*)(bst + BRING);                              // [NW][BM] partial window sums
+    int* xbuf = (int*)(lds + 2 * HBUF);                              // [NW][BM] partial window sums
     v4i* ctab = (v4i*)(xbuf + NW * BM);                                // [group][BN] {aw, corr_g, scale_g (bits), bias (bits)} per channel
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -97,13 +84,6 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
         srcH[j] = (unsigned)(((img * a.hp + yy) * a.wp + xx) * a.cin_total + c * 16);
         dstH[j] = blk * 1024;
     }
-    const int8_t* srcB;
-    {
-        const int p = wave * LB * 64 + lane, row = p >> 2, c = (p & 3) ^ ((row >> 2) & 3);
-        // weight tiles are [256][64] per step; this workgroup reads rows [(cb % NB) * BN, + BN) of tile cb / NB
-        srcB = a.wt + (size_t)(cb / NB) * total * (WTILE * 64) + (cb % NB) * BSTAGE + row * 64 + c * 16;   // + j KiB per instruction: rows advance by 16
-    }
-
     v16i acc[MT][NT];
     float facc[MT][NT][NF];
     int xs[MT];
@@ -129,17 +109,6 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
         }
     }
 
-    int b_step = 0;
-    auto issue_b = [&]() __attribute__((always_inline)) {
-        const int st = b_step < total ? b_step : total - 1;
-        int8_t* stage = bst + (b_step % S) * BSTAGE + wave * LB * 1024;
-        const int8_t* s0 = srcB + (size_t)st * (WTILE * 64);
-#pragma unroll
-        for (int j = 0; j < LB; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s0 + j * 1024),
-                                             (__attribute__((address_space(3))) void*)(stage + j * 1024), 16, 0, 0);
-        ++b_step;
-    };
     auto issue_halo = [&](int chunk) __attribute__((always_inline)) {
         const int cc = chunk < a.nchunks ? chunk : a.nchunks - 1;
         const int off = a.coff[cc];
@@ -155,17 +124,10 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
     // CONSECUTIVE halo pixels, so every 16-lane service group of ds_read_b128 ({0-3,12-15,20-27}, ...) covers 16
     // distinct hp mod 16 = 16 distinct 16-byte slots of the 256-byte bank row, whatever the tap shift.
     const int hp0 = lane & 31;
-    int offB[NT][2];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int row = (wave * NT + j) * 32 + (lane & 31);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) offB[j][ks] = row * 64 + (((ks * 2 + half) ^ ((row >> 2) & 3)) << 4);
-    }
-
-    // DIRECT: this lane's 2 x 16 bytes of step `st`: row = cout (wave, lane & 31), piece ks * 2 + half of the row's 64 bytes
+    // this lane's 2 x 16 bytes of the weight tile of step `st`: row = its output channel (wave, lane & 31), piece ks * 2 + half of the row's 64 bytes
     const int wstep = a.wtile * 64;                                    // bytes of one step's weight tile
     const int8_t* wdir = a.wt + (size_t)(n0 / a.wtile) * total * wstep + ((n0 % a.wtile) + wave * 32 + (lane & 31)) * 64 + half * 16;
+    static_assert(NT == 1, "one 32-channel tile per wave (weight ring, epilogue)");
     v4i wr[3][2];
     auto load_w = [&](auto slot_c, int st) __attribute__((always_inline)) {
         constexpr int SLOT = decltype(slot_c)::value;
@@ -174,12 +136,11 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
         wr[SLOT][1] = *(const v4i*)(p + 32);
     };
 
-    constexpr int NSET = NT == 2 ? 2 : 1;
-    v4i fa[NSET][2][MT], fb[NSET][2][NT];
+    constexpr int NSET = 1;
+    v4i fa[NSET][2][MT];
     auto read_frags = [&](auto set_c, int chunk, int tap, int step) __attribute__((always_inline)) {
         constexpr int SET = decltype(set_c)::value;
         const int8_t* hb = hbuf + (chunk & 1) * HBUF;
-        const int8_t* bs = bst + (step % S) * BSTAGE;
         const int d = (tap / 3) * HWD + (tap % 3);
         int hpl = hp0;
         if (NT == 1) asm volatile("" : "+v"(hpl));                      // keep the 45 tap addresses from being hoisted (and spilled)
@@ -190,13 +151,6 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
             const int a0 = hp * 64 + ((half ^ t) << 4);
             fa[SET][0][i] = *(const v4i*)(hb + a0);
             fa[SET][1][i] = *(const v4i*)(hb + (a0 ^ 32));
-        }
-        if (!DIRECT) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                fb[SET][0][j] = *(const v4i*)(bs + offB[j][0]);
-                fb[SET][1][j] = *(const v4i*)(bs + offB[j][1]);
-            }
         }
     };
 
@@ -240,15 +194,10 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
         }
     };
 
-    // ---- prologue: halo of chunk 0, weight tiles of steps 0 .. S-2 ------------------------------------------------
+    // ---- prologue: halo of chunk 0, weights of steps 0 and 1 --------------------------------------------------------
     issue_halo(0);
-    if (DIRECT) {
-        load_w(IC<0>{}, 0);
-        load_w(IC<1>{}, 1);
-    } else {
-#pragma unroll
-        for (int p = 0; p < S - 1; ++p) issue_b();
-    }
+    load_w(IC<0>{}, 0);
+    load_w(IC<1>{}, 1);
 
     // per-channel constants -> LDS table (younger than the prologue DMAs: waiting for them also lands the prologue, which the
     // first K step needs anyway)
@@ -267,31 +216,19 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
         }
     }
 
-    // One K-step = (chunk, tap).  At its barrier: weight tile step+1 and (from tap S-1 on) the next halo have landed for
-    // every wave, and every wave is done reading tile step-1 -- the stage the new DMA overwrites.  Taps 0..7 read the
-    // fragments of the next tap while they multiply; tap 0 reads its own first (one exposed LDS latency per chunk keeps
-    // the register-set parity the same in every chunk: 9 taps, sets 0 1 0 1 0 1 0 1 0).
+    // One K-step = (chunk, tap): request the weights of step + 2, read this tap's halo fragments, multiply.  The waves only meet at tap 0:
+    // by then every wave's share of this chunk's halo tile has landed and nobody reads the other halo buffer any more.
     auto one_step = [&](auto tap_c, int chunk) __attribute__((always_inline)) {
-        constexpr int TAP = decltype(tap_c)::value, SET = (NSET == 2) ? (TAP & 1) : 0;
-        constexpr int INFLIGHT = (S - 3) * LB + ((TAP >= 1 && TAP <= S - 2) ? LH : 0);
+        constexpr int TAP = decltype(tap_c)::value, SET = 0;
         const int step = chunk * 9 + TAP;
-        if (DIRECT) {
-            static_assert(!DIRECT || (NT == 1 && NSET == 1), "DIRECT is written for one 32-channel tile per wave");
-            load_w(IC<(TAP + 2) % 3>{}, step + 2);                     // slot of step - 1, which is done
-            if (TAP == 0) {
-                // the halo of this chunk was requested nine steps ago, before every weight load still in flight (steps +0, +1, +2)
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                __builtin_amdgcn_s_barrier();                          // ... by every wave; and every wave is done with the other halo buffer
-                issue_halo(chunk + 1);
-            }
-        } else {
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(INFLIGHT) : "memory");
-            __builtin_amdgcn_s_barrier();
-            issue_b();
-            if (TAP == 0) issue_halo(chunk + 1);
+        load_w(IC<(TAP + 2) % 3>{}, step + 2);                         // slot of step - 1, which is done
+        if (TAP == 0) {
+            // the halo of this chunk was requested nine steps ago, before every weight load still in flight (steps +0, +1, +2)
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                              // ... by every wave; and every wave is done with the other halo buffer
+            issue_halo(chunk + 1);
         }
-        if (TAP == 0 || NSET == 1) read_frags(IC<0>{}, chunk, TAP, step);
-        if (TAP < 8 && NSET == 2) read_frags(IC<(SET ^ 1) % NSET>{}, chunk, TAP + 1, step + 1);
+        read_frags(IC<0>{}, chunk, TAP, step);
         __builtin_amdgcn_sched_barrier(0);
         if (((chunk + TAP) & (NW - 1)) == wave_u) {                   // window sums: the waves take turns, one step each
 #pragma unroll
@@ -307,7 +244,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(DIRECT ? wr[TAP % 3][ks] : fb[SET][ks][j], fa[SET][ks][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wr[TAP % 3][ks], fa[SET][ks][i], acc[i][j], 0, 0, 0);
     };
     for (int chunk = 0; chunk < a.nchunks; ++chunk) {
         one_step(IC<0>{}, chunk); one_step(IC<1>{}, chunk); one_step(IC<2>{}, chunk);
@@ -464,12 +401,12 @@ extern "C" int qv2x_conv3x3_i8_wide(const qv2x_conv_desc* d, const int8_t* in, c
     const int bn = wide_bn(d);
     const dim3 grid(patches8 * (a.cout / bn));
     if (d->ngroups > 1) {
-        if (bn == 256) conv3x3_i8_wide_kernel<5, true, 8, 1, 256, true><<<grid, 512, 0, st>>>(a);
-        else conv3x3_i8_wide_kernel<5, true, 4, 1, 128, true><<<grid, 256, 0, st>>>(a);
+        if (bn == 256) conv3x3_i8_wide_kernel<true, 8, 1, 256><<<grid, 512, 0, st>>>(a);
+        else conv3x3_i8_wide_kernel<true, 4, 1, 128><<<grid, 256, 0, st>>>(a);
     } else {
-        if (bn == 256) conv3x3_i8_wide_kernel<5, false, 8, 1, 256, true><<<grid, 512, 0, st>>>(a);
-        else if (bn == 128) conv3x3_i8_wide_kernel<5, false, 4, 1, 128, true><<<grid, 256, 0, st>>>(a);
-        else conv3x3_i8_wide_kernel<5, false, 2, 1, 64, true><<<grid, 128, 0, st>>>(a);
+        if (bn == 256) conv3x3_i8_wide_kernel<false, 8, 1, 256><<<grid, 512, 0, st>>>(a);
+        else if (bn == 128) conv3x3_i8_wide_kernel<false, 4, 1, 128><<<grid, 256, 0, st>>>(a);
+        else conv3x3_i8_wide_kernel<false, 2, 1, 64><<<grid, 128, 0, st>>>(a);
     }
     return hip_check(hipGetLastError(), "qv2x_conv3x3_i8_wide launch");
 }
