@@ -351,6 +351,13 @@ static int launch_sp(const SpArgs& a, hipStream_t st) {
     return hip_check(hipGetLastError(), "qv2x_sp_conv_i8 launch");
 }
 
+// (a kernel, not hipMemsetAsync: inside a captured hipGraph the memset node did not stay ordered before the scatter on later replays)
+__global__ void fill_bytes_kernel(v4i* __restrict__ p, size_t n16, int8_t* __restrict__ tail, int ntail, int word) {
+    const v4i v = {word, word, word, word};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = (int8_t)word;
+}
+
 __global__ void to_bev_kernel(const int8_t* __restrict__ feat, const int32_t* __restrict__ coords, const int32_t* __restrict__ n_rows, int cap,
                               int C, int Cp, int D, int H, int W, int8_t* __restrict__ bev) {
     const int n = min(*n_rows, cap), c = threadIdx.x;
@@ -489,7 +496,10 @@ extern "C" int qv2x_sp_to_bev_i8(const int8_t* feat, const int32_t* coords, cons
     if ((uintptr_t)coords & 15) return fail(QV2X_EALIGN, "qv2x_sp_to_bev_i8: 16-byte aligned coords");
     hipStream_t st = (hipStream_t)stream;
     const size_t bytes = (size_t)agents * (H + 2) * (W + 2) * c * D;
-    if (int e = hip_check(hipMemsetAsync(bev, fill & 255, bytes, st), "qv2x_sp_to_bev_i8: fill")) return e;
+    if ((uintptr_t)bev & 15) return fail(QV2X_EALIGN, "qv2x_sp_to_bev_i8: 16-byte aligned map");
+    const int word = (int)((unsigned)(fill & 255) * 0x01010101u);
+    const size_t n16 = bytes / 16;
+    fill_bytes_kernel<<<(unsigned)min((n16 + 255) / 256 + 1, (size_t)4096), 256, 0, st>>>((v4i*)bev, n16, bev + n16 * 16, (int)(bytes - n16 * 16), word);
     to_bev_kernel<<<min(cap, 8192), ((c + 63) / 64) * 64, 0, st>>>(feat, coords, n_rows, cap, c, c_padded, D, H, W, bev);
     return hip_check(hipGetLastError(), "qv2x_sp_to_bev_i8 launch");
 }

@@ -94,3 +94,21 @@ def test_whole_model_with_a_second_modality(n_agents):
     sc = second_model_scene_np(n_agents)
     compare_frame(Oracle(state), eng, sc, state)
     compare_frame(Oracle(state), eng, sc, state, every_layer=False)      # again: the index volumes were left clean
+
+
+def test_second_model_as_a_hip_graph():
+    """The whole frame with the SECOND modality captured into one hipGraph (row counts never leave the device): replay == eager."""
+    from _common_second import calibrated_second_model, second_model_scene_np
+    from quantv2x_amd import synth
+    from quantv2x_amd.engine import deploy
+    from quantv2x_amd.ptq_state import export_ptq_state
+    eng = deploy(state=export_ptq_state(calibrated_second_model(n_agents=2)), device="cuda:0")
+    eng.second_max_voxels = 4096
+    sc = synth.scene_to_torch(second_model_scene_np(2), "cuda")
+    want = {k: v.clone() for k, v in eng(sc).items()}
+    rep = eng.capture(sc)
+    for _ in range(2):
+        out = rep()
+        torch.cuda.synchronize()
+        for k in want:
+            assert torch.equal(out[k], want[k]), k

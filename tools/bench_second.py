@@ -65,6 +65,11 @@ def main():
             eng(inp)
     torch.cuda.synchronize()
     out["graph_ms"] = timed(g.replay)
+    eager_codes = eng.dense_codes(eng(inp)).clone()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    out["graph_replay_equals_eager"] = bool(torch.equal(eng.dense_codes(), eager_codes))
     out["graph_int8_top_s"] = 2 * macs / (out["graph_ms"] * 1e-3) / 1e12
     print(json.dumps(out))
 
