@@ -14,7 +14,7 @@ OUT = os.path.join(HERE, "libqv2x.so")
 OBJDIR = os.path.join(HERE, "build")
 # -ffp-contract=off: every fma on the parity-critical paths is written as fmaf(); the compiler must not fuse
 # a separate multiply and add (oracle/qv2x_oracle.c is built the same way).
-CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=default"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=default", "-Wno-inline-asm"]
 FLAGS = CFLAGS + ["-shared"]            # one-shot form (tools that build a variant library use it with SOURCES)
 
 

@@ -21,9 +21,11 @@ namespace qv2x {
 namespace {
 
 constexpr int TH = 5, TW = 32, HWD = TW + 2, HPIX = (TH + 2) * HWD;    // 238 halo pixels
-constexpr int HBLK = (HPIX * 64 + 1023) / 1024;                       // 15 DMA instructions of 1 KiB
-constexpr int HBUF = HBLK * 1024;
-constexpr int BM = TH * TW, WTILE = 256;                             // pixels per workgroup; rows of one pre-tiled weight tile
+constexpr int HPAD = 256;                                              // halo pixels per plane, padded to four 64-pixel DMA blocks
+constexpr int PLANE = HPAD * 16;                                       // one 16-byte K piece of every halo pixel
+constexpr int HBLK = 4 * (HPAD / 64);                                  // 16 DMA instructions of 1 KiB per halo tile
+constexpr int HBUF = 4 * PLANE;                                        // 16 KiB per halo tile
+constexpr int BM = TH * TW, WTILE = 256;                               // pixels per workgroup; rows of one pre-tiled weight tile
 constexpr int MT = 5;
 constexpr int MAX_CHUNKS = 24;
 
@@ -40,23 +42,43 @@ struct WideArgs {
 
 template <int V> struct IC { static constexpr int value = V; };
 
+#ifdef QV2X_WIDE_TRACE      // dev build only (tools/wide_trace.py): s_memtime stamps of wave 0 of every workgroup
+__device__ long long g_wide_trace[8192 * 6];
+#define WTRACE(k) do { if (tid == 0 && blockIdx.x < 8192) g_wide_trace[blockIdx.x * 6 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WTRACE(k) do { } while (0)
+#endif
+
 // NW waves, each a 160 x 32 register tile (NT = 1), BN = NW * 32 output channels per workgroup:
-//   <8, 1, 256>  the shrinker: one workgroup per 5 x 32 patch (two waves per SIMD; a <4, 2> split -- one wave per SIMD, two channel
-//                tiles each -- measured slower, 37.5 vs 31.5 us, and the three-group layer's fp32 fold accumulators do not fit at NT = 2);
+//   <8, 1, 256>  the shrinker: one workgroup per 5 x 32 patch (two waves per SIMD);
 //   <4, 1, 128>  the backbone's 128-channel layers, and 256-channel layers whose patches alone would leave CUs idle (25 x 88 x 8 frames =
 //                120 patches): the two channel halves of a patch get block ids 8 apart (same XCD: one L2 serves the halo they both fetch);
 //   <2, 1, 64>   the backbone's 64-channel layers.
+//
+// Round 2, second form.  The first form ran every K step as {request weights, 10 fragment reads, 10 MFMAs} behind one scheduling
+// fence; the two waves of a SIMD fall into lockstep (both read, then both multiply), so a step cost the SUM of its MFMA time and of its
+// address / LDS / issue time: 34 % MFMA-busy.  Now
+//   * the halo tile is PLANAR in LDS -- [16-byte K piece][halo pixel][16 B] -- so a fragment read is one base register plus an
+//     immediate (the tap shift, the M tile and the K half are compile-time constants): no swizzle arithmetic in the loop, and a
+//     16-lane service group of ds_read_b128 covers 256 contiguous bytes (conflict-free for every tap);
+//   * the K loop is software-pipelined by HALF steps inside each wave: the five fragments of K half 1 are requested before the
+//     five MFMAs of K half 0 and the next step's K half 0 before this step's K half 1 -- in the same 40 fragment registers;
+//   * the window sums (sum of the input codes under each output's 3 x 3 x C window, needed for the zero-point terms) no longer
+//     come from dot4 instructions on the fragments inside the loop (with a branch: "whose turn is it"): each landed halo tile adds
+//     its per-pixel channel sums into a 256-entry LDS table once (two 1 KiB pieces per wave) and an output's window sum is nine
+//     table entries at the group fold.  The loop body is one basic block; the fold needs no barrier.
 template <bool MULTI, int NW, int NT, int BN>
 __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kernel(const WideArgs a) {
     static_assert(NW * NT * 32 == BN && WTILE % BN == 0, "wave layout");
-    constexpr int LH = (HBLK + NW - 1) / NW;                           // halo DMA instructions per wave
+    static_assert(HBLK % NW == 0, "every wave moves the same number of halo pieces");
+    constexpr int LH = HBLK / NW;                                      // halo DMA instructions per wave
     constexpr int NF = MULTI ? 16 : 1;
     static_assert(NT == 1, "the epilogue below is written for one 32-channel tile per wave");
     constexpr int NG = MULTI ? QV2X_MAX_GROUPS : 1;
-    __shared__ __attribute__((aligned(16))) int8_t lds[2 * HBUF + NW * BM * 4 + NG * BN * 16];
+    __shared__ __attribute__((aligned(16))) int8_t lds[2 * HBUF + (NG + 1) * HPAD * 4 + NG * BN * 16];
     int8_t* hbuf = lds;
-    int* xbuf = (int*)(lds + 2 * HBUF);                              // [NW][BM] partial window sums
-    v4i* ctab = (v4i*)(xbuf + NW * BM);                                // [group][BN] {aw, corr_g, scale_g (bits), bias (bits)} per channel
+    int* psum = (int*)(lds + 2 * HBUF);                                // [group | one spare][halo pixel] channel sums
+    v4i* ctab = (v4i*)(psum + (NG + 1) * HPAD);                        // [group][BN] {aw, corr_g, scale_g (bits), bias (bits)} per channel
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -67,37 +89,31 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
     const int txi = patch % a.tiles_x, tyi = (patch / a.tiles_x) % a.tiles_y, img = patch / (a.tiles_x * a.tiles_y);
     const int y0 = tyi * TH, x0 = txi * TW, n0 = cb * BN;
     const int total = a.nchunks * 9;
+    WTRACE(0);
 
-    // ---- DMA sources (the LDS side of global_load_lds is lane-linear, so the XOR swizzle lives in the source address)
+    // ---- DMA: piece blk = (plane = blk >> 2, pixel block = blk & 3); lane l of the instruction moves the 16 bytes `plane` of halo
+    //      pixel 64 (blk & 3) + l (the LDS side of global_load_lds is lane-linear: 1 KiB of ONE plane per instruction)
     unsigned srcH[LH];                                                 // byte offsets from a.in (the tensor is < 4 GiB)
-    int dstH[LH];
 #pragma unroll
     for (int j = 0; j < LH; ++j) {
-        int blk = wave + NW * j;
-        blk = blk < HBLK ? blk : blk - HBLK;                          // surplus slots re-load a block: same bytes
-        const int p = blk * 64 + lane;
-        int hpx = p >> 2;
-        const int c = (p & 3) ^ ((hpx >> 2) & 3);
+        const int blk = wave + NW * j;
+        int hpx = (blk & 3) * 64 + lane;
         hpx = hpx < HPIX ? hpx : HPIX - 1;
         const int hy = hpx / HWD, hx = hpx - hy * HWD;
         const int yy = min(y0 + hy, a.hp - 1), xx = min(x0 + hx, a.wp - 1);
-        srcH[j] = (unsigned)(((img * a.hp + yy) * a.wp + xx) * a.cin_total + c * 16);
-        dstH[j] = blk * 1024;
+        srcH[j] = (unsigned)(((img * a.hp + yy) * a.wp + xx) * a.cin_total + (blk >> 2) * 16);
     }
     v16i acc[MT][NT];
     float facc[MT][NT][NF];
-    int xs[MT];
     // The WEIGHTS are the A operand of the MFMA (out^T = W x^T): lane l holds pixel (l & 31) of every M tile and the 16 channels
     //   cl(r) = 32 wave + 8 (r >> 2) + 4 (l >> 5) + (r & 3)
-    // of this wave's tile -- the window sum is per lane, the constants of a channel come as one ds_read_b128 from `ctab`, and
-    // four consecutive channels pack into one dword of the output row (see conv_i8.hip).
+    // of this wave's tile -- the constants of a channel come as one ds_read_b128 from `ctab`, and four consecutive channels pack
+    // into one dword of the output row (see conv_i8.hip).
     const int half = lane >> 5;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        xs[i] = 0;
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][0][r] = 0;
-    }
     if (MULTI) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
@@ -113,21 +129,33 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
         const int cc = chunk < a.nchunks ? chunk : a.nchunks - 1;
         const int off = a.coff[cc];
         int8_t* buf = hbuf + (chunk & 1) * HBUF;
+        // Issued as inline asm ON PURPOSE: with a builtin LDS-DMA pending, hipcc turns the next vmcnt wait into vmcnt(0) (it treats the
+        // counter as out of order once DMA and plain loads are mixed), which drains the weight ring and the DMA itself right after
+        // issue.  Unseen by the compiler, its own counts for the weight loads are merely two too strict for one step after a tile
+        // request; the waits that cover the DMAs are the explicit ones (prologue, tap 8, before the epilogue).
+        const unsigned ldsb = (unsigned)(uintptr_t)((__attribute__((address_space(3))) int8_t*)buf) + wave_u * 1024;
 #pragma unroll
         for (int j = 0; j < LH; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.in + (size_t)(srcH[j] + (unsigned)off)),
-                                             (__attribute__((address_space(3))) void*)(buf + dstH[j]), 16, 0, 0);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :: "s"(ldsb + NW * j * 1024), "v"(srcH[j] + (unsigned)off), "s"(a.in) : "memory", "m0");
+    };
+    // per-pixel channel sums of a landed halo tile -> psum[slot] (four planes of a pixel arrive in four pieces: LDS atomics)
+    auto add_psum = [&](int chunk, int slot) __attribute__((always_inline)) {
+        const int8_t* buf = hbuf + (chunk & 1) * HBUF;
+#pragma unroll
+        for (int j = 0; j < LH; ++j) {
+            const int blk = wave + NW * j;
+            const v4i v = *(const v4i*)(buf + blk * 1024 + lane * 16);
+            int s = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s = __builtin_amdgcn_sdot4(v[q], 0x01010101, s, false);
+            __hip_atomic_fetch_add(psum + slot * HPAD + (blk & 3) * 64 + lane, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     };
 
-    // fragment addresses: A row r of m-tile i is output pixel (i, r) of the patch; tap (dy, dx) reads halo pixel
-    // hp = r + 34 (i + dy) + dx, its 16-byte chunk ch stored at ch ^ ((hp >> 2) & 3).  The 32 lanes of a half-wave read 32
-    // CONSECUTIVE halo pixels, so every 16-lane service group of ds_read_b128 ({0-3,12-15,20-27}, ...) covers 16
-    // distinct hp mod 16 = 16 distinct 16-byte slots of the 256-byte bank row, whatever the tap shift.
-    const int hp0 = lane & 31;
     // this lane's 2 x 16 bytes of the weight tile of step `st`: row = its output channel (wave, lane & 31), piece ks * 2 + half of the row's 64 bytes
     const int wstep = a.wtile * 64;                                    // bytes of one step's weight tile
     const int8_t* wdir = a.wt + (size_t)(n0 / a.wtile) * total * wstep + ((n0 % a.wtile) + wave * 32 + (lane & 31)) * 64 + half * 16;
-    static_assert(NT == 1, "one 32-channel tile per wave (weight ring, epilogue)");
     v4i wr[3][2];
     auto load_w = [&](auto slot_c, int st) __attribute__((always_inline)) {
         constexpr int SLOT = decltype(slot_c)::value;
@@ -136,47 +164,28 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
         wr[SLOT][1] = *(const v4i*)(p + 32);
     };
 
-    constexpr int NSET = 1;
-    v4i fa[NSET][2][MT];
-    auto read_frags = [&](auto set_c, int chunk, int tap, int step) __attribute__((always_inline)) {
-        constexpr int SET = decltype(set_c)::value;
-        const int8_t* hb = hbuf + (chunk & 1) * HBUF;
-        const int d = (tap / 3) * HWD + (tap % 3);
-        int hpl = hp0;
-        if (NT == 1) asm volatile("" : "+v"(hpl));                      // keep the 45 tap addresses from being hoisted (and spilled)
+    // fragment of (M tile i, tap, K half ks): 16 bytes of halo pixel (lane & 31) + 34 (i + dy) + dx in plane ks * 2 + half:
+    // lane part in one register, the rest an immediate
+    v4i fa[2][MT];
+    const int rlane = half * PLANE + (lane & 31) * 16;
+    auto read_half = [&](auto ks_c, auto tap_c, int chunk) __attribute__((always_inline)) {
+        constexpr int KS = decltype(ks_c)::value, TAP = decltype(tap_c)::value;
+        const int8_t* hb = hbuf + (chunk & 1) * HBUF + rlane;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int hp = hpl + HWD * i + d;
-            const int t = (hp >> 2) & 3;
-            const int a0 = hp * 64 + ((half ^ t) << 4);
-            fa[SET][0][i] = *(const v4i*)(hb + a0);
-            fa[SET][1][i] = *(const v4i*)(hb + (a0 ^ 32));
-        }
+        for (int i = 0; i < MT; ++i) fa[KS][i] = *(const v4i*)(hb + KS * 2 * PLANE + (HWD * (i + TAP / 3) + TAP % 3) * 16);
     };
 
     int g = 0;
     auto fold_group = [&]() __attribute__((always_inline)) {
+        // window sums of this group: nine psum entries per output pixel (rows i .. i + 2 of the halo, columns x .. x + 2)
+        int rowsum[MT + 2];
+        const int* ps = psum + g * HPAD + (lane & 31);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int tot = xs[i] + __shfl_xor(xs[i], 32);
-            if (lane < 32) xbuf[wave * BM + i * 32 + lane] = tot;
-            xs[i] = 0;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        for (int t = tid; t < BM; t += NW * 64) {                       // (a two-wave workgroup has fewer threads than the patch has pixels)
-            int v = 0;
+        for (int k = 0; k < MT + 2; ++k) rowsum[k] = ps[k * HWD] + ps[k * HWD + 1] + ps[k * HWD + 2];
+        int totv[MT];
 #pragma unroll
-            for (int w = 0; w < NW; ++w) v += xbuf[w * BM + t];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            xbuf[t] = v;                                               // only this thread touches column t of row 0
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        for (int i = 0; i < MT; ++i) totv[i] = rowsum[i] + rowsum[i + 1] + rowsum[i + 2];
         if (MULTI) {
-            int totv[MT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) totv[i] = xbuf[i * 32 + (lane & 31)];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const v4i c = ctab[g * BN + wave * 32 + 8 * (r >> 2) + 4 * half + (r & 3)];
@@ -189,18 +198,15 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
                     acc[i][0][r] = 0;
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                              // xbuf is rewritten by the next fold
         }
     };
 
-    // ---- prologue: halo of chunk 0, weights of steps 0 and 1 --------------------------------------------------------
+    // ---- prologue: halo tiles of chunks 0 and 1, weights of steps 0 and 1, tables -------------------------------------
     issue_halo(0);
     load_w(IC<0>{}, 0);
     load_w(IC<1>{}, 1);
-
-    // per-channel constants -> LDS table (younger than the prologue DMAs: waiting for them also lands the prologue, which the
-    // first K step needs anyway)
+    issue_halo(1);
+    for (int t = tid; t < (NG + 1) * HPAD; t += NW * 64) psum[t] = 0;
     if (tid < BN) {
         const int co = n0 + tid;
         const int awv = a.aw[co];
@@ -215,36 +221,38 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    add_psum(0, 0);
+    read_half(IC<0>{}, IC<0>{}, 0);
+    WTRACE(1);
 
-    // One K-step = (chunk, tap): request the weights of step + 2, read this tap's halo fragments, multiply.  The waves only meet at tap 0:
-    // by then every wave's share of this chunk's halo tile has landed and nobody reads the other halo buffer any more.
+    // One K step = (chunk, tap), in two halves.  On entry the K-half-0 fragments of the step are in flight or landed.
     auto one_step = [&](auto tap_c, int chunk) __attribute__((always_inline)) {
-        constexpr int TAP = decltype(tap_c)::value, SET = 0;
+        constexpr int TAP = decltype(tap_c)::value;
         const int step = chunk * 9 + TAP;
         load_w(IC<(TAP + 2) % 3>{}, step + 2);                         // slot of step - 1, which is done
-        if (TAP == 0) {
-            // the halo of this chunk was requested nine steps ago, before every weight load still in flight (steps +0, +1, +2)
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                              // ... by every wave; and every wave is done with the other halo buffer
-            issue_halo(chunk + 1);
-        }
-        read_frags(IC<0>{}, chunk, TAP, step);
+        read_half(IC<1>{}, tap_c, chunk);
         __builtin_amdgcn_sched_barrier(0);
-        if (((chunk + TAP) & (NW - 1)) == wave_u) {                   // window sums: the waves take turns, one step each
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) xs[i] = __builtin_amdgcn_sdot4(fa[SET][ks][i][q], 0x01010101, xs[i], false);
+        for (int i = 0; i < MT; ++i) acc[i][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wr[TAP % 3][0], fa[0][i], acc[i][0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (TAP < 8) {
+            read_half(IC<0>{}, IC<(TAP + 1) % 9>{}, chunk);
+        } else {
+            // the next chunk's halo tile was requested nine steps ago, before all but the youngest weight loads; every wave's reads of
+            // THIS chunk's tile are done once it has passed the wait below, so after the barrier the tile's buffer can be refilled
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int nxt = chunk + 1;
+            add_psum(nxt, nxt < a.nchunks ? (MULTI ? (nxt >= a.cend[g] ? g + 1 : g) : 0) : NG);   // (before the DMA below: an LDS write
+            issue_halo(chunk + 2);                                     //  after a pending LDS-DMA makes the compiler drain vmcnt)
+            read_half(IC<0>{}, IC<0>{}, nxt);
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wr[TAP % 3][ks], fa[SET][ks][i], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < MT; ++i) acc[i][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wr[TAP % 3][1], fa[1][i], acc[i][0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     };
     for (int chunk = 0; chunk < a.nchunks; ++chunk) {
         one_step(IC<0>{}, chunk); one_step(IC<1>{}, chunk); one_step(IC<2>{}, chunk);
@@ -252,17 +260,24 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
         one_step(IC<6>{}, chunk); one_step(IC<7>{}, chunk); one_step(IC<8>{}, chunk);
         if (MULTI && chunk + 1 == a.cend[g]) { fold_group(); ++g; }
     }
-    if (!MULTI) fold_group();
+    WTRACE(2);
+    int totv[MT];
+    if (!MULTI) {
+        const int* ps = psum + (lane & 31);
+        int rowsum[MT + 2];
+#pragma unroll
+        for (int k = 0; k < MT + 2; ++k) rowsum[k] = ps[k * HWD] + ps[k * HWD + 1] + ps[k * HWD + 2];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) totv[i] = rowsum[i] + rowsum[i + 1] + rowsum[i + 2];
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
+    WTRACE(3);
     // ---- epilogue: requantize four channels at a time, stage [pixel][32 channels] per M tile, 16-byte stores ---------------
     constexpr int SP = 48;                                             // staging row pitch (2-way bank spread for the dword writes)
     int8_t* stagebuf = lds + wave * (32 * SP);
     const float rd = 1.0f / a.out_delta, lo = a.relu ? 0.0f : -3.0e38f;
-    int totv[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) totv[i] = MULTI ? 0 : xbuf[i * 32 + (lane & 31)];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -295,6 +310,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
     }
+    WTRACE(4);
 }
 
 // [Cout][G][3][3][C_g] -> [Cout/wtile][chunk = (g, cc)][tap][wtile][64], wtile = min(Cout, 256)
@@ -357,9 +373,19 @@ int fill_args(const qv2x_conv_desc* d, WideArgs& a) {
 // output channels per workgroup: 256 (8 waves) while that fills the chip, else 128 (4 waves), 64 for the 64-channel layers
 static int wide_bn(const qv2x_conv_desc* d) {
     const long long patches = (long long)d->n * ((d->h + qv2x::TH - 1) / qv2x::TH) * ((d->w + qv2x::TW - 1) / qv2x::TW);
+#ifdef QV2X_WIDE_FORCE_BN128
+    if (d->cout % 256 == 0) return 128;
+#endif
     if (d->cout % 256 == 0) return patches * (d->cout / 256) >= 192 ? 256 : 128;
     return d->cout;
 }
+
+#ifdef QV2X_WIDE_TRACE
+extern "C" int qv2x_debug_wide_trace(long long* host_out, int nblocks) {
+    using namespace qv2x;
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wide_trace), (size_t)nblocks * 6 * sizeof(long long));
+}
+#endif
 
 extern "C" int qv2x_conv3x3_i8_wide_ok(const qv2x_conv_desc* d) {
     if (!d || d->stride != 1 || (d->cout != 64 && d->cout != 128 && d->cout % 256) || d->ngroups < 1 || d->ngroups > QV2X_MAX_GROUPS) return 0;

@@ -1,0 +1,28 @@
+"""Dev tool (GPU box): where a workgroup of the wide conv kernel spends its time (s_memtime stamps, build with -DQV2X_WIDE_TRACE).
+    python tools/wide_trace.py <tag> <n_frames>"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from quantv2x_amd import lib as L
+tag, n = sys.argv[1], int(sys.argv[2])
+L.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cache", "abl", f"libqv2x_{tag}.so")
+from quantv2x_amd import synth
+from quantv2x_amd.engine import deploy
+eng = deploy(path=os.path.join(os.path.dirname(os.path.abspath(__file__)), "cache", "v2xreal_state.npz"))
+dd = synth.scene_to_torch(synth.make_scene("v2xreal", n_agents=n, seed=3, n_points=60000), "cuda")
+eng(dd); torch.cuda.synchronize()
+raw = C.CDLL(L.LIB_PATH)
+for (kind, layer, x, h, w, o, c0, macs) in eng.conv_plan(n):
+    if kind != "conv" or not layer.name.startswith("shrinker"): continue
+    for _ in range(3): eng._conv(layer, x, n, h, w, o)
+    torch.cuda.synchronize()
+    nb = min(8192, ((n * 20 * 11 + 7) // 8) * 8)
+    buf = np.zeros((nb, 6), np.int64)
+    rc = raw.qv2x_debug_wide_trace(buf.ctypes.data_as(C.c_void_p), nb); assert rc == 0, rc
+    buf = buf[buf[:, 0] > 0]
+    d = np.diff(buf[:, :5], axis=1).astype(np.float64)   # s_memtime ticks are 100 MHz on gfx9 (10 ns)
+    t0 = buf[:, 0].min()
+    print(layer.name, "blocks", len(buf), "ticks: prologue %.0f  k-loop %.0f  fold %.0f  epilogue %.0f  | total %.0f  | kernel span %.0f" %
+          (d[:, 0].mean(), d[:, 1].mean(), d[:, 2].mean(), d[:, 3].mean(), (buf[:, 4] - buf[:, 0]).mean(), buf[:, 4].max() - t0))
+    starts = np.sort(buf[:, 0] - t0)
+    print("   start ticks percentiles 0/25/50/75/100:", [int(np.percentile(starts, q)) for q in (0, 25, 50, 75, 100)])
