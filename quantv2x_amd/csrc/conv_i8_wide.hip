@@ -42,9 +42,16 @@ struct WideArgs {
 
 template <int V> struct IC { static constexpr int value = V; };
 
+#if defined(QV2X_WABL) && QV2X_WABL == 1      // dev ablation: no MFMAs, the operands stay live
+__device__ __forceinline__ v16i wabl_nomfma(v4i a, v4i b, v16i c) { c[0] += a[0] + b[0]; c[1] += a[3] ^ b[3]; return c; }
+#define WMFMA(a, b, c) wabl_nomfma(a, b, c)
+#else
+#define WMFMA(a, b, c) __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0)
+#endif
+
 #ifdef QV2X_WIDE_TRACE      // dev build only (tools/wide_trace.py): s_memtime stamps of wave 0 of every workgroup
-__device__ long long g_wide_trace[8192 * 6];
-#define WTRACE(k) do { if (tid == 0 && blockIdx.x < 8192) g_wide_trace[blockIdx.x * 6 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ long long g_wide_trace[8192 * 8];
+#define WTRACE(k) do { if (tid == 0 && blockIdx.x < 8192) g_wide_trace[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define WTRACE(k) do { } while (0)
 #endif
@@ -75,9 +82,12 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
     constexpr int NF = MULTI ? 16 : 1;
     static_assert(NT == 1, "the epilogue below is written for one 32-channel tile per wave");
     constexpr int NG = MULTI ? QV2X_MAX_GROUPS : 1;
-    __shared__ __attribute__((aligned(16))) int8_t lds[2 * HBUF + (NG + 1) * HPAD * 4 + NG * BN * 16];
+    constexpr int SP = 48;                                             // epilogue staging row pitch (2-way bank spread for the dword writes)
+    constexpr int STAGE = NW * MT * 32 * SP;                           // every wave stages its MT tiles of [32 pixels][32 channels]
+    constexpr int UNI = 2 * HBUF > STAGE ? 2 * HBUF : STAGE;           // the halo tiles and the staging area share their bytes
+    __shared__ __attribute__((aligned(16))) int8_t lds[UNI + (NG + 1) * HPAD * 4 + NG * BN * 16];
     int8_t* hbuf = lds;
-    int* psum = (int*)(lds + 2 * HBUF);                                // [group | one spare][halo pixel] channel sums
+    int* psum = (int*)(lds + UNI);                                     // [group | one spare][halo pixel] channel sums
     v4i* ctab = (v4i*)(psum + (NG + 1) * HPAD);                        // [group][BN] {aw, corr_g, scale_g (bits), bias (bits)} per channel
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -90,6 +100,9 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
     const int y0 = tyi * TH, x0 = txi * TW, n0 = cb * BN;
     const int total = a.nchunks * 9;
     WTRACE(0);
+#ifdef QV2X_WIDE_TRACE
+    { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); if (tid == 0 && blockIdx.x < 8192) { g_wide_trace[blockIdx.x * 8 + 5] = hw; g_wide_trace[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime(); } }
+#endif
 
     // ---- DMA: piece blk = (plane = blk >> 2, pixel block = blk & 3); lane l of the instruction moves the 16 bytes `plane` of halo
     //      pixel 64 (blk & 3) + l (the LDS side of global_load_lds is lane-linear: 1 KiB of ONE plane per instruction)
@@ -155,13 +168,27 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
 
     // this lane's 2 x 16 bytes of the weight tile of step `st`: row = its output channel (wave, lane & 31), piece ks * 2 + half of the row's 64 bytes
     const int wstep = a.wtile * 64;                                    // bytes of one step's weight tile
-    const int8_t* wdir = a.wt + (size_t)(n0 / a.wtile) * total * wstep + ((n0 % a.wtile) + wave * 32 + (lane & 31)) * 64 + half * 16;
+    // (the tile is stored in fragment order -- [32-row block][K half][lane][16 B] -- so each load instruction reads 1 KiB contiguous)
+    const int8_t* wdir = a.wt + (size_t)(n0 / a.wtile) * total * wstep + ((n0 % a.wtile) / 32 + wave) * 2048 + lane * 16;
     v4i wr[3][2];
+#if defined(QV2X_WABL) && QV2X_WABL == 4
+    v4i wdummy[3][2];
+#endif
     auto load_w = [&](auto slot_c, int st) __attribute__((always_inline)) {
         constexpr int SLOT = decltype(slot_c)::value;
+#if defined(QV2X_WABL) && QV2X_WABL == 3
+        if (st > 1) return;
+#endif
+#if defined(QV2X_WABL) && QV2X_WABL == 4
+        if (st > 1) {
+            const int8_t* pd = wdir + (size_t)(st < total ? st : total - 1) * wstep;
+            wdummy[SLOT][0] = *(const v4i*)pd; wdummy[SLOT][1] = *(const v4i*)(pd + 1024);
+            return;
+        }
+#endif
         const int8_t* p = wdir + (size_t)(st < total ? st : total - 1) * wstep;
         wr[SLOT][0] = *(const v4i*)p;
-        wr[SLOT][1] = *(const v4i*)(p + 32);
+        wr[SLOT][1] = *(const v4i*)(p + 1024);
     };
 
     // fragment of (M tile i, tap, K half ks): 16 bytes of halo pixel (lane & 31) + 34 (i + dy) + dx in plane ks * 2 + half:
@@ -170,6 +197,9 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
     const int rlane = half * PLANE + (lane & 31) * 16;
     auto read_half = [&](auto ks_c, auto tap_c, int chunk) __attribute__((always_inline)) {
         constexpr int KS = decltype(ks_c)::value, TAP = decltype(tap_c)::value;
+#if defined(QV2X_WABL) && QV2X_WABL == 2
+        if (chunk > 0 || TAP > 0) return;
+#endif
         const int8_t* hb = hbuf + (chunk & 1) * HBUF + rlane;
 #pragma unroll
         for (int i = 0; i < MT; ++i) fa[KS][i] = *(const v4i*)(hb + KS * 2 * PLANE + (HWD * (i + TAP / 3) + TAP % 3) * 16);
@@ -235,7 +265,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
         read_half(IC<1>{}, tap_c, chunk);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) acc[i][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wr[TAP % 3][0], fa[0][i], acc[i][0], 0, 0, 0);
+        for (int i = 0; i < MT; ++i) acc[i][0] = WMFMA(wr[TAP % 3][0], fa[0][i], acc[i][0]);
         __builtin_amdgcn_sched_barrier(0);
         if (TAP < 8) {
             read_half(IC<0>{}, IC<(TAP + 1) % 9>{}, chunk);
@@ -251,7 +281,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) acc[i][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wr[TAP % 3][1], fa[1][i], acc[i][0], 0, 0, 0);
+        for (int i = 0; i < MT; ++i) acc[i][0] = WMFMA(wr[TAP % 3][1], fa[1][i], acc[i][0]);
         __builtin_amdgcn_sched_barrier(0);
     };
     for (int chunk = 0; chunk < a.nchunks; ++chunk) {
@@ -260,6 +290,9 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
         one_step(IC<6>{}, chunk); one_step(IC<7>{}, chunk); one_step(IC<8>{}, chunk);
         if (MULTI && chunk + 1 == a.cend[g]) { fold_group(); ++g; }
     }
+#if defined(QV2X_WABL) && QV2X_WABL == 4
+    asm volatile("" :: "v"(wdummy[0][0]), "v"(wdummy[0][1]), "v"(wdummy[1][0]), "v"(wdummy[1][1]), "v"(wdummy[2][0]), "v"(wdummy[2][1]));
+#endif
     WTRACE(2);
     int totv[MT];
     if (!MULTI) {
@@ -274,14 +307,19 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
     __builtin_amdgcn_s_barrier();
 
     WTRACE(3);
-    // ---- epilogue: requantize four channels at a time, stage [pixel][32 channels] per M tile, 16-byte stores ---------------
-    constexpr int SP = 48;                                             // staging row pitch (2-way bank spread for the dword writes)
-    int8_t* stagebuf = lds + wave * (32 * SP);
+    // ---- epilogue: a channel quad's constants are read once and applied to all MT tiles (MT independent chains in flight), the
+    //      bytes staged as [tile][pixel][32 channels] per wave, then MT 16-byte stores per lane back to back --------------------
+    int8_t* stagebuf = lds + wave * (MT * 32 * SP);
     const float rd = 1.0f / a.out_delta, lo = a.relu ? 0.0f : -3.0e38f;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+    for (int g4 = 0; g4 < 4; ++g4) {
+        v4i c[4];
+        if (!MULTI) {
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
+            for (int e = 0; e < 4; ++e) c[e] = ctab[wave * 32 + 8 * g4 + 4 * half + e];
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
             float y[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -289,38 +327,48 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
                 if (MULTI) {
                     y[e] = facc[i][0][r];
                 } else {
-                    const v4i c = ctab[wave * 32 + 8 * g4 + 4 * half + e];
-                    const int T = acc[i][0][r] + __mul24(c[0], totv[i]) + c[1];
-                    const int sci = c[2], bsi = c[3];
+                    const int T = acc[i][0][r] + __mul24(c[e][0], totv[i]) + c[e][1];
+                    const int sci = c[e][2], bsi = c[e][3];
                     y[e] = __int_as_float(bsi) + (float)T * __int_as_float(sci);
                 }
                 y[e] = fmaxf(y[e], lo);
             }
-            *(int*)(stagebuf + (lane & 31) * SP + 8 * g4 + 4 * half) = q_pack4(y[0], y[1], y[2], y[3], a.out_delta, rd, a.out_zp);
+            *(int*)(stagebuf + (i * 32 + (lane & 31)) * SP + 8 * g4 + 4 * half) = q_pack4(y[0], y[1], y[2], y[3], a.out_delta, rd, a.out_zp);
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        {
-            const int row = lane >> 1, chn = lane & 1;
-            const int yo = y0 + i, xo = x0 + row;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    {
+        const int row = lane >> 1, chn = lane & 1;
+        const int xo = x0 + row;
+        v4i ob[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) ob[i] = *(const v4i*)(stagebuf + (i * 32 + row) * SP + chn * 16);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int yo = y0 + i;
             if (yo < a.ho && xo < a.wo)
-                *(v4i*)(a.out + ((size_t)(img * (a.ho + 2) + yo + 1) * (a.wo + 2) + xo + 1) * a.out_ctotal + a.out_c0 + n0 + wave * 32 + chn * 16) =
-                    *(const v4i*)(stagebuf + row * SP + chn * 16);
+                *(v4i*)(a.out + ((size_t)(img * (a.ho + 2) + yo + 1) * (a.wo + 2) + xo + 1) * a.out_ctotal + a.out_c0 + n0 + wave * 32 + chn * 16) = ob[i];
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
     }
     WTRACE(4);
+#ifdef QV2X_WIDE_TRACE
+    if (tid == 0 && blockIdx.x < 8192) g_wide_trace[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
-// [Cout][G][3][3][C_g] -> [Cout/wtile][chunk = (g, cc)][tap][wtile][64], wtile = min(Cout, 256)
+// [Cout][G][3][3][C_g] -> [Cout/wtile][chunk = (g, cc)][tap][wtile/32][K half][lane][16], wtile = min(Cout, 256)
 __global__ void pack_wide_kernel(const int8_t* __restrict__ w, int8_t* __restrict__ wt, int cout, int ktot, int nchunks,
                                  WideArgs a) {
     const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one 16-byte unit each
     const long long units = (long long)cout * ktot / 16;
     if (u >= units) return;
-    const int c16 = u & 3;
-    const int row = (int)((u >> 2) % a.wtile);
+    // destination unit u = ((tile * (wtile / 32) + row block) * 2 + K half) * 64 + lane: the 16 bytes lane `lane` feeds to the MFMA as
+    // its A operand (row = lane & 31 of the block, K piece = 2 * half + (lane >> 5))
+    const int ln = u & 63, ksh = (int)((u >> 6) & 1);
+    const int rb = (int)((u >> 7) % (a.wtile / 32));
+    const int c16 = ksh * 2 + (ln >> 5);
+    const int row = rb * 32 + (ln & 31);
     const long long tile = u / (a.wtile * 4);
     const int step = tile % (nchunks * 9);
     const int nb = tile / (nchunks * 9);
@@ -383,7 +431,13 @@ static int wide_bn(const qv2x_conv_desc* d) {
 #ifdef QV2X_WIDE_TRACE
 extern "C" int qv2x_debug_wide_trace(long long* host_out, int nblocks) {
     using namespace qv2x;
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wide_trace), (size_t)nblocks * 6 * sizeof(long long));
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wide_trace), (size_t)nblocks * 8 * sizeof(long long));
+}
+extern "C" int qv2x_debug_wide_trace_clear() {
+    using namespace qv2x;
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_wide_trace)) != hipSuccess) return -1;
+    return (int)hipMemset(p, 0, sizeof(g_wide_trace));
 }
 #endif
 

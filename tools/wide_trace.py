@@ -13,16 +13,22 @@ dd = synth.scene_to_torch(synth.make_scene("v2xreal", n_agents=n, seed=3, n_poin
 eng(dd); torch.cuda.synchronize()
 raw = C.CDLL(L.LIB_PATH)
 for (kind, layer, x, h, w, o, c0, macs) in eng.conv_plan(n):
-    if kind != "conv" or not layer.name.startswith("shrinker"): continue
+    if kind != "conv" or not (layer.name.startswith("shrinker") or layer.name.endswith((".0.2", ".1.2", ".2.2"))): continue
+    torch.cuda.synchronize(); assert raw.qv2x_debug_wide_trace_clear() == 0
     for _ in range(3): eng._conv(layer, x, n, h, w, o)
     torch.cuda.synchronize()
-    nb = min(8192, ((n * 20 * 11 + 7) // 8) * 8)
-    buf = np.zeros((nb, 6), np.int64)
+    nb = 8192
+    buf = np.zeros((nb, 8), np.int64)
     rc = raw.qv2x_debug_wide_trace(buf.ctypes.data_as(C.c_void_p), nb); assert rc == 0, rc
     buf = buf[buf[:, 0] > 0]
     d = np.diff(buf[:, :5], axis=1).astype(np.float64)   # s_memtime ticks are 100 MHz on gfx9 (10 ns)
     t0 = buf[:, 0].min()
     print(layer.name, "blocks", len(buf), "ticks: prologue %.0f  k-loop %.0f  fold %.0f  epilogue %.0f  | total %.0f  | kernel span %.0f" %
           (d[:, 0].mean(), d[:, 1].mean(), d[:, 2].mean(), d[:, 3].mean(), (buf[:, 4] - buf[:, 0]).mean(), buf[:, 4].max() - t0))
+    rt = (buf[:, 7] - buf[:, 6]).astype(np.float64)          # s_memrealtime: 100 MHz
+    print("   shader clock seen by the workgroups: %.2f GHz (memtime ticks per 10 ns realtime tick / 10); kernel wall (realtime) %.1f us" %
+          (((buf[:, 4] - buf[:, 0]) / rt).mean() / 10.0, (buf[:, 7].max() - buf[:, 6].min()) / 100.0))
+    hw = buf[:, 5]
+    print("   wave slot histogram:", np.bincount((hw & 15).astype(int)), " simd:", np.bincount(((hw >> 4) & 3).astype(int)), " first 16 blocks slot/cu:", [(int(h & 15), int((h >> 8) & 15)) for h in hw[:16]])
     starts = np.sort(buf[:, 0] - t0)
     print("   start ticks percentiles 0/25/50/75/100:", [int(np.percentile(starts, q)) for q in (0, 25, 50, 75, 100)])
