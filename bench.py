@@ -338,7 +338,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=8, help="frames per step (per rank)")
-    ap.add_argument("--inflight", type=int, default=2, help="batches in flight at N = 1 (streams / engines)")
+    ap.add_argument("--inflight", type=int, default=2, help="batches in flight per rank (streams / engines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path (two HIP graphs around the collective) with one rank")
     ap.add_argument("--link", default="torch", choices=["torch", "rccl"], help="N>1 collective: torch.distributed or qv2x_allgather_codes")
@@ -387,12 +387,28 @@ def main():
         frames_per_step = B
     else:
         from quantv2x_amd.dist import AgentShardedModel
-        F = 1
-        sharded = AgentShardedModel(eng, frames=B, link=args.link, max_cav=5)
+        from quantv2x_amd.engine import deploy
+        # F batches in flight per rank, each with its own engine (workspace), graphs and stream; every rank issues the collectives in the
+        # same round-robin order, so the F all-gathers in flight on one communicator cannot cross
+        F = max(1, args.inflight)
+        engines = [eng] + [deploy(state=state) for _ in range(F - 1)]
+        streams = [torch.cuda.Stream() for _ in range(F)]
+        shardeds = [AgentShardedModel(e, frames=B, link=args.link, max_cav=5) for e in engines]
         pose = torch.from_numpy(poses[rank]).to(device)
-        step = lambda: sharded.forward(mine, pose)
+        for sh, st in zip(shardeds, streams):                         # capture (and the lazy one-off work) up front, slot by slot
+            with torch.cuda.stream(st):
+                sh.forward(mine, pose)
+            torch.cuda.synchronize()
+        it = [0]
+
+        def step():
+            i = it[0] % F
+            it[0] += 1
+            with torch.cuda.stream(streams[i]):
+                shardeds[i].forward(mine, pose)
         launch = (f"per rank: hipGraph (a1-a6, {B} frames) -> all-gather of code planes + poses "
-                  f"({'torch.distributed nccl = RCCL' if args.link == 'torch' else 'qv2x_allgather_codes (RCCL)'}) -> hipGraph (a7-a11)")
+                  f"({'torch.distributed nccl = RCCL' if args.link == 'torch' else 'qv2x_allgather_codes (RCCL)'}) -> hipGraph (a7-a11); "
+                  f"{F} batches in flight on {F} streams")
         frames_per_step = B * world
         print(f"[bench] rank {rank}/{world} on cuda:{local}: RCCL world size {dist.get_world_size()}", file=sys.stderr, flush=True)
 
