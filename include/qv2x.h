@@ -96,8 +96,9 @@ int qv2x_conv3x3_i8(const qv2x_conv_desc* desc /* host */, const int8_t* in, con
 
 /* The same convolution for wide layers (stride 1, cout % 256 == 0: the DoubleConv shrinker,
  * opencood/models/sub_modules/downsample_conv.py:17-31 under quant_block.py:552-572) with the weights pre-tiled:
- *   w_wide : i8 [Cout/256][chunk][tap][256][64], chunk = the 64-channel chunks of group 0, then of group 1, ...
- *            (16 KB contiguous per K-step; made from the row-major layout by qv2x_conv3x3_i8_pack_wide, once).
+ *   w_wide : i8 [Cout/T][chunk][tap][T/32][K half][lane][16], T = min(Cout, 256), chunk = the 64-channel chunks of group 0, then
+ *            of group 1, ...: the MFMA A-operand fragments of a K step in load order (T x 64 bytes contiguous per K step, 1 KiB per
+ *            wave-instruction); opaque to the caller, made from the row-major layout by qv2x_conv3x3_i8_pack_wide, once.
  * Results are bit-identical to qv2x_conv3x3_i8.  qv2x_conv3x3_i8_wide_ok returns 1 when the layer qualifies
  * (and is large enough for the wide kernel to pay: N*H*W >= 16384), else 0. */
 int qv2x_conv3x3_i8_wide_ok(const qv2x_conv_desc* desc /* host */);
