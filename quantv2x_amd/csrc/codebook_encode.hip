@@ -29,7 +29,10 @@ constexpr int LDF = 258;            // LDS row stride in floats: 32 rows x ds_re
 // dependent MFMAs issue back to back (an extra VALU between two MFMAs on one accumulator costs ~45 cycles on gfx950).
 __device__ __forceinline__ int kpos(int c) { return (c & ~3) | ((c & 1) << 1) | ((c >> 1) & 1); }
 constexpr int D = 256;
-constexpr int ENC_SMEM_FLOATS = 2 * ER * LDF + ER + 4 * ER + 8 * ER + ER;
+#ifndef QV2X_ENC_LDS_PAD        // dev builds: extra LDS floats per workgroup (occupancy experiments)
+#define QV2X_ENC_LDS_PAD 0
+#endif
+constexpr int ENC_SMEM_FLOATS = 2 * ER * LDF + ER + 4 * ER + 8 * ER + ER + QV2X_ENC_LDS_PAD;
 
 struct EncArgs {
     const int8_t* in; const float* in_f32; uint8_t* codes;      // in_f32 != null: the rows come as fp32 (un-quantized model)

@@ -42,6 +42,11 @@ def _padded(x_u8, zx_per_channel):
     (2, 13, 37, [(0, 64)], 64),
     (1, 5, 32, [(0, 128)], 128),
     (2, 13, 37, [(0, 128)], 128),
+    (1, 6, 33, [(0, 192)], 256),            # an odd number of 64-channel chunks (the halo double buffer ends on buffer 0)
+    (1, 4, 64, [(0, 64), (64, 64)], 256),   # one-chunk groups: a group fold after every chunk
+    (1, 7, 40, [(0, 64), (64, 64), (128, 64), (192, 64)], 256),   # QV2X_MAX_GROUPS groups: every slot of the window-sum table
+    (5, 9, 70, [(0, 128)], 64),             # two-wave workgroups looping over the halo pixels, two chunks
+    (1, 5, 32, [(0, 1536)], 256),           # MAX_CHUNKS chunks
 ])
 def test_wide_matches_regular_and_oracle(n, h, w, groups, cout):
     from oracle.spec import Oracle
