@@ -38,6 +38,7 @@ struct WideArgs {
     int wtile;                        // rows of one pre-tiled weight tile: min(cout, 256)
     int cend[QV2X_MAX_GROUPS];        // first chunk index past group g
     int coff[MAX_CHUNKS];             // channel byte offset of each 64-channel chunk inside a pixel
+    int items;                        // (patch, channel block) pairs, patches padded to a multiple of 8
 };
 
 template <int V> struct IC { static constexpr int value = V; };
@@ -84,20 +85,23 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
     constexpr int NG = MULTI ? QV2X_MAX_GROUPS : 1;
     constexpr int SP = 48;                                             // epilogue staging row pitch (2-way bank spread for the dword writes)
     constexpr int STAGE = NW * MT * 32 * SP;                           // every wave stages its MT tiles of [32 pixels][32 channels]
-    constexpr int UNI = 2 * HBUF > STAGE ? 2 * HBUF : STAGE;           // the halo tiles and the staging area share their bytes
-    __shared__ __attribute__((aligned(16))) int8_t lds[UNI + (NG + 1) * HPAD * 4 + NG * BN * 16];
+    // (the staging area is NOT the halo buffers any more: during an item's epilogue they already hold the next item's first tiles)
+    __shared__ __attribute__((aligned(16))) int8_t lds[2 * HBUF + STAGE + (NG + 1) * HPAD * 4 + NG * BN * 16];
     int8_t* hbuf = lds;
-    int* psum = (int*)(lds + UNI);                                     // [group | one spare][halo pixel] channel sums
+    int8_t* stage = lds + 2 * HBUF;
+    int* psum = (int*)(stage + STAGE);                                 // [group | one spare][halo pixel] channel sums
     v4i* ctab = (v4i*)(psum + (NG + 1) * HPAD);                        // [group][BN] {aw, corr_g, scale_g (bits), bias (bits)} per channel
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    // block id -> (patch, channel block): id = ((patch / 8) * nblk + cb) * 8 + patch % 8
-    const int nblk = a.cout / BN;
-    const int patch = (blockIdx.x / (8 * nblk)) * 8 + (blockIdx.x & 7), cb = (blockIdx.x >> 3) % nblk;
-    if (patch >= a.n * a.tiles_x * a.tiles_y) return;
-    const int txi = patch % a.tiles_x, tyi = (patch / a.tiles_x) % a.tiles_y, img = patch / (a.tiles_x * a.tiles_y);
-    const int y0 = tyi * TH, x0 = txi * TW, n0 = cb * BN;
+    // PERSISTENT workgroups: item id = ((patch / 8) * nblk + cb) * 8 + patch % 8 -> (patch, channel block); a workgroup takes the items
+    // blockIdx.x, + gridDim.x, ... -- the grid is a multiple of 8 * nblk, so its channel block (weights, constants) and its XCD never change.
+    // While an item's epilogue runs, the first two halo tiles and the first two weight steps of the next item are already in flight.
+    const int nblk = a.cout / BN, npatch = a.n * a.tiles_x * a.tiles_y;
+    int item = blockIdx.x;
+    auto patch_of = [&](int it) { return (it / (8 * nblk)) * 8 + (it & 7); };
+    if (item >= a.items || patch_of(item) >= npatch) return;
+    const int cb = (item >> 3) % nblk, n0 = cb * BN;
     const int total = a.nchunks * 9;
     WTRACE(0);
 #ifdef QV2X_WIDE_TRACE
@@ -106,16 +110,26 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
 
     // ---- DMA: piece blk = (plane = blk >> 2, pixel block = blk & 3); lane l of the instruction moves the 16 bytes `plane` of halo
     //      pixel 64 (blk & 3) + l (the LDS side of global_load_lds is lane-linear: 1 KiB of ONE plane per instruction)
-    unsigned srcH[LH];                                                 // byte offsets from a.in (the tensor is < 4 GiB)
-#pragma unroll
-    for (int j = 0; j < LH; ++j) {
+    struct Where { int y0, x0, img; };
+    auto place = [&](int it) __attribute__((always_inline)) {
+        const int patch = patch_of(it);
+        const int txi = patch % a.tiles_x, tyi = (patch / a.tiles_x) % a.tiles_y, img = patch / (a.tiles_x * a.tiles_y);
+        return Where{tyi * TH, txi * TW, img};
+    };
+    // byte offset (from a.in: the tensor is < 4 GiB) of this lane's 16 bytes of DMA piece j of an item's halo tile; recomputed at every
+    // request (once per nine K steps) rather than kept: the three-group kernel has no registers to spare
+    auto src_of = [&](const Where& w, int j) __attribute__((always_inline)) {
         const int blk = wave + NW * j;
         int hpx = (blk & 3) * 64 + lane;
         hpx = hpx < HPIX ? hpx : HPIX - 1;
         const int hy = hpx / HWD, hx = hpx - hy * HWD;
-        const int yy = min(y0 + hy, a.hp - 1), xx = min(x0 + hx, a.wp - 1);
-        srcH[j] = (unsigned)(((img * a.hp + yy) * a.wp + xx) * a.cin_total + (blk >> 2) * 16);
-    }
+        const int yy = min(w.y0 + hy, a.hp - 1), xx = min(w.x0 + hx, a.wp - 1);
+        return (unsigned)(((w.img * a.hp + yy) * a.wp + xx) * a.cin_total + (blk >> 2) * 16);
+    };
+    Where cur = place(item), nxw = cur;
+    bool has_next = false, first = true;
+    int pb = 0;                                                        // halo buffer of the current item's chunk 0
+
     v16i acc[MT][NT];
     float facc[MT][NT][NF];
     // The WEIGHTS are the A operand of the MFMA (out^T = W x^T): lane l holds pixel (l & 31) of every M tile and the 16 channels
@@ -123,38 +137,26 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
     // of this wave's tile -- the constants of a channel come as one ds_read_b128 from `ctab`, and four consecutive channels pack
     // into one dword of the output row (see conv_i8.hip).
     const int half = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0;
-    if (MULTI) {
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const v4f b = *(const v4f*)(a.bias + n0 + wave * 32 + 8 * g4 + 4 * half);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) facc[i][0][4 * g4 + e] = b[e];
-        }
-    }
 
-    auto issue_halo = [&](int chunk) __attribute__((always_inline)) {
-        const int cc = chunk < a.nchunks ? chunk : a.nchunks - 1;
-        const int off = a.coff[cc];
-        int8_t* buf = hbuf + (chunk & 1) * HBUF;
+    // halo tile of chunk c of the current item (c < nchunks) or of chunk c - nchunks of the next one, into buffer (pb + c) & 1
+    auto issue_halo = [&](int c) __attribute__((always_inline)) {
+        const int k = c - a.nchunks;
+        if (k >= 0 && (!has_next || k >= a.nchunks)) return;
+        const int off = a.coff[k < 0 ? c : k];
+        int8_t* buf = hbuf + ((pb + c) & 1) * HBUF;
         // Issued as inline asm ON PURPOSE: with a builtin LDS-DMA pending, hipcc turns the next vmcnt wait into vmcnt(0) (it treats the
         // counter as out of order once DMA and plain loads are mixed), which drains the weight ring and the DMA itself right after
         // issue.  Unseen by the compiler, its own counts for the weight loads are merely two too strict for one step after a tile
-        // request; the waits that cover the DMAs are the explicit ones (prologue, tap 8, before the epilogue).
+        // request; the waits that cover the DMAs are the explicit ones (item start, tap 8).
         const unsigned ldsb = (unsigned)(uintptr_t)((__attribute__((address_space(3))) int8_t*)buf) + wave_u * 1024;
 #pragma unroll
         for (int j = 0; j < LH; ++j)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                         :: "s"(ldsb + NW * j * 1024), "v"(srcH[j] + (unsigned)off), "s"(a.in) : "memory", "m0");
+                         :: "s"(ldsb + NW * j * 1024), "v"(src_of(k < 0 ? cur : nxw, j) + (unsigned)off), "s"(a.in) : "memory", "m0");
     };
     // per-pixel channel sums of a landed halo tile -> psum[slot] (four planes of a pixel arrive in four pieces: LDS atomics)
     auto add_psum = [&](int chunk, int slot) __attribute__((always_inline)) {
-        const int8_t* buf = hbuf + (chunk & 1) * HBUF;
+        const int8_t* buf = hbuf + ((pb + chunk) & 1) * HBUF;
 #pragma unroll
         for (int j = 0; j < LH; ++j) {
             const int blk = wave + NW * j;
@@ -171,22 +173,12 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
     // (the tile is stored in fragment order -- [32-row block][K half][lane][16 B] -- so each load instruction reads 1 KiB contiguous)
     const int8_t* wdir = a.wt + (size_t)(n0 / a.wtile) * total * wstep + ((n0 % a.wtile) / 32 + wave) * 2048 + lane * 16;
     v4i wr[3][2];
-#if defined(QV2X_WABL) && QV2X_WABL == 4
-    v4i wdummy[3][2];
-#endif
     auto load_w = [&](auto slot_c, int st) __attribute__((always_inline)) {
         constexpr int SLOT = decltype(slot_c)::value;
 #if defined(QV2X_WABL) && QV2X_WABL == 3
         if (st > 1) return;
 #endif
-#if defined(QV2X_WABL) && QV2X_WABL == 4
-        if (st > 1) {
-            const int8_t* pd = wdir + (size_t)(st < total ? st : total - 1) * wstep;
-            wdummy[SLOT][0] = *(const v4i*)pd; wdummy[SLOT][1] = *(const v4i*)(pd + 1024);
-            return;
-        }
-#endif
-        const int8_t* p = wdir + (size_t)(st < total ? st : total - 1) * wstep;
+        const int8_t* p = wdir + (size_t)(st < total ? st : st - total) * wstep;   // past the end: steps 0, 1 again -- the next item's
         wr[SLOT][0] = *(const v4i*)p;
         wr[SLOT][1] = *(const v4i*)(p + 1024);
     };
@@ -200,62 +192,37 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
 #if defined(QV2X_WABL) && QV2X_WABL == 2
         if (chunk > 0 || TAP > 0) return;
 #endif
-        const int8_t* hb = hbuf + (chunk & 1) * HBUF + rlane;
+        const int8_t* hb = hbuf + ((pb + chunk) & 1) * HBUF + rlane;
 #pragma unroll
         for (int i = 0; i < MT; ++i) fa[KS][i] = *(const v4i*)(hb + KS * 2 * PLANE + (HWD * (i + TAP / 3) + TAP % 3) * 16);
     };
 
     int g = 0;
-    auto fold_group = [&]() __attribute__((always_inline)) {
-        // window sums of this group: nine psum entries per output pixel (rows i .. i + 2 of the halo, columns x .. x + 2)
+    auto window_sums = [&](int (&totv)[MT]) __attribute__((always_inline)) {
+        // nine psum entries per output pixel (rows i .. i + 2 of the halo, columns x .. x + 2)
         int rowsum[MT + 2];
         const int* ps = psum + g * HPAD + (lane & 31);
 #pragma unroll
         for (int k = 0; k < MT + 2; ++k) rowsum[k] = ps[k * HWD] + ps[k * HWD + 1] + ps[k * HWD + 2];
-        int totv[MT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) totv[i] = rowsum[i] + rowsum[i + 1] + rowsum[i + 2];
-        if (MULTI) {
+    };
+    auto fold_group = [&]() __attribute__((always_inline)) {
+        int totv[MT];
+        window_sums(totv);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const v4i c = ctab[g * BN + wave * 32 + 8 * (r >> 2) + 4 * half + (r & 3)];
-                const int sci = c[2];                                  // (bit_cast straight from the vector element reads element 0)
-                const float sc = __int_as_float(sci);
+        for (int r = 0; r < 16; ++r) {
+            const v4i c = ctab[g * BN + wave * 32 + 8 * (r >> 2) + 4 * half + (r & 3)];
+            const int sci = c[2];                                      // (bit_cast straight from the vector element reads element 0)
+            const float sc = __int_as_float(sci);
 #pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    const int T = acc[i][0][r] + __mul24(c[0], totv[i]) + c[1];
-                    facc[i][0][r] = facc[i][0][r] + (float)T * sc;
-                    acc[i][0][r] = 0;
-                }
+            for (int i = 0; i < MT; ++i) {
+                const int T = acc[i][0][r] + __mul24(c[0], totv[i]) + c[1];
+                facc[i][0][r] = facc[i][0][r] + (float)T * sc;
+                acc[i][0][r] = 0;
             }
         }
     };
-
-    // ---- prologue: halo tiles of chunks 0 and 1, weights of steps 0 and 1, tables -------------------------------------
-    issue_halo(0);
-    load_w(IC<0>{}, 0);
-    load_w(IC<1>{}, 1);
-    issue_halo(1);
-    for (int t = tid; t < (NG + 1) * HPAD; t += NW * 64) psum[t] = 0;
-    if (tid < BN) {
-        const int co = n0 + tid;
-        const int awv = a.aw[co];
-        const float bs = a.bias[co];
-#pragma unroll
-        for (int gg = 0; gg < NG; ++gg) {
-            if (gg < a.ngroups) {
-                v4i c;
-                c[0] = awv; c[1] = a.corr[gg * a.cout + co];
-                c[2] = __float_as_int(a.scale[gg * a.cout + co]); c[3] = __float_as_int(bs);
-                ctab[gg * BN + tid] = c;
-            }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    add_psum(0, 0);
-    read_half(IC<0>{}, IC<0>{}, 0);
-    WTRACE(1);
 
     // One K step = (chunk, tap), in two halves.  On entry the K-half-0 fragments of the step are in flight or landed.
     auto one_step = [&](auto tap_c, int chunk) __attribute__((always_inline)) {
@@ -284,74 +251,129 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
         for (int i = 0; i < MT; ++i) acc[i][0] = WMFMA(wr[TAP % 3][1], fa[1][i], acc[i][0]);
         __builtin_amdgcn_sched_barrier(0);
     };
-    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-        one_step(IC<0>{}, chunk); one_step(IC<1>{}, chunk); one_step(IC<2>{}, chunk);
-        one_step(IC<3>{}, chunk); one_step(IC<4>{}, chunk); one_step(IC<5>{}, chunk);
-        one_step(IC<6>{}, chunk); one_step(IC<7>{}, chunk); one_step(IC<8>{}, chunk);
-        if (MULTI && chunk + 1 == a.cend[g]) { fold_group(); ++g; }
-    }
-#if defined(QV2X_WABL) && QV2X_WABL == 4
-    asm volatile("" :: "v"(wdummy[0][0]), "v"(wdummy[0][1]), "v"(wdummy[1][0]), "v"(wdummy[1][1]), "v"(wdummy[2][0]), "v"(wdummy[2][1]));
-#endif
-    WTRACE(2);
-    int totv[MT];
-    if (!MULTI) {
-        const int* ps = psum + (lane & 31);
-        int rowsum[MT + 2];
-#pragma unroll
-        for (int k = 0; k < MT + 2; ++k) rowsum[k] = ps[k * HWD] + ps[k * HWD + 1] + ps[k * HWD + 2];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) totv[i] = rowsum[i] + rowsum[i + 1] + rowsum[i + 2];
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
 
-    WTRACE(3);
-    // ---- epilogue: a channel quad's constants are read once and applied to all MT tiles (MT independent chains in flight), the
-    //      bytes staged as [tile][pixel][32 channels] per wave, then MT 16-byte stores per lane back to back --------------------
-    int8_t* stagebuf = lds + wave * (MT * 32 * SP);
-    const float rd = 1.0f / a.out_delta, lo = a.relu ? 0.0f : -3.0e38f;
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-        v4i c[4];
-        if (!MULTI) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) c[e] = ctab[wave * 32 + 8 * g4 + 4 * half + e];
-        }
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            float y[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 4 * g4 + e;
-                if (MULTI) {
-                    y[e] = facc[i][0][r];
-                } else {
-                    const int T = acc[i][0][r] + __mul24(c[e][0], totv[i]) + c[e][1];
-                    const int sci = c[e][2], bsi = c[e][3];
-                    y[e] = __int_as_float(bsi) + (float)T * __int_as_float(sci);
-                }
-                y[e] = fmaxf(y[e], lo);
-            }
-            *(int*)(stagebuf + (i * 32 + (lane & 31)) * SP + 8 * g4 + 4 * half) = q_pack4(y[0], y[1], y[2], y[3], a.out_delta, rd, a.out_zp);
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
+    // ---- once per workgroup: the constants of its channel block, the first item's first tiles and weight steps ---------------
     {
-        const int row = lane >> 1, chn = lane & 1;
-        const int xo = x0 + row;
-        v4i ob[MT];
+        const int nx = item + (int)gridDim.x;
+        has_next = nx < a.items && patch_of(nx) < npatch;
+        if (has_next) nxw = place(nx);
+    }
+    issue_halo(0);
+    load_w(IC<0>{}, 0);
+    load_w(IC<1>{}, 1);
+    issue_halo(1);
+    if (tid < BN) {
+        const int co = n0 + tid;
+        const int awv = a.aw[co];
+        const float bs = a.bias[co];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) ob[i] = *(const v4i*)(stagebuf + (i * 32 + row) * SP + chn * 16);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int yo = y0 + i;
-            if (yo < a.ho && xo < a.wo)
-                *(v4i*)(a.out + ((size_t)(img * (a.ho + 2) + yo + 1) * (a.wo + 2) + xo + 1) * a.out_ctotal + a.out_c0 + n0 + wave * 32 + chn * 16) = ob[i];
+        for (int gg = 0; gg < NG; ++gg) {
+            if (gg < a.ngroups) {
+                v4i c;
+                c[0] = awv; c[1] = a.corr[gg * a.cout + co];
+                c[2] = __float_as_int(a.scale[gg * a.cout + co]); c[3] = __float_as_int(bs);
+                ctab[gg * BN + tid] = c;
+            }
         }
     }
-    WTRACE(4);
+
+    for (;;) {
+        // ---- item start: the window-sum table is free once every wave has left the previous item's fold ----------------------
+        __builtin_amdgcn_s_barrier();
+        for (int t = tid; t < (NG + 1) * HPAD; t += NW * 64) psum[t] = 0;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][0][r] = 0;
+        if (MULTI) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const v4f b = *(const v4f*)(a.bias + n0 + wave * 32 + 8 * g4 + 4 * half);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) facc[i][0][4 * g4 + e] = b[e];
+            }
+        }
+        g = 0;
+        // this item's first tile has landed: everything for the first item; afterwards the tile was requested at least 18 weight loads ago
+        // (before the previous item's last chunk), so the previous epilogue's stores -- the youngest five -- need not drain here
+        if (first) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+        first = false;
+        __builtin_amdgcn_s_barrier();
+        add_psum(0, 0);
+        read_half(IC<0>{}, IC<0>{}, 0);
+        WTRACE(1);
+
+        for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+            one_step(IC<0>{}, chunk); one_step(IC<1>{}, chunk); one_step(IC<2>{}, chunk);
+            one_step(IC<3>{}, chunk); one_step(IC<4>{}, chunk); one_step(IC<5>{}, chunk);
+            one_step(IC<6>{}, chunk); one_step(IC<7>{}, chunk); one_step(IC<8>{}, chunk);
+            if (MULTI && chunk + 1 == a.cend[g]) { fold_group(); ++g; }
+        }
+        WTRACE(2);
+        int totv[MT];
+        if (!MULTI) window_sums(totv);
+        WTRACE(3);
+
+        // ---- epilogue: a channel quad's constants are read once and applied to all MT tiles (MT independent chains in flight), the
+        //      bytes staged as [tile][pixel][32 channels] per wave, then MT 16-byte stores per lane back to back --------------------
+        int8_t* stagebuf = stage + wave * (MT * 32 * SP);
+        const float rd = 1.0f / a.out_delta, lo = a.relu ? 0.0f : -3.0e38f;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            v4i c[4];
+            if (!MULTI) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) c[e] = ctab[wave * 32 + 8 * g4 + 4 * half + e];
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                float y[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g4 + e;
+                    if (MULTI) {
+                        y[e] = facc[i][0][r];
+                    } else {
+                        const int T = acc[i][0][r] + __mul24(c[e][0], totv[i]) + c[e][1];
+                        const int sci = c[e][2], bsi = c[e][3];
+                        y[e] = __int_as_float(bsi) + (float)T * __int_as_float(sci);
+                    }
+                    y[e] = fmaxf(y[e], lo);
+                }
+                *(int*)(stagebuf + (i * 32 + (lane & 31)) * SP + 8 * g4 + 4 * half) = q_pack4(y[0], y[1], y[2], y[3], a.out_delta, rd, a.out_zp);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int row = lane >> 1, chn = lane & 1;
+            const int xo = cur.x0 + row;
+            v4i ob[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) ob[i] = *(const v4i*)(stagebuf + (i * 32 + row) * SP + chn * 16);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int yo = cur.y0 + i;
+                if (yo < a.ho && xo < a.wo)
+                    *(v4i*)(a.out + ((size_t)(cur.img * (a.ho + 2) + yo + 1) * (a.wo + 2) + xo + 1) * a.out_ctotal + a.out_c0 + n0 + wave * 32 + chn * 16) = ob[i];
+            }
+        }
+        WTRACE(4);
+        if (!has_next) break;
+        // ---- rotate to the next item: its tiles 0 (and 1) and weight steps 0, 1 are in flight since the last taps of the K loop ----------
+        item += (int)gridDim.x;
+        cur = nxw;
+        pb = (pb + a.nchunks) & 1;
+        {
+            const int nx = item + (int)gridDim.x;
+            has_next = nx < a.items && patch_of(nx) < npatch;
+            if (has_next) nxw = place(nx);
+        }
+        if (a.nchunks == 1) issue_halo(1);                             // (a one-chunk layer's K loop only requested the next item's tile 0)
+    }
 #ifdef QV2X_WIDE_TRACE
     if (tid == 0 && blockIdx.x < 8192) g_wide_trace[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -479,7 +501,10 @@ extern "C" int qv2x_conv3x3_i8_wide(const qv2x_conv_desc* d, const int8_t* in, c
     hipStream_t st = (hipStream_t)stream;
     const int patches8 = (a.n * a.tiles_x * a.tiles_y + 7) / 8 * 8;   // block ids come in groups of 8 (one per XCD)
     const int bn = wide_bn(d);
-    const dim3 grid(patches8 * (a.cout / bn));
+    a.items = patches8 * (a.cout / bn);
+    // persistent workgroups: one round of what a CU holds (LDS: 98-113 / 67-76 / 50 KB per workgroup), a multiple of 8 * (cout / bn)
+    const int slots = 256 * (bn == 256 ? 1 : (bn == 128 ? 2 : 3));
+    const dim3 grid(a.items < slots ? a.items : slots);
     if (d->ngroups > 1) {
         if (bn == 256) conv3x3_i8_wide_kernel<true, 8, 1, 256><<<grid, 512, 0, st>>>(a);
         else conv3x3_i8_wide_kernel<true, 4, 1, 128><<<grid, 256, 0, st>>>(a);
