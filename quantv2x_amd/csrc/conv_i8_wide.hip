@@ -503,7 +503,8 @@ extern "C" int qv2x_conv3x3_i8_wide(const qv2x_conv_desc* d, const int8_t* in, c
     const int bn = wide_bn(d);
     a.items = patches8 * (a.cout / bn);
     // persistent workgroups: one round of what a CU holds (LDS: 98-113 / 67-76 / 50 KB per workgroup), a multiple of 8 * (cout / bn)
-    const int slots = 256 * (bn == 256 ? 1 : (bn == 128 ? 2 : 3));
+    const int period = 8 * (a.cout / bn);                              // ids `period` apart share the channel block and the XCD
+    const int slots = 256 * (bn == 256 ? 1 : (bn == 128 ? 2 : 3)) / period * period;
     const dim3 grid(a.items < slots ? a.items : slots);
     if (d->ngroups > 1) {
         if (bn == 256) conv3x3_i8_wide_kernel<true, 8, 1, 256><<<grid, 512, 0, st>>>(a);

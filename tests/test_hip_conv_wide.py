@@ -47,6 +47,10 @@ def _padded(x_u8, zx_per_channel):
     (1, 7, 40, [(0, 64), (64, 64), (128, 64), (192, 64)], 256),   # QV2X_MAX_GROUPS groups: every slot of the window-sum table
     (5, 9, 70, [(0, 128)], 64),             # two-wave workgroups looping over the halo pixels, two chunks
     (1, 5, 32, [(0, 1536)], 256),           # MAX_CHUNKS chunks
+    (12, 50, 96, [(0, 64)], 768),           # 3 channel blocks x 360 patches: persistent workgroups take several items each; the grid
+                                            # must stay a multiple of 8 x 3 for a workgroup to keep its channel block
+    (30, 50, 64, [(0, 64)], 64),            # 600 one-chunk patches on 768 two-wave slots ... and
+    (80, 50, 64, [(0, 64)], 64),            # 1600: two or three items per workgroup, the next-next tile requested at the rotation
 ])
 def test_wide_matches_regular_and_oracle(n, h, w, groups, cout):
     from oracle.spec import Oracle
