@@ -169,6 +169,30 @@ def rooflines(eng, full, frames, iters):
     return roof, stages
 
 
+def multi_agent_line(eng, device):
+    """BASELINE configs[2] / [3] on ONE GPU (every agent of a scene on this device): scenes of 2 and of 4 agents, 8 agent-frames per
+    HIP graph, one graph at a time.  A fused frame = one ego-view detection output of one scene."""
+    import torch
+    out = {}
+    for agents in (2, 4):
+        scenes = 8 // agents
+        rep = eng.capture(frame_batch(agents, 0, scenes, device)[1])
+        for _ in range(3):
+            rep()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            rep()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 20 * 1e3
+        out[f"{agents}_agents"] = {"scenes_per_graph": scenes, "ms_per_graph": round(ms, 3), "fused_frames_per_s": round(scenes / ms * 1e3, 1),
+                                   "agent_frames_per_s": round(8 / ms * 1e3, 1)}
+        del rep
+    out["note"] = ("V2X-Real grid, synthetic sweeps, line (2) / ring (4) layout; a1-a6 per agent, decode + warp + attention over the scene's agents, "
+                   "heads on the fused map + *_single heads; not the headline metric (that is the single-agent configuration)")
+    return out
+
+
 def pyramid_model_line(device):
     """SURVEY.md §8(f) rank 3, reported beside the headline: the HEAL Pyramid-fusion model (2 agents per scene, V2X-Real grid) on its
     own engine -- one frame as a HIP graph, and batches of 4 scenes."""
@@ -492,6 +516,7 @@ def main():
             line["fp32_hip_path"] = {"ms_per_frame": round(ms32, 3), "frames_per_s": round(1e3 / ms32, 1),
                                      "note": "un-quantized model, one frame at a time, f32-MFMA convolutions; compare value_one_frame_at_a_time"}
             del e32, r32
+            line["multi_agent_one_gpu"] = multi_agent_line(eng, device)
             line["pyramid_model"] = pyramid_model_line(device)
             line["second_encoder"] = second_encoder_line(device)
             line["collapsed_encode_opt_in"] = collapsed_encode_line(state, full, B, F, args.steps, device)
