@@ -14,6 +14,8 @@ OUT = os.path.join(HERE, "libqv2x.so")
 OBJDIR = os.path.join(HERE, "build")
 # -ffp-contract=off: every fma on the parity-critical paths is written as fmaf(); the compiler must not fuse
 # a separate multiply and add (oracle/qv2x_oracle.c is built the same way).
+# -Wno-inline-asm: conv_i8_wide.hip issues its LDS-DMA as inline asm that writes M0 (see the comment there); hipcc warns that M0 is a
+# reserved register -- the kernel has no other M0 user (no builtin LDS-DMA, no ds_*_addtid, no GWS / sendmsg).
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=default", "-Wno-inline-asm"]
 FLAGS = CFLAGS + ["-shared"]            # one-shot form (tools that build a variant library use it with SOURCES)
 
