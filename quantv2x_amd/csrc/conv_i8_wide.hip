@@ -76,7 +76,7 @@ __device__ long long g_wide_trace[8192 * 8];
 //     its per-pixel channel sums into a 256-entry LDS table once (two 1 KiB pieces per wave) and an output's window sum is nine
 //     table entries at the group fold.  The loop body is one basic block; the fold needs no barrier.
 template <bool MULTI, int NW, int NT, int BN>
-__global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kernel(const WideArgs a) {
+__global__ __launch_bounds__(NW * 64, (NW >= 8 || (MULTI && NW == 4)) ? 1 : 2) void conv3x3_i8_wide_kernel(const WideArgs a) {
     static_assert(NW * NT * 32 == BN && WTILE % BN == 0, "wave layout");
     static_assert(HBLK % NW == 0, "every wave moves the same number of halo pieces");
     constexpr int LH = HBLK / NW;                                      // halo DMA instructions per wave
@@ -86,11 +86,14 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
     constexpr int SP = 48;                                             // epilogue staging row pitch (2-way bank spread for the dword writes)
     constexpr int STAGE = NW * MT * 32 * SP;                           // every wave stages its MT tiles of [32 pixels][32 channels]
     // (the staging area is NOT the halo buffers any more: during an item's epilogue they already hold the next item's first tiles)
-    __shared__ __attribute__((aligned(16))) int8_t lds[2 * HBUF + STAGE + (NG + 1) * HPAD * 4 + NG * BN * 16];
+    __shared__ __attribute__((aligned(16))) int8_t lds[2 * HBUF + STAGE + 3 * NG * HPAD * 4 + NG * BN * 16];
     int8_t* hbuf = lds;
     int8_t* stage = lds + 2 * HBUF;
-    int* psum = (int*)(stage + STAGE);                                 // [group | one spare][halo pixel] channel sums
-    v4i* ctab = (v4i*)(psum + (NG + 1) * HPAD);                        // [group][BN] {aw, corr_g, scale_g (bits), bias (bits)} per channel
+    // window-sum tables [set][group][halo pixel]: item k of a workgroup uses set k % 3.  Its first tile is summed into the set by the
+    // previous item's last tap 8, and item k's start clears set (k + 1) % 3 -- last read two items ago, i.e. before barriers every wave has
+    // passed -- so an item starts without a barrier or a wait of its own.
+    int* psum = (int*)(stage + STAGE);
+    v4i* ctab = (v4i*)(psum + 3 * NG * HPAD);                          // [group][BN] {aw, corr_g, scale_g (bits), bias (bits)} per channel
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
         return (unsigned)(((w.img * a.hp + yy) * a.wp + xx) * a.cin_total + (blk >> 2) * 16);
     };
     Where cur = place(item), nxw = cur;
-    bool has_next = false, first = true;
+    bool has_next = false;
     int pb = 0;                                                        // halo buffer of the current item's chunk 0
 
     v16i acc[MT][NT];
@@ -155,7 +158,8 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
                          :: "s"(ldsb + NW * j * 1024), "v"(src_of(k < 0 ? cur : nxw, j) + (unsigned)off), "s"(a.in) : "memory", "m0");
     };
     // per-pixel channel sums of a landed halo tile -> psum[slot] (four planes of a pixel arrive in four pieces: LDS atomics)
-    auto add_psum = [&](int chunk, int slot) __attribute__((always_inline)) {
+    int pset = 0;                                                      // this item's window-sum set
+    auto add_psum = [&](int chunk, int slot) __attribute__((always_inline)) {   // slot = set * NG + group
         const int8_t* buf = hbuf + ((pb + chunk) & 1) * HBUF;
 #pragma unroll
         for (int j = 0; j < LH; ++j) {
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
     auto window_sums = [&](int (&totv)[MT]) __attribute__((always_inline)) {
         // nine psum entries per output pixel (rows i .. i + 2 of the halo, columns x .. x + 2)
         int rowsum[MT + 2];
-        const int* ps = psum + g * HPAD + (lane & 31);
+        const int* ps = psum + (pset * NG + g) * HPAD + (lane & 31);
 #pragma unroll
         for (int k = 0; k < MT + 2; ++k) rowsum[k] = ps[k * HWD] + ps[k * HWD + 1] + ps[k * HWD + 2];
 #pragma unroll
@@ -241,9 +245,10 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
             // THIS chunk's tile are done once it has passed the wait below, so after the barrier the tile's buffer can be refilled
             asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            const int nxt = chunk + 1;
-            add_psum(nxt, nxt < a.nchunks ? (MULTI ? (nxt >= a.cend[g] ? g + 1 : g) : 0) : NG);   // (before the DMA below: an LDS write
-            issue_halo(chunk + 2);                                     //  after a pending LDS-DMA makes the compiler drain vmcnt)
+            const int nxt = chunk + 1;                                 // (past the last chunk: the next item's first tile, into ITS set)
+            add_psum(nxt, nxt < a.nchunks ? pset * NG + (MULTI ? (nxt >= a.cend[g] ? g + 1 : g) : 0) : (pset == 2 ? 0 : pset + 1) * NG);
+            issue_halo(chunk + 2);                                     // (after the LDS atomics above: an LDS write after a pending
+                                                                       //  LDS-DMA makes the compiler drain vmcnt)
             read_half(IC<0>{}, IC<0>{}, nxt);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -277,10 +282,17 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
         }
     }
 
+    for (int t = tid; t < 3 * NG * HPAD; t += NW * 64) psum[t] = 0;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    add_psum(0, 0);
+
     for (;;) {
-        // ---- item start: the window-sum table is free once every wave has left the previous item's fold ----------------------
-        __builtin_amdgcn_s_barrier();
-        for (int t = tid; t < (NG + 1) * HPAD; t += NW * 64) psum[t] = 0;
+        // ---- item start: no barrier, no wait -- tile 0 landed and was summed at the previous item's last tap 8 (or just above) ------------
+        {
+            int* nz = psum + (pset == 2 ? 0 : pset + 1) * NG * HPAD;   // the next item's set
+            for (int t = tid; t < NG * HPAD; t += NW * 64) nz[t] = 0;
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -296,13 +308,6 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
             }
         }
         g = 0;
-        // this item's first tile has landed: everything for the first item; afterwards the tile was requested at least 18 weight loads ago
-        // (before the previous item's last chunk), so the previous epilogue's stores -- the youngest five -- need not drain here
-        if (first) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
-        first = false;
-        __builtin_amdgcn_s_barrier();
-        add_psum(0, 0);
         read_half(IC<0>{}, IC<0>{}, 0);
         WTRACE(1);
 
@@ -367,6 +372,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void conv3x3_i8_wide_kern
         item += (int)gridDim.x;
         cur = nxw;
         pb = (pb + a.nchunks) & 1;
+        pset = pset == 2 ? 0 : pset + 1;
         {
             const int nx = item + (int)gridDim.x;
             has_next = nx < a.items && patch_of(nx) < npatch;
@@ -502,9 +508,9 @@ extern "C" int qv2x_conv3x3_i8_wide(const qv2x_conv_desc* d, const int8_t* in, c
     const int patches8 = (a.n * a.tiles_x * a.tiles_y + 7) / 8 * 8;   // block ids come in groups of 8 (one per XCD)
     const int bn = wide_bn(d);
     a.items = patches8 * (a.cout / bn);
-    // persistent workgroups: one round of what a CU holds (LDS: 98-113 / 67-76 / 50 KB per workgroup), a multiple of 8 * (cout / bn)
+    // persistent workgroups: one round of what a CU holds (LDS: 99-120 / 67-82 / 51 KB per workgroup), a multiple of 8 * (cout / bn)
     const int period = 8 * (a.cout / bn);                              // ids `period` apart share the channel block and the XCD
-    const int slots = 256 * (bn == 256 ? 1 : (bn == 128 ? 2 : 3)) / period * period;
+    const int slots = 256 * (bn == 256 ? 1 : (bn == 128 ? (d->ngroups > 1 ? 1 : 2) : 3)) / period * period;
     const dim3 grid(a.items < slots ? a.items : slots);
     if (d->ngroups > 1) {
         if (bn == 256) conv3x3_i8_wide_kernel<true, 8, 1, 256><<<grid, 512, 0, st>>>(a);
