@@ -37,7 +37,9 @@ __device__ __forceinline__ float q_code(float y, float delta, float zp) {
 // the two round alike unless t lies within 1e-4 of a half-integer.  One test per group of four: max |t - rint(t)| > 0.4999 on
 // any lane sends the wave through the exact divisions (5 % of the groups).  The clamped code is read from the low mantissa byte
 // of (code + 2^23), with zp + 2^23 added in one step (exact: both are integers below 2^24).
-__device__ __forceinline__ int q_pack4(float y0, float y1, float y2, float y3, float delta, float rdelta, float zp) {
+// `lowc`: lowest code + 2^23.  8388608.0f (code 0) for the plain quantizer; zp + 2^23 folds a ReLU in front of the quantizer into the
+// clamp -- rint is monotone and rint(0) = 0, so q(max(y, 0)) = max(rint(y / delta), 0) + zp -- and saves the caller one fmaxf per output.
+__device__ __forceinline__ int q_pack4(float y0, float y1, float y2, float y3, float delta, float rdelta, float zp, float lowc = 8388608.0f) {
     const float y[4] = {y0, y1, y2, y3};
     float k[4], dmax = 0.0f;
 #pragma unroll
@@ -53,7 +55,7 @@ __device__ __forceinline__ int q_pack4(float y0, float y1, float y2, float y3, f
     const float zm = zp + 8388608.0f;
     unsigned b[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) b[e] = __builtin_bit_cast(unsigned, fminf(fmaxf(k[e] + zm, 8388608.0f), 8388863.0f));
+    for (int e = 0; e < 4; ++e) b[e] = __builtin_bit_cast(unsigned, fminf(fmaxf(k[e] + zm, lowc), 8388863.0f));
     const unsigned lo = __builtin_amdgcn_perm(b[1], b[0], 0x0c0c0400u);      // byte 0 of b0, byte 0 of b1
     const unsigned hi = __builtin_amdgcn_perm(b[3], b[2], 0x0c0c0400u);
     return (int)(__builtin_amdgcn_perm(hi, lo, 0x05040100u) ^ 0x80808080u);

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 || (MULTI && NW == 4)) ? 1 : 2) v
         // ---- epilogue: a channel quad's constants are read once and applied to all MT tiles (MT independent chains in flight), the
         //      bytes staged as [tile][pixel][32 channels] per wave, then MT 16-byte stores per lane back to back --------------------
         int8_t* stagebuf = stage + wave * (MT * 32 * SP);
-        const float rd = 1.0f / a.out_delta, lo = a.relu ? 0.0f : -3.0e38f;
+        const float rd = 1.0f / a.out_delta, lowc = a.relu ? a.out_zp + 8388608.0f : 8388608.0f;   // the ReLU lives in the clamp (q_pack4)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             v4i c[4];
@@ -346,9 +346,8 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 || (MULTI && NW == 4)) ? 1 : 2) v
                         const int sci = c[e][2], bsi = c[e][3];
                         y[e] = __int_as_float(bsi) + (float)T * __int_as_float(sci);
                     }
-                    y[e] = fmaxf(y[e], lo);
                 }
-                *(int*)(stagebuf + (i * 32 + (lane & 31)) * SP + 8 * g4 + 4 * half) = q_pack4(y[0], y[1], y[2], y[3], a.out_delta, rd, a.out_zp);
+                *(int*)(stagebuf + (i * 32 + (lane & 31)) * SP + 8 * g4 + 4 * half) = q_pack4(y[0], y[1], y[2], y[3], a.out_delta, rd, a.out_zp, lowc);
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
