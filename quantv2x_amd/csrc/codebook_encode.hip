@@ -41,6 +41,14 @@ struct EncArgs {
     float dx;
 };
 
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() is fence + barrier, and the fence drains vmcnt: the next phase's weight
+// k-quads, requested ahead of the barrier on purpose, would have to land before the barrier instead of behind it.  Nothing in this
+// kernel passes data between waves through global memory, so ordering the LDS traffic is all a barrier has to do here.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
 __device__ __forceinline__ size_t off_stage_w() { return 0; }
 __device__ __host__ __forceinline__ int64_t level_floats(int kc) { return 3LL * (D * D + D) + (int64_t)D * kc + (int64_t)kc * D + kc; }
 
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(512, 4) void codebook_encode_kernel(const EncArgs a
         }
     }
     GemmHead head = gemm_head((const float2*)a.lvl[0], a.lvl[0] + D * D, wave, lane);      // stage_w / stage_b of level 0
-    __syncthreads();
+    lds_barrier();
 
     v16f acc[ERT];
     for (int l = 0; l < a.levels; ++l) {
@@ -205,11 +213,11 @@ __global__ __launch_bounds__(512, 4) void codebook_encode_kernel(const EncArgs a
         gemm_rows_x32(bufA, (const float2*)stage_w, head, wave, lane, acc);         // z = stage(x)
         head = gemm_head((const float2*)qhead_w, qhead_b, wave, lane);
         store_tile(bufB, wave, lane, acc);
-        __syncthreads();
+        lds_barrier();
         gemm_rows_x32(bufB, (const float2*)qhead_w, head, wave, lane, acc);         // q = qhead(z)
         if (l + 1 < a.levels) head = gemm_head((const float2*)lhead_w, lhead_b, wave, lane);      // used after the argmin
         store_tile(bufA, wave, lane, acc);                                        // x is dead since the barrier above
-        __syncthreads();
+        lds_barrier();
 
         if (tid < ER * 4) {   // |q|^2: four 64-wide ascending fma chains per row; thread = (chain = tid / ER, row = tid % ER)
             const int row = tid % ER, part = tid / ER;
@@ -234,9 +242,9 @@ __global__ __launch_bounds__(512, 4) void codebook_encode_kernel(const EncArgs a
             for (int t = 0; t < 4; ++t) dhead[t] = cl[(size_t)t * a.kc * 2];
             c2v = c2[code];
         }
-        __syncthreads();
+        lds_barrier();
         if (tid < ER) x2[tid] = (pval[tid] + pval[ER + tid]) + (pval[2 * ER + tid] + pval[3 * ER + tid]);
-        __syncthreads();
+        lds_barrier();
 
         // ---- distances: wave -> (row tile = wave >> 2, codes [32*(wave & 3), +32)), then the argmin ------------
         if (has_dist) {
@@ -288,7 +296,7 @@ __global__ __launch_bounds__(512, 4) void codebook_encode_kernel(const EncArgs a
                 if ((lane & 31) == 0) pkey[ct * ER + row] = key;
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (tid < ER) {
             unsigned long long bk = pkey[tid];
             for (int wv = 1; wv * 32 < a.kc; ++wv) {
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(512, 4) void codebook_encode_kernel(const EncArgs a
             code_s[tid] = bi;
             if (m0 + tid < a.M) a.codes[(size_t)l * a.M + m0 + tid] = (uint8_t)bi;
         }
-        __syncthreads();
+        lds_barrier();
 
         if (l + 1 < a.levels) {      // x <- lhead(z) - C[code]
             // the chosen codewords' entries of this lane's column: 16 gathers requested ahead of the GEMM that produces the minuend
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(512, 4) void codebook_encode_kernel(const EncArgs a
             for (int i = 0; i < ERT; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) bufA[(i * 32 + mfma32_row(r, lane)) * LDF + kpos(col)] = acc[i][r] - cv[i][r];
-            __syncthreads();
+            lds_barrier();
         }
     }
 #ifdef QV2X_ENC_TRACE
