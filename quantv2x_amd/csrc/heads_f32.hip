@@ -20,6 +20,13 @@ namespace qv2x {
 // one short-lived wave per cell and many of them per CU, which a 32-row GEMM tile does not give it.)
 enum { ROWS_GLOBAL = 0, ROWS_DECODE = 2 };
 
+#ifdef QV2X_HEADS_TRACE     // dev build only (tools/heads_trace.py): s_memtime stamps of thread 0 of every workgroup
+__device__ long long g_heads_trace[32768 * 6];
+#define HTRACE(k) do { const int hb_ = ((blockIdx.x >> 3) & 1) * (gridDim.x >> 1) + (blockIdx.x >> 4) * 8 + (blockIdx.x & 7); if (threadIdx.x == 0 && hb_ < 32768) g_heads_trace[hb_ * 6 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define HTRACE(k) do { } while (0)
+#endif
+
 struct HeadArgs {
     const float* x; int R, hw, cout, cout_pad;
     const float* w; const float* bias; const float* da; const float* za; float* out;
@@ -28,25 +35,68 @@ struct HeadArgs {
 template <int SRC>
 __device__ __forceinline__ void rows_heads_tile(const HeadArgs& h, const FuseArgs& fa, const int tm, float* smem) {
     float* rows = smem;
+    HTRACE(0);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nct = h.cout_pad >> 5;
     const int par = lane >> 5;
 
+    if (SRC == ROWS_GLOBAL) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int r = wave * 8 + j;
-        const int m = tm * 32 + r;
-        if (SRC == ROWS_GLOBAL) {
+        for (int j = 0; j < 8; ++j) {
+            const int r = wave * 8 + j;
+            const int m = tm * 32 + r;
             const int mc = m < h.R ? m : h.R - 1;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(h.x + (size_t)mc * 256 + ((lane ^ r) << 2)),
                                              (__attribute__((address_space(3))) void*)(rows + r * 256), 16, 0, 0);
-        } else {
-            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < h.R) {
-                const int agent = m / h.hw;
-                o = tap_value(fa, agent, m - agent * h.hw, lane);
+        }
+    } else {
+        // the wave's eight rows, four at a time: all their code bytes first, then all their table rows, then the sums in level order
+        // (tap_value's arithmetic).  Row by row and level by level -- and with a run-time level count, which makes every load
+        // conditional and hipcc wait for each code byte before it requests the next -- this was 48 dependent L2 round trips per wave:
+        // 20k of the 36k cycles a *_single workgroup lived (tools/heads_trace.py).  Three levels (every model of the reference) take
+        // the unrolled form; other counts the row-by-row one.
+        if (fa.levels == 3) {
+            constexpr int LV = 3;
+            const float4 bias4 = fa.lut_bias[lane];
+#pragma unroll
+            for (int j0 = 0; j0 < 8; j0 += 4) {
+                int code[4][LV];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = tm * 32 + wave * 8 + j0 + j;
+                    const int mc = m < h.R ? m : h.R - 1;
+                    const int agent = mc / h.hw, cell = mc - agent * h.hw;
+                    const uint8_t* cp = fa.codes + (size_t)agent * fa.code_agent_stride + cell;
+#pragma unroll
+                    for (int l = 0; l < LV; ++l) code[j][l] = cp[(size_t)l * fa.code_level_stride];
+                }
+                float4 t[4][LV];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int l = 0; l < LV; ++l) t[j][l] = fa.lut[((size_t)l * fa.kc + code[j][l]) * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = wave * 8 + j0 + j;
+                    float4 v = bias4;
+#pragma unroll
+                    for (int l = 0; l < LV; ++l) { v.x += t[j][l].x; v.y += t[j][l].y; v.z += t[j][l].z; v.w += t[j][l].w; }
+                    if (tm * 32 + r >= h.R) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *(float4*)(rows + r * 256 + ((lane ^ r) << 2)) = v;
+                }
             }
-            *(float4*)(rows + r * 256 + ((lane ^ r) << 2)) = o;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = wave * 8 + j;
+                const int m = tm * 32 + r;
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < h.R) {
+                    const int agent = m / h.hw;
+                    o = tap_value(fa, agent, m - agent * h.hw, lane);
+                }
+                *(float4*)(rows + r * 256 + ((lane ^ r) << 2)) = o;
+            }
         }
     }
     // a workgroup's wave i sits on SIMD i: rotate the column tiles over the waves from one row tile to the next, or the
@@ -68,6 +118,7 @@ __device__ __forceinline__ void rows_heads_tile(const HeadArgs& h, const FuseArg
     }
     if (active) loadB(wa, 0);
     __syncthreads();                                // rows (DMA or ds_write) of every wave have landed
+    HTRACE(1);
 
     if (active) {
         const int r = lane & 31;
@@ -96,7 +147,9 @@ __device__ __forceinline__ void rows_heads_tile(const HeadArgs& h, const FuseArg
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    HTRACE(2);
     __syncthreads();                                // every wave is done reading the rows: the transpose tiles reuse that LDS
+    HTRACE(3);
     if (active) {
         float (*tr)[33] = (float (*)[33])(smem + ct * 32 * 33);
         const int co = ct * 32 + (lane & 31);
@@ -119,6 +172,7 @@ __device__ __forceinline__ void rows_heads_tile(const HeadArgs& h, const FuseArg
             if (ch < h.cout && mm < h.R) ob[(size_t)ch * h.hw] = tr[lane & 31][par + 2 * c];
         }
     }
+    HTRACE(4);
 }
 
 template <int SRC>
@@ -129,12 +183,16 @@ __global__ __launch_bounds__(256) void rows_heads_kernel(const HeadArgs h, const
 
 // The fused-feature heads (rows from memory) and the *_single heads (rows decoded from the codes) of one frame in ONE
 // launch, blockIdx.y = job: two 1100-workgroup grids whose copy-in / GEMM / store phases interleave, one launch gap less.
+// (block id = 16 (tile / 8) + 8 job + tile % 8: block ids go round the eight XCDs, so the job bit sits above them -- every XCD and CU gets
+// both jobs alternately and the MFMA-bound fused-map tiles run beside the latency-bound decode tiles; as a (tiles, 2) grid every job-0
+// workgroup was dispatched before the first job-1 one, and with the job in bit 0 four XCDs would get all the fused-map tiles)
 __global__ __launch_bounds__(256) void rows_heads_pair_kernel(const HeadArgs h0, const HeadArgs h1, const FuseArgs fa1) {
     __shared__ __attribute__((aligned(16))) float smem[32 * 256];
-    if (blockIdx.y == 0) {
-        if ((int)blockIdx.x * 32 < h0.R) rows_heads_tile<ROWS_GLOBAL>(h0, fa1, blockIdx.x, smem);
+    const int tile = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
+    if (((blockIdx.x >> 3) & 1) == 0) {
+        if (tile * 32 < h0.R) rows_heads_tile<ROWS_GLOBAL>(h0, fa1, tile, smem);
     } else {
-        if ((int)blockIdx.x * 32 < h1.R) rows_heads_tile<ROWS_DECODE>(h1, fa1, blockIdx.x, smem);
+        if (tile * 32 < h1.R) rows_heads_tile<ROWS_DECODE>(h1, fa1, tile, smem);
     }
 }
 
@@ -226,6 +284,13 @@ extern "C" int qv2x_decode_lut_f32(const uint8_t* codes, int R, int levels, int 
     return hip_check(hipGetLastError(), "qv2x_decode_lut_f32 launch");
 }
 
+#ifdef QV2X_HEADS_TRACE
+extern "C" int qv2x_debug_heads_trace(long long* host_out, int nblocks) {
+    using namespace qv2x;
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_heads_trace), (size_t)nblocks * 6 * sizeof(long long));
+}
+#endif
+
 extern "C" int qv2x_heads_pair_f32(const float* x, int R, int hw, int cout, int cout_pad, const float* w, const float* bias,
                                    const float* da, const float* za, float* out,
                                    const uint8_t* codes, int R1, int levels, int kc, const float* lut, const float* lut_bias,
@@ -244,6 +309,6 @@ extern "C" int qv2x_heads_pair_f32(const float* x, int R, int hw, int cout, int 
     fa.levels = levels; fa.kc = kc; fa.hw = hw;
     fa.code_agent_stride = hw; fa.code_level_stride = R1;
     const int tiles = ((R > R1 ? R : R1) + 31) / 32;
-    rows_heads_pair_kernel<<<dim3(tiles, 2), 256, 0, (hipStream_t)stream>>>(h0, h1, fa);
+    rows_heads_pair_kernel<<<dim3(16 * ((tiles + 7) / 8)), 256, 0, (hipStream_t)stream>>>(h0, h1, fa);
     return hip_check(hipGetLastError(), "qv2x_heads_pair_f32 launch");
 }
