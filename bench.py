@@ -139,11 +139,10 @@ def rooflines(eng, full, frames, iters):
     fused = torch.empty((n, hw, 256), dtype=torch.float32, device=eng.dev)
     import ctypes as C
 
-    def fuse_all():
-        for f in range(n):
-            eng.fuse(C.c_void_p(codes.data_ptr() + f * hw), hw, n * hw, None, pw[f], 1, fused[f])
-    stage("decode_warp_attfuse", fuse_all, "hbm", n * (3 * hw + 3 * 128 * 1024 + hw * 1024), "GB/s", HBM_PEAK_GBS, n,
-          f"{n} x (105.6 KB codes + 384 KiB LUT read, 36.0 MB fp32 fused map written)")
+    def fuse_all():                                  # as DeployedModel.forward does: every scene of the batch in one launch
+        eng.fuse_scenes(C.c_void_p(codes.data_ptr()), hw, n * hw, None, pw, [f * hw for f in range(n)], [1] * n, fused)
+    stage("decode_warp_attfuse", fuse_all, "hbm", n * (3 * hw + 3 * 128 * 1024 + hw * 1024), "GB/s", HBM_PEAK_GBS, 1,
+          f"{n} x (105.6 KB codes + 384 KiB LUT read, 36.0 MB fp32 fused map written), one launch for the batch's scenes")
     stage("heads_f32", lambda: eng._heads_pair(fused, n, codes, n), "mfma-f32", n * 2 * 2 * 0.649e9, "TFLOP/s", F32_MFMA_PEAK_TFLOPS, 1,
           f"{n} x 2 x 0.649 GMAC: heads on the fused map + *_single heads on the decoded own feature, one launch")
     enc = stages["codebook_encode_f32"]

@@ -203,6 +203,14 @@ typedef struct {
 int qv2x_fuse_att_f32(const qv2x_fuse_desc* desc /* host */, const uint8_t* codes, const float* lut, const float* lut_bias,
                       const float* feats, const double* pairwise, float* fused, void* stream);
 
+/* The same for several scenes of ONE call in one launch (the reference's loop over record_len in AttFusion.forward,
+ * fusion_in_one.py:131-151): scene s fuses `scene_agents[s]` agents whose first code plane starts `scene_offset[s]` BYTES into `codes`
+ * (or whose first fp32 map starts `scene_offset[s]` FLOATS into `feats`), with pairwise + s * max_cav * max_cav * 16, into
+ * fused + s * h * w * 256; every scene's ego is `desc->ego` of its own agents.  `desc->agents` is ignored.  1..64 scenes. */
+int qv2x_fuse_att_batch_f32(const qv2x_fuse_desc* desc /* host */, int n_scenes, const int64_t* scene_offset /* host */,
+                            const int32_t* scene_agents /* host */, const uint8_t* codes, const float* lut, const float* lut_bias,
+                            const float* feats, const double* pairwise, float* fused, void* stream);
+
 /* codes -> fp32 rows (decode only), used for the *_single heads: out f32 [R][256] */
 int qv2x_decode_lut_f32(const uint8_t* codes, int R, int levels, int kc, const float* lut, const float* lut_bias,
                         float* out, void* stream);

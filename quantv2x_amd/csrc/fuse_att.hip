@@ -19,6 +19,24 @@ __global__ __launch_bounds__(256) void fuse_att_kernel(const FuseArgs a) {
     a.fused[(size_t)cell * 64 + lane] = fuse_cell_n<NA>(a, cell, lane);
 }
 
+// several scenes in one launch: blockIdx.y = scene
+constexpr int MAX_SCENES = 64;
+struct SceneList { long long off[MAX_SCENES]; int agents[MAX_SCENES]; };
+
+template <int NA>
+__global__ __launch_bounds__(256) void fuse_att_batch_kernel(FuseArgs a, const SceneList sl) {
+    const int lane = threadIdx.x & 63;
+    int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
+    cell = __builtin_amdgcn_readfirstlane(cell);
+    if (cell >= a.hw) return;
+    const int sc = blockIdx.y;
+    a.agents = sl.agents[sc];
+    if (a.feats) a.feats = (const float4*)((const float*)a.feats + sl.off[sc]);
+    else a.codes += sl.off[sc];
+    a.pairwise += (size_t)sc * a.L * a.L * 16;
+    a.fused[((size_t)sc * a.hw + cell) * 64 + lane] = fuse_cell_n<NA>(a, cell, lane);
+}
+
 int fuse_args_from_desc(const qv2x_fuse_desc* d, const uint8_t* codes, const float* lut, const float* lut_bias, const float* feats,
                         const double* pairwise, const char* who, FuseArgs& a) {
     if (!d || !pairwise) return fail(QV2X_EINVAL, "%s: null pointer", who);
@@ -56,4 +74,34 @@ extern "C" int qv2x_fuse_att_f32(const qv2x_fuse_desc* d, const uint8_t* codes, 
         default: fuse_att_kernel<MAXA><<<grid, 256, 0, st>>>(a); break;
     }
     return hip_check(hipGetLastError(), "qv2x_fuse_att_f32 launch");
+}
+
+extern "C" int qv2x_fuse_att_batch_f32(const qv2x_fuse_desc* d, int n_scenes, const int64_t* scene_offset, const int32_t* scene_agents,
+                                       const uint8_t* codes, const float* lut, const float* lut_bias, const float* feats,
+                                       const double* pairwise, float* fused, void* stream) {
+    using namespace qv2x;
+    if (!fused || !scene_offset || !scene_agents || !d) return fail(QV2X_EINVAL, "qv2x_fuse_att_batch_f32: null pointer");
+    if (n_scenes < 1 || n_scenes > MAX_SCENES) return fail(QV2X_EINVAL, "qv2x_fuse_att_batch_f32: 1..%d scenes, got %d", MAX_SCENES, n_scenes);
+    SceneList sl{};
+    int most = 1;
+    for (int s = 0; s < n_scenes; ++s) {
+        if (scene_offset[s] < 0 || (feats && scene_offset[s] % 4) || scene_agents[s] < 1 || scene_agents[s] > MAXA || scene_agents[s] > d->max_cav || d->ego >= scene_agents[s])
+            return fail(QV2X_EINVAL, "qv2x_fuse_att_batch_f32: scene %d: offset %lld, agents %d (1..%d, <= max_cav, > ego)", s, (long long)scene_offset[s], scene_agents[s], MAXA);
+        sl.off[s] = scene_offset[s]; sl.agents[s] = scene_agents[s];
+        most = scene_agents[s] > most ? scene_agents[s] : most;
+    }
+    qv2x_fuse_desc d1 = *d;
+    d1.agents = most;
+    FuseArgs a;
+    if (int rc = fuse_args_from_desc(&d1, codes, lut, lut_bias, feats, pairwise, "qv2x_fuse_att_batch_f32", a)) return rc;
+    a.fused = (float4*)fused;
+    const dim3 grid((a.hw + 3) / 4, n_scenes);
+    hipStream_t st = (hipStream_t)stream;
+    switch (fuse_bound(most)) {
+        case 1: fuse_att_batch_kernel<1><<<grid, 256, 0, st>>>(a, sl); break;
+        case 2: fuse_att_batch_kernel<2><<<grid, 256, 0, st>>>(a, sl); break;
+        case 4: fuse_att_batch_kernel<4><<<grid, 256, 0, st>>>(a, sl); break;
+        default: fuse_att_batch_kernel<MAXA><<<grid, 256, 0, st>>>(a, sl); break;
+    }
+    return hip_check(hipGetLastError(), "qv2x_fuse_att_batch_f32 launch");
 }

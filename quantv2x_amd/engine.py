@@ -581,8 +581,8 @@ class DeployedModel(nn.Module):
         ``*_single`` heads of this rank's own agent run in the same launch as the heads on the fused maps."""
         hw = self.fh * self.fw
         fused = torch.empty((frames, hw, 256), dtype=torch.float32, device=self.dev)
-        for f in range(frames):
-            self.fuse(C.c_void_p(gathered.data_ptr() + f * frame_stride), agent_stride, level_stride, None, pairwise[f], n_agents, fused[f], ego)
+        self.fuse_scenes(L.ptr(gathered), agent_stride, level_stride, None, pairwise, [f * frame_stride for f in range(frames)],
+                         [n_agents] * frames, fused, ego)
         sp = None
         if self.heads_single is not None and own_codes is not None:
             preds, sp = self._heads_pair(fused, frames, own_codes, frames)
@@ -632,6 +632,20 @@ class DeployedModel(nn.Module):
         lb = L.ptr(self.lut_bias) if self.has_codebook else None
         L.check(self.lib.qv2x_fuse_att_f32(C.byref(d), codes_ptr, lut, lb, L.ptr(feats) if feats is not None else None,
                                            L.ptr(pairwise_b), L.ptr(out), L.current_stream()), "qv2x_fuse_att_f32")
+
+    def fuse_scenes(self, codes_ptr, agent_stride, level_stride, feats, pairwise, offsets, counts, out, ego=0):
+        """a7-a10 for several scenes in ONE launch: scene s = ``counts[s]`` agents starting ``offsets[s]`` bytes into the codes (floats into
+        ``feats``); ``pairwise`` f64 [scenes, L, L, 4, 4], ``out`` f32 [scenes, H*W, 256].  Chunks of 64 scenes."""
+        for s0 in range(0, len(counts), 64):
+            s1 = min(len(counts), s0 + 64)
+            d = self._fuse_desc(agent_stride, level_stride, pairwise[s0], max(counts[s0:s1]), ego)
+            offs = (C.c_int64 * (s1 - s0))(*offsets[s0:s1])
+            cnts = (C.c_int32 * (s1 - s0))(*counts[s0:s1])
+            lut = L.ptr(self.lut) if self.has_codebook else None
+            lb = L.ptr(self.lut_bias) if self.has_codebook else None
+            L.check(self.lib.qv2x_fuse_att_batch_f32(C.byref(d), s1 - s0, offs, cnts, codes_ptr, lut, lb,
+                                                     L.ptr(feats) if feats is not None else None, L.ptr(pairwise[s0]), L.ptr(out[s0]),
+                                                     L.current_stream()), "qv2x_fuse_att_batch_f32")
 
     def fuse_and_heads(self, codes, agent_stride, level_stride, pairwise_b, n_agents, ego=0) -> dict:
         """a7-a11 on an (all-gathered) code tensor for one scene; ``pairwise_b`` f64 [L, L, 4, 4] on the device."""
@@ -723,14 +737,11 @@ class DeployedModel(nn.Module):
         bufs = self._workspace(n_total)
         feats = None if self.has_codebook else self._shared_features(enc, n_total)
         fused = torch.empty((nb, hw, 256), dtype=torch.float32, device=self.dev)
-        start = 0
-        for bi, n in enumerate(lens):
-            if self.has_codebook:
-                base = C.c_void_p(enc.data_ptr() + start * hw)
-                self.fuse(base, hw, n_total * hw, None, pairwise[bi], n, fused[bi])
-            else:
-                self.fuse(None, 0, 0, feats[start:start + n], pairwise[bi], n, fused[bi])
-            start += n
+        starts = [sum(lens[:bi]) for bi in range(nb)]
+        if self.has_codebook:                                            # every scene of the call in one launch
+            self.fuse_scenes(L.ptr(enc), hw, n_total * hw, None, pairwise, [st * hw for st in starts], lens, fused)
+        else:
+            self.fuse_scenes(None, 0, 0, feats, pairwise, [st * hw * 256 for st in starts], lens, fused)
         sp = None
         if self.heads_single is not None and self.has_codebook:
             # the heads on the fused map and the *_single heads on every agent's own decoded feature: one launch

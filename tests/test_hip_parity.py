@@ -187,3 +187,33 @@ def test_padding_pillar_rows_are_dropped(tiny):
     torch.cuda.synchronize()
     for k in want:
         assert torch.equal(got[k], want[k]), k
+
+
+def test_scenes_of_different_sizes_in_one_call(tiny):
+    """Two scenes with 3 and 1 agents in one ``forward`` (record_len = [3, 1]): the fusion of both runs as ONE launch
+    (qv2x_fuse_att_batch_f32: per-scene code offsets and agent counts) and must give what each scene gives alone, bit for bit."""
+    from quantv2x_amd import synth
+    _, _, eng = tiny
+    a, b = scene_np(3), scene_np(1, seed=11)
+    alone = []
+    for sc in (a, b):
+        taps = {}
+        out = eng(synth.scene_to_torch(sc, "cuda"), taps)
+        torch.cuda.synchronize()
+        alone.append(({k: v.clone() for k, v in out.items()}, taps["fused"].clone()))
+    inp = {}
+    for k in a["inputs_m1"]:
+        pb = b["inputs_m1"][k].copy()
+        if k == "voxel_coords":
+            pb[:, 0] += 3
+        inp[k] = torch.from_numpy(np.concatenate([a["inputs_m1"][k], pb])).cuda()
+    both = {"inputs_m1": inp, "agent_modality_list": ["m1"] * 4, "record_len": torch.tensor([3, 1], dtype=torch.int64),
+            "pairwise_t_matrix": torch.from_numpy(np.concatenate([a["pairwise_t_matrix"], b["pairwise_t_matrix"]])).cuda()}
+    taps = {}
+    out = eng(both, taps)
+    torch.cuda.synchronize()
+    for s, (o1, f1) in enumerate(alone):
+        assert torch.equal(taps["fused"][s], f1[0]), f"fused map of scene {s}"
+        for k in ("cls_preds", "reg_preds", "dir_preds"):
+            assert torch.equal(out[k][s], o1[k][0]), (k, s)
+    assert torch.equal(out["cls_preds_single"][:3], alone[0][0]["cls_preds_single"]) and torch.equal(out["cls_preds_single"][3:], alone[1][0]["cls_preds_single"])
