@@ -506,6 +506,10 @@ int qv2x_allgather_codes(void* comm, const uint8_t* send, uint8_t* recv, int64_t
  *   pairwise: f64 [max_cav][max_cav][4][4] (what qv2x_fuse_att_f32 takes) */
 int qv2x_pairwise_from_poses_f64(const uint8_t* gathered, int world, int64_t agent_stride_bytes, int64_t pose_offset_bytes,
                                  int max_cav, double* pairwise, void* stream);
+/* The same for `frames` scenes in one launch: frame f reads every agent's pose `frame_stride_bytes` * f further inside its payload and
+ * writes pairwise + f * max_cav * max_cav * 16. */
+int qv2x_pairwise_from_poses_batch_f64(const uint8_t* gathered, int world, int64_t agent_stride_bytes, int64_t pose_offset_bytes,
+                                       int frames, int64_t frame_stride_bytes, int max_cav, double* pairwise, void* stream);
 
 #ifdef __cplusplus
 }

@@ -7,12 +7,14 @@
 
 namespace qv2x {
 
+// blockIdx.y = frame: its poses lie `frame_stride` bytes further inside every agent's payload, its matrix L * L * 16 doubles further in `out`
 __global__ void pairwise_from_poses_kernel(const uint8_t* __restrict__ gathered, int world, long long agent_stride, long long pose_offset,
-                                           int L, double* __restrict__ out) {
+                                           long long frame_stride, int L, double* __restrict__ out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= L * L) return;
     const int i = idx / L, j = idx - i * L;
-    double* o = out + (size_t)idx * 16;
+    pose_offset += (long long)blockIdx.y * frame_stride;
+    double* o = out + ((size_t)blockIdx.y * L * L + idx) * 16;
     if (i == j || i >= world || j >= world) {
         for (int e = 0; e < 16; ++e) o[e] = (e % 5 == 0) ? 1.0 : 0.0;
         return;
@@ -67,6 +69,21 @@ extern "C" int qv2x_pairwise_from_poses_f64(const uint8_t* gathered, int world, 
     if (((uintptr_t)gathered & 7) || (agent_stride_bytes & 7) || (pose_offset_bytes & 7) || pose_offset_bytes < 0 || agent_stride_bytes < pose_offset_bytes + 128)
         return fail(QV2X_EALIGN, "qv2x_pairwise_from_poses_f64: the pose block is 16 float64, 8-byte aligned, inside the agent stride");
     const int n = max_cav * max_cav;
-    pairwise_from_poses_kernel<<<(n + 63) / 64, 64, 0, (hipStream_t)stream>>>(gathered, world, agent_stride_bytes, pose_offset_bytes, max_cav, pairwise);
+    pairwise_from_poses_kernel<<<(n + 63) / 64, 64, 0, (hipStream_t)stream>>>(gathered, world, agent_stride_bytes, pose_offset_bytes, 0, max_cav, pairwise);
     return hip_check(hipGetLastError(), "qv2x_pairwise_from_poses_f64 launch");
+}
+
+extern "C" int qv2x_pairwise_from_poses_batch_f64(const uint8_t* gathered, int world, int64_t agent_stride_bytes, int64_t pose_offset_bytes,
+                                                  int frames, int64_t frame_stride_bytes, int max_cav, double* pairwise, void* stream) {
+    using namespace qv2x;
+    if (!gathered || !pairwise) return fail(QV2X_EINVAL, "qv2x_pairwise_from_poses_batch_f64: null pointer");
+    if (world < 1 || max_cav < world || max_cav > 64 || frames < 1 || frames > 65535)
+        return fail(QV2X_EINVAL, "qv2x_pairwise_from_poses_batch_f64: 1 <= world <= max_cav <= 64, 1 <= frames <= 65535");
+    if (((uintptr_t)gathered & 7) || (agent_stride_bytes & 7) || (pose_offset_bytes & 7) || (frame_stride_bytes & 7) || pose_offset_bytes < 0 ||
+        frame_stride_bytes < 128 || agent_stride_bytes < pose_offset_bytes + (int64_t)(frames - 1) * frame_stride_bytes + 128)
+        return fail(QV2X_EALIGN, "qv2x_pairwise_from_poses_batch_f64: the pose blocks are 16 float64 each, 8-byte aligned, inside the agent stride");
+    const int n = max_cav * max_cav;
+    pairwise_from_poses_kernel<<<dim3((n + 63) / 64, frames), 64, 0, (hipStream_t)stream>>>(gathered, world, agent_stride_bytes, pose_offset_bytes,
+                                                                                           frame_stride_bytes, max_cav, pairwise);
+    return hip_check(hipGetLastError(), "qv2x_pairwise_from_poses_batch_f64 launch");
 }

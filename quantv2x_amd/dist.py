@@ -123,8 +123,12 @@ class AgentShardedModel:
 
     def _post(self) -> dict:
         eng, ego = self.engine, (0 if self.ego_only else self.rank)
-        for f in range(self.frames):
-            eng.pairwise_from_poses(self.gathered, self.world, self.payload_bytes, self.pose_off + f * POSE_BYTES, self.max_cav, self.pairwise[f])
+        if hasattr(eng, "pairwise_frames_from_poses"):                  # every frame's matrix in one launch
+            eng.pairwise_frames_from_poses(self.gathered, self.world, self.payload_bytes, self.pose_off, self.frames, POSE_BYTES, self.max_cav,
+                                           self.pairwise)
+        else:
+            for f in range(self.frames):
+                eng.pairwise_from_poses(self.gathered, self.world, self.payload_bytes, self.pose_off + f * POSE_BYTES, self.max_cav, self.pairwise[f])
         return eng.fuse_frames_and_heads(self.gathered, self.payload_bytes, self.frames * self.hw, self.hw, self.pairwise,
                                          self.world, ego, self.my_codes, self.frames)
 

@@ -574,6 +574,12 @@ class DeployedModel(nn.Module):
         L.check(self.lib.qv2x_pairwise_from_poses_f64(L.ptr(gathered), world, agent_stride, pose_offset, max_cav, L.ptr(out),
                                                       L.current_stream()), "qv2x_pairwise_from_poses_f64")
 
+    def pairwise_frames_from_poses(self, gathered: torch.Tensor, world: int, agent_stride: int, pose_offset: int, frames: int, frame_stride: int,
+                                   max_cav: int, out: torch.Tensor):
+        """the same for ``frames`` scenes in one launch; ``out`` f64 [frames, max_cav, max_cav, 4, 4]"""
+        L.check(self.lib.qv2x_pairwise_from_poses_batch_f64(L.ptr(gathered), world, agent_stride, pose_offset, frames, frame_stride, max_cav,
+                                                            L.ptr(out), L.current_stream()), "qv2x_pairwise_from_poses_batch_f64")
+
     def fuse_frames_and_heads(self, gathered: torch.Tensor, agent_stride: int, level_stride: int, frame_stride: int, pairwise: torch.Tensor,
                               n_agents: int, ego: int, own_codes: Optional[torch.Tensor], frames: int) -> dict:
         """a7-a11 for ``frames`` scenes whose agents' code planes lie ``agent_stride`` bytes apart in ``gathered`` (frame f at

@@ -23,7 +23,7 @@ SYMBOLS = [
     "qv2x_deconv_f32in", "qv2x_codebook_decode_f32", "qv2x_occ_score_i8",
     "qv2x_codebook64_level_floats", "qv2x_codebook64_c2_f32", "qv2x_codebook_encode64_f32", "qv2x_codebook_encode64_f32in",
     "qv2x_add_relu_f32", "qv2x_occ_sigmoid_f32", "qv2x_pyramid_weighted_fuse_f32p", "qv2x_bottleneck_i8",
-    "qv2x_comm_unique_id", "qv2x_comm_init", "qv2x_comm_destroy", "qv2x_allgather_codes", "qv2x_pairwise_from_poses_f64",
+    "qv2x_comm_unique_id", "qv2x_comm_init", "qv2x_comm_destroy", "qv2x_allgather_codes", "qv2x_pairwise_from_poses_f64", "qv2x_pairwise_from_poses_batch_f64",
     "qv2x_codebook_encode_collapsed_f32", "qv2x_mean_vfe_f32", "qv2x_sp_index_scatter", "qv2x_sp_out_sites_workspace_bytes", "qv2x_sp_out_sites", "qv2x_sp_rulebook", "qv2x_sp_conv_f32in", "qv2x_sp_conv_i8", "qv2x_sp_to_bev_i8",
 ]
 COMM_ID_BYTES = 128
@@ -200,6 +200,7 @@ def load() -> C.CDLL:
     lib.qv2x_comm_destroy.argtypes = [vp]
     lib.qv2x_allgather_codes.argtypes = [vp, vp, vp, C.c_int64, vp]
     lib.qv2x_pairwise_from_poses_f64.argtypes = [vp, C.c_int, C.c_int64, C.c_int64, C.c_int, vp, vp]
+    lib.qv2x_pairwise_from_poses_batch_f64.argtypes = [vp, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_int, vp, vp]
     for s in SYMBOLS:
         if s not in ("qv2x_last_error", "qv2x_codebook_level_floats", "qv2x_codebook64_level_floats", "qv2x_voxelize_workspace_bytes", "qv2x_postprocess_workspace_bytes",
                      "qv2x_postprocess_late_workspace_bytes", "qv2x_sp_out_sites_workspace_bytes"):
