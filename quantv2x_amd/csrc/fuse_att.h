@@ -25,6 +25,20 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ float4 tap_value(const FuseArgs& a, int agent, int cell, int lane) {
     if (a.feats) return a.feats[((size_t)agent * a.hw + cell) * 64 + lane];
     float4 v = a.lut_bias[lane];
+    if (a.levels == 3) {
+        // three levels (every model of the reference): the three code bytes, then the three table rows, then the sum in level order.  With
+        // the run-time level count below every load is conditional and hipcc waits for each before it requests the next: six dependent L2
+        // round trips per tap instead of two.
+        const uint8_t* cp = a.codes + (size_t)agent * a.code_agent_stride + cell;
+        const int c0 = cp[0], c1 = cp[(size_t)a.code_level_stride], c2 = cp[2 * (size_t)a.code_level_stride];
+        const float4 t0 = a.lut[((size_t)c0) * 64 + lane];
+        const float4 t1 = a.lut[((size_t)a.kc + c1) * 64 + lane];
+        const float4 t2 = a.lut[((size_t)2 * a.kc + c2) * 64 + lane];
+        v.x += t0.x; v.y += t0.y; v.z += t0.z; v.w += t0.w;
+        v.x += t1.x; v.y += t1.y; v.z += t1.z; v.w += t1.w;
+        v.x += t2.x; v.y += t2.y; v.z += t2.z; v.w += t2.w;
+        return v;
+    }
     for (int l = 0; l < a.levels; ++l) {
         const int code = a.codes[(size_t)agent * a.code_agent_stride + (size_t)l * a.code_level_stride + cell];
         const float4 t = a.lut[((size_t)l * a.kc + code) * 64 + lane];
