@@ -266,7 +266,6 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 || (MULTI && NW == 4)) ? 1 : 2) v
     issue_halo(0);
     load_w(IC<0>{}, 0);
     load_w(IC<1>{}, 1);
-    issue_halo(1);
     if (tid < BN) {
         const int co = n0 + tid;
         const int awv = a.aw[co];
@@ -284,6 +283,9 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 || (MULTI && NW == 4)) ? 1 : 2) v
 
     for (int t = tid; t < 3 * NG * HPAD; t += NW * 64) psum[t] = 0;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // the second tile only now: when a launch is one round of workgroups they all fetch their prologue at once (~11 B / cycle / CU), and the
+    // first K steps need tile 0 alone -- tile 1 has nine steps to land like every later one
+    issue_halo(1);
     __builtin_amdgcn_s_barrier();
     add_psum(0, 0);
 
