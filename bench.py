@@ -120,10 +120,14 @@ def rooflines(eng, full, frames, iters):
         stages[name] = {"bound": bound, "us_per_batch": round(us, 2), "launches": launches, "achieved": round(ach, 1), "peak": peak, "unit": unit,
                         "frac": round(ach / peak, 4), "work": note}
 
-    eng.pillars_to_canvas(inp, n)
-    stage("pfn_scatter+clear", lambda: eng.pillars_to_canvas(inp, n), "hbm",
+    def pfn_resident():                             # as the engine runs it: scatter into the resident clean canvas, un-scatter afterwards
+        eng.pillars_to_canvas(inp, n, resident=True)
+        eng.clear_pillars(inp, n)
+    pfn_resident()
+    stage("pfn_scatter+clear", pfn_resident, "hbm",
           pillars * (32 * 16 + 16 + 4) + n * 64 * eng.ny * eng.nx, "GB/s", HBM_PEAK_GBS, 2,
-          f"{pillars} pillars x 532 B read + {n} x 9.0 MB u8 canvas written (SURVEY 8(d) a1+a2)")
+          f"{pillars} pillars x 532 B read + {n} x 9.0 MB u8 canvas written (SURVEY 8(d) a1+a2: the reference's bytes; the resident canvas is "
+          f"kept clean by un-scattering the frame's pillars, so only their cells are written, twice)")
     stage("backbone_convs_i8", lambda: eng.run_plan(n, only=lambda k, l: k in ("conv", "chain") and l.name.startswith("backbone")), "mfma-i8",
           sum(2.0 * p[7] for p in bb), "TOP/s", INT8_MFMA_PEAK_TOPS, len(bb),
           f"{sum(2.0 * p[7] for p in bb) / 1e9:.1f} GOP: 19 conv layers in {len(bb)} launches"

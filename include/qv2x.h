@@ -69,6 +69,9 @@ typedef struct {
 int qv2x_pfn_scatter_i8(const float* voxel_features, const int32_t* voxel_coords, const int32_t* voxel_num_points,
                         int M, int max_points, const qv2x_pfn_params* params /* host */,
                         int8_t* canvas, int N, int ny, int nx, void* stream);
+/* Sets the cells the same pillars were scattered to back to `value` (the code of 0.0 minus 128): a canvas that was clean before
+ * qv2x_pfn_scatter_i8 is clean again, without the full qv2x_fill_i8 per frame.  Same coordinate checks as the scatter. */
+int qv2x_pfn_unscatter_i8(const int32_t* voxel_coords, int M, int value, int8_t* canvas, int N, int ny, int nx, void* stream);
 
 /* a3 / a4 / a5.  One QuantModule 3x3 convolution (zero padding 1, stride 1 or 2) + folded BN bias + ReLU +
  * output activation quantizer (opencood/quant/quant_layer.py:391-410 on F.conv2d; blocks of

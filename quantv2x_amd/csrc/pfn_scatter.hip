@@ -61,7 +61,34 @@ __global__ __launch_bounds__(256) void pfn_scatter_kernel(const float4* __restri
     canvas[cell * 64 + lane] = (int8_t)(code - 128);
 }
 
+// The canvas stays resident and CLEAN between frames: instead of re-filling all of it before every scatter (9 MB per V2X-Real frame), the
+// ~27k cells a frame's pillars wrote are set back to the code of 0.0 once the first convolution has read them.  One thread per (pillar,
+// 16-byte piece); the same bounds test as the scatter.
+__global__ __launch_bounds__(256) void pfn_unscatter_kernel(const int4* __restrict__ coords, int M, int value4, int8_t* __restrict__ canvas,
+                                                            int N, int ny, int nx) {
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int m = (int)(id >> 2), piece = (int)(id & 3);
+    if (m >= M) return;
+    const int4 c = coords[m];
+    if (c.x < 0 || c.x >= N || c.z < 0 || c.z >= ny || (c.y + c.w) < 0 || (c.y + c.w) >= nx) return;
+    const size_t cell = ((size_t)c.x * (ny + 2) + (c.z + 1)) * (nx + 2) + (size_t)(c.y + c.w + 1);
+    v4i v; v[0] = v[1] = v[2] = v[3] = value4;
+    *(v4i*)(canvas + cell * 64 + piece * 16) = v;
+}
+
 }  // namespace qv2x
+
+extern "C" int qv2x_pfn_unscatter_i8(const int32_t* voxel_coords, int M, int value, int8_t* canvas, int N, int ny, int nx, void* stream) {
+    using namespace qv2x;
+    if (M == 0) return QV2X_OK;
+    if (!voxel_coords || !canvas) return fail(QV2X_EINVAL, "qv2x_pfn_unscatter_i8: null pointer");
+    if (M < 0 || N <= 0 || ny <= 0 || nx <= 0 || value < -128 || value > 127) return fail(QV2X_EINVAL, "qv2x_pfn_unscatter_i8: bad sizes / value");
+    if (((uintptr_t)voxel_coords & 15) || ((uintptr_t)canvas & 15)) return fail(QV2X_EALIGN, "qv2x_pfn_unscatter_i8: coords / canvas must be 16-byte aligned");
+    const int b = value & 0xff, v4 = b | (b << 8) | (b << 16) | (b << 24);
+    const long long threads = (long long)M * 4;
+    pfn_unscatter_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, (hipStream_t)stream>>>((const int4*)voxel_coords, M, v4, canvas, N, ny, nx);
+    return hip_check(hipGetLastError(), "qv2x_pfn_unscatter_i8 launch");
+}
 
 extern "C" int qv2x_pfn_scatter_i8(const float* voxel_features, const int32_t* voxel_coords, const int32_t* voxel_num_points,
                                    int M, int max_points, const qv2x_pfn_params* params, int8_t* canvas, int N, int ny, int nx,
