@@ -7,7 +7,7 @@
 
 namespace qv2x {
 
-__global__ __launch_bounds__(256) void pfn_scatter_kernel(const float4* __restrict__ vf, const int4* __restrict__ coords,
+__global__ __launch_bounds__(256, 8) void pfn_scatter_kernel(const float4* __restrict__ vf, const int4* __restrict__ coords,
                                                           const int* __restrict__ npts, int M, int P,
                                                           const qv2x_pfn_params prm, int8_t* __restrict__ canvas,
                                                           int N, int ny, int nx) {
