@@ -125,9 +125,9 @@ def rooflines(eng, full, frames, iters):
         eng.clear_pillars(inp, n)
     pfn_resident()
     stage("pfn_scatter+clear", pfn_resident, "hbm",
-          pillars * (32 * 16 + 16 + 4) + n * 64 * eng.ny * eng.nx, "GB/s", HBM_PEAK_GBS, 2,
-          f"{pillars} pillars x 532 B read + {n} x 9.0 MB u8 canvas written (SURVEY 8(d) a1+a2: the reference's bytes; the resident canvas is "
-          f"kept clean by un-scattering the frame's pillars, so only their cells are written, twice)")
+          pillars * (32 * 16 + 16 + 4) + 2 * pillars * 64, "GB/s", HBM_PEAK_GBS, 2,
+          f"bytes actually moved: {pillars} pillars x 532 B read + their 64-byte cells written twice (scatter, then set back: the canvas stays "
+          f"resident and clean).  SURVEY 8(d) a1+a2 counts {n} x 9.0 MB of canvas writes on top, which this design no longer performs")
     stage("backbone_convs_i8", lambda: eng.run_plan(n, only=lambda k, l: k in ("conv", "chain") and l.name.startswith("backbone")), "mfma-i8",
           sum(2.0 * p[7] for p in bb), "TOP/s", INT8_MFMA_PEAK_TOPS, len(bb),
           f"{sum(2.0 * p[7] for p in bb) / 1e9:.1f} GOP: 19 conv layers in {len(bb)} launches"
@@ -359,6 +359,48 @@ def cpu_baseline_torch(fp_model, qt, sc_np, cores, budget_s=10.0):
     return out
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(n, argv, check_devices=True):
+    """``python bench.py --gpus N`` without a launcher: start ``python -m torch.distributed.run --nproc-per-node N bench.py ...`` as a
+    FRESH CHILD (this process has not touched a GPU: counting devices does not initialise one, and a process that did must never
+    be replaced by exec), pass its output through (rank 0's JSON line is the last line of stdout) and return its exit code.
+    Reference analogue of the launch: opencood/tools/train_ddp.py:46-106, tools/multi_gpu_utils.py:16-38 (env:// rendezvous)."""
+    import subprocess
+    if check_devices:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} but this node has {have} GPU(s); not printing a line for a job that did not run", file=sys.stderr)
+            return 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    print("[bench] launching: " + " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run_ranks(rank, world, args):
+    """The launcher path without GPUs: gloo group, one all-reduce, rank 0 prints a line carrying the world size."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    ok = float(t.item()) == world * (world + 1) / 2
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "launcher dry run (no GPU work)", "n_gpus": world, "dry_run": True, "ranks_joined": ok,
+                          "steps": args.steps, "warmup": args.warmup}), flush=True)
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -369,15 +411,25 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path (two HIP graphs around the collective) with one rank")
     ap.add_argument("--link", default="torch", choices=["torch", "rccl"], help="N>1 collective: torch.distributed or qv2x_allgather_codes")
+    ap.add_argument("--dry-run-ranks", action="store_true",
+                    help="launcher check (CPU, gloo): every rank joins the group, rank 0 prints a line with n_gpus = world size; no GPU work")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a bare `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU) and relay rank 0's line
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:], check_devices=not args.dry_run_ranks))
 
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would not describe the job that ran")
+    if args.dry_run_ranks:
+        raise SystemExit(dry_run_ranks(rank, world, args))
+    if torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {args.gpus}: this node has {torch.cuda.device_count()} GPU(s)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     sharded_mode = world > 1 or args.force_sharded

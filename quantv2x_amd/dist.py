@@ -109,8 +109,11 @@ class AgentShardedModel:
             self._comm = None
 
     # ---- the three phases ---------------------------------------------------------------------------------------------------
-    def _pre(self, my_inputs: dict, my_pose: torch.Tensor):
+    def _pre(self, my_inputs: dict):
         self.engine.encode_into(my_inputs, self.frames, self.my_codes)
+
+    def _set_pose(self, my_pose: torch.Tensor):
+        """The step's pose goes straight into the payload, outside the graphs: a fresh pose tensor every step re-captures nothing."""
         self.my_poses.copy_(my_pose.to(torch.float64).expand(self.frames, 4, 4))
 
     def _exchange(self):
@@ -141,14 +144,17 @@ class AgentShardedModel:
         if self._dev is None:
             self._alloc(my_inputs["voxel_features"].device)
         skip_post = self.ego_only and self.rank != 0
+        self._set_pose(my_pose)
         if not self.graphs:
-            self._pre(my_inputs, my_pose)
+            self._pre(my_inputs)
             self._exchange()
             return None if skip_post else self._post()
         key = (my_inputs["voxel_features"].data_ptr(), my_inputs["voxel_coords"].data_ptr(), my_inputs["voxel_num_points"].data_ptr(),
-               my_pose.data_ptr(), tuple(my_inputs["voxel_features"].shape))
+               tuple(my_inputs["voxel_features"].shape))
         if self._captured is None or self._captured[0] != key:
-            self._captured = (key,) + self._capture(my_inputs, my_pose, skip_post)
+            # Capturing is RANK-LOCAL (no collective is issued by it, see _capture): a rank whose input buffers moved may re-capture
+            # on its own without the ranks' all-gathers falling out of step.
+            self._captured = (key,) + self._capture(my_inputs, skip_post)
         _, pre, post, out = self._captured
         pre.replay()
         self._exchange()
@@ -156,23 +162,26 @@ class AgentShardedModel:
             post.replay()
         return out
 
-    def _capture(self, my_inputs, my_pose, skip_post):
+    def _capture(self, my_inputs, skip_post):
         """Two HIP graphs around the collective.  The pillar count and the input addresses are baked in: refresh the input
-        tensors in place between steps (pad unused pillar rows with agent index -1)."""
+        tensors in place between steps (pad unused pillar rows with agent index -1).
+
+        No collective runs here -- neither in the warm-up nor between the two captures.  Every all-gather has the same size, so one
+        issued by a rank that re-captures alone would pair with the other ranks' NEXT step and leave the ranks out of phase for good.
+        The warm-up's post stage runs on this rank's own payload copied into every agent slot (valid codes and poses)."""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):                                   # warm-up outside capture (lazy one-off work: weight re-tiling, allocations)
-                self._pre(my_inputs, my_pose)
-                self._exchange()
+                self._pre(my_inputs)
+                self.gathered.copy_(self.payload.unsqueeze(0).expand(self.world, -1))
                 if not skip_post:
                     self._post()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         pre = torch.cuda.CUDAGraph()
         with torch.cuda.graph(pre):
-            self._pre(my_inputs, my_pose)
-        self._exchange()
+            self._pre(my_inputs)
         post, out = None, None
         if not skip_post:
             post = torch.cuda.CUDAGraph()

@@ -156,3 +156,26 @@ def test_exchange_world_one_is_a_copy():
         assert payload_layout(3, 1, 35200) == (105600, 105600, 105728) and payload_layout(3, 2, 15) == (90, 96, 352)
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks through torch.distributed.run (a fresh child) and
+    relays rank 0's line; the dry-run flag keeps the ranks on gloo / CPU.  Without two GPUs the real bench refuses instead of
+    printing an `n_gpus: 1` line for a job that did not run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run-ranks"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["ranks_joined"] and line["steps"] == 3
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode != 0 and "n_gpus" not in r.stdout
+    # a launcher whose world size contradicts --gpus is an error, not a silently different job
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--dry-run-ranks"],
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr

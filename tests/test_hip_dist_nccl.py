@@ -87,6 +87,39 @@ def test_sharded_driver_world1_equals_forward(nccl_world1, link, frames, graphs)
     model.close()
 
 
+def test_capture_is_rank_local_and_a_new_pose_does_not_recapture(nccl_world1):
+    """One collective per step, none from capturing: a rank that re-captures alone (its input buffers moved) must not issue an
+    all-gather the other ranks never see -- every gather has the same size, so it would pair with their next step.  A fresh pose
+    tensor per step (what a data loader hands over) re-captures nothing."""
+    from quantv2x_amd import synth
+    from quantv2x_amd.dist import AgentShardedModel
+    from quantv2x_amd.engine import deploy
+    from quantv2x_amd.ptq_state import export_ptq_state
+    eng = deploy(state=export_ptq_state(calibrated_plugin()))
+    inp = {k: torch.from_numpy(v.copy()).cuda() for k, v in scene_np(1)["inputs_m1"].items()}
+    model = AgentShardedModel(eng, frames=1, link="torch", graphs=True, max_cav=5)
+    calls = [0]
+    inner = model._exchange
+
+    def counted():
+        calls[0] += 1
+        inner()
+    model._exchange = counted
+    p0 = torch.from_numpy(synth.pose_matrix(3.0, -1.0, 0.2)).cuda()
+    a = model.forward(inp, p0)["preds_tensor"].clone()
+    assert calls[0] == 1
+    graphs = model._captured[1:3]
+    p1 = torch.from_numpy(synth.pose_matrix(3.0, -1.0, 0.2)).cuda()           # same pose, another tensor
+    b = model.forward(inp, p1)["preds_tensor"].clone()
+    assert calls[0] == 2 and model._captured[1:3] == graphs
+    moved = {k: v.clone() for k, v in inp.items()}                           # the input buffers moved: this rank re-captures on its own
+    c = model.forward(moved, p1)["preds_tensor"].clone()
+    torch.cuda.synchronize()
+    assert calls[0] == 3 and model._captured[1] is not graphs[0]
+    assert torch.equal(a, b) and torch.equal(a, c)
+    model.close()
+
+
 @pytest.mark.parametrize("link,frames", [("torch", 1), ("rccl", 2)])
 def test_sharded_driver_world1_pyramid_model(nccl_world1, link, frames):
     """The same driver over the Pyramid engine: the payload is the 64-wide codebook's planes, the ego side is decode_features."""
