@@ -83,16 +83,12 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 || (MULTI && NW == 4)) ? 1 : 2) v
     constexpr int NF = MULTI ? 16 : 1;
     static_assert(NT == 1, "the epilogue below is written for one 32-channel tile per wave");
     constexpr int NG = MULTI ? QV2X_MAX_GROUPS : 1;
-    constexpr int SP = 48;                                             // epilogue staging row pitch (2-way bank spread for the dword writes)
-    constexpr int STAGE = NW * MT * 32 * SP;                           // every wave stages its MT tiles of [32 pixels][32 channels]
-    // (the staging area is NOT the halo buffers any more: during an item's epilogue they already hold the next item's first tiles)
-    __shared__ __attribute__((aligned(16))) int8_t lds[2 * HBUF + STAGE + 3 * NG * HPAD * 4 + NG * BN * 16];
+    __shared__ __attribute__((aligned(16))) int8_t lds[2 * HBUF + 3 * NG * HPAD * 4 + NG * BN * 16];
     int8_t* hbuf = lds;
-    int8_t* stage = lds + 2 * HBUF;
     // window-sum tables [set][group][halo pixel]: item k of a workgroup uses set k % 3.  Its first tile is summed into the set by the
     // previous item's last tap 8, and item k's start clears set (k + 1) % 3 -- last read two items ago, i.e. before barriers every wave has
     // passed -- so an item starts without a barrier or a wait of its own.
-    int* psum = (int*)(stage + STAGE);
+    int* psum = (int*)(lds + 2 * HBUF);
     v4i* ctab = (v4i*)(psum + 3 * NG * HPAD);                          // [group][BN] {aw, corr_g, scale_g (bits), bias (bits)} per channel
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -325,9 +321,9 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 || (MULTI && NW == 4)) ? 1 : 2) v
         WTRACE(3);
 
         // ---- epilogue: a channel quad's constants are read once and applied to all MT tiles (MT independent chains in flight), the
-        //      bytes staged as [tile][pixel][32 channels] per wave, then MT 16-byte stores per lane back to back --------------------
-        int8_t* stagebuf = stage + wave * (MT * 32 * SP);
+        //      packed bytes stay in registers and leave as MT 16-byte stores per lane -------------------------------------------
         const float rd = 1.0f / a.out_delta, lowc = a.relu ? a.out_zp + 8388608.0f : 8388608.0f;   // the ReLU lives in the clamp (q_pack4)
+        int pk[MT][4];                                                 // [tile][channel quad g4]: channels 8 g4 + 4 half + (0..3) of pixel lane & 31
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             v4i c[4];
@@ -349,22 +345,23 @@ __global__ __launch_bounds__(NW * 64, (NW >= 8 || (MULTI && NW == 4)) ? 1 : 2) v
                         y[e] = __int_as_float(bsi) + (float)T * __int_as_float(sci);
                     }
                 }
-                *(int*)(stagebuf + (i * 32 + (lane & 31)) * SP + 8 * g4 + 4 * half) = q_pack4(y[0], y[1], y[2], y[3], a.out_delta, rd, a.out_zp, lowc);
+                pk[i][g4] = q_pack4(y[0], y[1], y[2], y[3], a.out_delta, rd, a.out_zp, lowc);
             }
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
+        // No LDS staging: the half-wave exchange v_permlane32_swap turns the lane's four channel quads (0-3 | 8-11 | 16-19 | 24-27 in the
+        // lower half-wave, +4 in the upper) into 16 contiguous channels -- lower half 0-15, upper half 16-31 of the same pixel -- and
+        // every tile leaves as one 16-byte store per lane.
         {
-            const int row = lane >> 1, chn = lane & 1;
-            const int xo = cur.x0 + row;
-            v4i ob[MT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) ob[i] = *(const v4i*)(stagebuf + (i * 32 + row) * SP + chn * 16);
+            const int xo = cur.x0 + (lane & 31);
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
+                const auto s02 = __builtin_amdgcn_permlane32_swap(pk[i][0], pk[i][2], false, false);
+                const auto s13 = __builtin_amdgcn_permlane32_swap(pk[i][1], pk[i][3], false, false);
+                v4i ob;
+                ob[0] = s02[0]; ob[1] = s02[1]; ob[2] = s13[0]; ob[3] = s13[1];
                 const int yo = cur.y0 + i;
                 if (yo < a.ho && xo < a.wo)
-                    *(v4i*)(a.out + ((size_t)(cur.img * (a.ho + 2) + yo + 1) * (a.wo + 2) + xo + 1) * a.out_ctotal + a.out_c0 + n0 + wave * 32 + chn * 16) = ob[i];
+                    *(v4i*)(a.out + ((size_t)(cur.img * (a.ho + 2) + yo + 1) * (a.wo + 2) + xo + 1) * a.out_ctotal + a.out_c0 + n0 + wave * 32 + half * 16) = ob;
             }
         }
         WTRACE(4);
@@ -509,9 +506,10 @@ extern "C" int qv2x_conv3x3_i8_wide(const qv2x_conv_desc* d, const int8_t* in, c
     const int patches8 = (a.n * a.tiles_x * a.tiles_y + 7) / 8 * 8;   // block ids come in groups of 8 (one per XCD)
     const int bn = wide_bn(d);
     a.items = patches8 * (a.cout / bn);
-    // persistent workgroups: one round of what a CU holds (LDS: 99-120 / 67-82 / 51 KB per workgroup), a multiple of 8 * (cout / bn)
+    // persistent workgroups: one round of what a CU holds (two waves per SIMD: 174-256 VGPRs; LDS 36-60 KB per workgroup), a multiple
+    // of 8 * (cout / bn)
     const int period = 8 * (a.cout / bn);                              // ids `period` apart share the channel block and the XCD
-    const int slots = 256 * (bn == 256 ? 1 : (bn == 128 ? (d->ngroups > 1 ? 1 : 2) : 3)) / period * period;
+    const int slots = 256 * (bn == 256 ? 1 : (bn == 128 ? (d->ngroups > 1 ? 1 : 2) : 4)) / period * period;
     const dim3 grid(a.items < slots ? a.items : slots);
     if (d->ngroups > 1) {
         if (bn == 256) conv3x3_i8_wide_kernel<true, 8, 1, 256><<<grid, 512, 0, st>>>(a);

@@ -10,7 +10,8 @@ what = sys.argv[1] if len(sys.argv) > 1 else "all"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 chains = (sys.argv[3] != "nochain") if len(sys.argv) > 3 else True
 eng = deploy(path=os.path.join(os.path.dirname(os.path.abspath(__file__)), "cache", "v2xreal_state.npz"))
-dd = synth.scene_to_torch(synth.make_scene("v2xreal", n_agents=n, seed=3, n_points=60000), "cuda")
+import bench
+dd = bench.frame_batch(1, 0, n, torch.device("cuda", 0))[1]          # n single-agent frames (a batch), as bench.py builds them
 eng.use_chains = chains
 eng(dd); torch.cuda.synchronize()
 

@@ -9,7 +9,8 @@ L.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cache", "
 from quantv2x_amd import synth
 from quantv2x_amd.engine import deploy
 eng = deploy(path=os.path.join(os.path.dirname(os.path.abspath(__file__)), "cache", "v2xreal_state.npz"))
-dd = synth.scene_to_torch(synth.make_scene("v2xreal", n_agents=n, seed=3, n_points=60000), "cuda")
+import bench
+dd = bench.frame_batch(1, 0, n, torch.device("cuda", 0))[1]          # n single-agent frames (a batch), as bench.py builds them
 eng(dd); torch.cuda.synchronize()
 raw = C.CDLL(L.LIB_PATH)
 for (kind, layer, x, h, w, o, c0, macs) in eng.conv_plan(n):
