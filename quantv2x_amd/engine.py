@@ -314,6 +314,7 @@ class DeployedModel(nn.Module):
         self._bufs: Dict[int, dict] = {}
         # launch-plan switches for the ablation tools (tools/bench_*_abl.py); the defaults are the shipped configuration
         self.use_wide_conv, self.batch_deconvs, self.use_chains = True, True, True
+        self.wide_form = 0                                             # QV2X_WIDE_AUTO; the ablation tools name a form
         self.chain_max_agents = 1
         # "exact": the reference's eleven chained GEMMs, bit-identical indices (the parity configuration).  "collapsed": opt-in, see collapse_encoder
         self.encode_mode, self._collapsed = "exact", None
@@ -404,8 +405,9 @@ class DeployedModel(nn.Module):
             if layer.w_wide is None:                                    # one-off re-tiling of the weights (not capturable)
                 layer.w_wide = torch.empty_like(layer.w)
                 L.check(self.lib.qv2x_conv3x3_i8_pack_wide(C.byref(d), L.ptr(layer.w), L.ptr(layer.w_wide), L.current_stream()), layer.name)
-            L.check(self.lib.qv2x_conv3x3_i8_wide(C.byref(d), L.ptr(x), L.ptr(layer.w_wide), L.ptr(layer.scale), L.ptr(layer.corr),
-                                                  L.ptr(layer.aw), L.ptr(layer.bias), L.ptr(out), L.current_stream()), layer.name)
+            form = self.wide_form if (len(layer.groups) == 1 and layer.groups[0][1] in (64, 128, 256)) else 0
+            L.check(self.lib.qv2x_conv3x3_i8_wide_form(C.byref(d), L.ptr(x), L.ptr(layer.w_wide), L.ptr(layer.scale), L.ptr(layer.corr),
+                                                       L.ptr(layer.aw), L.ptr(layer.bias), L.ptr(out), form, L.current_stream()), layer.name)
             return
         L.check(self.lib.qv2x_conv3x3_i8(C.byref(d), L.ptr(x), L.ptr(layer.w), L.ptr(layer.scale), L.ptr(layer.corr),
                                          L.ptr(layer.aw), L.ptr(layer.bias), L.ptr(out), L.current_stream()), layer.name)

@@ -51,6 +51,10 @@ def _padded(x_u8, zx_per_channel):
                                             # must stay a multiple of 8 x 3 for a workgroup to keep its channel block
     (30, 50, 64, [(0, 64)], 64),            # 600 one-chunk patches on 768 two-wave slots ... and
     (80, 50, 64, [(0, 64)], 64),            # 1600: two or three items per workgroup, the next-next tile requested at the rotation
+    (140, 25, 64, [(0, 64)], 64),           # 1400 patches on 1024 ping-pong groups: one or two items per group, idle tail slots
+    (64, 50, 96, [(0, 128)], 128),          # 1920 items on 512 four-wave groups: 3 or 4 each, two chunks (three slots per item)
+    (24, 25, 88, [(0, 256)], 256),          # the 25 x 88 level: 360 patches x two 128-channel blocks on 512 groups, four chunks
+    (2, 10, 40, [(0, 192)], 128),           # three chunks (odd): the late half starts two slots behind; most groups idle
 ])
 def test_wide_matches_regular_and_oracle(n, h, w, groups, cout):
     from oracle.spec import Oracle
@@ -76,19 +80,22 @@ def test_wide_matches_regular_and_oracle(n, h, w, groups, cout):
     d.out_delta, d.out_zp = layer.out_q[0], float(layer.out_q[1])
     st = L.current_stream()
     outs = []
-    for wide in (False, True):
+    # the regular kernel, then the wide one: auto, plain, ping-pong, software-pipelined (one input group of 1 | 2 | 4 chunks)
+    forms = [None, 0, 1] + ([2] if len(groups) == 1 else []) + ([3] if len(groups) == 1 and cin in (64, 128, 256) else [])
+    for form in forms:
         out = torch.full((n, h + 2, w + 2, cout), -77, dtype=torch.int8, device=dev)
-        if wide:
+        if form is not None:
             w_wide = torch.empty_like(layer.w)
             L.check(lib.qv2x_conv3x3_i8_pack_wide(C.byref(d), L.ptr(layer.w), L.ptr(w_wide), st), "pack")
-            L.check(lib.qv2x_conv3x3_i8_wide(C.byref(d), L.ptr(xin), L.ptr(w_wide), L.ptr(layer.scale), L.ptr(layer.corr),
-                                             L.ptr(layer.aw), L.ptr(layer.bias), L.ptr(out), st), "wide")
+            L.check(lib.qv2x_conv3x3_i8_wide_form(C.byref(d), L.ptr(xin), L.ptr(w_wide), L.ptr(layer.scale), L.ptr(layer.corr),
+                                                  L.ptr(layer.aw), L.ptr(layer.bias), L.ptr(out), form, st), "wide")
         else:
             L.check(lib.qv2x_conv3x3_i8(C.byref(d), L.ptr(xin), L.ptr(layer.w), L.ptr(layer.scale), L.ptr(layer.corr),
                                         L.ptr(layer.aw), L.ptr(layer.bias), L.ptr(out), st), "regular")
         torch.cuda.synchronize()
         outs.append(out.cpu().numpy())
-    np.testing.assert_array_equal(outs[1], outs[0])                    # interior AND the untouched border
+    for form, o in zip(forms[1:], outs[1:]):
+        np.testing.assert_array_equal(o, outs[0], err_msg=f"form {form}")   # interior AND the untouched border
     assert (outs[1][:, 0] == -77).all() and (outs[1][:, :, 0] == -77).all()
 
     orc = Oracle.__new__(Oracle)
@@ -119,3 +126,9 @@ def test_wide_rejects_unsupported():
     d.stride = 2
     rc = lib.qv2x_conv3x3_i8_wide(C.byref(d), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), None)
     assert rc != 0 and b"stride" in lib.qv2x_last_error()
+    d.stride, d.ngroups, d.cin_total = 1, 2, 128
+    d.group_c0[1], d.group_c[1] = 64, 64
+    rc = lib.qv2x_conv3x3_i8_wide_form(C.byref(d), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), 2, None)
+    assert rc != 0 and b"one input group" in lib.qv2x_last_error()      # the ping-pong form folds one group only
+    rc = lib.qv2x_conv3x3_i8_wide_form(C.byref(d), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), 7, None)
+    assert rc != 0 and b"form 7" in lib.qv2x_last_error()

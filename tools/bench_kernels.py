@@ -4,6 +4,9 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from quantv2x_amd import synth
+from quantv2x_amd import lib as _L
+if os.environ.get("QV2X_LIB_TAG"):           # a side library from tools/build_variant.py
+    _L.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cache", "abl", f"libqv2x_{os.environ['QV2X_LIB_TAG']}.so")
 from quantv2x_amd.engine import deploy
 
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
@@ -13,6 +16,8 @@ eng = deploy(path=os.path.join(os.path.dirname(os.path.abspath(__file__)), "cach
 import bench
 dd = bench.frame_batch(1, 0, n, torch.device("cuda", 0))[1]          # n single-agent frames (a batch), as bench.py builds them
 eng.use_chains = chains
+if os.environ.get("QV2X_WIDE_FORM"):          # dev: name the wide kernel's form (include/qv2x.h QV2X_WIDE_*) for every layer that can take it
+    eng.wide_form = int(os.environ["QV2X_WIDE_FORM"])
 eng(dd); torch.cuda.synchronize()
 
 
