@@ -657,6 +657,120 @@ def gen_pyramid_model():
     print("pyramid_tiny.npz: %d arrays, %d modules, %d blocks" % (len(out), len(names), len(blocks)))
 
 
+# ---- full-size vectors (SURVEY.md 8(c) items 5 and 6): checksums only, plus one 35 200-row index golden --------------------------
+FULL_POINTS = 60000
+
+
+def tensor_stats(t):
+    """[sum, sum of |x|, absmax] in float64 -- too large to store, enough to pin a restatement's forward pass"""
+    a = t.detach().double()
+    return np.array([a.sum().item(), a.abs().sum().item(), a.abs().max().item()], np.float64)
+
+
+def ref_calibrated(shape, n_agents):
+    """The reference's QuantModel under the W8A8 min-max recipe of gen_w8a8 at a full-size shape, frozen after one EMA pass."""
+    qt = quant_wrap(build_ref(shape))
+    for a in act_quantizers(qt):
+        a.set_inited(False)
+    qt.set_quant_state(True, True)
+    dd = synth.scene_to_torch(synth.make_scene(shape, n_agents=n_agents, seed=SEED_SCENE, n_points=FULL_POINTS))
+    with torch.no_grad():
+        torch.manual_seed(0)
+        qt(dd)
+    for a in act_quantizers(qt):
+        a.set_inited(True)
+    return qt, dd
+
+
+def gen_fullsize():
+    """Per-tensor checksums of the reference's fp32 and W8A8 forward at V2X-Real and OPV2V shape (one agent, 60k points), the
+    (delta, zero point) of every quantizer and the histogram of every QuantModule's output codes."""
+    torch.set_num_threads(8)       # (sums are compared with a tolerance; thread count does not change the PTQ state beyond it)
+    out = {}
+    for shape in ("v2xreal", "opv2v"):
+        dd = synth.scene_to_torch(synth.make_scene(shape, n_agents=1, seed=SEED_SCENE, n_points=FULL_POINTS))
+        with torch.no_grad():
+            taps = {}
+            hard_forward(build_ref(shape), dd, taps)
+        for k in ('spatial_features', 'backbone', 'shrinker', 'decoded', 'fused', 'preds_tensor'):
+            out[f'{shape}/fp32/{k}'] = tensor_stats(taps[k])
+        out[f'{shape}/fp32/code_hist'] = np.stack([np.bincount(np32(taps['codes'][l]).reshape(-1).astype(np.int64), minlength=128) for l in range(3)])
+        qt, dd = ref_calibrated(shape, 1)
+        model = qt.model
+        hooks, outs = [], {}
+        for name, m in model.named_modules():
+            if isinstance(m, QuantModule):
+                hooks.append(m.register_forward_hook(lambda mod, i, o, name=name: outs.__setitem__(name, o)))
+        with torch.no_grad():
+            taps = {}
+            hard_forward(model, dd, taps)
+        for h in hooks:
+            h.remove()
+        names = []
+        for name, m in model.named_modules():
+            if not isinstance(m, QuantModule):
+                continue
+            names.append(name)
+            key = f'{shape}/w8a8/' + name.replace('.', '/')
+            wqz, aqz = m.weight_quantizer, m.act_quantizer
+            wcode = np32(torch.clamp(torch.round(m.weight / wqz.delta) + wqz.zero_point, 0, 255)).astype(np.uint8)
+            out[key + '/w_code_checksum'] = weight_checksums(wcode)
+            out[key + '/w_delta_sum'] = np.float64(wqz.delta.double().sum().item())
+            out[key + '/a_delta'], out[key + '/a_zp'] = np.float32(aqz.delta), np.float32(aqz.zero_point)
+            if name in outs:
+                code = torch.round(outs[name] / aqz.delta + aqz.zero_point).clamp(0, 255)
+                out[key + '/out_hist'] = np.bincount(np32(code).reshape(-1).astype(np.int64), minlength=256)
+        out[f'{shape}/w8a8/module_names'] = np.array(names)
+        for k in ('shrinker', 'decoded', 'fused', 'preds_tensor'):
+            out[f'{shape}/w8a8/{k}'] = tensor_stats(taps[k])
+        out[f'{shape}/w8a8/code_hist'] = np.stack([np.bincount(np32(taps['codes'][l]).reshape(-1).astype(np.int64), minlength=128) for l in range(3)])
+        print(shape, "done", flush=True)
+    np.savez_compressed(os.path.join(HERE, "fullsize.npz"), **out)
+    print("fullsize.npz: %d arrays" % len(out))
+
+
+def gen_codebook_full():
+    """Index parity at scale: the 35 200 rows of ONE V2X-Real agent-frame.  The rows are what the deployed path encodes -- the dequantized
+    uint8 shrinker output of the integer path (this build's CPU restatement, bit-identical to the HIP kernels), produced from the PTQ state
+    that quantv2x_amd.ptq_state.export_ptq_state freezes out of the REFERENCE's own calibrated QuantModel -- and the codes / top-2 gaps are
+    the reference's ``UMGMQuantizer.encode`` / ``_distance`` on exactly those rows.  Stored: codes u8 [3, 35200], gaps f32 [3, 35200], the
+    checksum of the input codes (the tests regenerate the input from seeds and must arrive at the same bytes)."""
+    from oracle.spec import Oracle
+    from quantv2x_amd.ptq_state import export_ptq_state
+    torch.set_num_threads(8)
+    qt, dd = ref_calibrated("v2xreal", 1)
+    state = export_ptq_state(qt)
+    sc = synth.make_scene("v2xreal", n_agents=1, seed=SEED_SCENE, n_points=FULL_POINTS)
+    taps = {}
+    Oracle(state).forward(sc, taps)
+    shr = taps["shrinker_m1.layers.0.double_conv.1"]                  # u8 [1, 100, 352, 256]
+    dq, zq = taps["shrinker_q"]
+    rows = ((shr.astype(np.float32) - np.float32(zq)) * np.float32(dq)).reshape(-1, shr.shape[-1])
+    out = {"in_checksum": weight_checksums(shr), "in_delta": np.float32(dq), "in_zp": np.float32(zq), "rows": np.int64(rows.shape[0])}
+    cb = qt.model.codebook
+    with torch.no_grad():
+        xt = torch.from_numpy(rows)
+        codes = cb.encode(xt)
+        out["codes"] = np.stack([np32(c[:, 0]) for c in codes]).astype(np.uint8)
+        cur, gaps = xt, []
+        for enc in cb._encoders:
+            z = enc._latentStageEncoder(cur)
+            d = enc._quantizer._distance(enc._quantizationHead(z))[:, 0]
+            top2 = torch.topk(d, 2, dim=-1, largest=False)[0]
+            gaps.append(np32(top2[:, 1] - top2[:, 0]))
+            cur, _ = enc.encode(cur)
+        out["gaps"] = np.stack(gaps).astype(np.float32)
+        out["decoded_stats"] = tensor_stats(cb.decode(codes))
+    # the same rows with torch's single-thread matmul: how many indices move with the reference's OWN summation order
+    torch.set_num_threads(1)
+    with torch.no_grad():
+        codes1 = np.stack([np32(c[:, 0]) for c in cb.encode(torch.from_numpy(rows))]).astype(np.uint8)
+    out["codes_single_thread_differs"] = np.int64((codes1 != out["codes"]).sum())
+    np.savez_compressed(os.path.join(HERE, "codebook_full.npz"), **out)
+    print("codebook_full.npz", {k: np.asarray(v).shape for k, v in out.items()}, "min gap", out["gaps"].min(),
+          "rows under 1e-4:", int((out["gaps"] < 1e-4).sum()), "thread-order flips:", int(out["codes_single_thread_differs"]))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["fp32", "w8a8", "uaq", "geometry", "codebook", "postprocess", "postprocess_mc", "recon", "pyramid", "pyramid_model", "maxfuse"]
     with torch.no_grad():
@@ -672,3 +786,5 @@ if __name__ == "__main__":
     if "pyramid" in which: gen_pyramid()
     if "pyramid_model" in which: gen_pyramid_model()
     if "maxfuse" in which: gen_maxfuse()
+    if "fullsize" in which: gen_fullsize()                 # (not in the default list: minutes of CPU time each)
+    if "codebook_full" in which: gen_codebook_full()
