@@ -19,9 +19,13 @@ def quant_params(n_bits_w=8, n_bits_a=8, scale_method="minmax", prob=0.5):
     return wq, aq
 
 
-def wrap(model, scale_method="minmax"):
-    wq, aq = quant_params(scale_method=scale_method)
+def wrap(model, scale_method="minmax", n_bits_w=8, n_bits_a=8, first_last_8bit=False):
+    """``first_last_8bit``: ``set_first_last_layer_to_8bit`` (quant_model.py:115-127) between the wrap and the weight-quantizer
+    initialisation, where the driver has it (inference_quant.py:248-250) -- the usual companion of ``--n_bits_w 4``."""
+    wq, aq = quant_params(n_bits_w, n_bits_a, scale_method=scale_method)
     qt = QuantModel(model, wq, aq).eval()
+    if first_last_8bit:
+        qt.set_first_last_layer_to_8bit()
     set_weight_quantize_params(qt)
     return qt
 

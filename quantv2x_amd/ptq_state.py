@@ -114,8 +114,14 @@ def export_ptq_state(qt_model) -> Dict[str, np.ndarray]:
     for name, m in model.named_modules():
         if not _is_quant_module(m):
             continue
-        if m.weight_quantizer.n_bits != 8 or m.act_quantizer.n_bits != 8:
-            raise ValueError(f"{name}: the deployed path is W8A8 only")
+        # W4A8 and the other sub-8-bit WEIGHT widths of the reference's PTQ script (scripts/inference/inference_quant.sh: --n_bits_w 4
+        # --n_bits_a 8; quant_layer.py:337-340 bitwidth_refactor, quant_model.py:115-127 set_first_last_layer_to_8bit) deploy unchanged:
+        # a b-bit code and its zero point lie in [0, 2^b - 1], stay uint8 and run on the same int8 kernels.  Activations stay 8-bit:
+        # the requantizing epilogues clamp to [0, 255].
+        if not 2 <= int(m.weight_quantizer.n_bits) <= 8:
+            raise ValueError(f"{name}: weight bit width {m.weight_quantizer.n_bits} (2..8 deploy)")
+        if m.act_quantizer.n_bits != 8:
+            raise NotImplementedError(f"{name}: {m.act_quantizer.n_bits}-bit activations -- the deployed path is WxA8 (every epilogue clamps codes to [0, 255])")
         # AdaRoundQuantizer (adaptive_rounding.py:6-21) has no `inited`: it is built from an initialised quantizer
         if not (getattr(m.weight_quantizer, "inited", True) and m.act_quantizer.inited):
             raise ValueError(f"{name}: quantizers must be frozen (set_inited(True)) before export")
@@ -130,6 +136,7 @@ def export_ptq_state(qt_model) -> Dict[str, np.ndarray]:
         out[name + "/a_zp"] = np.float32(_np(torch.as_tensor(aq.zero_point)).reshape(-1)[0])
         out[name + "/a_off"] = np.bool_(bool(m.disable_act_quant))
     out["meta/module_names"] = np.array(names)
+    out["meta/w_bits"] = np.array([int(dict(model.named_modules())[n].weight_quantizer.n_bits) for n in names], dtype=np.int32)   # 8, or 2..7 (W4A8)
 
     enc = model.encoder_m1
     if type(enc).__name__ == "QuantSECOND":                       # the sparse encoder in front of the same 2-D path
@@ -226,8 +233,8 @@ def export_second_state(enc) -> Dict[str, np.ndarray]:
     layers = second_layers(enc)
     for i, (name, m) in enumerate(layers):
         wq, aq, conv = m.weight_quantizer, m.act_quantizer, m.spconv_module
-        if wq.n_bits != 8 or aq.n_bits != 8 or m.disable_act_quant:
-            raise ValueError(f"{name}: the deployed path is W8A8 with every output quantized")
+        if not 2 <= int(wq.n_bits) <= 8 or aq.n_bits != 8 or m.disable_act_quant:
+            raise ValueError(f"{name}: the deployed path is WxA8 (2..8-bit weights, 8-bit activations) with every output quantized")
         if not (getattr(wq, "inited", True) and aq.inited):
             raise ValueError(f"{name}: quantizers must be frozen before export")
         if type(m.activation_function).__name__ != "ReLU" or type(m.norm_function).__name__ != "BatchNorm1d" or m.bias is not None:

@@ -657,6 +657,66 @@ def gen_pyramid_model():
     print("pyramid_tiny.npz: %d arrays, %d modules, %d blocks" % (len(out), len(names), len(blocks)))
 
 
+def gen_w4a8():
+    """The reference's own PTQ configuration (scripts/inference/inference_quant.sh:1: --n_bits_w 4 --n_bits_a 8) on the tiny model:
+    QuantModel(n_bits_w=4) + set_first_last_layer_to_8bit (quant_model.py:115-127) + the min-max recipe of gen_w8a8."""
+    out = {}
+    wq = dict(n_bits=4, channel_wise=True, scale_method="minmax")
+    aq = dict(n_bits=8, channel_wise=False, scale_method="minmax", leaf_param=True, prob=0.5)
+    qt = QuantModel(build_ref(), wq, aq).eval()
+    qt.set_first_last_layer_to_8bit()
+    set_weight_quantize_params(qt)
+    for a in act_quantizers(qt):
+        a.set_inited(False)
+    qt.set_quant_state(True, True)
+    dd = scene(2)
+    with torch.no_grad():
+        torch.manual_seed(0)
+        qt(dd)
+    for a in act_quantizers(qt):
+        a.set_inited(True)
+    model = qt.model
+    names, hooks, outs = [], [], {}
+    for name, m in model.named_modules():
+        if isinstance(m, QuantModule):
+            names.append(name)
+            hooks.append(m.register_forward_hook(lambda mod, i, o, name=name: outs.__setitem__(name, o)))
+    with torch.no_grad():
+        taps = {}
+        hard_forward(model, dd, taps)
+    for h in hooks:
+        h.remove()
+    out['module_names'] = np.array(names)
+    bits_w, bits_a = [], []
+    for name, m in model.named_modules():
+        if not isinstance(m, QuantModule):
+            continue
+        wqz, aqz = m.weight_quantizer, m.act_quantizer
+        key = name.replace('.', '/')
+        bits_w.append(wqz.n_bits); bits_a.append(aqz.n_bits)
+        out[key + '/w_delta'] = np32(wqz.delta).reshape(-1)
+        out[key + '/w_zp'] = np32(wqz.zero_point).reshape(-1)
+        wcode = np32(torch.clamp(torch.round(m.weight / wqz.delta) + wqz.zero_point, 0, wqz.n_levels - 1)).astype(np.uint8)
+        out[key + '/w_code_checksum'] = weight_checksums(wcode)
+        out[key + '/w_code_max'] = np.int32(wcode.max())
+        out[key + '/a_delta'], out[key + '/a_zp'] = np.float32(aqz.delta), np.float32(aqz.zero_point)
+        if name in outs and 'pfn_layers' not in name:
+            out[key + '/out_code'] = np32(torch.round(outs[name] / aqz.delta + aqz.zero_point)).astype(np.uint8)
+    out['bits_w'], out['bits_a'] = np.array(bits_w, np.int32), np.array(bits_a, np.int32)
+    pfn = model.encoder_m1.pillar_vfe.pfn_layers[0]
+    out['pfn/a2_delta'], out['pfn/a2_zp'] = np.float32(pfn.act_quantizer.delta), np.float32(pfn.act_quantizer.zero_point)
+    with torch.no_grad():
+        bd = {k: dd['inputs_m1'][k] for k in dd['inputs_m1']}
+        pf = model.encoder_m1.pillar_vfe(dict(bd))['pillar_features']
+        out['pfn/pillar_code'] = np32(torch.round(pf / pfn.act_quantizer.delta + pfn.act_quantizer.zero_point)).astype(np.uint8)
+    for k in ('shrinker', 'decoded', 'fused'):
+        out['hard/' + k] = sub8(taps[k])
+    out['hard/preds_tensor'] = np32(taps['preds_tensor'])
+    out['hard/codes'] = np32(taps['codes']).astype(np.uint8)
+    np.savez_compressed(os.path.join(HERE, "tiny_w4a8.npz"), **out)
+    print("tiny_w4a8.npz: %d arrays; weight bits %s" % (len(out), bits_w))
+
+
 # ---- full-size vectors (SURVEY.md 8(c) items 5 and 6): checksums only, plus one 35 200-row index golden --------------------------
 FULL_POINTS = 60000
 
@@ -772,7 +832,7 @@ def gen_codebook_full():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["fp32", "w8a8", "uaq", "geometry", "codebook", "postprocess", "postprocess_mc", "recon", "pyramid", "pyramid_model", "maxfuse"]
+    which = sys.argv[1:] or ["fp32", "w8a8", "uaq", "geometry", "codebook", "postprocess", "postprocess_mc", "recon", "pyramid", "pyramid_model", "maxfuse", "w4a8"]
     with torch.no_grad():
         pass
     if "fp32" in which: gen_fp32()
@@ -786,5 +846,6 @@ if __name__ == "__main__":
     if "pyramid" in which: gen_pyramid()
     if "pyramid_model" in which: gen_pyramid_model()
     if "maxfuse" in which: gen_maxfuse()
+    if "w4a8" in which: gen_w4a8()
     if "fullsize" in which: gen_fullsize()                 # (not in the default list: minutes of CPU time each)
     if "codebook_full" in which: gen_codebook_full()
