@@ -249,6 +249,44 @@ def make_state_dict(template: Dict[str, "object"], seed: int = 0) -> Dict[str, n
     return out
 
 
+def make_state_dict_contractive(template: Dict[str, "object"], seed: int = 0, pass_gain: float = 0.9, noise: float = 0.25) -> Dict[str, np.ndarray]:
+    """A weight set on which a +-1 code flip is NOT amplified by the convolution stack (tests/test_hip_box_agreement.py's yardstick).
+
+    With He-normal weights one flipped input code shifts each of its 9 x C_out fan-out sums by ~N(0, 1/sqrt(9 C_in)) output LSBs, i.e.
+    ~0.8 sqrt(18 C_out^2 / C_in) ~ 27 expected new flips per flip and layer: the integer path and the reference's fp32-emulated path
+    decorrelate until ~5 % of the codes differ, whatever the implementation.  Here every backbone / shrinker convolution is
+    ``pass_gain`` x (centre tap, channel co <- co mod C_in) plus a random part whose fan-out L1 norm is ``noise``: one flip in makes
+    ~pass_gain + noise flips out, so differences stay at the per-layer floor of fresh flips.  BatchNorms are the identity, deconvolutions
+    copy channel ci to co = ci mod C_out on every tap.  PFN, codebook and heads keep ``make_state_dict``'s values."""
+    out = make_state_dict(template, seed)
+    for key in sorted(template.keys()):
+        if not key.startswith(("backbone_m", "shrinker_m")):
+            continue
+        shape = tuple(int(v) for v in template[key].shape)
+        leaf = key.rsplit(".", 1)[-1]
+        g = _rng(seed + 7919, key)
+        if leaf == "running_mean":
+            out[key] = np.zeros(shape, np.float32)
+        elif leaf == "running_var":
+            out[key] = np.ones(shape, np.float32)          # (eps = 1e-3 makes the fold 0.9995: harmless)
+        elif leaf == "weight" and len(shape) == 1:
+            out[key] = np.ones(shape, np.float32)
+        elif leaf == "bias":
+            out[key] = np.full(shape, 0.02, np.float32)
+        elif leaf == "weight" and len(shape) == 4:
+            deconv = ".deblocks." in key
+            fan_out = (shape[1] if deconv else shape[0] * shape[2] * shape[3])      # outputs one input value reaches
+            w = g.normal(0.0, noise / (0.8 * fan_out), shape).astype(np.float32)
+            if deconv:                                     # [C_in, C_out, k, k]: every tap copies ci -> ci mod C_out
+                ci = np.arange(shape[0])
+                w[ci, ci % shape[1], :, :] += pass_gain
+            else:                                          # [C_out, C_in, 3, 3]
+                co = np.arange(shape[0])
+                w[co, co % shape[1], shape[2] // 2, shape[3] // 2] += pass_gain
+            out[key] = w
+    return out
+
+
 def load_state_dict_numpy(model, sd: Dict[str, np.ndarray]) -> None:
     import torch
     tsd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
