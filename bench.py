@@ -232,6 +232,75 @@ def pyramid_model_line(device):
     return out
 
 
+def points_to_boxes_line(state, device):
+    """The deployment chain around the model, as ONE HIP graph per batch: LiDAR sweeps -> pillars (qv2x_voxelize_f32, replacing the
+    reference's CPU spconv voxelizer, pre_processor/sp_voxel_preprocessor.py:54-85) -> the model (a1-a11) -> boxes (qv2x_postprocess_f32:
+    VoxelPostprocessor3Heads.post_process, data_utils/post_processor/voxel_postprocessor_3heads.py:318-478; what
+    tools/inference_utils.py:201-225 calls per frame).  No host read-back inside the graph: every sweep hands a fixed number of pillar rows
+    on (unused rows carry batch index -1) and the box count stays on the device.  Not part of ``value``."""
+    import numpy as np
+    import torch
+    from quantv2x_amd import synth
+    from quantv2x_amd.engine import deploy
+    from quantv2x_amd.plugin.data_utils.post_processor import build_postprocessor
+    from quantv2x_amd.plugin.data_utils.post_processor.voxel_postprocessor import gpu_post_process
+    from quantv2x_amd.voxelizer import GpuVoxelizer
+    lidar, vox, max_vox, _ = synth.SHAPES[SHAPE]
+    gw, gh, _ = synth.grid_size(lidar, vox)
+    eng = deploy(state=state)
+    vz = GpuVoxelizer(lidar, vox, 32, max_vox)
+    pp = build_postprocessor(synth.mc_postprocess_params(lidar, gw, gh), train=False)
+    all_anchors, _ = pp.generate_anchor_box()
+    a = torch.as_tensor(np.array(all_anchors)).to(torch.float32).permute(1, 2, 0, 3, 4).contiguous()     # (H, W, class, anchor, 7)
+    anchors_dev, per_cell = a.reshape(-1, 7).to(device), int(a.shape[2] * a.shape[3])
+    cap = 40960                                       # pillar rows handed on per sweep (the synthetic sweeps fill ~27k; the yaml's limit is 70k)
+    out = {"pillar_rows_per_sweep": cap}
+    for frames in (1, 8):
+        sweeps = [torch.from_numpy(synth.make_points(lidar, N_POINTS, 3000 + f)).to(device) for f in range(frames)]
+        pairwise = torch.eye(4, dtype=torch.float64).reshape(1, 1, 1, 4, 4).repeat(frames, 5, 5, 1, 1).to(device)
+        rl = torch.ones(frames, dtype=torch.int64)
+
+        def run():
+            inp = vz.fixed(sweeps, cap)
+            o = eng({"inputs_m1": inp, "agent_modality_list": ["m1"] * frames, "record_len": rl, "pairwise_t_matrix": pairwise})
+            res = []
+            for f in range(frames):
+                res.append(gpu_post_process(pp, o["cls_preds"][f:f + 1], o["reg_preds"][f:f + 1], None, anchors_dev, torch.eye(4),
+                                            anchors_per_cell=per_cell, num_classes=int(o["cls_preds"].shape[1] // per_cell), num_bins=0,
+                                            dir_offset=0.0, rng=pp.gt_range, range_xy_only=True, max_extent=100.0, z_lim=(-100.0, 100.0),
+                                            max_boxes=1000, sync=False))
+            return inp, res
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                run()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            inp, res = run()
+        graph.replay()
+        torch.cuda.synchronize()
+        us = event_time_us(graph.replay, 30)
+        key = "one_frame" if frames == 1 else f"batch{frames}"
+        out[key] = {"ms_per_frame": round(us / frames / 1e3, 4), "frames_per_s": round(frames * 1e6 / us, 1),
+                    "pillars": [int(v) for v in inp["voxel_counts"].tolist()][:2], "boxes": [int(r[3].item()) for r in res][:2]}
+        if frames == 1:
+            lat = []
+            for _ in range(30):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                graph.replay()
+                torch.cuda.synchronize()
+                lat.append((time.perf_counter() - t0) * 1e3)
+            out[key]["latency_ms_p50"] = round(sorted(lat)[len(lat) // 2], 4)
+        del graph
+    out["note"] = ("60k-point synthetic sweeps -> voxelize -> W8A8 model -> sigmoid / decode / rotated NMS (random-weight heads: ~450 boxes "
+                   "out of 1000 candidates, the NMS works hard) as one hipGraph; the model body alone is `value` / `latency_ms_p50`")
+    return out
+
+
 def collapsed_encode_line(state, full, B, F, steps, device):
     """NOT the headline: the same step (B frames per graph, F graphs in flight) with the OPT-IN collapsed codebook encode
     (engine.encode_mode = "collapsed": the encoder's affine heads multiplied out on the host, one GEMM + an argmin chain per cell).  Its
@@ -575,6 +644,7 @@ def main():
             line["pyramid_model"] = pyramid_model_line(device)
             line["second_encoder"] = second_encoder_line(device)
             line["collapsed_encode_opt_in"] = collapsed_encode_line(state, full, B, F, args.steps, device)
+            line["points_to_boxes"] = points_to_boxes_line(state, device)
         if not args.no_cpu_baseline and world == 1:       # reported on rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(state, frame_batch(1, 0, 1, "cpu")[0])
             line["cpu_baseline_torch"] = cpu_baseline_torch(fp_model, qt, frame_batch(1, 0, 1, "cpu")[0], cores)

@@ -44,7 +44,9 @@ int qv2x_fill_i8(int8_t* buf, int64_t bytes, int value, void* stream);
  * coords (agent, z, y, x), zero padded; deterministic.
  *   points f32 [n_points][4] (x, y, z, intensity), n_points < 2^20; lidar_range [6], voxel_size [3] HOST floats
  *   outputs sized for max_voxels: voxel_features f32 [max_voxels][max_points][4] (zero filled), voxel_coords i32 [..][4],
- *   voxel_num_points i32 [..]; n_voxels: DEVICE int32 = number of voxels written
+ *   voxel_num_points i32 [..]; n_voxels: DEVICE int32 = number of voxels written.  Rows past that count are left defined --
+ *   coords (-1, -1, -1, -1) (an agent index qv2x_pfn_scatter_i8 drops), zero points, zero features -- so a caller may hand all
+ *   max_voxels rows on without reading the count back.  Every clear is a kernel: the call is HIP-graph capturable.
  *   workspace: qv2x_voxelize_workspace_bytes(n_points) bytes of device memory */
 int64_t qv2x_voxelize_workspace_bytes(int n_points);
 int qv2x_voxelize_f32(const float* points, int n_points, const float* lidar_range, const float* voxel_size, int agent,

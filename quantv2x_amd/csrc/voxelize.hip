@@ -65,6 +65,23 @@ __global__ void vox_scatter_kernel(const float4* __restrict__ pts, const unsigne
     }
 }
 
+// Clears done by a kernel, not by hipMemsetAsync / hipMemcpyAsync nodes: inside a captured hipGraph a memset node did not stay ordered
+// before the kernel that follows it on later replays (found on the SECOND encoder, csrc/sparse_conv.hip) -- and the whole pre-step is
+// meant to be captured with the model behind it.  Rows past the voxel count are left in a defined state: coords (-1, -1, -1, -1)
+// -- the agent index the PFN kernel drops -- zero points, zero features: a caller may hand ALL max_voxels rows to the model and never
+// read the count back.
+__global__ void vox_clear_kernel(int4* __restrict__ flags4, long long nflags4, int4* __restrict__ feats4, long long nfeats4,
+                                 int4* __restrict__ coords, int* __restrict__ nump, int max_voxels, int* __restrict__ count) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *count = 0;
+    for (long long k = i; k < nflags4; k += stride) flags4[k] = make_int4(0, 0, 0, 0);
+    for (long long k = i; k < nfeats4; k += stride) feats4[k] = make_int4(0, 0, 0, 0);
+    for (long long k = i; k < max_voxels; k += stride) { coords[k] = make_int4(-1, -1, -1, -1); nump[k] = 0; }
+}
+
+__global__ void vox_count_kernel(const int* __restrict__ count, int max_voxels, int* __restrict__ out) { *out = *count < max_voxels ? *count : max_voxels; }
+
 struct VoxWorkspace {
     unsigned long long *keys_in, *keys_out;
     int *head, *first_flag, *vox_of_first, *count;
@@ -121,9 +138,11 @@ extern "C" int qv2x_voxelize_f32(const float* points, int n_points, const float*
     ws.cub = w; ws.cub_bytes = (size_t)workspace_bytes - (size_t)(w - (char*)workspace);
 
     int rc;
-    if ((rc = hip_check(hipMemsetAsync(ws.first_flag, 0, (size_t)P * 4, st), "voxelize memset"))) return rc;
-    if ((rc = hip_check(hipMemsetAsync(ws.count, 0, 4, st), "voxelize memset"))) return rc;
-    if ((rc = hip_check(hipMemsetAsync(voxel_features, 0, (size_t)max_voxels * max_points * 16, st), "voxelize memset"))) return rc;
+    {
+        const long long nflags4 = (long long)(align_up((size_t)P * 4) / 16), nfeats4 = (long long)max_voxels * max_points;
+        vox_clear_kernel<<<2048, 256, 0, st>>>((int4*)ws.first_flag, nflags4, (int4*)voxel_features, nfeats4, (int4*)voxel_coords,
+                                                voxel_num_points, max_voxels, ws.count);
+    }
     const int B = 256, G = (P + B - 1) / B;
     vox_keys_kernel<<<G, B, 0, st>>>((const float4*)points, P, g, ws.keys_in);
     size_t tb = ws.cub_bytes;
@@ -135,6 +154,6 @@ extern "C" int qv2x_voxelize_f32(const float* points, int n_points, const float*
     if ((rc = hip_check(hipcub::DeviceScan::ExclusiveSum(ws.cub, tb, ws.first_flag, ws.vox_of_first, P, st), "voxelize scan"))) return rc;
     vox_scatter_kernel<<<G, B, 0, st>>>((const float4*)points, ws.keys_out, ws.head, ws.vox_of_first, P, g, agent, max_points, max_voxels,
                                         (float4*)voxel_features, (int4*)voxel_coords, voxel_num_points, ws.count);
-    if ((rc = hip_check(hipMemcpyAsync(n_voxels, ws.count, 4, hipMemcpyDeviceToDevice, st), "voxelize count"))) return rc;
+    vox_count_kernel<<<1, 1, 0, st>>>(ws.count, max_voxels, n_voxels);
     return hip_check(hipGetLastError(), "qv2x_voxelize_f32 launch");
 }

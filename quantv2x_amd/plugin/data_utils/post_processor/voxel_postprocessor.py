@@ -27,7 +27,7 @@ def load_point_pillar_anchor_args(hypes: dict) -> dict:
 
 
 def gpu_post_process(owner, cls, reg, dirp, anchors_dev, transformation_matrix, *, anchors_per_cell, num_classes, num_bins, dir_offset,
-                     rng, range_xy_only, max_extent, z_lim, max_boxes):
+                     rng, range_xy_only, max_extent, z_lim, max_boxes, sync=True):
     """One ``qv2x_postprocess_f32`` call (or, when ``cls`` / ``reg`` / ``dirp`` / ``anchors_dev`` / ``transformation_matrix`` are lists with
     one entry per CAV, one ``qv2x_postprocess_late_f32`` call); ``owner`` keeps the workspace between frames.
     -> (corners [K, 8, 3], scores [K], labels i32 [K]) on the GPU, or (None, None, None)."""
@@ -70,6 +70,8 @@ def gpu_post_process(owner, cls, reg, dirp, anchors_dev, transformation_matrix, 
     arr = lambda ts: (C.c_void_p * ncav)(*[(t.data_ptr() if t is not None else None) for t in ts])
     check(lib.qv2x_postprocess_late_f32(C.byref(d), ncav, arr(cls_l), arr(reg_l), arr(dir_l), arr(anc_l), tf, ptr(owner._ws), need,
                                         ptr(corners), ptr(scores), ptr(labels), ptr(count), current_stream()), "qv2x_postprocess_late_f32")
+    if not sync:                                     # HIP-graph capture: fixed-size outputs + the box count left on the device
+        return corners, scores, labels, count
     k = int(count.item())                            # the one host synchronisation of the frame (the reference goes to numpy here)
     if k == 0:
         return None, None, None

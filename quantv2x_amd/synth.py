@@ -190,6 +190,18 @@ def make_pyramid_hypes(shape: str = "v2xreal", codebook: bool = True, dict_size:
 
 # --------------------------------------------------------------------------- weights
 
+# The V2X-Real multi-class post-processor configuration (hypes_yaml/v2x_real/*: three anchor sets, VoxelPostprocessor3Heads)
+MC_ANCHOR_CFGS = [dict(class_name=n, anchor_sizes=[sz], anchor_rotations=[0, 1.57], anchor_bottom_heights=[zb], align_center=True,
+                       feature_map_stride=2, matched_threshold=0.6, unmatched_threshold=0.45)
+                  for n, sz, zb in (("vehicle", [3.9, 1.6, 1.56], -1.78), ("pedestrian", [0.8, 0.6, 1.73], -0.6), ("truck", [8, 3, 3], -1.78))]
+
+
+def mc_postprocess_params(lidar_range: Sequence[float], grid_w: int, grid_h: int) -> dict:
+    return {"core_method": "VoxelPostprocessor3Heads", "gt_range": list(lidar_range), "order": "hwl", "nms_thresh": 0.15,
+            "anchor_args": {"cav_lidar_range": list(lidar_range), "W": grid_w, "H": grid_h, "anchor_generator_config": MC_ANCHOR_CFGS},
+            "target_args": {"score_threshold": 0.2}}
+
+
 def _rng(seed: int, tag: str) -> np.random.Generator:
     # independent stream per parameter name so that key order never matters
     h = np.frombuffer(tag.encode(), dtype=np.uint8).astype(np.uint64)

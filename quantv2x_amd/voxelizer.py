@@ -43,6 +43,25 @@ class GpuVoxelizer:
         m = int(count.item())            # the one host sync of the pre-step: the pillar count sizes every later launch
         return feats[:m], coords[:m], nump[:m]
 
+    def fixed(self, sweeps: Sequence[torch.Tensor], capacity: int) -> dict:
+        """HIP-graph capturable form: one sweep per batch index, EVERY sweep's ``capacity`` rows handed on (rows past a sweep's voxel count
+        carry batch index -1, which the PFN kernel drops), no host read-back.  The returned dict also holds ``voxel_counts`` i32 [n] on
+        the device.  Sweeps must keep their point counts between replays of a captured graph."""
+        n = len(sweeps)
+        feats = torch.empty((n * capacity, self.max_points, 4), dtype=torch.float32, device=self.dev)
+        coords = torch.empty((n * capacity, 4), dtype=torch.int32, device=self.dev)
+        nump = torch.empty((n * capacity,), dtype=torch.int32, device=self.dev)
+        counts = torch.zeros(n, dtype=torch.int32, device=self.dev)
+        need = max(int(self.lib.qv2x_voxelize_workspace_bytes(int(p.shape[0]))) for p in sweeps)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        for a, pts in enumerate(sweeps):
+            pts = pts.contiguous()
+            L.check(self.lib.qv2x_voxelize_f32(L.ptr(pts), int(pts.shape[0]), self.range, self.vsize, a, self.max_points, capacity,
+                                               L.ptr(self._ws), need, L.ptr(feats[a * capacity:]), L.ptr(coords[a * capacity:]),
+                                               L.ptr(nump[a * capacity:]), L.ptr(counts[a:]), L.current_stream()), "qv2x_voxelize_f32")
+        return {"voxel_features": feats, "voxel_coords": coords, "voxel_num_points": nump, "voxel_counts": counts}
+
     def __call__(self, sweeps: Sequence[torch.Tensor]) -> dict:
         """One sweep per agent -> ``inputs_m1``; agents are the batch index, as ``collate_batch`` does."""
         parts = [self.one(pts, a) for a, pts in enumerate(sweeps)]

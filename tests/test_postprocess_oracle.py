@@ -67,15 +67,7 @@ def test_nms_is_greedy_in_score_order(gold):
 
 
 # ---- multi-class (VoxelPostprocessor3Heads, the V2X-Real yaml) ---------------------------------------------------------
-MC_CFGS = [dict(class_name=n, anchor_sizes=[sz], anchor_rotations=[0, 1.57], anchor_bottom_heights=[zb], align_center=True,
-                feature_map_stride=2, matched_threshold=0.6, unmatched_threshold=0.45)
-           for n, sz, zb in (("vehicle", [3.9, 1.6, 1.56], -1.78), ("pedestrian", [0.8, 0.6, 1.73], -0.6), ("truck", [8, 3, 3], -1.78))]
-
-
-def mc_params(lidar, grid_w, grid_h):
-    return {"core_method": "VoxelPostprocessor3Heads", "gt_range": list(lidar), "order": "hwl", "nms_thresh": 0.15,
-            "anchor_args": {"cav_lidar_range": list(lidar), "W": grid_w, "H": grid_h, "anchor_generator_config": MC_CFGS},
-            "target_args": {"score_threshold": 0.2}}
+from quantv2x_amd.synth import MC_ANCHOR_CFGS as MC_CFGS, mc_postprocess_params as mc_params  # noqa: E402  (shared with bench.py)
 
 
 @pytest.fixture(scope="module")

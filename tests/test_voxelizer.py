@@ -59,3 +59,46 @@ def test_gpu_voxelizer_full_size_feeds_the_model_inputs():
     want = synth.make_scene("v2xreal", n_agents=2, seed=3, n_points=60000)["inputs_m1"]
     for k in ("voxel_features", "voxel_coords", "voxel_num_points"):
         np.testing.assert_array_equal(got[k].cpu().numpy(), want[k], err_msg=k)
+
+
+@pytest.mark.gpu
+def test_fixed_capacity_form_inside_a_hip_graph_equals_the_eager_chain():
+    """``GpuVoxelizer.fixed``: every sweep hands ``capacity`` rows on (tail rows: batch index -1, dropped by the PFN kernel), nothing is
+    read back, so voxelizer + model replay as ONE HIP graph -- with the same predictions as the eager chain with its host-side pillar
+    count, also after the sweeps' contents changed in place between replays (the clears are kernels, not memset nodes)."""
+    import torch
+    from _common import calibrated_plugin
+    from quantv2x_amd.engine import deploy
+    from quantv2x_amd.ptq_state import export_ptq_state
+    from quantv2x_amd.voxelizer import GpuVoxelizer
+    rng, vs, _, _ = synth.SHAPES["tiny"]
+    eng = deploy(state=export_ptq_state(calibrated_plugin()))
+    vz = GpuVoxelizer(rng, vs, 32, 2048)
+    clouds = [[synth.make_points(rng, 3000, 50 + 2 * k + a, 6.0)[:2400].copy() for a in range(2)] for k in range(2)]   # (a graph fixes the point count)
+    assert all(c.shape[0] == 2400 for cs in clouds for c in cs)
+    sweeps = [torch.from_numpy(c).cuda() for c in clouds[0]]
+    pairwise = torch.eye(4, dtype=torch.float64).reshape(1, 1, 1, 4, 4).repeat(1, 5, 5, 1, 1).cuda()
+
+    def model(inp):
+        return eng({"inputs_m1": inp, "agent_modality_list": ["m1", "m1"], "record_len": torch.tensor([2]), "pairwise_t_matrix": pairwise})
+    fixed = vz.fixed(sweeps, 1024)
+    counts = fixed["voxel_counts"].cpu().numpy()
+    eager = vz(sweeps)
+    m0 = int(counts[0])
+    assert counts.sum() == eager["voxel_features"].shape[0] and (fixed["voxel_coords"][m0:1024, 0] == -1).all()
+    assert torch.equal(fixed["voxel_features"][:m0], eager["voxel_features"][:m0]) and (fixed["voxel_num_points"][m0:1024] == 0).all()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        model(vz.fixed(sweeps, 1024))
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = model(vz.fixed(sweeps, 1024))
+    for k in (0, 1, 0):
+        for s, c in zip(sweeps, clouds[k]):
+            s.copy_(torch.from_numpy(c))
+        graph.replay()
+        torch.cuda.synchronize()
+        want = model(vz([torch.from_numpy(c).cuda() for c in clouds[k]]))
+        assert torch.equal(out["preds_tensor"], want["preds_tensor"]), k
