@@ -533,12 +533,29 @@ class DeployedModel(nn.Module):
         if vf.dtype != torch.float32 or vf.dim() != 3 or tuple(vf.shape[1:]) != (32, 4):
             raise ValueError("voxel_features must be float32 [M, 32, 4]")
         canvas = b["canvas"]
+        # INVARIANT of the resident canvas: between calls it holds the code of 0.0 everywhere (`canvas_clean`), so a resident call needs
+        # no fill -- and a HIP graph captured in that state contains none.  Such a graph cannot see this host flag: once one exists
+        # (`fill_less_graphs`), nothing may leave the canvas dirty behind its back -- the non-resident form (which returns a canvas the
+        # caller is going to read) is refused on that workspace, and `forward` refills at once if it fails between scatter and clear.
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not resident and b.get("fill_less_graphs", False):
+            raise L.Qv2xError("pillars_to_canvas(resident=False) on a workspace whose captured graphs rely on the clean resident canvas: "
+                              "use resident=True + clear_pillars, or another DeployedModel")
         if not (resident and b.get("canvas_clean", False)):
             L.check(self.lib.qv2x_fill_i8(L.ptr(canvas), canvas.numel(), int(self.pfn.z2) - 128, st), "qv2x_fill_i8")
+        elif capturing:
+            b["fill_less_graphs"] = True
         b["canvas_clean"] = False
         L.check(self.lib.qv2x_pfn_scatter_i8(L.ptr(vf), L.ptr(co), L.ptr(npnt), vf.shape[0], 32, C.byref(self.pfn),
                                              L.ptr(canvas), n_agents, self.ny, self.nx, st), "qv2x_pfn_scatter_i8")
         return canvas
+
+    def _restore_canvas(self, n_agents: int):
+        """After a failure between scatter and clear: put the whole canvas back to the code of 0.0 (outside any capture)."""
+        b = self._workspace(n_agents)
+        if self.encoder_kind != "second" and not torch.cuda.is_current_stream_capturing():
+            L.check(self.lib.qv2x_fill_i8(L.ptr(b["canvas"]), b["canvas"].numel(), int(self.pfn.z2) - 128, L.current_stream()), "qv2x_fill_i8")
+            b["canvas_clean"] = True
 
     def clear_pillars(self, inputs: dict, n_agents: int):
         """Sets the cells ``pillars_to_canvas(..., resident=True)`` wrote back to the code of 0.0: the canvas is clean for the next frame."""
@@ -581,8 +598,12 @@ class DeployedModel(nn.Module):
     def encode_into(self, inputs: dict, frames: int, codes_out: torch.Tensor):
         """a1-a6 for ``frames`` frames of ONE agent (batch index = frame); codes u8 [levels, frames, H*W] written to ``codes_out``."""
         self.pillars_to_canvas(inputs, frames, resident=True)
-        self.run_plan(frames)
-        self.clear_pillars(inputs, frames)
+        try:
+            self.run_plan(frames)
+            self.clear_pillars(inputs, frames)
+        except Exception:
+            self._restore_canvas(frames)
+            raise
         return self.encode_codes(frames, out=codes_out)
 
     def pairwise_from_poses(self, gathered: torch.Tensor, world: int, agent_stride: int, pose_offset: int, max_cav: int, out: torch.Tensor):
@@ -621,10 +642,14 @@ class DeployedModel(nn.Module):
         """a1-a6 for ``n_agents`` agents.  Returns codes u8 [levels, n, H*W] (or the i8 shrinker output without a codebook)."""
         b = self._workspace(n_agents)
         canvas = self.pillars_to_canvas(inputs, n_agents, resident=True)
-        self.run_plan(n_agents, taps=taps)
-        if taps is not None:
-            taps["canvas"], taps["cat"] = canvas.clone(), b["cat"]     # (a copy: the canvas itself is handed back clean just below)
-        self.clear_pillars(inputs, n_agents)
+        try:
+            self.run_plan(n_agents, taps=taps)
+            if taps is not None:
+                taps["canvas"], taps["cat"] = canvas.clone(), b["cat"]     # (a copy: the canvas itself is handed back clean just below)
+            self.clear_pillars(inputs, n_agents)
+        except Exception:
+            self._restore_canvas(n_agents)                             # never leave pillars behind (see pillars_to_canvas)
+            raise
         if taps is not None:
             taps[self.shrink0.name], taps[self.shrink1.name] = b["s0"], b["s1"]
         if taps is not None and self.compress:
@@ -790,6 +815,8 @@ class DeployedModel(nn.Module):
         """Capture one frame into a HIP graph (torch.cuda.CUDAGraph on ROCm).  The returned callable replays it on
         the same input tensors (refresh their contents in place between replays) and returns the same output dict.
 
+        The graph relies on the resident canvas being clean between calls (``pillars_to_canvas``): every path of this class leaves it
+        so; ``pillars_to_canvas(resident=False)`` refuses to run on a workspace that has such graphs.
         The pillar count M = ``voxel_features.shape[0]`` is baked into the graph: keep M fixed across replays and pad
         unused rows with an out-of-range agent index (``voxel_coords[:, 0] = -1``), which ``pfn_scatter_kernel`` drops.
         ``record_len`` (several scenes per call) must be a CPU tensor: its values shape the launch list."""

@@ -129,12 +129,17 @@ class VoxelPostprocessor:
                 raise ValueError(f"cls_preds {tuple(cls.shape)}: batch 1 and {self.anchor_num} anchors per cell expected")
             h, w = int(cls.shape[2]), int(cls.shape[3])
             anchors = cav["anchor_box"]
-            if self._anchors_dev is None or self._anchors_dev[0] is not anchors:
+            # device copies by anchor OBJECT (late fusion: every CAV carries its own `anchor_box`; one slot keyed on identity missed on
+            # every CAV of every frame and re-uploaded H*W*A*7 floats each time); the entry keeps the object alive, so its id is not reused
+            hit = self._anchors_dev.get(id(anchors)) if self._anchors_dev else None
+            if hit is None or hit[0] is not anchors:
                 a32 = torch.as_tensor(np.asarray(anchors.cpu() if torch.is_tensor(anchors) else anchors)).to(torch.float32)
                 if tuple(a32.shape) != (h, w, self.anchor_num, 7):
                     raise ValueError(f"anchor_box {tuple(a32.shape)} does not match the head maps ({h}, {w}, {self.anchor_num}, 7)")
-                self._anchors_dev = (anchors, a32.reshape(-1, 7).contiguous().to(cls.device))
-            cls_l.append(cls); reg_l.append(reg); dir_l.append(dirp); anc_l.append(self._anchors_dev[1]); t_l.append(cav["transformation_matrix"])
+                if self._anchors_dev is None or len(self._anchors_dev) >= 16:
+                    self._anchors_dev = {}
+                hit = self._anchors_dev[id(anchors)] = (anchors, a32.reshape(-1, 7).contiguous().to(cls.device))
+            cls_l.append(cls); reg_l.append(reg); dir_l.append(dirp); anc_l.append(hit[1]); t_l.append(cav["transformation_matrix"])
         has_dir = all(x is not None for x in dir_l)
         boxes, scores, _ = gpu_post_process(
             self, cls_l, reg_l, dir_l if has_dir else None, anc_l, t_l, anchors_per_cell=self.anchor_num,

@@ -81,11 +81,14 @@ class VoxelPostprocessor3Heads:
             if not cls.is_cuda:
                 raise RuntimeError("VoxelPostprocessor3Heads.post_process runs on the GPU (libqv2x): the head maps must be CUDA tensors")
             all_anchors = cav["all_anchors"]                       # (num_class, H, W, anchor_num, 7)
-            if self._anchors_dev is None or self._anchors_dev[0] is not all_anchors:
+            hit = self._anchors_dev.get(id(all_anchors)) if self._anchors_dev else None      # one device copy per anchor object (see VoxelPostprocessor)
+            if hit is None or hit[0] is not all_anchors:
                 a = torch.as_tensor(np.asarray(all_anchors.cpu() if torch.is_tensor(all_anchors) else all_anchors)).to(torch.float32)
                 a = a.permute(1, 2, 0, 3, 4).contiguous()           # (H, W, num_class, anchor_num, 7), :354
-                self._anchors_dev = (all_anchors, a.reshape(-1, 7).to(cls.device), int(a.shape[2] * a.shape[3]), tuple(a.shape[:2]))
-            _, anchors_dev, per_cell, hw = self._anchors_dev
+                if self._anchors_dev is None or len(self._anchors_dev) >= 16:
+                    self._anchors_dev = {}
+                hit = self._anchors_dev[id(all_anchors)] = (all_anchors, a.reshape(-1, 7).to(cls.device), int(a.shape[2] * a.shape[3]), tuple(a.shape[:2]))
+            _, anchors_dev, per_cell, hw = hit
             if cls.shape[0] != 1 or tuple(cls.shape[2:]) != hw or cls.shape[1] % per_cell or reg.shape[1] != per_cell * 7:
                 raise ValueError(f"cls_preds {tuple(cls.shape)} / reg_preds {tuple(reg.shape)} do not match {per_cell} anchors per cell on {hw}")
             cls_l.append(cls); reg_l.append(reg); anc_l.append(anchors_dev); t_l.append(cav["transformation_matrix"])

@@ -216,65 +216,67 @@ class UniformAffineQuantizer(nn.Module):
         return 'bit={}, is_training={}, inited={}'.format(self.n_bits, self.is_training, self.inited)
 
 
+# torch functional + the constructor attributes it takes over from the wrapped module, by module type (first match wins)
+_FWD_TABLE = (
+    (nn.Conv2d, F.conv2d, ("stride", "padding", "dilation", "groups")),
+    (nn.ConvTranspose2d, F.conv_transpose2d, ("stride", "padding", "output_padding", "groups", "dilation")),
+    (nn.Linear, F.linear, ()),
+)
+
+
 class QuantModule(nn.Module):
+    """One conv / deconv / linear under fake quantization -- the reference's ``QuantModule`` (quant_layer.py:349-420) as far as its
+    users see it: the attribute set below is a contract (``quant_model.py``, ``fold_bn.py``, the ``*_recon.py`` loops and
+    ``inference_quant.py`` read and assign ``weight, org_weight, bias, org_bias, fwd_func, fwd_kwargs, use_weight_quant, use_act_quant,
+    weight_quantizer, act_quantizer, norm_function, activation_function, ignore_reconstruction, disable_act_quant, trained``).
+
+    forward = ``act_quantizer(activation(norm(op(x, W', b'))))`` with ``(W', b')`` the fake-quantized pair while weight quantization is
+    on and the untouched originals otherwise; the output quantizer is skipped while activation quantization is off or the layer feeds an
+    element-wise sum (``disable_act_quant``: the block quantizes after the sum)."""
+
     def __init__(self, org_module: Union[nn.Conv2d, nn.ConvTranspose2d, nn.Linear], weight_quant_params: dict = {},
                  act_quant_params: dict = {}, disable_act_quant=False):
         super().__init__()
-        if isinstance(org_module, nn.Conv2d):
-            self.fwd_func = F.conv2d
-            self.fwd_kwargs = dict(stride=org_module.stride, padding=org_module.padding,
-                                   dilation=org_module.dilation, groups=org_module.groups)
-        elif isinstance(org_module, nn.ConvTranspose2d):
-            self.fwd_func = F.conv_transpose2d
-            self.fwd_kwargs = dict(stride=org_module.stride, padding=org_module.padding,
-                                   output_padding=org_module.output_padding, groups=org_module.groups,
-                                   dilation=org_module.dilation)
-        else:
-            self.fwd_func = F.linear
-            self.fwd_kwargs = dict()
-        self.weight = org_module.weight
-        self.org_weight = org_module.weight.data.clone()
-        if org_module.bias is not None:
-            self.bias = org_module.bias
-            self.org_bias = org_module.bias.data.clone()
-        else:
-            self.bias = None
-            self.org_bias = None
-        self.use_weight_quant = False
-        self.use_act_quant = False
+        for kind, func, attrs in _FWD_TABLE:
+            if isinstance(org_module, kind):
+                self.fwd_func, self.fwd_kwargs = func, {a: getattr(org_module, a) for a in attrs}
+                break
+        else:                                                   # (the reference sends everything else down the linear path too)
+            self.fwd_func, self.fwd_kwargs = F.linear, {}
+        has_bias = org_module.bias is not None
+        self.weight, self.org_weight = org_module.weight, org_module.weight.data.clone()
+        self.bias, self.org_bias = (org_module.bias, org_module.bias.data.clone()) if has_bias else (None, None)
         self.weight_quantizer = UniformAffineQuantizer(**weight_quant_params)
         self.act_quantizer = UniformAffineQuantizer(**act_quant_params)
-        self.norm_function = StraightThrough()
-        self.activation_function = StraightThrough()
-        self.ignore_reconstruction = False
+        self.norm_function, self.activation_function = StraightThrough(), StraightThrough()   # fold_bn / the wrapper blocks fill these in
+        self.set_quant_state(False, False)                      # a fresh wrapper runs the original arithmetic
+        self.ignore_reconstruction, self.trained = False, False
         self.disable_act_quant = disable_act_quant
-        self.trained = False
+
+    def _effective_params(self, device):
+        """(weight, bias) the op runs on right now, on ``device``"""
+        if self.use_weight_quant:
+            w, b = self.weight_quantizer(self.weight), self.bias
+        else:
+            w, b = self.org_weight, self.org_bias
+        return w.to(device), (b.to(device) if b is not None else None)
+
+    def _normalize(self, out):
+        if type(self.norm_function) is nn.BatchNorm1d:          # pillar layout [M, P, C]: BatchNorm1d wants the channels second
+            return self.norm_function(out.transpose(1, 2)).transpose(1, 2)
+        return self.norm_function(out)
 
     def forward(self, input: torch.Tensor):
-        if self.use_weight_quant:
-            weight = self.weight_quantizer(self.weight).to(input.device)
-            bias = None if self.bias is None else self.bias.to(input.device)
-        else:
-            weight = self.org_weight.to(input.device)
-            bias = None if self.org_bias is None else self.org_bias.to(input.device)
-        out = self.fwd_func(input, weight, bias, **self.fwd_kwargs)
-        if type(self.norm_function) == nn.BatchNorm1d:   # [M, P, C] pillar layout
-            out = self.norm_function(out.permute(0, 2, 1)).permute(0, 2, 1)
-        else:
-            out = self.norm_function(out)
-        out = self.activation_function(out)
-        if self.disable_act_quant or not self.use_act_quant:
-            return out
-        return self.act_quantizer(out)
+        out = self.activation_function(self._normalize(self.fwd_func(input, *self._effective_params(input.device), **self.fwd_kwargs)))
+        quantize_output = self.use_act_quant and not self.disable_act_quant
+        return self.act_quantizer(out) if quantize_output else out
 
     def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
-        self.use_weight_quant = weight_quant
-        self.use_act_quant = act_quant
+        self.use_weight_quant, self.use_act_quant = weight_quant, act_quant
 
     @torch.jit.export
     def extra_repr(self):
-        return 'wbit={}, abit={}, disable_act_quant={}'.format(
-            self.weight_quantizer.n_bits, self.act_quantizer.n_bits, self.disable_act_quant)
+        return f"wbit={self.weight_quantizer.n_bits}, abit={self.act_quantizer.n_bits}, disable_act_quant={self.disable_act_quant}"
 
 
 class QuantSpconvModule(nn.Module):

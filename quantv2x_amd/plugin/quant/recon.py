@@ -164,12 +164,13 @@ def reconstruct(model, fp_model, block, fp_block, cali_data: list, batch_size: i
         out_drop = first_output(block(drop_inp, *(extras[idx] if extras is not None else ())))
         output_qt = None
         if prediction_loss:
-            output_qt = prediction_fn(model.model, out_drop)
-            want = output_fp if output_fp.dim() == output_qt.dim() else output_fp.unsqueeze(0) if output_qt is not None else None
-            if output_qt is not None and want is not None and output_qt.shape == want.shape:
-                output_fp = want
-            else:
-                output_qt = None                                # e.g. fused prediction [B, ...] vs per-agent features [N, ...]
+            output_qt = prediction_fn(model.model, out_drop)  # None when no head takes this feature width: the reference then skips the
+            if output_qt is not None:                         # prediction-level terms (block_recon.py:190-200)
+                want = output_fp if output_fp.dim() == output_qt.dim() else output_fp.unsqueeze(0)
+                if output_qt.shape == want.shape:
+                    output_fp = want
+                else:
+                    output_qt = None                            # e.g. fused prediction [B, ...] vs per-agent features [N, ...]
         err = loss_func(out_drop, cur_out, output_qt, output_fp if output_qt is not None else None)
         err.backward()
         if w_opt:

@@ -107,9 +107,12 @@ def test_export_refuses_unfrozen_or_non_w8a8():
     with pytest.raises(ValueError):
         export_second_state(enc)
     second_layers(enc)[3][1].act_quantizer.set_inited(True)
-    second_layers(enc)[5][1].weight_quantizer.bitwidth_refactor(4)
+    second_layers(enc)[5][1].act_quantizer.bitwidth_refactor(4)        # sub-8-bit ACTIVATIONS: the epilogues clamp to [0, 255]
     with pytest.raises(ValueError):
         export_second_state(enc)
+    second_layers(enc)[5][1].act_quantizer.bitwidth_refactor(8)
+    second_layers(enc)[5][1].weight_quantizer.bitwidth_refactor(4)     # sub-8-bit weights export (WxA8, round 3)
+    assert "second/5/w_code" in export_second_state(enc)
 
 
 def test_cabi_argument_checks():
