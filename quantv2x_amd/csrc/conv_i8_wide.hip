@@ -603,6 +603,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_i8_pipe_kernel(const WideA
         }
     };
     auto epi_at = [&](auto set_c, auto hs_c) __attribute__((always_inline)) {   // what the epilogue does after half step HS of the K loop
+#if defined(QV2X_PIPE_ABL)      // dev ablations (timing only): 1 = no epilogue anywhere, 2 = the whole epilogue after the K loop instead of woven in
+        return;
+#endif
         constexpr int HSI = decltype(hs_c)::value, PC = Sched::piece_at(HSI);
         if constexpr (HSI == 0) epi_begin();
         if constexpr (PC >= 0) epi_piece(set_c, IC<PC>{});
@@ -672,6 +675,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_i8_pipe_kernel(const WideA
         return true;
     };
     auto epi_alone = [&](auto set_c) __attribute__((always_inline)) {  // the last item's epilogue: nothing left to weave it into
+#if defined(QV2X_PIPE_ABL) && QV2X_PIPE_ABL == 1
+        asm volatile("" :: "v"(acc[decltype(set_c)::value][0][0]));
+        return;
+#endif
         epi_begin();
         epi_piece(set_c, IC<0>{}); epi_piece(set_c, IC<1>{}); epi_piece(set_c, IC<2>{}); epi_piece(set_c, IC<3>{});
         epi_piece(set_c, IC<4>{}); epi_piece(set_c, IC<5>{}); epi_piece(set_c, IC<6>{}); epi_piece(set_c, IC<7>{});
@@ -703,8 +710,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_i8_pipe_kernel(const WideA
     one_item(IC<0>{}, IC<0>{});                                        // the first item: nothing to requantize yet
     for (;;) {
         if (!rotate()) { epi_alone(IC<0>{}); break; }
+#if defined(QV2X_PIPE_ABL) && QV2X_PIPE_ABL == 2
+        epi_alone(IC<0>{});
+#endif
         one_item(IC<1>{}, IC<1>{});
         if (!rotate()) { epi_alone(IC<1>{}); break; }
+#if defined(QV2X_PIPE_ABL) && QV2X_PIPE_ABL == 2
+        epi_alone(IC<1>{});
+#endif
         one_item(IC<0>{}, IC<1>{});
     }
 }
