@@ -6,7 +6,7 @@
         bench.py --gpus N --steps K --warmup W
 
 A *step* is one pass of the whole hot path (a1-a11: PFN + scatter, int8 backbone + shrinker, codebook encode, exchange,
-decode + warp + attention, heads) over one batch of B synthetic V2X-Real-shaped frames (default B = 8: the reference's
+decode + warp + attention, heads) over one batch of B synthetic V2X-Real-shaped frames (default B = 32: the reference's
 model contract has a batch dimension, ``record_len`` / ``pairwise_t_matrix[B]``), replayed as HIP graphs; at N = 1, F = 2
 such batches are in flight on two streams (the next batch's PFN / backbone fill the tail of the previous batch's encode).
 ``value`` = frames per second over exactly K steps; the p50 latency of ONE frame run alone is reported next to it, and
@@ -147,15 +147,21 @@ def rooflines(eng, full, frames, iters):
         eng.fuse_scenes(C.c_void_p(codes.data_ptr()), hw, n * hw, None, pw, [f * hw for f in range(n)], [1] * n, fused)
     stage("decode_warp_attfuse", fuse_all, "hbm", n * (3 * hw + 3 * 128 * 1024 + hw * 1024), "GB/s", HBM_PEAK_GBS, 1,
           f"{n} x (105.6 KB codes + 384 KiB LUT read, 36.0 MB fp32 fused map written), one launch for the batch's scenes")
-    stage("heads_f32", lambda: eng._heads_pair(fused, n, codes, n), "mfma-f32", n * 2 * 2 * 0.649e9, "TFLOP/s", F32_MFMA_PEAK_TFLOPS, 1,
-          f"{n} x 2 x 0.649 GMAC: heads on the fused map + *_single heads on the decoded own feature, one launch")
+    heads_macs = hw * 256 * (eng.heads.cout + (eng.heads_single.cout if eng.heads_single is not None else 0))
+    stage("heads_f32", lambda: eng._heads_pair(fused, n, codes, n), "mfma-f32", n * 2.0 * heads_macs, "TFLOP/s", F32_MFMA_PEAK_TFLOPS, 1,
+          f"{n} x {heads_macs / 1e9:.3f} GMAC: the {eng.heads.cout}-channel heads on the fused map + the {eng.heads_single.cout if eng.heads_single is not None else 0}-channel "
+          f"*_single heads on the decoded own feature, one launch (rounds 1-2 priced both at the 72-channel figure: 2 x 0.649 GMAC; the kernel "
+          f"multiplies 96 + 32 padded columns)")
     enc = stages["codebook_encode_f32"]
     traffic, note = None, "no PMC profile committed for this round yet"
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_encode.json")
+    pmc = os.path.join(ROOT, "profiles", "r03_pmc_encode.json")
     if os.path.exists(pmc):
         with open(pmc) as f:
             j = json.load(f)
-        traffic, note = j.get("traffic_bytes_per_launch"), j.get("note", "")
+        if j.get("agent_frames_per_launch") == n:        # (a stored figure only describes launches of the batch size it was taken at)
+            traffic, note = j.get("traffic_bytes_per_launch"), j.get("note", "")
+        else:
+            note = f"profiles/r03_pmc_encode.json was taken at {j.get('agent_frames_per_launch')} agent-frames per launch, this run has {n}"
     roof = {"bound": "mfma", "achieved": enc["achieved"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": enc["frac"],
             "traffic": traffic, "traffic_note": "STORED figure, not measured by this run: " + note,
             "kernel": "codebook_encode_kernel (f32 MFMA v_mfma_f32_32x32x2_f32; the dominant kernel by time)", "launches_per_batch": 1,
@@ -475,7 +481,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=8, help="frames per step (per rank)")
+    ap.add_argument("--batch", type=int, default=32, help="frames per step (per rank); 32: every persistent conv workgroup owns several items in a row (DESIGN.md 5)")
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight per rank (streams / engines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path (two HIP graphs around the collective) with one rank")

@@ -378,6 +378,13 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
         }
         WTRACE(2);
         WFINE(6);
+#if defined(QV2X_WABL) && QV2X_WABL == 4     // dev ablation: the K loop alone (no window sums, no epilogue, no stores)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) asm volatile("" :: "v"(acc[i][0]));
+        if (NGRP > 1) __builtin_amdgcn_s_barrier();
+        if (!has_next) break;
+        goto next_item;
+#endif
         int totv[MT];
         if (!MULTI) window_sums(totv);
         WTRACE(3);
@@ -434,6 +441,9 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
         WFINE(10);
         ++nit;
         if (!has_next) break;
+#if defined(QV2X_WABL) && QV2X_WABL == 4
+    next_item:
+#endif
         // ---- rotate to the next item: its tiles 0 (and 1) and weight steps 0, 1 are in flight since the last taps of the K loop ----------
         item += vstride;
         cur = nxw;
@@ -550,18 +560,21 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_i8_pipe_kernel(const WideA
             }
         }
     };
-    // weights: a UNIFORM running pointer (scalar registers) plus the lane's 16 bytes -- with every step a compile-time constant the
-    // compiler would otherwise hoist one 64-bit address per step out of the item loop (72 registers at four chunks)
+    // weights: buffer loads -- resource = the workgroup's slice of the pre-tiled weights, a SCALAR running offset for the step and the
+    // lane's constant 16-byte offset.  With plain pointers hipcc forms one 64-bit per-lane address per (step, K half) and, every step
+    // being a compile-time constant here, hoists all of them out of the item loop: 18-72 register pairs, i.e. spills (first version of
+    // this form).  An empty asm statement to pin a running pointer is worse: any inline asm in the loop makes the waitcnt pass put
+    // s_waitcnt vmcnt(0) lgkmcnt(0) in front of every MFMA group (second version).
     constexpr int wstep = WT * 64;                                     // bytes of one step's weight tile (WT = min(cout, 256) rows)
-    const int8_t* const wbase = a.wt + (size_t)(n0 / WT) * total * wstep + ((n0 % WT) / 32 + wave_u) * 2048;
-    const int8_t* wnext = wbase;                                       // the tile of the next step to request
-    const unsigned wlane = lane * 16;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.wt + (size_t)(n0 / WT) * total * wstep + ((n0 % WT) / 32 + wave_u) * 2048), 0, total * wstep, 0x00020000);
+    int wnext = 0;                                                     // byte offset of the next step to request (uniform)
+    const int wlane = lane * 16;
     auto load_w = [&](auto slot_c, auto last_c) __attribute__((always_inline)) {
         constexpr int SLOT = decltype(slot_c)::value;
-        wr[SLOT][0] = *(const v4i*)(wnext + wlane);
-        wr[SLOT][1] = *(const v4i*)(wnext + wlane + 1024);
-        if (decltype(last_c)::value) wnext = wbase; else wnext += wstep;   // (past an item's last step: the next item's step 0)
-        asm volatile("" : "+s"(wnext));                                 // (keep it a loop-carried scalar: no closed forms per step)
+        wr[SLOT][0] = (v4i)__builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, wnext, 0);
+        wr[SLOT][1] = (v4i)__builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + 1024, wnext, 0);
+        wnext = decltype(last_c)::value ? 0 : wnext + wstep;           // (past an item's last step: the next item's step 0)
     };
     const int rlane = half * PLANE + (lane & 31) * 16;
     auto read_half = [&](auto ks_c, auto tap_c, int chunk) __attribute__((always_inline)) {
@@ -662,6 +675,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_i8_pipe_kernel(const WideA
     };
     // rotate: the item just accumulated becomes `prv`, the next one `cur`; false when there is no next item
     auto rotate = [&]() __attribute__((always_inline)) {
+#if defined(QV2X_PIPE_ABL) && QV2X_PIPE_ABL == 1
+#pragma unroll
+        for (int i = 0; i < MT; ++i) { asm volatile("" :: "v"(acc[0][i])); asm volatile("" :: "v"(acc[1][i])); }
+#endif
         prv = cur; eset = pset;
         if (!has_next) return false;
         item += (int)gridDim.x;
@@ -676,7 +693,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_i8_pipe_kernel(const WideA
     };
     auto epi_alone = [&](auto set_c) __attribute__((always_inline)) {  // the last item's epilogue: nothing left to weave it into
 #if defined(QV2X_PIPE_ABL) && QV2X_PIPE_ABL == 1
-        asm volatile("" :: "v"(acc[decltype(set_c)::value][0][0]));
+#pragma unroll
+        for (int i = 0; i < MT; ++i) asm volatile("" :: "v"(acc[decltype(set_c)::value][i]));
         return;
 #endif
         epi_begin();

@@ -1,19 +1,28 @@
 """HBM-side traffic of the dominant kernel (codebook_encode_kernel) from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the
-bench command -> profiles/r02_pmc_encode.json (the figure bench.py's roofline.traffic quotes).  FETCH_SIZE / WRITE_SIZE are in KiB."""
+bench command -> profiles/r03_pmc_encode.json (the figure bench.py's roofline.traffic quotes).  FETCH_SIZE / WRITE_SIZE are in KiB.
+Only the launches of the bench's own batch (the largest grid) are averaged.  MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports half
+the bytes of wide coalesced streaming reads -- the corrected figure doubles it; WRITE_SIZE is taken as reported."""
 import csv, glob, json, sys
 fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
 def mean(d, counter):
-    v = []
-    for f in glob.glob(d + "/*counter_collection.csv"):
+    rows = []
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "codebook_encode_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter and int(r["Grid_Size"]) > 512 * 2000:
-                v.append(float(r["Counter_Value"]))
-    return (sum(v) / len(v), len(v)) if v else (None, 0)
-f, nf = mean(fetch_dir, "FETCH_SIZE")
-w, nw = mean(write_dir, "WRITE_SIZE")
-res = {"kernel": "codebook_encode_kernel", "launches_averaged": [nf, nw], "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
-       "traffic_bytes_per_launch": None if f is None or w is None else int((f + w) * 1024),
+            if "codebook_encode_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                rows.append((int(r["Grid_Size"]), float(r["Counter_Value"])))
+    if not rows:
+        return None, 0, 0
+    g = max(r[0] for r in rows)
+    v = [c for (gs, c) in rows if gs == g]
+    return sum(v) / len(v), len(v), g
+f, nf, gf = mean(fetch_dir, "FETCH_SIZE")
+w, nw, gw = mean(write_dir, "WRITE_SIZE")
+res = {"kernel": "codebook_encode_kernel", "launches_averaged": [nf, nw], "grid_threads": gf, "agent_frames_per_launch": gf // 512 * 32 // 35200 if gf else None,
+       "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
+       "traffic_bytes_per_launch_raw": None if f is None or w is None else int((f + w) * 1024),
+       "traffic_bytes_per_launch": None if f is None or w is None else int((2 * f + w) * 1024),
        "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline`; "
-               "batch-of-8 launches only (grid > 1M threads); raw counter values x 1 KiB, no gfx950 doubling applied (see DESIGN.md §5)"}
+               "the launches of the bench's own batch only; traffic_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1 KiB (gfx950: FETCH_SIZE counts "
+               "64 B per 128-B request, MI355X_MICROARCH.md), _raw = the counters as reported"}
 json.dump(res, open(out, "w"), indent=1)
 print(res)
