@@ -148,10 +148,10 @@ def rooflines(eng, full, frames, iters):
     stage("decode_warp_attfuse", fuse_all, "hbm", n * (3 * hw + 3 * 128 * 1024 + hw * 1024), "GB/s", HBM_PEAK_GBS, 1,
           f"{n} x (105.6 KB codes + 384 KiB LUT read, 36.0 MB fp32 fused map written), one launch for the batch's scenes")
     heads_macs = hw * 256 * (eng.heads.cout + (eng.heads_single.cout if eng.heads_single is not None else 0))
-    stage("heads_f32", lambda: eng._heads_pair(fused, n, codes, n), "mfma-f32", n * 2.0 * heads_macs, "TFLOP/s", F32_MFMA_PEAK_TFLOPS, 1,
+    stage("heads_f32", lambda: eng._heads_pair(fused, n, codes, n), "mfma-f32", n * 2.0 * heads_macs, "TFLOP/s", F32_MFMA_PEAK_TFLOPS, 2 if getattr(eng, "single_by_tables", False) else 1,
           f"{n} x {heads_macs / 1e9:.3f} GMAC: the {eng.heads.cout}-channel heads on the fused map + the {eng.heads_single.cout if eng.heads_single is not None else 0}-channel "
-          f"*_single heads on the decoded own feature, one launch (rounds 1-2 priced both at the 72-channel figure: 2 x 0.649 GMAC; the kernel "
-          f"multiplies 96 + 32 padded columns)")
+          f"*_single heads on the decoded own feature (round 3: three table rows per cell, no GEMM; rounds 1-2 priced both at 2 x 0.649 GMAC; the fused-map kernel "
+          f"multiplies 96 padded columns)")
     enc = stages["codebook_encode_f32"]
     traffic, note = None, "no PMC profile committed for this round yet"
     pmc = os.path.join(ROOT, "profiles", "r03_pmc_encode.json")
@@ -484,6 +484,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="frames per step (per rank); 32: every persistent conv workgroup owns several items in a row (DESIGN.md 5)")
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight per rank (streams / engines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra fields (fp32 path, multi-agent, Pyramid, SECOND, collapsed encode, "
+                    "points -> boxes): the line's contract fields, roofline and roofline_stages only (profiling passes)")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path (two HIP graphs around the collective) with one rank")
     ap.add_argument("--link", default="torch", choices=["torch", "rccl"], help="N>1 collective: torch.distributed or qv2x_allgather_codes")
     ap.add_argument("--dry-run-ranks", action="store_true",
@@ -630,7 +632,7 @@ def main():
         }
         roof, stages = rooflines(eng, full if not sharded_mode else frame_batch(1, 0, B, device)[1], B, iters=max(10, args.steps // 5))
         line["roofline"], line["roofline_stages"] = roof, stages
-        if world == 1 and not sharded_mode:
+        if world == 1 and not sharded_mode and not args.no_extras:
             # the same frame on the fp32 HIP path (the un-quantized model, engine_fp32.py): what W8A8 buys on this GPU
             from quantv2x_amd.engine import deploy as _deploy
             e32 = _deploy(fp_model)

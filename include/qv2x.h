@@ -248,6 +248,14 @@ int qv2x_decode_heads_f32(const uint8_t* codes, int R, int hw, int levels, int k
                           int cout, int cout_pad, const float* w, const float* bias, const float* da, const float* za,
                           float* out, void* stream);
 
+/* *_preds_single (heter_model_baseline.py:224-230) without a GEMM: decode (codebook.py:339-343) is a sum of per-level table rows and a
+ * 1x1 head is linear, so head(decode(codes)) = bias + sum_l tables[l][code_l] with tables f32 [levels][kc][cout] = decode table x W^T
+ * made by the caller (engine.py: float64 on the host); then the head's output quantizer (da[co] <= 0: off).  codes u8 [levels][R],
+ * rows agent-major (R = agents * hw); out f32 [agents][cout][hw].  A different fp32 association than qv2x_decode_heads_f32: equal up to
+ * the rounding boundaries of the output quantizer. */
+int qv2x_single_heads_lut_f32(const uint8_t* codes, int R, int hw, int levels, int kc, int cout, const float* tables,
+                              const float* bias, const float* da, const float* za, float* out, void* stream);
+
 /* qv2x_heads_f32 on the fused rows AND qv2x_decode_heads_f32 on the agents' own codes in one launch (same results): the
  * two 1x1-head passes of a frame are independent of each other. */
 int qv2x_heads_pair_f32(const float* x, int R, int hw, int cout, int cout_pad, const float* w, const float* bias,

@@ -221,6 +221,36 @@ __global__ __launch_bounds__(256) void decode_lut_kernel(const uint8_t* __restri
     out[(size_t)r * 64 + lane] = v;
 }
 
+// *_preds_single without a GEMM: decode is a sum of per-level table rows (decode_tables, engine.py) and a 1x1 head is linear, so
+//     head(decode(c_0, c_1, c_2))[co] = b'[co] + T'_0[c_0][co] + T'_1[c_1][co] + T'_2[c_2][co],   T'_l = T_l W^T, b' = bias_lut W^T + b
+// (made on the host in float64, stored fp32).  The launch this replaces gathered 3 KB of decode-table rows per cell from L2 (845 MB per
+// batch of eight frames) to multiply them by a 20-column weight matrix on 32 padded MFMA columns.  Here the tables are
+// levels x kc x cout floats (30 KB for 3 x 128 x 20: in LDS), a thread owns one cell: 3 code bytes in, cout floats out (NCHW: coalesced
+// over the cells of a wave).  The sum is a different fp32 association than decode-then-dot-product: results agree to ~1e-6 relative before
+// the head's output quantizer and to the code except at its rounding boundaries (the tests bound that as for the other heads).
+__global__ __launch_bounds__(256) void single_heads_lut_kernel(const uint8_t* __restrict__ codes, int R, int hw, int levels, int kc, int cout,
+                                                               const float* __restrict__ tables, const float* __restrict__ bias,
+                                                               const float* __restrict__ da, const float* __restrict__ za, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float tab[];       // [levels][kc][cout] then bias [cout], da [cout], za [cout]
+    const int nt = levels * kc * cout;
+    for (int i = threadIdx.x; i < nt; i += blockDim.x) tab[i] = tables[i];
+    for (int i = threadIdx.x; i < cout; i += blockDim.x) { tab[nt + i] = bias[i]; tab[nt + cout + i] = da[i]; tab[nt + 2 * cout + i] = za[i]; }
+    __syncthreads();
+    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < R; m += gridDim.x * blockDim.x) {
+        const int agent = m / hw, cell = m - agent * hw;
+        const float* row[4];
+        for (int l = 0; l < levels; ++l) row[l] = tab + ((size_t)l * kc + codes[(size_t)l * R + m]) * cout;
+        float* ob = out + (size_t)agent * cout * hw + cell;
+        for (int c = 0; c < cout; ++c) {
+            float y = tab[nt + c];
+            for (int l = 0; l < levels; ++l) y += row[l][c];
+            const float d = tab[nt + cout + c], z = tab[nt + 2 * cout + c];
+            if (d > 0.0f) y = (q_code(y, d, z) - z) * d;
+            ob[(size_t)c * hw] = y;
+        }
+    }
+}
+
 // interior of a padded i8 BEV tensor -> fp32 rows [N*H*W][C]: x = (code - zp) * delta  (models without the codebook)
 __global__ __launch_bounds__(256) void dequant_i8_kernel(const int8_t* __restrict__ in, int n, int h, int w, int c, int ax, float delta,
                                                          float* __restrict__ out) {
@@ -273,6 +303,19 @@ extern "C" int qv2x_decode_heads_f32(const uint8_t* codes, int R, int hw, int le
     fa.code_agent_stride = hw; fa.code_level_stride = R;           // codes [levels][R], agent-major rows
     rows_heads_kernel<ROWS_DECODE><<<(R + 31) / 32, 256, 0, (hipStream_t)stream>>>(h, fa);
     return hip_check(hipGetLastError(), "qv2x_decode_heads_f32 launch");
+}
+
+extern "C" int qv2x_single_heads_lut_f32(const uint8_t* codes, int R, int hw, int levels, int kc, int cout, const float* tables,
+                                         const float* bias, const float* da, const float* za, float* out, void* stream) {
+    using namespace qv2x;
+    if (!codes || !tables || !bias || !da || !za || !out) return fail(QV2X_EINVAL, "qv2x_single_heads_lut_f32: null pointer");
+    if (R <= 0 || hw <= 0 || R % hw || levels < 1 || levels > 4 || kc < 1 || kc > 256 || cout < 1 || cout > 96)
+        return fail(QV2X_EINVAL, "qv2x_single_heads_lut_f32: R=%d hw=%d levels=%d kc=%d cout=%d", R, hw, levels, kc, cout);
+    const size_t lds = ((size_t)levels * kc * cout + 3 * cout) * sizeof(float);
+    if (lds > 64 * 1024) return fail(QV2X_EINVAL, "qv2x_single_heads_lut_f32: tables of %zu bytes do not fit the 64 KB of LDS this kernel takes", lds);
+    const int blocks = (R + 1023) / 1024 < 2048 ? (R + 1023) / 1024 : 2048;       // ~four cells per thread: the table copy-in is paid once per 1024 cells
+    single_heads_lut_kernel<<<blocks, 256, lds, (hipStream_t)stream>>>(codes, R, hw, levels, kc, cout, tables, bias, da, za, out);
+    return hip_check(hipGetLastError(), "qv2x_single_heads_lut_f32 launch");
 }
 
 extern "C" int qv2x_decode_lut_f32(const uint8_t* codes, int R, int levels, int kc, const float* lut, const float* lut_bias,

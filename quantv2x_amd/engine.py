@@ -209,6 +209,15 @@ class _Heads:
         self.bias = _dev(np.concatenate(bs + [np.zeros(pad, np.float32)]), dev)
         self.da = _dev(np.concatenate(das + [np.full(pad, -1.0, np.float32)]), dev)
         self.za = _dev(np.concatenate(zas + [np.zeros(pad, np.float32)]), dev)
+        self._w_np, self._b_np = np.concatenate(ws).astype(np.float64), np.concatenate(bs).astype(np.float64)
+        self.lut_tables = None
+
+    def collapse_over_decode(self, lut: np.ndarray, lut_bias: np.ndarray, dev):
+        """head(decode(codes)) = b' + sum_l T'_l[code_l]: decode is a sum of table rows (``decode_tables``), the head is linear.
+        float64 on the host -> ``(tables f32 [L][kc][cout], bias f32 [cout])`` on the device (qv2x_single_heads_lut_f32)."""
+        t = np.einsum("lkd,cd->lkc", lut.astype(np.float64), self._w_np)
+        b = lut_bias.astype(np.float64) @ self._w_np.T + self._b_np
+        self.lut_tables = (_dev(t.astype(np.float32), dev), _dev(b.astype(np.float32), dev))
 
 
 class DeployedModel(nn.Module):
@@ -311,6 +320,10 @@ class DeployedModel(nn.Module):
         # ---- a11: heads ------------------------------------------------------------------------------------
         self.heads = _Heads(s, "", dev)
         self.heads_single = _Heads(s, "_single", dev) if (self.emit_single and "cls_head_single/w_code" in s) else None
+        # the *_single heads see one agent's own decoded feature: with the codebook that is three table rows per cell -- no GEMM
+        self.single_by_tables = self.heads_single is not None and self.has_codebook and self.levels * self.kc * self.heads_single.cout * 4 <= 60 * 1024
+        if self.single_by_tables:
+            self.heads_single.collapse_over_decode(lut, lut_bias, dev)
         self._bufs: Dict[int, dict] = {}
         # launch-plan switches for the ablation tools (tools/bench_*_abl.py); the defaults are the shipped configuration
         self.use_wide_conv, self.batch_deconvs, self.use_chains = True, True, True
@@ -711,15 +724,22 @@ class DeployedModel(nn.Module):
         hw = self.fh * self.fw
         hd = self.heads_single
         sp = torch.empty((n_agents, hd.cout, self.fh, self.fw), dtype=torch.float32, device=self.dev)
+        if getattr(self, "single_by_tables", False):          # (engines that build their own heads -- the fp32 one -- keep the GEMM form)
+            tab, tb = hd.lut_tables
+            L.check(self.lib.qv2x_single_heads_lut_f32(L.ptr(codes), n_agents * hw, hw, self.levels, self.kc, hd.cout, L.ptr(tab), L.ptr(tb),
+                                                       L.ptr(hd.da), L.ptr(hd.za), L.ptr(sp), L.current_stream()), "qv2x_single_heads_lut_f32")
+            return sp
         L.check(self.lib.qv2x_decode_heads_f32(L.ptr(codes), n_agents * hw, hw, self.levels, self.kc, L.ptr(self.lut), L.ptr(self.lut_bias),
                                                hd.cout, hd.cout_pad, L.ptr(hd.w), L.ptr(hd.bias), L.ptr(hd.da), L.ptr(hd.za),
                                                L.ptr(sp), L.current_stream()), "qv2x_decode_heads_f32")
         return sp
 
     def _heads_pair(self, fused, nb, codes, n_agents):
-        """heads on the fused rows [nb*hw, 256] + *_single heads on the agents' own codes [levels, n_agents*hw]: one launch"""
+        """heads on the fused rows [nb*hw, 256] + *_single heads on the agents' own codes [levels, n_agents*hw]"""
         hw = self.fh * self.fw
         hd, hs = self.heads, self.heads_single
+        if getattr(self, "single_by_tables", False):                   # the single heads are a table look-up: their own small launch
+            return self._run_heads(hd, fused, nb, hw), self._decode_heads_single(codes, n_agents)
         preds = torch.empty((nb, hd.cout, self.fh, self.fw), dtype=torch.float32, device=self.dev)
         sp = torch.empty((n_agents, hs.cout, self.fh, self.fw), dtype=torch.float32, device=self.dev)
         L.check(self.lib.qv2x_heads_pair_f32(L.ptr(fused), nb * hw, hw, hd.cout, hd.cout_pad, L.ptr(hd.w), L.ptr(hd.bias), L.ptr(hd.da),

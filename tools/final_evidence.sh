@@ -1,0 +1,30 @@
+#!/bin/bash
+# Round evidence on the GPU box, in three separate gpurun calls (raw profiler output is deleted before the call ends: gpurun_out/ is capped at 64 MiB):
+#   gpurun --timeout 1500 -- 'bash tools/final_evidence.sh r03 tests'      GPU tests + the bench line
+#   gpurun --timeout 900  -- 'bash tools/final_evidence.sh r03 trace'      rocprofv3 --kernel-trace --stats of the bench command
+#   gpurun --timeout 1500 -- 'bash tools/final_evidence.sh r03 pmc'        FETCH_SIZE, WRITE_SIZE, MFMA-busy passes
+tag=${1:-r03}; what=${2:-tests}
+out=gpurun_out/$tag; mkdir -p $out
+export TMPDIR=/tmp
+if [ $what = tests ]; then
+  timeout 1200 python -m pytest tests -q -m gpu > $out/gpu_tests.log 2>&1; tail -3 $out/gpu_tests.log
+  python bench.py > $out/bench_n1.json 2> $out/bench_n1.err; tail -c 300 $out/bench_n1.json
+fi
+if [ $what = trace ]; then
+  rocprofv3 --kernel-trace --stats -d /tmp/prof -o bench -- python3 bench.py --no-cpu-baseline --no-extras --steps 30 --warmup 5 > $out/bench_n1_under_rocprof.json 2> $out/prof.err
+  db=$(find /tmp/prof -name "*results.db" | head -1)
+  python tools/rocpd_stats.py $db > $out/bench_n1_kernel_stats.txt 2>&1
+  python tools/prof_summary.py $db 60 > $out/bench_n1_kernel_stats_by_grid.txt 2>&1
+  head -30 $out/bench_n1_kernel_stats_by_grid.txt
+fi
+if [ $what = pmc ]; then
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c -d /tmp/pmc_$c -o p -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $out/pmc_$c.err
+  done
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pmc_mfma -o p -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $out/pmc_mfma.err
+  python tools/pmc_encode_traffic.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE $out/pmc_encode.json > $out/pmc_encode.log 2>&1; cat $out/pmc_encode.log
+  python tools/pmc_by_grid.py /tmp/pmc_mfma > $out/pmc_mfma_busy.csv 2>&1
+  python tools/pmc_by_grid.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE > $out/pmc_fetch_write_summary.csv 2>&1
+  head -20 $out/pmc_mfma_busy.csv
+fi
+du -sh gpurun_out
