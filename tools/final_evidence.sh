@@ -19,9 +19,9 @@ if [ $what = trace ]; then
 fi
 if [ $what = pmc ]; then
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c -d /tmp/pmc_$c -o p -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $out/pmc_$c.err
+    rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $out/pmc_$c.err
   done
-  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pmc_mfma -o p -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $out/pmc_mfma.err
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma -o p -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $out/pmc_mfma.err
   python tools/pmc_encode_traffic.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE $out/pmc_encode.json > $out/pmc_encode.log 2>&1; cat $out/pmc_encode.log
   python tools/pmc_by_grid.py /tmp/pmc_mfma > $out/pmc_mfma_busy.csv 2>&1
   python tools/pmc_by_grid.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE > $out/pmc_fetch_write_summary.csv 2>&1
