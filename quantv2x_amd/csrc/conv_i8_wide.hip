@@ -416,25 +416,23 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
                     }
                 }
                 pk[i][g4] = q_pack4(y[0], y[1], y[2], y[3], a.out_delta, rd, a.out_zp, lowc);
+                // A tile leaves as soon as its last quad is packed.  (Five stores back to back behind the whole epilogue showed as 2.9k cycles
+                // of "store issue" per item in the phase stamps; spreading them over the last quad pass changes no layer's time -- the
+                // epilogue is bound by the SIMD's VALU issue, the stores only took the blame.)  No LDS staging: the half-wave exchange
+                // v_permlane32_swap turns the lane's four channel quads (0-3 | 8-11 | 16-19 | 24-27 in the lower half-wave, +4 in the upper)
+                // into 16 contiguous channels -- lower half 0-15, upper half 16-31 of the same pixel.
+                if (g4 == 3) {
+                    const auto s02 = __builtin_amdgcn_permlane32_swap(pk[i][0], pk[i][2], false, false);
+                    const auto s13 = __builtin_amdgcn_permlane32_swap(pk[i][1], pk[i][3], false, false);
+                    v4i ob;
+                    ob[0] = s02[0]; ob[1] = s02[1]; ob[2] = s13[0]; ob[3] = s13[1];
+                    const int yo = cur.y0 + i, xo = cur.x0 + (lane & 31);
+                    if (yo < a.ho && xo < a.wo)
+                        *(v4i*)(a.out + ((size_t)(cur.img * (a.ho + 2) + yo + 1) * (a.wo + 2) + xo + 1) * a.out_ctotal + a.out_c0 + n0 + wave * 32 + half * 16) = ob;
+                }
             }
         }
         WFINE(8);
-        // No LDS staging: the half-wave exchange v_permlane32_swap turns the lane's four channel quads (0-3 | 8-11 | 16-19 | 24-27 in the
-        // lower half-wave, +4 in the upper) into 16 contiguous channels -- lower half 0-15, upper half 16-31 of the same pixel -- and
-        // every tile leaves as one 16-byte store per lane.
-        {
-            const int xo = cur.x0 + (lane & 31);
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const auto s02 = __builtin_amdgcn_permlane32_swap(pk[i][0], pk[i][2], false, false);
-                const auto s13 = __builtin_amdgcn_permlane32_swap(pk[i][1], pk[i][3], false, false);
-                v4i ob;
-                ob[0] = s02[0]; ob[1] = s02[1]; ob[2] = s13[0]; ob[3] = s13[1];
-                const int yo = cur.y0 + i;
-                if (yo < a.ho && xo < a.wo)
-                    *(v4i*)(a.out + ((size_t)(cur.img * (a.ho + 2) + yo + 1) * (a.wo + 2) + xo + 1) * a.out_ctotal + a.out_c0 + n0 + wave * 32 + half * 16) = ob;
-            }
-        }
         WTRACE(4);
         WFINE(9);
         if (NGRP > 1) __builtin_amdgcn_s_barrier();                    // end of the epilogue slot
