@@ -229,19 +229,25 @@ __global__ __launch_bounds__(256) void decode_lut_kernel(const uint8_t* __restri
 // over the cells of a wave).  The sum is a different fp32 association than decode-then-dot-product: results agree to ~1e-6 relative before
 // the head's output quantizer and to the code except at its rounding boundaries (the tests bound that as for the other heads).
 __global__ __launch_bounds__(256) void single_heads_lut_kernel(const uint8_t* __restrict__ codes, int R, int hw, int levels, int kc, int cout,
-                                                               const float* __restrict__ tables, const float* __restrict__ bias,
+                                                               int groups, const float* __restrict__ tables, const float* __restrict__ bias,
                                                                const float* __restrict__ da, const float* __restrict__ za, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float tab[];       // [levels][kc][cout] then bias [cout], da [cout], za [cout]
     const int nt = levels * kc * cout;
     for (int i = threadIdx.x; i < nt; i += blockDim.x) tab[i] = tables[i];
     for (int i = threadIdx.x; i < cout; i += blockDim.x) { tab[nt + i] = bias[i]; tab[nt + cout + i] = da[i]; tab[nt + 2 * cout + i] = za[i]; }
     __syncthreads();
-    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < R; m += gridDim.x * blockDim.x) {
+    // a workgroup = `groups` runs of 64 cells; wave w takes the channels c = w, w + 4, ... of every cell of a run (lane = cell: the NCHW
+    // stores of a wave are 256 contiguous bytes per channel).  One frame alone gives 550 workgroups -- with one thread per cell and all its
+    // channels the launch was 35 workgroups and 37 us.
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int g = 0; g < groups; ++g) {
+        const int m = (blockIdx.x * groups + g) * 64 + lane;
+        if (m >= R) break;
         const int agent = m / hw, cell = m - agent * hw;
         const float* row[4];
         for (int l = 0; l < levels; ++l) row[l] = tab + ((size_t)l * kc + codes[(size_t)l * R + m]) * cout;
         float* ob = out + (size_t)agent * cout * hw + cell;
-        for (int c = 0; c < cout; ++c) {
+        for (int c = wv; c < cout; c += 4) {
             float y = tab[nt + c];
             for (int l = 0; l < levels; ++l) y += row[l][c];
             const float d = tab[nt + cout + c], z = tab[nt + 2 * cout + c];
@@ -313,8 +319,9 @@ extern "C" int qv2x_single_heads_lut_f32(const uint8_t* codes, int R, int hw, in
         return fail(QV2X_EINVAL, "qv2x_single_heads_lut_f32: R=%d hw=%d levels=%d kc=%d cout=%d", R, hw, levels, kc, cout);
     const size_t lds = ((size_t)levels * kc * cout + 3 * cout) * sizeof(float);
     if (lds > 64 * 1024) return fail(QV2X_EINVAL, "qv2x_single_heads_lut_f32: tables of %zu bytes do not fit the 64 KB of LDS this kernel takes", lds);
-    const int blocks = (R + 1023) / 1024 < 2048 ? (R + 1023) / 1024 : 2048;       // ~four cells per thread: the table copy-in is paid once per 1024 cells
-    single_heads_lut_kernel<<<blocks, 256, lds, (hipStream_t)stream>>>(codes, R, hw, levels, kc, cout, tables, bias, da, za, out);
+    const int runs = (R + 63) / 64;                                   // runs of 64 cells; ~1024 workgroups, each paying the table copy-in once
+    const int groups = runs <= 1024 ? 1 : (runs + 1023) / 1024;
+    single_heads_lut_kernel<<<(runs + groups - 1) / groups, 256, lds, (hipStream_t)stream>>>(codes, R, hw, levels, kc, cout, groups, tables, bias, da, za, out);
     return hip_check(hipGetLastError(), "qv2x_single_heads_lut_f32 launch");
 }
 
