@@ -399,6 +399,11 @@ static int conv3x3_entry(const qv2x_conv_desc* d, const int8_t* in, const int8_t
     if (a.gc[0] % 256 == 0 && (QV2X_CONV_FORCE ? QV2X_CONV_FORCE < 2 : wgs64 <= 256)) return launch_dma<64, 64, 2, 2, 256, false, 3, 1>(a, st);
     // three stages rather than four: the extra resident workgroup (3 or 6 per CU) hides more latency than the fourth stage did
     // (64->64 layer at batch 8: 38.7 -> 32.4 us; 25x88 128-channel layer at batch 4: 20.4 -> 15.7 us)
+#if QV2X_CONV_FORCE != 4
+    // a 64-channel layer over a large map (the stride-2 first layer of level 0 at a batch): 192-pixel tiles -- three 32 x 32 accumulators
+    // per wave and K chunk instead of one against the same weight tile and barrier
+    if (!k128 && a.cout == 64 && a.M >= 262144) return launch_dma<192, 64, 2, 2, 64, false, 3, 3>(a, st);
+#endif
     return k128 ? launch_dma<64, 64, 2, 2, 128, false, 3, 3>(a, st) : launch_dma<64, 64, 2, 2, 64, false, 3, 6>(a, st);
 }
 
