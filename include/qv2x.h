@@ -105,7 +105,10 @@ int qv2x_conv3x3_i8(const qv2x_conv_desc* desc /* host */, const int8_t* in, con
  *            of group 1, ...: the MFMA A-operand fragments of a K step in load order (T x 64 bytes contiguous per K step, 1 KiB per
  *            wave-instruction); opaque to the caller, made from the row-major layout by qv2x_conv3x3_i8_pack_wide, once.
  * Results are bit-identical to qv2x_conv3x3_i8.  qv2x_conv3x3_i8_wide_ok returns 1 when the layer qualifies
- * (and is large enough for the wide kernel to pay: N*H*W >= 16384), else 0. */
+ * (and is large enough for the wide kernel to pay: N*H*W >= 16384), else 0.
+ * Round 3: stride 2 too (the ZeroPad2d + stride-2 first convolution of a backbone level, base_bev_backbone.py:60-66): one input group; the
+ * kernel reads the input as four parity planes, each an ordinary halo tile with 4 / 2 / 2 / 1 of the nine taps, and w_wide stores the nine
+ * steps of 64 input channels in that order (taps 0 2 6 8 | 1 7 | 3 5 | 4).  _ok() answers 1 for it from 256 output channels up. */
 int qv2x_conv3x3_i8_wide_ok(const qv2x_conv_desc* desc /* host */);
 int qv2x_conv3x3_i8_pack_wide(const qv2x_conv_desc* desc /* host */, const int8_t* w, int8_t* w_wide, void* stream);
 int qv2x_conv3x3_i8_wide(const qv2x_conv_desc* desc /* host */, const int8_t* in, const int8_t* w_wide,

@@ -39,6 +39,8 @@ struct WideArgs {
     int cend[QV2X_MAX_GROUPS];        // first chunk index past group g
     int coff[MAX_CHUNKS];             // channel byte offset of each 64-channel chunk inside a pixel
     int items;                        // (patch, channel block) pairs, patches padded to a multiple of 8
+    int nsteps;                       // weight steps of an item's K loop: 9 per 64 input channels
+    int stride2;                      // 1: the stride-2 form (four parity-plane chunks per 64 input channels)
 };
 
 template <int V> struct IC { static constexpr int value = V; };
@@ -89,7 +91,12 @@ __device__ long long g_wide_fine[4096 * 16];
 // (matrix pipe), its partner requantizes and stores (VALU / memory), instead of both doing the same thing at the same time.  Measured
 // before (s_memtime stamps, batch of 32): a 64 -> 64 layer spent 5.1k cycles per item in the K loop and 7.5k in the epilogue with the
 // co-resident workgroups in lockstep; the barriers are what keeps the halves out of phase (left alone they drift back into step).
-template <bool MULTI, int NW, int NT, int BN, int NGRP = 1, int MTP = 5>
+// Round 3: S2 = the ZeroPad2d + stride-2 first convolution of a backbone level (base_bev_backbone.py:60-66) on the same kernel.  The input
+// is read as four PARITY PLANES (row parity, column parity of the padded input): tap (dy, dx) of output pixel (y, x) is pixel
+// (y + dy / 2, x + dx / 2) of plane (dy & 1, dx & 1), so a plane's halo tile is an ordinary 6 x 33 tile and a "chunk" becomes
+// (64 input channels, plane) with 4 / 2 / 2 / 1 taps -- the same nine K steps per 64 channels, the same fragment reads (base + immediate),
+// four halo tiles instead of one.  Only the DMA's source addresses know about the stride (the global side of an LDS-DMA is per lane).
+template <bool MULTI, int NW, int NT, int BN, int NGRP = 1, int MTP = 5, bool S2 = false>
 #ifdef QV2X_WIDE_W3     // dev variant: the plain four-wave form held to 168 VGPRs (three waves per SIMD, three workgroups per CU)
 #define QV2X_WIDE_BOUNDS(MULTI, NW, NGRP) ((NGRP) == 1 && !(MULTI) && (NW) == 4 ? 3 : (((NW) * (NGRP) >= 8 || ((MULTI) && (NW) == 4)) ? ((NGRP) > 1 ? 2 : 1) : 2))
 #else
@@ -98,6 +105,8 @@ template <bool MULTI, int NW, int NT, int BN, int NGRP = 1, int MTP = 5>
 __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) void conv3x3_i8_wide_kernel(const WideArgs a) {
     static_assert(NW * NT * 32 == BN && WTILE % BN == 0, "wave layout");
     static_assert(NGRP == 1 || ((NW * NGRP == 8 || NW * NGRP == 16) && NGRP % 2 == 0), "ping-pong: 8 or 16 waves, group g beside group g + NGRP / 2 on the SIMDs");
+    static_assert(!S2 || (NGRP == 1 && !MULTI), "the stride-2 form: plain workgroups, one input group");
+    constexpr int NPL = S2 ? 4 : 1;                                    // window-sum tables per set: one per parity plane
     constexpr int MT = MTP, TH = MTP, HPIX = (TH + 2) * HWD;           // (shadow the file-scope values: patch height = M tiles per wave)
     static_assert(HPIX <= HPAD, "halo tile");
     static_assert(HBLK % NW == 0, "every wave moves the same number of halo pieces");
@@ -105,7 +114,7 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
     constexpr int NF = MULTI ? 16 : 1;
     static_assert(NT == 1, "the epilogue below is written for one 32-channel tile per wave");
     constexpr int NG = MULTI ? QV2X_MAX_GROUPS : 1;
-    constexpr int GLDS = 2 * HBUF + 3 * NG * HPAD * 4 + NG * BN * 16;  // per group
+    constexpr int GLDS = 2 * HBUF + 3 * NG * NPL * HPAD * 4 + NG * BN * 16;  // per group
     __shared__ __attribute__((aligned(16))) int8_t lds_all[NGRP * GLDS];
     // window-sum tables [set][group][halo pixel]: item k of a workgroup uses set k % 3.  Its first tile is summed into the set by the
     // previous item's last tap 8, and item k's start clears set (k + 1) % 3 -- last read two items ago, i.e. before barriers every wave has
@@ -116,7 +125,7 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
     int8_t* lds = lds_all + grp * GLDS;
     int8_t* hbuf = lds;
     int* psum = (int*)(lds + 2 * HBUF);
-    v4i* ctab = (v4i*)(psum + 3 * NG * HPAD);                          // [group][BN] {aw, corr_g, scale_g (bits), bias (bits)} per channel
+    v4i* ctab = (v4i*)(psum + 3 * NG * NPL * HPAD);                    // [group][BN] {aw, corr_g, scale_g (bits), bias (bits)} per channel
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     // PERSISTENT workgroups: item id = ((patch / 8) * nblk + cb) * 8 + patch % 8 -> (patch, channel block); a workgroup takes the items
     // blockIdx.x, + gridDim.x, ... -- the grid is a multiple of 8 * nblk, so its channel block (weights, constants) and its XCD never change.
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
     }
     const bool idle = NGRP > 1 && my_slots == 0;                       // a group without items only keeps the barrier count
     const int cb = idle ? 0 : (item >> 3) % nblk, n0 = cb * BN;
-    const int total = a.nchunks * 9;
+    const int total = a.nsteps;
     WTRACE(0);
 #ifdef QV2X_WIDE_TRACE
     { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); if (tid == 0 && blockIdx.x < 8192) { g_wide_trace[blockIdx.x * 8 + 5] = hw; g_wide_trace[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime(); } }
@@ -159,12 +168,13 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
     };
     // byte offset (from a.in: the tensor is < 4 GiB) of this lane's 16 bytes of DMA piece j of an item's halo tile; recomputed at every
     // request (once per nine K steps) rather than kept: the three-group kernel has no registers to spare
-    auto src_of = [&](const Where& w, int j) __attribute__((always_inline)) {
+    auto src_of = [&](const Where& w, int j, int plane) __attribute__((always_inline)) {
         const int blk = wave + NW * j;
         int hpx = (blk & 3) * 64 + lane;
         hpx = hpx < HPIX ? hpx : HPIX - 1;
         const int hy = hpx / HWD, hx = hpx - hy * HWD;
-        const int yy = min(w.y0 + hy, a.hp - 1), xx = min(w.x0 + hx, a.wp - 1);
+        const int yy = S2 ? min(2 * (w.y0 + hy) + (plane >> 1), a.hp - 1) : min(w.y0 + hy, a.hp - 1);
+        const int xx = S2 ? min(2 * (w.x0 + hx) + (plane & 1), a.wp - 1) : min(w.x0 + hx, a.wp - 1);
         return (unsigned)(((w.img * a.hp + yy) * a.wp + xx) * a.cin_total + (blk >> 2) * 16);
     };
     Where cur = place(item), nxw = cur;
@@ -193,11 +203,12 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
 #pragma unroll
         for (int j = 0; j < LH; ++j)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                         :: "s"(ldsb + NW * j * 1024), "v"(src_of(k < 0 ? cur : nxw, j) + (unsigned)off), "s"(a.in) : "memory", "m0");
+                         :: "s"(ldsb + NW * j * 1024), "v"(src_of(k < 0 ? cur : nxw, j, (k < 0 ? c : k) & 3) + (unsigned)off), "s"(a.in) : "memory", "m0");
     };
     // per-pixel channel sums of a landed halo tile -> psum[slot] (four planes of a pixel arrive in four pieces: LDS atomics)
     int pset = 0;                                                      // this item's window-sum set
     auto add_psum = [&](int chunk, int slot) __attribute__((always_inline)) {   // slot = set * NG + group
+        if (S2) slot = slot * NPL + ((chunk >= a.nchunks ? chunk - a.nchunks : chunk) & 3);     // one table per parity plane
         const int8_t* buf = hbuf + ((pb + chunk) & 1) * HBUF;
         // every piece is read before the first atomic is issued: the compiler cannot move a read above an LDS atomic it may alias, and one
         // read -> wait -> dot -> atomic round trip per piece was 1.3k cycles per item in the two-wave form (eight pieces per wave)
@@ -233,6 +244,7 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
     // lane part in one register, the rest an immediate
     v4i fa[2][MT];
     const int rlane = half * PLANE + (lane & 31) * 16;
+    // (TAP = 3 oy + ox names the tile offset (oy, ox) of the step's pixels: the tap itself at stride 1, the plane-local offset at stride 2)
     auto read_half = [&](auto ks_c, auto tap_c, int chunk) __attribute__((always_inline)) {
         constexpr int KS = decltype(ks_c)::value, TAP = decltype(tap_c)::value;
 #if defined(QV2X_WABL) && QV2X_WABL == 2
@@ -248,6 +260,16 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
     (void)nit;
     auto window_sums = [&](int (&totv)[MT]) __attribute__((always_inline)) {
         // nine psum entries per output pixel (rows i .. i + 2 of the halo, columns x .. x + 2)
+        if (S2) {                                                      // plane (0,0): four taps, (0,1): two rows, (1,0): two columns, (1,1): one
+            const int* p0 = psum + (pset * NPL) * HPAD + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int o = i * HWD;
+                totv[i] = (p0[o] + p0[o + 1] + p0[o + HWD] + p0[o + HWD + 1]) + (p0[HPAD + o] + p0[HPAD + o + HWD])
+                          + (p0[2 * HPAD + o] + p0[2 * HPAD + o + 1]) + p0[3 * HPAD + o];
+            }
+            return;
+        }
         int rowsum[MT + 2];
         const int* ps = psum + (pset * NG + g) * HPAD + (lane & 31);
 #pragma unroll
@@ -273,22 +295,27 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
     };
 
     // One K step = (chunk, tap), in two halves.  On entry the K-half-0 fragments of the step are in flight or landed.
-    auto one_step = [&](auto tap_c, int chunk) __attribute__((always_inline)) {
-        constexpr int TAP = decltype(tap_c)::value;
-        const int step = chunk * 9 + TAP;
-        load_w(IC<(TAP + 2) % 3>{}, step + 2);                         // slot of step - 1, which is done
-        read_half(IC<1>{}, tap_c, chunk);
+    // Q: the step's index inside its nine-step period (weight ring slot Q % 3); OFF = 3 oy + ox: tile offset of its pixels; LAST: last step
+    // of its chunk (the next chunk's tile must have landed: wait, barrier, window sums, refill); NOFF: offset of the chunk's next step;
+    // VM2: the chunk is ONE step long (see below).
+    auto gstep = [&](auto q_c, auto off_c, auto last_c, auto noff_c, auto vm2_c, int chunk, int step) __attribute__((always_inline)) {
+        constexpr int Q = decltype(q_c)::value;
+        constexpr bool LAST = decltype(last_c)::value != 0;
+        load_w(IC<(Q + 2) % 3>{}, step + 2);                           // slot of step - 1, which is done
+        read_half(IC<1>{}, off_c, chunk);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) acc[i][0] = WMFMA(wr[TAP % 3][0], fa[0][i], acc[i][0]);
+        for (int i = 0; i < MT; ++i) acc[i][0] = WMFMA(wr[Q % 3][0], fa[0][i], acc[i][0]);
         __builtin_amdgcn_sched_barrier(0);
-        if (TAP < 8) {
-            read_half(IC<0>{}, IC<(TAP + 1) % 9>{}, chunk);
+        if (!LAST) {
+            read_half(IC<0>{}, noff_c, chunk);
         } else {
-            // the next chunk's halo tile was requested nine steps ago, before all but the youngest weight loads; every wave's reads of
+            // the next chunk's halo tile was requested before all but the youngest weight loads (four of them: steps + 1 and + 2; when this
+            // chunk is a single step, the pair for step + 1 is OLDER than the request, so only two are younger); every wave's reads of
             // THIS chunk's tile are done once it has passed the wait below, so after the barrier the tile's buffer can be refilled
             WFINE(2);
-            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            if (decltype(vm2_c)::value) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
             WFINE(3);
             __builtin_amdgcn_s_barrier();
             WFINE(4);
@@ -301,8 +328,27 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) acc[i][0] = WMFMA(wr[TAP % 3][1], fa[1][i], acc[i][0]);
+        for (int i = 0; i < MT; ++i) acc[i][0] = WMFMA(wr[Q % 3][1], fa[1][i], acc[i][0]);
         __builtin_amdgcn_sched_barrier(0);
+    };
+    // One K step = (chunk, tap) of a stride-1 layer.  On entry the K-half-0 fragments of the step are in flight or landed.
+    auto one_step = [&](auto tap_c, int chunk) __attribute__((always_inline)) {
+        constexpr int TAP = decltype(tap_c)::value;
+        gstep(tap_c, tap_c, IC<TAP == 8>{}, IC<(TAP + 1) % 9>{}, IC<0>{}, chunk, chunk * 9 + TAP);
+    };
+    // The nine steps of 64 input channels at stride 2: planes (0,0) | (0,1) | (1,0) | (1,1) = chunks 4 cc .. 4 cc + 3 with 4 | 2 | 2 | 1 steps
+    // (taps 0 2 6 8 | 1 7 | 3 5 | 4: the order qv2x_conv3x3_i8_pack_wide stores the weight steps in)
+    auto s2_period = [&](int cc) __attribute__((always_inline)) {
+        const int c0 = 4 * cc, s0 = 9 * cc;
+        gstep(IC<0>{}, IC<0>{}, IC<0>{}, IC<1>{}, IC<0>{}, c0, s0);
+        gstep(IC<1>{}, IC<1>{}, IC<0>{}, IC<3>{}, IC<0>{}, c0, s0 + 1);
+        gstep(IC<2>{}, IC<3>{}, IC<0>{}, IC<4>{}, IC<0>{}, c0, s0 + 2);
+        gstep(IC<3>{}, IC<4>{}, IC<1>{}, IC<0>{}, IC<0>{}, c0, s0 + 3);
+        gstep(IC<4>{}, IC<0>{}, IC<0>{}, IC<3>{}, IC<0>{}, c0 + 1, s0 + 4);
+        gstep(IC<5>{}, IC<3>{}, IC<1>{}, IC<0>{}, IC<0>{}, c0 + 1, s0 + 5);
+        gstep(IC<6>{}, IC<0>{}, IC<0>{}, IC<1>{}, IC<0>{}, c0 + 2, s0 + 6);
+        gstep(IC<7>{}, IC<1>{}, IC<1>{}, IC<0>{}, IC<0>{}, c0 + 2, s0 + 7);
+        gstep(IC<8>{}, IC<0>{}, IC<1>{}, IC<0>{}, IC<1>{}, c0 + 3, s0 + 8);
     };
 
     // ---- once per workgroup: the constants of its channel block, the first item's first tiles and weight steps ---------------
@@ -333,7 +379,7 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
         }
     }
 
-    for (int t = tid; t < 3 * NG * HPAD; t += NW * 64) psum[t] = 0;
+    for (int t = tid; t < 3 * NG * NPL * HPAD; t += NW * 64) psum[t] = 0;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     // the second tile only now: when a launch is one round of workgroups they all fetch their prologue at once (~11 B / cycle / CU), and the
     // first K steps need tile 0 alone -- tile 1 has nine steps to land like every later one
@@ -348,8 +394,8 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
         WFINE(0);
         // ---- item start: no barrier, no wait -- tile 0 landed and was summed at the previous item's last tap 8 (or just above) ------------
         {
-            int* nz = psum + (pset == 2 ? 0 : pset + 1) * NG * HPAD;   // the next item's set
-            for (int t = tid; t < NG * HPAD; t += NW * 64) nz[t] = 0;
+            int* nz = psum + (pset == 2 ? 0 : pset + 1) * NG * NPL * HPAD;   // the next item's set
+            for (int t = tid; t < NG * NPL * HPAD; t += NW * 64) nz[t] = 0;
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -370,6 +416,9 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
         WTRACE(1);
         WFINE(1);
 
+        if (S2) {
+            for (int cc = 0; cc < a.nchunks / 4; ++cc) s2_period(cc);
+        } else
         for (int chunk = 0; chunk < a.nchunks; ++chunk) {
             one_step(IC<0>{}, chunk); one_step(IC<1>{}, chunk); one_step(IC<2>{}, chunk);
             one_step(IC<3>{}, chunk); one_step(IC<4>{}, chunk); one_step(IC<5>{}, chunk);
@@ -751,20 +800,26 @@ __global__ void pack_wide_kernel(const int8_t* __restrict__ w, int8_t* __restric
     const int c16 = ksh * 2 + (ln >> 5);
     const int row = rb * 32 + (ln & 31);
     const long long tile = u / (a.wtile * 4);
-    const int step = tile % (nchunks * 9);
-    const int nb = tile / (nchunks * 9);
-    const int chunk = step / 9, tap = step % 9;
+    const int step = tile % a.nsteps;
+    const int nb = tile / a.nsteps;
+    // stride 1: chunk = 64 channels, nine taps each.  Stride 2 (one group): the nine steps of 64 channels run plane by plane --
+    // taps 0 2 6 8 | 1 7 | 3 5 | 4 (conv3x3_i8_wide_kernel<.., S2>::s2_period)
+    const int s2seq[9] = {0, 2, 6, 8, 1, 7, 3, 5, 4};
+    const int chunk = step / 9, tap = a.stride2 ? s2seq[step % 9] : step % 9;
     // group of this chunk and its K offset in the row-major layout
     int g = 0, k0 = 0, cfirst = 0;
-    while (chunk >= a.cend[g]) { const int gc = (a.cend[g] - cfirst) * 64; k0 += 9 * gc; cfirst = a.cend[g]; ++g; }
-    const int gc = (a.cend[g] - cfirst) * 64;
+    const int per = a.stride2 ? 4 : 1;                                 // (stride 2: cend counts four plane chunks per 64 channels)
+    while (chunk >= a.cend[g] / per) { const int gc = (a.cend[g] / per - cfirst) * 64; k0 += 9 * gc; cfirst = a.cend[g] / per; ++g; }
+    const int gc = (a.cend[g] / per - cfirst) * 64;
     const int k = k0 + tap * gc + (chunk - cfirst) * 64 + c16 * 16;
     *(v4i*)(wt + u * 16) = *(const v4i*)(w + (size_t)(nb * a.wtile + row) * ktot + k);
 }
 
 int fill_args(const qv2x_conv_desc* d, WideArgs& a) {
     if (d->n <= 0 || d->h <= 0 || d->w <= 0) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_wide: bad shape n=%d h=%d w=%d", d->n, d->h, d->w);
-    if (d->stride != 1 || (d->cout != 64 && d->cout != 128 && d->cout % 256)) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_wide: stride 1 and cout 64 | 128 | a multiple of 256");
+    if ((d->stride != 1 && d->stride != 2) || (d->cout != 64 && d->cout != 128 && d->cout % 256))
+        return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_wide: stride 1 | 2 and cout 64 | 128 | a multiple of 256");
+    if (d->stride == 2 && d->ngroups != 1) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_wide: the stride-2 form takes one input group");
     if (d->cout < 256 && d->ngroups != 1) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_wide: the 64 / 128-channel form takes one input group");
     a.wtile = d->cout < 256 ? d->cout : 256;
     if (d->ngroups < 1 || d->ngroups > QV2X_MAX_GROUPS) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_wide: 1..%d input groups", QV2X_MAX_GROUPS);
@@ -772,7 +827,8 @@ int fill_args(const qv2x_conv_desc* d, WideArgs& a) {
         return fail(QV2X_EALIGN, "qv2x_conv3x3_i8_wide: cin_total, out_ctotal, out_c0 %% 16; out channel window");
     if (!(d->out_delta > 0.0f)) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_wide: out_delta must be positive");
     a.n = d->n; a.hp = d->h + 2; a.wp = d->w + 2; a.cin_total = d->cin_total; a.cout = d->cout;
-    a.ho = d->h; a.wo = d->w;
+    a.stride2 = d->stride == 2;
+    a.ho = (d->h + 2 - 3) / d->stride + 1; a.wo = (d->w + 2 - 3) / d->stride + 1;     // (stride 1: h x w)
     a.tiles_x = (a.wo + TW - 1) / TW; a.tiles_y = (a.ho + TH - 1) / TH;
     a.out_ctotal = d->out_ctotal; a.out_c0 = d->out_c0; a.relu = d->relu; a.out_delta = d->out_delta; a.out_zp = d->out_zp;
     a.ngroups = d->ngroups;
@@ -792,6 +848,13 @@ int fill_args(const qv2x_conv_desc* d, WideArgs& a) {
         }
     }
     a.nchunks = n;
+    a.nsteps = 9 * n;
+    if (a.stride2) {                                                   // chunk = (64 channels, parity plane): four per 64 channels
+        if (4 * n > MAX_CHUNKS) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_wide: stride 2 takes at most %d input channels", MAX_CHUNKS / 4 * 64);
+        for (int c = 4 * n - 1; c >= 0; --c) a.coff[c] = a.coff[c / 4];
+        a.nchunks = 4 * n;
+        a.cend[0] = 4 * n;
+    }
     return QV2X_OK;
 }
 
@@ -800,8 +863,13 @@ int fill_args(const qv2x_conv_desc* d, WideArgs& a) {
 }  // namespace qv2x
 
 // output channels per workgroup: 256 (8 waves) while that fills the chip, else 128 (4 waves), 64 for the 64-channel layers
+static long long wide_patches(const qv2x_conv_desc* d) {
+    const int ho = (d->h + 2 - 3) / d->stride + 1, wo = (d->w + 2 - 3) / d->stride + 1;      // output map (stride 1: h x w)
+    return (long long)d->n * ((ho + qv2x::TH - 1) / qv2x::TH) * ((wo + qv2x::TW - 1) / qv2x::TW);
+}
+
 static int wide_bn(const qv2x_conv_desc* d) {
-    const long long patches = (long long)d->n * ((d->h + qv2x::TH - 1) / qv2x::TH) * ((d->w + qv2x::TW - 1) / qv2x::TW);
+    const long long patches = wide_patches(d);
 #ifdef QV2X_WIDE_FORCE_BN128
     if (d->cout % 256 == 0) return 128;
 #endif
@@ -836,8 +904,8 @@ extern "C" int qv2x_debug_wide_trace_clear() {
 #endif
 
 extern "C" int qv2x_conv3x3_i8_wide_ok(const qv2x_conv_desc* d) {
-    if (!d || d->stride != 1 || (d->cout != 64 && d->cout != 128 && d->cout % 256) || d->ngroups < 1 || d->ngroups > QV2X_MAX_GROUPS) return 0;
-    if (d->cout < 256 && d->ngroups != 1) return 0;
+    if (!d || (d->stride != 1 && d->stride != 2) || (d->cout != 64 && d->cout != 128 && d->cout % 256) || d->ngroups < 1 || d->ngroups > QV2X_MAX_GROUPS) return 0;
+    if ((d->cout < 256 || d->stride == 2) && d->ngroups != 1) return 0;
     int chunks = 0;
     for (int g = 0; g < d->ngroups; ++g) {
         if (d->group_c[g] <= 0 || d->group_c[g] % 64 || d->group_c0[g] % 16) return 0;
@@ -845,9 +913,12 @@ extern "C" int qv2x_conv3x3_i8_wide_ok(const qv2x_conv_desc* d) {
     }
     // enough workgroups (a 5 x 32 patch x 64 / 128 / 256 output channels each) to fill the chip: below that the 64 x 64-tile kernel
     // of qv2x_conv3x3_i8 spreads the layer over more CUs
-    const long long patches = (long long)d->n * ((d->h + qv2x::TH - 1) / qv2x::TH) * ((d->w + qv2x::TW - 1) / qv2x::TW);
+    const long long patches = wide_patches(d);
     const long long wgs = patches * (d->cout / wide_bn(d));
-    return chunks <= qv2x::MAX_CHUNKS && (long long)d->n * d->h * d->w >= 16384 && wgs >= (d->cout == 64 ? 1024 : 192);
+    // Stride 2 (measured, batch of 32 / 8): four tiles, barriers and window-sum passes per nine K steps instead of one -- 256 output
+    // channels amortise them (34 vs 39 us, 13.8 vs 17.6 us), 128 do not (46 vs 44 us) and 64 lose (149 vs 129 us on the 192-pixel im2col tiles)
+    if (d->stride == 2 && d->cout % 256) return 0;
+    return chunks * (d->stride == 2 ? 4 : 1) <= qv2x::MAX_CHUNKS && patches * qv2x::TH * qv2x::TW >= 16384 && wgs >= (d->cout == 64 ? 1024 : 192);
 }
 
 extern "C" int qv2x_conv3x3_i8_pack_wide(const qv2x_conv_desc* d, const int8_t* w, int8_t* w_wide, void* stream) {
@@ -856,7 +927,7 @@ extern "C" int qv2x_conv3x3_i8_pack_wide(const qv2x_conv_desc* d, const int8_t* 
     if (((uintptr_t)w & 15) || ((uintptr_t)w_wide & 15)) return fail(QV2X_EALIGN, "qv2x_conv3x3_i8_pack_wide: 16-byte alignment");
     WideArgs a{};
     if (int rc = fill_args(d, a)) return rc;
-    const int ktot = a.nchunks * 9 * 64;
+    const int ktot = a.nsteps * 64;                                    // bytes of one output channel's weights
     const long long units = (long long)d->cout * ktot / 16;
     pack_wide_kernel<<<(unsigned)((units + 255) / 256), 256, 0, (hipStream_t)stream>>>(w, w_wide, d->cout, ktot, a.nchunks, a);
     return hip_check(hipGetLastError(), "qv2x_conv3x3_i8_pack_wide launch");
@@ -879,7 +950,7 @@ extern "C" int qv2x_conv3x3_i8_wide_form(const qv2x_conv_desc* d, const int8_t* 
     a.in = in; a.wt = w_wide; a.scale = scale; a.corr = corr; a.aw = aw; a.bias = bias; a.out = out;
     hipStream_t st = (hipStream_t)stream;
     // Pipelined form (epilogue of item i inside the K loop of item i + 1; 4 x 32 patches): one input group of 1, 2 or 4 chunks
-    const bool can_pipe = d->ngroups == 1 && (a.nchunks == 1 || a.nchunks == 2 || a.nchunks == 4);
+    const bool can_pipe = d->stride == 1 && d->ngroups == 1 && (a.nchunks == 1 || a.nchunks == 2 || a.nchunks == 4);
     if (form == QV2X_WIDE_PIPE && !can_pipe)
         return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_wide_form: the pipelined form takes one input group of 64, 128 or 256 channels");
     if (form == QV2X_WIDE_PIPE) {
@@ -913,7 +984,7 @@ extern "C" int qv2x_conv3x3_i8_wide_form(const qv2x_conv_desc* d, const int8_t* 
     if (const char* e = getenv("QV2X_WIDE_PP")) pp_min_x2 = atoi(e);   // 0: never; dev builds only
 #endif
     const int bn_pp = d->cout % 256 == 0 ? 128 : d->cout, ngrp = bn_pp == 64 ? 4 : 2;
-    const bool can_pp = d->ngroups == 1;
+    const bool can_pp = d->ngroups == 1 && d->stride == 1;
     if (form == QV2X_WIDE_PINGPONG && !can_pp)
         return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_wide_form: the ping-pong form takes one input group");
     const bool pp = form == QV2X_WIDE_PINGPONG ||
@@ -946,9 +1017,14 @@ extern "C" int qv2x_conv3x3_i8_wide_form(const qv2x_conv_desc* d, const int8_t* 
 #else
     const int per_cu128 = 2;
 #endif
-    const int slots = 256 * (bn == 256 ? 1 : (bn == 128 ? (d->ngroups > 1 ? 1 : per_cu128) : 4)) / period * period;
+    // (stride 2: four window-sum tables per set -- 45 KB of LDS: three 64-channel workgroups per CU)
+    const int slots = 256 * (bn == 256 ? 1 : (bn == 128 ? (d->ngroups > 1 ? 1 : per_cu128) : (a.stride2 ? 3 : 4))) / period * period;
     const dim3 grid(a.items < slots ? a.items : slots);
-    if (d->ngroups > 1) {
+    if (a.stride2) {
+        if (bn == 256) conv3x3_i8_wide_kernel<false, 8, 1, 256, 1, 5, true><<<grid, 512, 0, st>>>(a);
+        else if (bn == 128) conv3x3_i8_wide_kernel<false, 4, 1, 128, 1, 5, true><<<grid, 256, 0, st>>>(a);
+        else conv3x3_i8_wide_kernel<false, 2, 1, 64, 1, 5, true><<<grid, 128, 0, st>>>(a);
+    } else if (d->ngroups > 1) {
         if (bn == 256) conv3x3_i8_wide_kernel<true, 8, 1, 256><<<grid, 512, 0, st>>>(a);
         else conv3x3_i8_wide_kernel<true, 4, 1, 128><<<grid, 256, 0, st>>>(a);
     } else {

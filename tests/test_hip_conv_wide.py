@@ -105,13 +105,65 @@ def test_wide_matches_regular_and_oracle(n, h, w, groups, cout):
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout", [
+    (1, 10, 64, 64, 64),            # one exact patch row (5 x 32 outputs), one period of plane chunks
+    (2, 27, 75, 64, 64),            # ragged output map (14 x 38)
+    (3, 20, 130, 64, 128),          # level 1's first layer: 64 -> 128
+    (2, 50, 66, 128, 256),          # level 2's: two periods, eight plane chunks
+    (40, 50, 64, 64, 64),           # 1000 patches on 768 slots: the next item's first tile requested from a one-step chunk
+    (16, 50, 176, 128, 256),        # 480 patches: eight-wave workgroups, persistent items
+])
+def test_wide_stride2_matches_regular_and_oracle(n, h, w, cin, cout):
+    """The ZeroPad2d + stride-2 first convolution of a backbone level on the halo-patch kernel (parity-plane chunks): equal to the im2col
+    kernel and to the oracle, bit for bit."""
+    from oracle.spec import Oracle
+    from quantv2x_amd import lib as L
+    from quantv2x_amd.engine import _ConvLayer
+    lib = L.load()
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(h * 1000 + w + cin)
+    name = "layer"
+    state = _layer_state(rng, name, cin, cout)
+    in_q = [(0, cin, np.float32(0.04), 77)]
+    layer = _ConvLayer(state, name, in_q, 2, dev)
+    x = rng.integers(0, 256, size=(n, h, w, cin), dtype=np.uint8)
+    xin = torch.from_numpy(_padded(x, np.full(cin, 77))).to(dev)
+    ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    d = L.ConvDesc()
+    d.n, d.h, d.w, d.cin_total, d.stride, d.cout, d.ngroups = n, h, w, cin, 2, cout, 1
+    d.group_c0[0], d.group_c[0], d.group_zx[0] = 0, cin, 77
+    d.out_ctotal, d.out_c0, d.relu = cout, 0, 1
+    d.out_delta, d.out_zp = layer.out_q[0], float(layer.out_q[1])
+    st = L.current_stream()
+    outs = []
+    for wide in (False, True):
+        out = torch.full((n, ho + 2, wo + 2, cout), -77, dtype=torch.int8, device=dev)
+        if wide:
+            w_wide = torch.empty_like(layer.w)
+            L.check(lib.qv2x_conv3x3_i8_pack_wide(C.byref(d), L.ptr(layer.w), L.ptr(w_wide), st), "pack")
+            L.check(lib.qv2x_conv3x3_i8_wide_form(C.byref(d), L.ptr(xin), L.ptr(w_wide), L.ptr(layer.scale), L.ptr(layer.corr),
+                                                  L.ptr(layer.aw), L.ptr(layer.bias), L.ptr(out), 1, st), "wide")
+        else:
+            L.check(lib.qv2x_conv3x3_i8(C.byref(d), L.ptr(xin), L.ptr(layer.w), L.ptr(layer.scale), L.ptr(layer.corr),
+                                        L.ptr(layer.aw), L.ptr(layer.bias), L.ptr(out), st), "regular")
+        torch.cuda.synchronize()
+        outs.append(out.cpu().numpy())
+    np.testing.assert_array_equal(outs[1], outs[0])
+    orc = Oracle.__new__(Oracle)
+    orc.s = state
+    want, _ = orc.conv(name, x, in_q, stride=2)
+    np.testing.assert_array_equal((outs[1][:, 1:-1, 1:-1].astype(np.int16) + 128).astype(np.uint8), want)
+
+
 def test_wide_rejects_unsupported():
     from quantv2x_amd import lib as L
     lib = L.load()
     d = L.ConvDesc()
     d.n, d.h, d.w, d.cin_total, d.stride, d.cout, d.ngroups = 1, 100, 352, 64, 2, 256, 1
     d.group_c[0], d.out_ctotal, d.out_delta = 64, 256, 0.1
-    assert lib.qv2x_conv3x3_i8_wide_ok(C.byref(d)) == 0               # stride 2
+    assert lib.qv2x_conv3x3_i8_wide_ok(C.byref(d)) == 0               # stride 2 on one frame: 55 patches do not fill the chip
+    d.stride = 3
+    assert lib.qv2x_conv3x3_i8_wide_ok(C.byref(d)) == 0
     d.stride, d.cout = 1, 192
     assert lib.qv2x_conv3x3_i8_wide_ok(C.byref(d)) == 0               # cout: 64, 128 or a multiple of 256
     d.cout = 128
@@ -123,7 +175,7 @@ def test_wide_rejects_unsupported():
     d.n, d.cout = 1, 256
     assert lib.qv2x_conv3x3_i8_wide_ok(C.byref(d)) == 1
     x = torch.zeros(64, dtype=torch.int8, device="cuda")
-    d.stride = 2
+    d.stride = 3
     rc = lib.qv2x_conv3x3_i8_wide(C.byref(d), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), None)
     assert rc != 0 and b"stride" in lib.qv2x_last_error()
     d.stride, d.ngroups, d.cin_total = 1, 2, 128
