@@ -32,30 +32,33 @@ __device__ __forceinline__ float q_code(float y, float delta, float zp) {
 }
 
 // Four outputs -> one dword of (code - 128) bytes (byte e = element e), the same values q_code gives.  `rdelta` = 1.0f / delta,
-// hoisted by the caller.  t = y * rdelta is within 1.8e-7 |t| of fl(y / delta); a code only depends on rint(.) for |t| < 256.5
-// (0 <= zp <= 255: beyond that both values clamp to 0 or 255 even when they differ by one), where the gap is < 4.7e-5, so
-// the two round alike unless t lies within 1e-4 of a half-integer.  One test per group of four: max |t - rint(t)| > 0.4999 on
-// any lane sends the wave through the exact divisions (5 % of the groups).  The clamped code is read from the low mantissa byte
-// of (code + 2^23), with zp + 2^23 added in one step (exact: both are integers below 2^24).
+// hoisted by the caller.  The product p = y * rdelta is within 1.2e-7 |p| of y / delta and fl(y / delta) within 6e-8 more; a code only
+// depends on rint(.) for |p| < 256.5 (0 <= zp <= 255: beyond that both values clamp to 0 or 255 even when they differ by one), where the
+// gap is < 4.7e-5, so the two round alike unless p lies within 1e-4 of a half-integer.
+//   r = fma(y, rdelta, zp + 2^23)    ONE rounding of the exact p + zp + 2^23 to an integer (ulp 1 in [2^23, 2^24)): r = code + 2^23
+//   e = fma(y, rdelta, (zp + 2^23) - r) = fl(p - k), k = r - zp - 2^23 exactly: how far p is from the integer it was rounded to
+// One test per group of four: max |e| > 0.4999 on any lane sends the wave through the exact divisions (5 % of the groups).  Below code 0
+// (p + zp < 0) r falls under 2^23 where its ulp is 1/2 and k may be a half-integer: the clamp sets those to the lowest code, which is what
+// they are.  The clamped code is read from the low mantissa byte of r.  (Round 3: 5.25 instead of 7.25 instructions per output -- the
+// epilogues are bound by the SIMD's VALU issue)
 // `lowc`: lowest code + 2^23.  8388608.0f (code 0) for the plain quantizer; zp + 2^23 folds a ReLU in front of the quantizer into the
 // clamp -- rint is monotone and rint(0) = 0, so q(max(y, 0)) = max(rint(y / delta), 0) + zp -- and saves the caller one fmaxf per output.
 __device__ __forceinline__ int q_pack4(float y0, float y1, float y2, float y3, float delta, float rdelta, float zp, float lowc = 8388608.0f) {
     const float y[4] = {y0, y1, y2, y3};
-    float k[4], dmax = 0.0f;
+    const float zm = zp + 8388608.0f;
+    float r[4], dmax = 0.0f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const float t = y[e] * rdelta;
-        k[e] = rintf(t);
-        dmax = fmaxf(dmax, fabsf(t - k[e]));
+        r[e] = __builtin_fmaf(y[e], rdelta, zm);
+        dmax = fmaxf(dmax, fabsf(__builtin_fmaf(y[e], rdelta, zm - r[e])));
     }
     if (__builtin_amdgcn_ballot_w64(dmax > 0.4999f) != 0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) k[e] = rintf(y[e] / delta);
+        for (int e = 0; e < 4; ++e) r[e] = rintf(y[e] / delta) + zm;
     }
-    const float zm = zp + 8388608.0f;
     unsigned b[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) b[e] = __builtin_bit_cast(unsigned, fminf(fmaxf(k[e] + zm, lowc), 8388863.0f));
+    for (int e = 0; e < 4; ++e) b[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_fmed3f(r[e], lowc, 8388863.0f));   // ONE v_med3_f32 (fminf(fmaxf()) is two: NaN rules); r is never NaN here
     const unsigned lo = __builtin_amdgcn_perm(b[1], b[0], 0x0c0c0400u);      // byte 0 of b0, byte 0 of b1
     const unsigned hi = __builtin_amdgcn_perm(b[3], b[2], 0x0c0c0400u);
     return (int)(__builtin_amdgcn_perm(hi, lo, 0x05040100u) ^ 0x80808080u);

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_i8_dma_kernel(const ConvArg
         constexpr int SP = TN + 16;                              // staging row pitch: 2-way bank spread for the dword writes
         static_assert(4 * TM * SP <= S * STAGE, "epilogue staging fits the idle ring");
         int8_t* stage = lds + wave * (TM * SP);                  // this wave's [TM pixels][TN channels]
-        const float rd = 1.0f / a.out_delta, lo = a.relu ? 0.0f : -3.0e38f;
+        const float rd = 1.0f / a.out_delta, lowc = a.relu ? a.out_zp + 8388608.0f : 8388608.0f;    // the ReLU lives in the clamp (q_pack4)
         const int half = lane >> 5, l31 = lane & 31;
         int tot[MT];
 #pragma unroll
@@ -278,9 +278,9 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_i8_dma_kernel(const ConvArg
                         const int T = acc[i][j][r] + __mul24(c_aw[r], tot[i]) + c_cr[r];
                         float yv = c_bs[r] + (float)T * c_sc[r];
                         if (EPI != 0) yv = yv + rs[e];
-                        y[e] = fmaxf(yv, lo);
+                        y[e] = yv;
                     }
-                    *(int*)(stage + (i * 32 + l31) * SP + j * 32 + 8 * g + 4 * half) = q_pack4(y[0], y[1], y[2], y[3], a.out_delta, rd, a.out_zp);
+                    *(int*)(stage + (i * 32 + l31) * SP + j * 32 + 8 * g + 4 * half) = q_pack4(y[0], y[1], y[2], y[3], a.out_delta, rd, a.out_zp, lowc);
                 }
             }
         }

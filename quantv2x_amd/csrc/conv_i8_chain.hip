@@ -140,7 +140,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_i8_chain64_kernel(const ChainA
         int8_t* dst = lds + ((d & 1) ? 0 : A0);
         const float od = a.out_delta[d], oz = a.out_zp[d], rd = 1.0f / od;
         const int padb = ((int)oz - 128) & 0xff, padw = padb * 0x01010101;
-        const float lo = a.relu ? 0.0f : -3.0e38f;                       // ReLU as one max
+        const float lowc = a.relu ? oz + 8388608.0f : 8388608.0f;        // the ReLU lives in the clamp (q_pack4)
         const int Yo = y0 - (D - 1 - d), Xo = x0 - (D - 1 - d);
         // LDS byte offset of tap t for this lane in M tile 0; tile i adds 2048 i (the swizzle has a period of 16 pixels)
         int off[9];
@@ -192,9 +192,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_i8_chain64_kernel(const ChainA
                     const int r = 4 * g + e;
                     const int T = acc[r] + __mul24(c_aw[r], tot) + c_cr[r];
                     y[e] = c_bs[r] + (float)T * c_sc[r];
-                    y[e] = fmaxf(y[e], lo);
                 }
-                int pk = QV2X_CHAIN_DBG == 1 ? acc[4 * g] + acc[4 * g + 1] + acc[4 * g + 2] + acc[4 * g + 3] + tot : q_pack4(y[0], y[1], y[2], y[3], od, rd, oz);
+                int pk = QV2X_CHAIN_DBG == 1 ? acc[4 * g] + acc[4 * g + 1] + acc[4 * g + 2] + acc[4 * g + 3] + tot : q_pack4(y[0], y[1], y[2], y[3], od, rd, oz, lowc);
                 pk = inside ? pk : padw;                                // outside the image: the zero padding of the next layer
                 if (valid) *(int*)(o + (((2 * nt + (g >> 1)) ^ swz) << 4) + 8 * (g & 1)) = pk;
             }

@@ -321,8 +321,10 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
             WFINE(4);
             const int nxt = chunk + 1;                                 // (past the last chunk: the next item's first tile, into ITS set)
             add_psum(nxt, nxt < a.nchunks ? pset * NG + (MULTI ? (nxt >= a.cend[g] ? g + 1 : g) : 0) : (pset == 2 ? 0 : pset + 1) * NG);
+#if !defined(QV2X_WABL) || QV2X_WABL != 5                             // (dev ablation 5: no halo DMA inside the K loop)
             issue_halo(chunk + 2);                                     // (after the LDS atomics above: an LDS write after a pending
                                                                        //  LDS-DMA makes the compiler drain vmcnt)
+#endif
             WFINE(5);
             read_half(IC<0>{}, IC<0>{}, nxt);
         }
@@ -380,6 +382,9 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
     }
 
     for (int t = tid; t < 3 * NG * NPL * HPAD; t += NW * 64) psum[t] = 0;
+    int corr0[16];                                                     // single-group layers: accumulator r starts at its channel's corr (one add per output less)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) corr0[r] = MULTI ? 0 : a.corr[n0 + wave * 32 + 8 * (r >> 2) + 4 * half + (r & 3)];
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     // the second tile only now: when a launch is one round of workgroups they all fetch their prologue at once (~11 B / cycle / CU), and the
     // first K steps need tile 0 alone -- tile 1 has nine steps to land like every later one
@@ -400,7 +405,7 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][0][r] = 0;
+            for (int r = 0; r < 16; ++r) acc[i][0][r] = MULTI ? 0 : corr0[r];     // the item's sums start AT the channel's correction term
         if (MULTI) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
@@ -459,7 +464,7 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
                     if (MULTI) {
                         y[e] = facc[i][0][r];
                     } else {
-                        const int T = acc[i][0][r] + __mul24(c[e][0], totv[i]) + c[e][1];
+                        const int T = __mul24(c[e][0], totv[i]) + acc[i][0][r];                  // (corr is in the accumulator since the item's start)
                         const int sci = c[e][2], bsi = c[e][3];
                         y[e] = __int_as_float(bsi) + (float)T * __int_as_float(sci);
                     }

@@ -110,7 +110,7 @@ __device__ __forceinline__ void deconv_tile(const DeconvArgs& a, const int tile,
     // of 32, so the tile's 32 columns are 32 consecutive output channels of ONE sub-position (di, dj)
     int8_t* stage = stagebuf[threadIdx.x >> 6];
     const int orow = a.wd * a.s + 2;             // output pixels per padded row
-    const float rd = 1.0f / a.out_delta, lo = a.relu ? 0.0f : -3.0e38f;
+    const float rd = 1.0f / a.out_delta, lowc = a.relu ? a.out_zp + 8388608.0f : 8388608.0f;    // the ReLU lives in the clamp (q_pack4)
     const int half = lane >> 5, l31 = lane & 31;
     const int pb = __shfl(pixbase, lane >> 1);   // the copy-out below moves 16 bytes per lane: pixel lane >> 1, chunk lane & 1
 #pragma unroll
@@ -123,8 +123,8 @@ __device__ __forceinline__ void deconv_tile(const DeconvArgs& a, const int tile,
             const v4f b4 = *(const v4f*)(a.bias + co0 + 8 * g + 4 * half);
             float yv[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) yv[e] = fmaxf(acc[t][4 * g + e] + b4[e], lo);
-            *(int*)(stage + l31 * DSP + 8 * g + 4 * half) = q_pack4(yv[0], yv[1], yv[2], yv[3], a.out_delta, rd, a.out_zp);
+            for (int e = 0; e < 4; ++e) yv[e] = acc[t][4 * g + e] + b4[e];
+            *(int*)(stage + l31 * DSP + 8 * g + 4 * half) = q_pack4(yv[0], yv[1], yv[2], yv[3], a.out_delta, rd, a.out_zp, lowc);
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
