@@ -20,6 +20,12 @@ namespace qv2x {
 #ifdef QV2X_ENC_TRACE   // dev build (tools/enc_block_trace.py): when and on which CU every workgroup ran
 __device__ unsigned long long g_enc_blk[4096][4];
 #endif
+#ifdef QV2X_ENC_FINE    // dev build (tools/enc_fine.py): s_memtime stamps of thread 0 at the phase boundaries of every level (12 per level)
+__device__ long long g_enc_fine[2048][40];
+#define EFINE(k) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_enc_fine[blockIdx.x][12 * l + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define EFINE(k) do { } while (0)
+#endif
 
 constexpr int ER = 32;              // rows per workgroup (two workgroups share a CU: 4 waves per SIMD)
 constexpr int ERT = ER / 32;        // 32-row MFMA tiles per workgroup
@@ -130,15 +136,6 @@ __device__ __forceinline__ unsigned long long dist_key(float d, int code) {
 }
 
 // one step of the key-min reduction: combine with the lane `shift` positions up inside the 16-lane DPP row
-template <int CTRL>
-__device__ __forceinline__ void keymin_dpp(unsigned long long& k) {
-    const int lo = (int)(unsigned)k, hi = (int)(unsigned)(k >> 32);
-    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
-    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
-    k = o < k ? o : k;
-}
-
 __device__ __forceinline__ void store_tile(float* __restrict__ dst, int wave, int lane, const v16f (&acc)[ERT]) {
 #pragma unroll
     for (int i = 0; i < ERT; ++i)
@@ -210,14 +207,19 @@ __global__ __launch_bounds__(512, 4) void codebook_encode_kernel(const EncArgs a
         const float* cb = cbp + (size_t)D * a.kc;             // [kc][256]
         const float* c2 = cb + (size_t)a.kc * D;              // [kc]
 
+        EFINE(0);
         gemm_rows_x32(bufA, (const float2*)stage_w, head, wave, lane, acc);         // z = stage(x)
+        EFINE(1);
         head = gemm_head((const float2*)qhead_w, qhead_b, wave, lane);
         store_tile(bufB, wave, lane, acc);
         lds_barrier();
+        EFINE(2);
         gemm_rows_x32(bufB, (const float2*)qhead_w, head, wave, lane, acc);         // q = qhead(z)
+        EFINE(3);
         if (l + 1 < a.levels) head = gemm_head((const float2*)lhead_w, lhead_b, wave, lane);      // used after the argmin
         store_tile(bufA, wave, lane, acc);                                        // x is dead since the barrier above
         lds_barrier();
+        EFINE(4);
 
         if (tid < ER * 4) {   // |q|^2: four 64-wide ascending fma chains per row; thread = (chain = tid / ER, row = tid % ER)
             const int row = tid % ER, part = tid / ER;
@@ -243,8 +245,10 @@ __global__ __launch_bounds__(512, 4) void codebook_encode_kernel(const EncArgs a
             c2v = c2[code];
         }
         lds_barrier();
+        EFINE(5);
         if (tid < ER) x2[tid] = (pval[tid] + pval[ER + tid]) + (pval[2 * ER + tid] + pval[3 * ER + tid]);
         lds_barrier();
+        EFINE(6);
 
         // ---- distances: wave -> (row tile = wave >> 2, codes [32*(wave & 3), +32)), then the argmin ------------
         if (has_dist) {
@@ -281,22 +285,41 @@ __global__ __launch_bounds__(512, 4) void codebook_encode_kernel(const EncArgs a
                 dist4(s1, q0 + 4);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            EFINE(7);
+            // (distance, code) minimum of every row over this wave's 32 codes.  The distance's fp32 bits map monotonically onto u32 (as in
+            // dist_key); its minimum over the half-wave that holds the row takes four v_min_u32 with DPP operands (quad_perm, quad_perm,
+            // row_half_mirror, row_mirror: a butterfly, every lane of a 16-lane row ends with the row's minimum) and one v_permlane16_swap
+            // across the two rows; the FIRST lane holding it (= the lowest code: ties go to the lower code, the reference's first-argmin) is
+            // a find-first-bit of the equality mask.  ~20 VALU instructions per register against 64 for the 64-bit key chain this
+            // replaces, whose 1000 instructions stood between the distance GEMM and the barrier the other four waves wait at
+            // (tools/enc_fine.py: 21-28k of a workgroup's 387k ticks per level).  Lane j < 16 of each half-wave collects register j's result.
+            unsigned resk = 0xffffffffu;
+            int resc = 0;
+            const int l31 = lane & 31, hi = lane >> 5;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rt * 32 + mfma32_row(r, lane);
-                unsigned long long key = dist_key((x2[row] + c2v) - 2.0f * dacc[r], code);
-                // reduced towards lane 0 of each 16-lane row with DPP row shifts (full-rate VALU; the ds_bpermute butterfly
-                // this replaces cost ~20 us per workgroup), then rows 0|1 (lanes 0, 16) and 2|3 (lanes 32, 48) of the wave
-                keymin_dpp<0x108>(key); keymin_dpp<0x104>(key); keymin_dpp<0x102>(key); keymin_dpp<0x101>(key);
-                const int klo = (int)(unsigned)key, khi = (int)(unsigned)(key >> 32);
-                const unsigned lo16 = (unsigned)__builtin_amdgcn_readlane(klo, 16), hi16 = (unsigned)__builtin_amdgcn_readlane(khi, 16);
-                const unsigned lo48 = (unsigned)__builtin_amdgcn_readlane(klo, 48), hi48 = (unsigned)__builtin_amdgcn_readlane(khi, 48);
-                const unsigned long long o = lane < 32 ? (((unsigned long long)hi16 << 32) | lo16) : (((unsigned long long)hi48 << 32) | lo48);
-                key = o < key ? o : key;
-                if ((lane & 31) == 0) pkey[ct * ER + row] = key;
+                const float d = (x2[row] + c2v) - 2.0f * dacc[r];
+                unsigned b = __builtin_bit_cast(unsigned, d);
+                b ^= (unsigned)((int)b >> 31) | 0x80000000u;
+                unsigned m = b, o;
+                o = (unsigned)__builtin_amdgcn_update_dpp((int)m, (int)m, 0xB1, 0xf, 0xf, false); m = o < m ? o : m;      // quad_perm [1,0,3,2]
+                o = (unsigned)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x4E, 0xf, 0xf, false); m = o < m ? o : m;      // quad_perm [2,3,0,1]
+                o = (unsigned)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x141, 0xf, 0xf, false); m = o < m ? o : m;     // row_half_mirror
+                o = (unsigned)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x140, 0xf, 0xf, false); m = o < m ? o : m;     // row_mirror
+                const auto sw = __builtin_amdgcn_permlane16_swap(m, m, false, false);   // rows 1 | 3 of the first <-> rows 0 | 2 of the second
+                m = sw[0] < sw[1] ? sw[0] : sw[1];
+                const unsigned long long eq = __builtin_amdgcn_ballot_w64(b == m);
+                const int c_lo = __builtin_ctz((unsigned)eq), c_hi = __builtin_ctz((unsigned)(eq >> 32));
+                const int c = hi ? c_hi : c_lo;
+                const bool mine = l31 == r;
+                resk = mine ? m : resk;
+                resc = mine ? c : resc;
             }
+            if (l31 < 16) pkey[ct * ER + rt * 32 + mfma32_row(l31, lane)] = ((unsigned long long)resk << 32) | (unsigned)(ct * 32 + resc);
         }
         lds_barrier();
+        EFINE(8);
         if (tid < ER) {
             unsigned long long bk = pkey[tid];
             for (int wv = 1; wv * 32 < a.kc; ++wv) {
@@ -308,6 +331,7 @@ __global__ __launch_bounds__(512, 4) void codebook_encode_kernel(const EncArgs a
             if (m0 + tid < a.M) a.codes[(size_t)l * a.M + m0 + tid] = (uint8_t)bi;
         }
         lds_barrier();
+        EFINE(9);
 
         if (l + 1 < a.levels) {      // x <- lhead(z) - C[code]
             // the chosen codewords' entries of this lane's column: 16 gathers requested ahead of the GEMM that produces the minuend
@@ -318,12 +342,14 @@ __global__ __launch_bounds__(512, 4) void codebook_encode_kernel(const EncArgs a
 #pragma unroll
                 for (int r = 0; r < 16; ++r) cv[i][r] = cb[(size_t)code_s[i * 32 + mfma32_row(r, lane)] * D + col];
             gemm_rows_x32(bufB, (const float2*)lhead_w, head, wave, lane, acc);
+            EFINE(10);
             head = gemm_head((const float2*)a.lvl[l + 1], a.lvl[l + 1] + D * D, wave, lane);     // the next level's stage
 #pragma unroll
             for (int i = 0; i < ERT; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) bufA[(i * 32 + mfma32_row(r, lane)) * LDF + kpos(col)] = acc[i][r] - cv[i][r];
             lds_barrier();
+            EFINE(11);
         }
     }
 #ifdef QV2X_ENC_TRACE
@@ -387,6 +413,11 @@ static int encode_launch(const qv2x_encode_desc* d, const int8_t* in, const floa
     return hip_check(hipGetLastError(), "qv2x_codebook_encode_f32 launch");
 }
 
+#ifdef QV2X_ENC_FINE
+extern "C" int qv2x_debug_encode_fine(long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(qv2x::g_enc_fine), (size_t)n * 40 * sizeof(long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef QV2X_ENC_TRACE
 extern "C" int qv2x_debug_encode_blocks(unsigned long long* host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(qv2x::g_enc_blk), (size_t)n * 4 * sizeof(unsigned long long));
