@@ -789,7 +789,14 @@ class DeployedModel(nn.Module):
         agents = data_dict["agent_modality_list"]
         n_total = len(agents)
         if any(a != "m1" for a in agents):
-            raise NotImplementedError("deployed path: every agent is the LiDAR modality 'm1'")
+            raise NotImplementedError("deployed path: every agent is the LiDAR modality 'm1' (a heterogeneous model deploys as DeployedHeterModel)")
+        enc = self.encode_agents(data_dict["inputs_m1"], n_total, taps)
+        return self.finish(enc, n_total, data_dict, taps)
+
+    @torch.no_grad()
+    def finish(self, enc, n_total: int, data_dict: dict, taps: Optional[dict] = None) -> dict:
+        """a7-a11 on the agents' wire data ``enc`` (code planes u8 [levels, n_total * H*W] in agent order, or the i8 shrinker output of a
+        model without a codebook): decode + warp + fusion per scene, the heads, the ``*_single`` heads."""
         pairwise = data_dict["pairwise_t_matrix"]
         if pairwise.dtype != torch.float64 or not pairwise.is_contiguous():
             pairwise = pairwise.to(torch.float64).contiguous()
@@ -801,7 +808,6 @@ class DeployedModel(nn.Module):
             if isinstance(rl, torch.Tensor) and rl.is_cuda and torch.cuda.is_current_stream_capturing():
                 raise ValueError("record_len on the GPU cannot be read during HIP-graph capture: pass a CPU tensor")
             lens = [int(v) for v in (rl.tolist() if isinstance(rl, torch.Tensor) else rl)]
-        enc = self.encode_agents(data_dict["inputs_m1"], n_total, taps)
         hw = self.fh * self.fw
         bufs = self._workspace(n_total)
         feats = None if self.has_codebook else self._shared_features(enc, n_total)
@@ -860,6 +866,80 @@ class DeployedModel(nn.Module):
         return replay
 
 
+class DeployedHeterModel(nn.Module):
+    """A heterogeneous scene (heter_model_baseline.py:169-216): every modality has its own encoder / backbone / shrinker, the agents'
+    features are assembled in ``agent_modality_list`` order, fusion and heads are shared.  One ``DeployedModel`` per modality runs a1-a6
+    on that modality's agents (each from its own PTQ state, ``export_ptq_state(qt, modality=m)``: own weights, own quantizers -- the
+    encoder's input scale differs per modality); the code planes go into one buffer in agent order; the ego modality's engine runs
+    a7-a11 on it.  The code planes ARE the interface, so nothing else is shared.  Codebook models only."""
+
+    def __init__(self, states: Dict[str, Dict[str, np.ndarray]], ego_modality: Optional[str] = None, device="cuda", **kw):
+        super().__init__()
+        if not states:
+            raise ValueError("DeployedHeterModel: no modality")
+        self.engines = {m: DeployedModel(st, device=device, **kw) for m, st in states.items()}
+        self.main = self.engines[ego_modality if ego_modality in self.engines else next(iter(self.engines))]
+        for m, e in self.engines.items():
+            e._workspace(1)                                            # (the feature-map size is known once a workspace exists)
+            if not e.has_codebook:
+                raise NotImplementedError("deployed heterogeneous path: codebook models (the code planes are what the modalities share)")
+            if (e.fh, e.fw, e.levels, e.kc) != (self.main.fh, self.main.fw, self.main.levels, self.main.kc):
+                raise ValueError(f"modality {m}: feature map {e.fh} x {e.fw} / codebook {e.levels} x {e.kc} differs from the ego modality's")
+        self.dev = self.main.dev
+        self._slots: Dict[tuple, Dict[str, torch.Tensor]] = {}         # agent layout -> per modality, the agent slots as a device index
+
+    @torch.no_grad()
+    def forward(self, data_dict: dict, taps: Optional[dict] = None) -> dict:
+        agents = list(data_dict["agent_modality_list"])
+        n_total, hw, lv = len(agents), self.main.fh * self.main.fw, self.main.levels
+        unknown = sorted(set(agents) - set(self.engines))
+        if unknown:
+            raise NotImplementedError(f"deployed heterogeneous path: no engine for modality {unknown}")
+        slots = self._slots.get(tuple(agents))
+        if slots is None:                                              # (built once per layout, outside any HIP-graph capture: capture() warms up first)
+            slots = {m: torch.as_tensor([i for i, a in enumerate(agents) if a == m], dtype=torch.int64, device=self.dev) for m in self.engines}
+            self._slots[tuple(agents)] = slots
+        enc = torch.empty((lv, n_total * hw), dtype=torch.uint8, device=self.dev)
+        for m, eng in self.engines.items():
+            k = int(slots[m].numel())
+            if not k:
+                continue
+            mt = {} if taps is not None else None
+            codes = eng.encode_agents(data_dict["inputs_" + m], k, mt).view(lv, k, hw)
+            enc.view(lv, n_total, hw).index_copy_(1, slots[m], codes)                                # agent order (a copy, no arithmetic)
+            if taps is not None:
+                taps["modality/" + m] = mt
+        return self.main.finish(enc, n_total, data_dict, taps)
+
+    def capture(self, data_dict: dict):
+        """One heterogeneous frame as a HIP graph (see ``DeployedModel.capture``: fixed pillar counts, resident canvases, CPU ``record_len``)."""
+        rl = data_dict.get("record_len")
+        if data_dict["pairwise_t_matrix"].shape[0] > 1 and isinstance(rl, torch.Tensor) and rl.is_cuda:
+            data_dict = dict(data_dict, record_len=rl.cpu())
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self.forward(data_dict)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self.forward(data_dict)
+
+        def replay():
+            graph.replay()
+            return out
+        replay.graph = graph
+        return replay
+
+
+def deploy_heter(qt_model, device="cuda", **kw) -> DeployedHeterModel:
+    """Freeze every modality of a calibrated heterogeneous ``QuantModel`` (``export_ptq_state(qt, modality=m)``) into its own engine."""
+    model = qt_model.model if hasattr(qt_model, "model") else qt_model
+    states = {m: export_ptq_state(qt_model, modality=m) for m in model.modality_name_list}
+    return DeployedHeterModel(states, ego_modality=getattr(model, "ego_modality", None), device=device, **kw)
+
+
 def deploy(qt_model=None, state: Optional[Dict[str, np.ndarray]] = None, path: Optional[str] = None,
            device="cuda", **kw) -> DeployedModel:
     """Freeze a calibrated ``QuantModel`` (or load a saved PTQ state) into the HIP int8 path.  A plain, un-quantized model (what
@@ -868,6 +948,9 @@ def deploy(qt_model=None, state: Optional[Dict[str, np.ndarray]] = None, path: O
         if path is not None:
             state = load_ptq_state(path)
         elif any(hasattr(m, "weight_quantizer") for m in qt_model.modules()):
+            inner = qt_model.model if hasattr(qt_model, "model") else qt_model
+            if len(getattr(inner, "modality_name_list", ["m1"])) > 1:        # heter_model_baseline.py:41-75: one stack per modality
+                return deploy_heter(qt_model, device=device, **kw)
             state = export_ptq_state(qt_model)
         elif hasattr(qt_model, "pyramid_backbone"):
             from .engine_pyramid_fp32 import export_fp32_pyramid_state

@@ -18,6 +18,7 @@ used -- and collects exactly what the deployed integer path needs:
 """
 from __future__ import annotations
 
+import re
 from typing import Dict
 
 import numpy as np
@@ -104,16 +105,33 @@ def _check_structure(model) -> None:
             raise NotImplementedError(f"{name}: residual blocks end in ReLU + a frozen 8-bit quantizer on the deployed path")
 
 
-def export_ptq_state(qt_model) -> Dict[str, np.ndarray]:
+_PER_MODALITY = re.compile(r"^(encoder|backbone|shrinker|aligner)_(m\d+)(\.|$)")
+
+
+def export_ptq_state(qt_model, modality: str = "m1") -> Dict[str, np.ndarray]:
+    """``modality``: which of a heterogeneous model's per-modality stacks (``encoder_<m>`` / ``backbone_<m>`` / ``shrinker_<m>``,
+    heter_model_baseline.py:41-75) this state carries, next to the shared codebook / fusion / heads.  Its keys are written under the
+    ``_m1`` names, so every engine sees "its" modality as m1 (``engine.DeployedHeterModel`` holds one engine per modality)."""
     model = qt_model.model if hasattr(qt_model, "model") and not _is_quant_module(qt_model) else qt_model
     _check_structure(model)
     out: Dict[str, np.ndarray] = {}
     pyramid = _is_pyramid(model)
+    if modality != "m1" and pyramid:
+        raise NotImplementedError("deployed Pyramid path: one modality (m1)")
+    if not hasattr(model, "encoder_" + modality):
+        raise ValueError(f"the model has no modality {modality!r}")
     out["meta/fusion_method"] = np.array("pyramid" if pyramid else ("max" if type(getattr(model, "fusion_net", None)).__name__ == "MaxFusion" else "att"))
-    names = []
-    for name, m in model.named_modules():
+    if modality != "m1":
+        out["meta/modality"] = np.array(modality)                   # (m1 states keep the key set the golden export pins)
+    names, src_of = [], {}
+    modules = dict(model.named_modules())
+    for src_name, m in modules.items():
         if not _is_quant_module(m):
             continue
+        pm = _PER_MODALITY.match(src_name)
+        if pm and pm.group(2) != modality:
+            continue                                                # another modality's stack: in that modality's own state
+        name = _PER_MODALITY.sub(lambda g: f"{g.group(1)}_m1{g.group(3)}", src_name) if pm else src_name
         # W4A8 and the other sub-8-bit WEIGHT widths of the reference's PTQ script (scripts/inference/inference_quant.sh: --n_bits_w 4
         # --n_bits_a 8; quant_layer.py:337-340 bitwidth_refactor, quant_model.py:115-127 set_first_last_layer_to_8bit) deploy unchanged:
         # a b-bit code and its zero point lie in [0, 2^b - 1], stay uint8 and run on the same int8 kernels.  Activations stay 8-bit:
@@ -126,6 +144,7 @@ def export_ptq_state(qt_model) -> Dict[str, np.ndarray]:
         if not (getattr(m.weight_quantizer, "inited", True) and m.act_quantizer.inited):
             raise ValueError(f"{name}: quantizers must be frozen (set_inited(True)) before export")
         names.append(name)
+        src_of[name] = src_name
         wq, aq = m.weight_quantizer, m.act_quantizer
         out[name + "/w_code"] = weight_codes(m)
         out[name + "/w_delta"] = _np(torch.as_tensor(wq.delta)).reshape(-1).astype(np.float32)
@@ -136,9 +155,9 @@ def export_ptq_state(qt_model) -> Dict[str, np.ndarray]:
         out[name + "/a_zp"] = np.float32(_np(torch.as_tensor(aq.zero_point)).reshape(-1)[0])
         out[name + "/a_off"] = np.bool_(bool(m.disable_act_quant))
     out["meta/module_names"] = np.array(names)
-    out["meta/w_bits"] = np.array([int(dict(model.named_modules())[n].weight_quantizer.n_bits) for n in names], dtype=np.int32)   # 8, or 2..7 (W4A8)
+    out["meta/w_bits"] = np.array([int(modules[src_of[n]].weight_quantizer.n_bits) for n in names], dtype=np.int32)   # 8, or 2..7 (W4A8)
 
-    enc = model.encoder_m1
+    enc = getattr(model, "encoder_" + modality)
     if type(enc).__name__ == "QuantSECOND":                       # the sparse encoder in front of the same 2-D path
         if pyramid:
             raise NotImplementedError("deployed Pyramid path: PointPillar agents")
@@ -177,7 +196,7 @@ def export_ptq_state(qt_model) -> Dict[str, np.ndarray]:
         out["meta/upsample_strides"] = np.array(cfg_p["upsample_strides"], dtype=np.int64)
         out["meta/supervise_single"] = np.bool_(False)
     else:
-        bb = model.backbone_m1
+        bb = getattr(model, "backbone_" + modality)
         out["meta/layer_nums"] = np.array([len(b) - 2 for b in bb.blocks], dtype=np.int64)
         out["meta/layer_strides"] = np.array([int(b[1].fwd_kwargs["stride"][0]) for b in bb.blocks], dtype=np.int64)
         out["meta/upsample_strides"] = np.array([int(d[0].fwd_kwargs["stride"][0]) for d in bb.deblocks], dtype=np.int64)

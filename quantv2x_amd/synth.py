@@ -82,8 +82,10 @@ def grid_size(lidar_range: Sequence[float], voxel_size: Sequence[float]) -> Tupl
 
 def make_hypes(shape: str = "v2xreal", multiclass: bool = True, codebook: bool = True,
                supervise_single: bool = True, dict_size: int = 128, seg_num: int = 1, fusion: str = "att", compress_ratio: int = 0,
-               encoder: str = "point_pillar") -> dict:
-    """Return a ``hypes`` dict with the ``model`` section the reference's yaml would give.  ``encoder="second"``: the m1 modality is the
+               encoder: str = "point_pillar", modalities: Sequence[str] = ("m1",)) -> dict:
+    """Return a ``hypes`` dict with the ``model`` section the reference's yaml would give.  ``modalities=("m1", "m2")``: a heterogeneous
+    model (heter_model_baseline.py:41-75: one encoder / backbone / shrinker per modality; here both LiDAR PointPillar, same architecture,
+    their own weights).  ``encoder="second"``: the m1 modality is the
     SECOND encoder over ``SECOND_SHAPES["second_" + shape]`` (same metric range, 0.1 m voxels); its 256-channel map is already at the
     resolution PointPillar's first backbone level reaches, so the backbone starts with stride 1 and ``inplanes: 256``."""
     lidar_range, voxel_size, max_voxels, max_cav = SHAPES[shape]
@@ -129,6 +131,9 @@ def make_hypes(shape: str = "v2xreal", multiclass: bool = True, codebook: bool =
         args["m1"]["backbone_args"].update({"layer_strides": [1, 2, 2], "inplanes": 256})
     elif encoder != "point_pillar":
         raise ValueError(encoder)
+    for m in modalities:
+        if m != "m1":
+            args[m] = copy.deepcopy(args["m1"])
     core = "heter_baseline_collab_codebook" if codebook else "heter_model_baseline"
     if multiclass:
         core += "_mc"
@@ -409,9 +414,11 @@ def pairwise_t_matrix(poses: Sequence[np.ndarray], max_cav: int) -> np.ndarray:
 # --------------------------------------------------------------------------- scenes
 
 def make_scene(shape: str = "v2xreal", n_agents: int = 1, seed: int = 0, n_points: int = 60000,
-               layout: str = "line", sigma_m: Optional[float] = None, max_cav: Optional[int] = None, encoder: str = "point_pillar") -> dict:
+               layout: str = "line", sigma_m: Optional[float] = None, max_cav: Optional[int] = None, encoder: str = "point_pillar",
+               modalities: Optional[Sequence[str]] = None) -> dict:
     """Build the numpy form of ``batch_data['ego']`` for one frame (batch size 1).  ``encoder="second"``: ``inputs_m1`` holds the 0.1 m
-    voxels of ``make_second_scene`` over the same range."""
+    voxels of ``make_second_scene`` over the same range.  ``modalities``: one name per agent (default all ``m1``); every modality gets its
+    own ``inputs_<m>`` whose ``voxel_coords[:, 0]`` counts that modality's agents (what the reference's collate gives its encoders)."""
     lidar_range, voxel_size, max_voxels, L = SHAPES[shape]
     if max_cav is not None:
         L = max_cav
@@ -419,24 +426,29 @@ def make_scene(shape: str = "v2xreal", n_agents: int = 1, seed: int = 0, n_point
     if sigma_m is None:
         sigma_m = 0.25 * (lidar_range[3] - lidar_range[0]) / 2.0 + 0.0
         sigma_m = {"v2xreal": 35.0, "opv2v": 45.0}.get(shape, sigma_m)
-    feats, coords, nums = [], [], []
+    modalities = ["m1"] * n_agents if modalities is None else list(modalities)
+    assert len(modalities) == n_agents
+    per = {m: ([], [], []) for m in dict.fromkeys(modalities)}
     for a in range(n_agents):
         pts = make_points(lidar_range, n_points, seed * 1000 + a, sigma_m)
         f, c, n = voxelize(pts, lidar_range, voxel_size, 32, max_voxels)
+        feats, coords, nums = per[modalities[a]]
+        coords.append(np.concatenate([np.full((c.shape[0], 1), len(feats), dtype=np.int32), c], axis=1))     # index among ITS modality's agents
         feats.append(f)
-        coords.append(np.concatenate([np.full((c.shape[0], 1), a, dtype=np.int32), c], axis=1))
         nums.append(n)
     poses = agent_poses(n_agents, layout)
-    inputs = {"voxel_features": np.concatenate(feats, axis=0), "voxel_coords": np.concatenate(coords, axis=0),
-              "voxel_num_points": np.concatenate(nums, axis=0)}
+    out = {}
+    for m, (feats, coords, nums) in per.items():
+        out["inputs_" + m] = {"voxel_features": np.concatenate(feats, axis=0), "voxel_coords": np.concatenate(coords, axis=0),
+                              "voxel_num_points": np.concatenate(nums, axis=0)}
     if encoder == "second":
-        inputs = make_second_scene({"tiny": "second_tiny", "small": "second_small", "v2xreal": "second_full"}[shape], n_agents, seed, n_points)
-    return {
-        "inputs_m1": inputs,
-        "agent_modality_list": ["m1"] * n_agents,
+        out["inputs_m1"] = make_second_scene({"tiny": "second_tiny", "small": "second_small", "v2xreal": "second_full"}[shape], n_agents, seed, n_points)
+    out.update({
+        "agent_modality_list": modalities,
         "record_len": np.asarray([n_agents], dtype=np.int64),
         "pairwise_t_matrix": pairwise_t_matrix(poses, L)[None].astype(np.float64),
-    }
+    })
+    return out
 
 
 def scene_to_torch(scene: dict, device="cpu") -> dict:

@@ -131,3 +131,82 @@ def compare_frame(orc, eng, sc_np, state, every_layer=True, preds_exact_tol=None
             lsb = head_lsb(state, "_single" if key.endswith("_single") else "")
             assert d.max() <= lsb * 1.001 and (d > 1e-5).mean() < 1e-3, (key, d.max(), (d > 1e-5).mean())
     return otaps, gtaps, want, got
+
+
+# ---- heterogeneous scenes (heter_model_baseline.py:169-216): the tiny_heter_w8a8.npz recipe ----------------------------------
+HETER_MODALITIES = ["m1", "m2", "m1"]
+
+
+def heter_scene_np(modalities=HETER_MODALITIES, shape="tiny", seed=SEED_SCENE, n_points=N_POINTS):
+    return synth.make_scene(shape, n_agents=len(modalities), seed=seed, n_points=n_points, modalities=modalities)
+
+
+def calibrated_heter_plugin(shape="tiny", n_points=N_POINTS):
+    """Two LiDAR modalities with their own weights, W8A8 min-max, one EMA pass on the [m1, m2, m1] scene, frozen."""
+    from quantv2x_amd.plugin.tools.inference_quant import calibrate_minmax
+    model = build_plugin(shape, modalities=("m1", "m2"))
+    return calibrate_minmax(quant_wrap(model), [synth.scene_to_torch(heter_scene_np(shape=shape, n_points=n_points))])
+
+
+def hard_forward_heter(model, dd, taps=None):
+    """The mirror's heterogeneous forward with the deterministic codebook pair."""
+    from quantv2x_amd.plugin.utils.transformation_utils import normalize_pairwise_tfm
+    taps = {} if taps is None else taps
+    affine = normalize_pairwise_tfm(dd['pairwise_t_matrix'].clone(), model.H, model.W, model.fake_voxel_size)
+    per = {}
+    for m in model.modality_name_list:
+        if m in dd['agent_modality_list']:
+            per[m] = getattr(model, 'shrinker_' + m)(getattr(model, 'backbone_' + m)(getattr(model, 'encoder_' + m)(dd, m)))
+            taps['shrinker_' + m] = per[m]
+    taken = {m: 0 for m in per}
+    rows = []
+    for m in dd['agent_modality_list']:
+        rows.append(per[m][taken[m]])
+        taken[m] += 1
+    f = torch.stack(rows)
+    n, c, h, w = f.shape
+    codes = model.codebook.encode(f.permute(0, 2, 3, 1).contiguous().view(-1, c))
+    dec = model.codebook.decode(codes)
+    taps['codes'] = torch.stack([cd[:, 0] for cd in codes]).view(3, n, h, w)
+    taps['decoded'] = dec.view(n, h, w, c).permute(0, 3, 1, 2).contiguous()
+    taps['fused'] = model.fusion_net(taps['decoded'], dd['record_len'], affine)
+    taps['preds_tensor'] = torch.cat([model.cls_head(taps['fused']), model.reg_head(taps['fused']), model.dir_head(taps['fused'])], dim=1)
+    return taps['preds_tensor']
+
+
+def heter_oracle_forward(states, sc_np, taps=None):
+    """The CPU oracle on a heterogeneous scene: every modality's own oracle (its PTQ state) runs a1-a6 on that modality's agents, the
+    code planes are put in agent order, the ego modality's oracle decodes, fuses and runs the heads."""
+    from oracle.spec import Oracle
+    taps = {} if taps is None else taps
+    agents = list(sc_np["agent_modality_list"])
+    per = {}
+    for m, st in states.items():
+        idx = [i for i, a in enumerate(agents) if a == m]
+        if not idx:
+            continue
+        orc = Oracle(st)
+        sub = {"inputs_m1": sc_np["inputs_" + m], "agent_modality_list": ["m1"] * len(idx)}
+        pcodes, canvas, cq = orc.pfn_scatter(sub, len(idx))
+        mt = {}
+        cat, cat_q = orc.backbone(canvas, cq, mt)
+        shr, shr_q = orc.shrinker(cat, cat_q, mt)
+        per[m] = (idx, orc.encode(shr, shr_q).reshape(-1, len(idx), shr.shape[1] * shr.shape[2]), shr)
+        taps["shrinker_" + m] = shr
+    main = Oracle(states[agents[0]] if agents[0] in states else next(iter(states.values())))
+    lv, hw = next(iter(per.values()))[1].shape[0], next(iter(per.values()))[1].shape[2]
+    codes = np.zeros((lv, len(agents), hw), np.uint8)
+    for m, (idx, c, _) in per.items():
+        codes[:, idx, :] = c
+    shr = next(iter(per.values()))[2]
+    h, w = shr.shape[1], shr.shape[2]
+    taps["codes"] = codes.reshape(lv, len(agents), h, w)
+    feats = main.decode(codes.reshape(lv, -1)).reshape(len(agents), h, w, 256)
+    fused = main.fuse(feats, sc_np["pairwise_t_matrix"], sc_np["record_len"])
+    taps["fused"] = fused
+    cls, reg, dr = main.heads(fused)
+    out = {"cls_preds": cls, "reg_preds": reg, "dir_preds": dr, "preds_tensor": np.concatenate([cls, reg, dr], axis=1)}
+    if bool(main.s["meta/supervise_single"]):
+        s_cls, s_reg, s_dir = main.heads(feats, "_single")
+        out.update({"cls_preds_single": s_cls, "reg_preds_single": s_reg, "dir_preds_single": s_dir})
+    return out

@@ -12,6 +12,8 @@ only expected outputs are stored):
                    ``forward`` under ``torch.manual_seed(0)``; preds for N = 1 and N = 3; state-dict keys
   tiny_w8a8.npz    the same model under the reference ``QuantModel`` (W8A8, min-max, one EMA pass,
                    then frozen): every (delta, zero_point), integer weight codes, per-module output codes
+  tiny_heter_w8a8.npz  (``heter``) a TWO-modality model (m1, m2: LiDAR PointPillar, own weights) under the reference QuantModel on the
+                   scene [m1, m2, m1]: every (delta, zero_point) of both stacks, weight-code checksums, hard-path codes / fused / preds
   uaq_units.npz    ``UniformAffineQuantizer`` unit vectors (minmax / mse, EMA sequence, channel-wise
                    conv / deconv / linear), ``fold_bn`` vectors, AdaRound hard rounding
   geometry.npz     ``normalize_pairwise_tfm`` + ``warp_affine_simple`` + ``AttFusion`` vectors
@@ -213,6 +215,83 @@ def gen_w8a8():
     out['ptq_export/absum'] = np.array([float(np.abs(np.asarray(st[k], dtype=np.float64)).sum()) for k in keys])
     np.savez_compressed(os.path.join(HERE, "tiny_w8a8.npz"), **out)
     print("tiny_w8a8.npz: %d arrays, %d modules" % (len(out), len(names)))
+
+
+HETER_MODALITIES = ["m1", "m2", "m1"]              # agent 1 is the second LiDAR modality
+
+
+def hard_forward_heter(model, dd, taps=None):
+    """The reference's heterogeneous forward (heter_model_baseline.py:169-216) with the deterministic codebook pair: every modality's own
+    encoder / backbone / shrinker on its agents, the features picked in ``agent_modality_list`` order, codebook, fusion, heads."""
+    taps = {} if taps is None else taps
+    affine = normalize_pairwise_tfm(dd['pairwise_t_matrix'].clone(), model.H, model.W, model.fake_voxel_size)
+    per = {}
+    for m in model.modality_name_list:
+        if m in dd['agent_modality_list']:
+            f = getattr(model, 'encoder_' + m)(dd, m)
+            f = getattr(model, 'backbone_' + m)(f)
+            per[m] = getattr(model, 'shrinker_' + m)(f)
+            taps['shrinker_' + m] = per[m]
+    taken = {m: 0 for m in per}
+    rows = []
+    for m in dd['agent_modality_list']:
+        rows.append(per[m][taken[m]])
+        taken[m] += 1
+    f = torch.stack(rows)
+    taps['shrinker'] = f
+    n, c, h, w = f.shape
+    codes = model.codebook.encode(f.permute(0, 2, 3, 1).contiguous().view(-1, c))
+    dec = model.codebook.decode(codes)
+    taps['codes'] = torch.stack([cd[:, 0] for cd in codes]).view(3, n, h, w)
+    taps['decoded'] = dec.view(n, h, w, c).permute(0, 3, 1, 2).contiguous()
+    fused = model.fusion_net(taps['decoded'], dd['record_len'], affine); taps['fused'] = fused
+    taps['preds_tensor'] = torch.cat([model.cls_head(fused), model.reg_head(fused), model.dir_head(fused)], dim=1)
+    return taps['preds_tensor']
+
+
+def gen_heter():
+    """tiny_heter_w8a8.npz: a two-modality model (m1, m2: both LiDAR PointPillar, own weights) under the reference's QuantModel, W8A8
+    min-max, one EMA pass on a three-agent scene [m1, m2, m1], frozen; every (delta, zero_point) of both stacks, weight-code checksums,
+    the hard path's codes / fused map / predictions."""
+    out = {}
+    qt = quant_wrap(build_ref(modalities=("m1", "m2")))
+    for a in act_quantizers(qt):
+        a.set_inited(False)
+    qt.set_quant_state(True, True)
+    dd = synth.scene_to_torch(synth.make_scene("tiny", n_agents=3, seed=SEED_SCENE, n_points=N_POINTS, modalities=HETER_MODALITIES))
+    with torch.no_grad():
+        torch.manual_seed(0)
+        qt(dd)
+    for a in act_quantizers(qt):
+        a.set_inited(True)
+    model = qt.model
+    assert model.modality_name_list == ["m1", "m2"]
+    names = []
+    for name, m in model.named_modules():
+        if not isinstance(m, QuantModule):
+            continue
+        names.append(name)
+        wqz, aqz = m.weight_quantizer, m.act_quantizer
+        key = name.replace('.', '/')
+        out[key + '/w_delta'] = np32(wqz.delta).reshape(-1)
+        out[key + '/w_zp'] = np32(wqz.zero_point).reshape(-1)
+        wcode = np32(torch.clamp(torch.round(m.weight / wqz.delta) + wqz.zero_point, 0, 255)).astype(np.uint8)
+        out[key + '/w_code_checksum'] = weight_checksums(wcode)
+        out[key + '/a_delta'] = np.float32(aqz.delta)
+        out[key + '/a_zp'] = np.float32(aqz.zero_point)
+    out['module_names'] = np.array(names)
+    out['state_dict_keys'] = np.array(sorted(model.state_dict().keys()))
+    with torch.no_grad():
+        taps = {}
+        hard_forward_heter(model, dd, taps)
+    for m in ("m1", "m2"):
+        aq = getattr(model, 'shrinker_' + m).layers[0].double_conv[1].act_quantizer
+        out[f'hard/shrinker_{m}_code'] = np32(torch.round(taps['shrinker_' + m] / aq.delta + aq.zero_point)).astype(np.uint8)[:, ::8]
+    out['hard/codes'] = np32(taps['codes']).astype(np.uint8)
+    out['hard/fused'] = sub8(taps['fused'])
+    out['hard/preds_tensor'] = np32(taps['preds_tensor'])
+    np.savez_compressed(os.path.join(HERE, "tiny_heter_w8a8.npz"), **out)
+    print("tiny_heter_w8a8.npz: %d arrays, %d modules" % (len(out), len(names)))
 
 
 def gen_uaq_units():
@@ -859,3 +938,4 @@ if __name__ == "__main__":
     if "w4a8" in which: gen_w4a8()
     if "fullsize" in which: gen_fullsize()                 # (not in the default list: minutes of CPU time each)
     if "codebook_full" in which: gen_codebook_full()
+    if "heter" in which: gen_heter()
