@@ -150,6 +150,7 @@ struct DeconvBatch {
     int n;
 };
 
+template <int NT>
 __global__ __launch_bounds__(256) void deconv_f32_batch_kernel(const DeconvBatch b) {
     __shared__ __attribute__((aligned(16))) int8_t stagebuf[4][32 * DSP];
     const int tile = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
@@ -157,10 +158,10 @@ __global__ __launch_bounds__(256) void deconv_f32_batch_kernel(const DeconvBatch
     while (l < b.n - 1 && tile >= b.tile_end[l]) { begin = b.tile_end[l]; ++l; }
     if (tile >= b.tile_end[b.n - 1]) return;
     switch (l) {                              // constant indices: the argument structs stay in SGPRs / kernarg loads
-        case 0: deconv_tile<1>(b.a[0], tile - begin, stagebuf); break;
-        case 1: deconv_tile<1>(b.a[1], tile - begin, stagebuf); break;
-        case 2: deconv_tile<1>(b.a[2], tile - begin, stagebuf); break;
-        default: deconv_tile<1>(b.a[3], tile - begin, stagebuf); break;
+        case 0: deconv_tile<NT>(b.a[0], tile - begin, stagebuf); break;
+        case 1: deconv_tile<NT>(b.a[1], tile - begin, stagebuf); break;
+        case 2: deconv_tile<NT>(b.a[2], tile - begin, stagebuf); break;
+        default: deconv_tile<NT>(b.a[3], tile - begin, stagebuf); break;
     }
 }
 
@@ -208,14 +209,24 @@ extern "C" int qv2x_deconv_i8_batch(const qv2x_deconv_desc* descs, int n, const 
     if (!descs || !ins || !ws || !biases || !outs) return fail(QV2X_EINVAL, "qv2x_deconv_i8_batch: null pointer");
     if (n < 1 || n > MAX_BATCH) return fail(QV2X_EINVAL, "qv2x_deconv_i8_batch: 1..%d layers", MAX_BATCH);
     DeconvBatch b{};
-    int total = 0;
+    int total1 = 0;
     for (int i = 0; i < n; ++i) {
         if (int rc = deconv_args(&descs[i], ins[i], ws[i], biases[i], outs[i], "qv2x_deconv_i8_batch", b.a[i])) return rc;
-        total += ((b.a[i].M + 31) / 32) * (b.a[i].ncols / 32);
+        total1 += ((b.a[i].M + 31) / 32) * (b.a[i].ncols / 32);
+    }
+    // Wave tiles of 32 pixels x 32 columns balance best while a launch is a few rounds of waves (one frame: 13.7 / 21.4 / 36.4 us against
+    // 15.4 / 23.7 / 39.5 with 64 columns); from ~16 tiles per SIMD on, 64 columns per wave halve the pixel loads and the int8 -> fp32
+    // conversions per MFMA (every s*s*cout is a multiple of 64): 1325 -> 1211 us for the three deblocks of a batch of 32 frames (128
+    // columns per wave: 1262)
+    const int nt = total1 >= 16384 ? 2 : 1;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        total += ((b.a[i].M + 31) / 32) * (b.a[i].ncols / (32 * nt));
         b.tile_end[i] = total;
     }
     b.n = n;
-    deconv_f32_batch_kernel<<<(total + 3) / 4, 256, 0, (hipStream_t)stream>>>(b);
+    if (nt == 2) deconv_f32_batch_kernel<2><<<(total + 3) / 4, 256, 0, (hipStream_t)stream>>>(b);
+    else deconv_f32_batch_kernel<1><<<(total + 3) / 4, 256, 0, (hipStream_t)stream>>>(b);
     return hip_check(hipGetLastError(), "qv2x_deconv_i8_batch launch");
 }
 
