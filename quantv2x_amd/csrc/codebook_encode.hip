@@ -27,8 +27,11 @@ __device__ long long g_enc_fine[2048][40];
 #define EFINE(k) do { } while (0)
 #endif
 
-constexpr int ER = 32;              // rows per workgroup (two workgroups share a CU: 4 waves per SIMD)
-constexpr int ERT = ER / 32;        // 32-row MFMA tiles per workgroup
+// ER = rows per workgroup (template parameter of the kernel), ERT = ER / 32 MFMA row tiles per wave:
+//   32  two workgroups share a CU (4 waves per SIMD): the finer grain -- one frame is 1100 workgroups on 512 slots;
+//   64  one workgroup per CU with two accumulator chains per wave: every weight element fetched feeds two MFMAs and a wave waits for
+//       LDS / L2 once per 16 MFMAs instead of 8 -- 11.2 against 11.8 ms per batch of 32 frames (0.795 against 0.76 of the f32 peak), but
+//       550 workgroups on 256 slots for one frame (519 against 475 us): launches of two frames and more take it.
 constexpr int LDF = 258;            // LDS row stride in floats: 32 rows x ds_read_b64 land on 32 distinct bank pairs
 // Within every group of four consecutive k the LDS tiles and the packed weights are stored in the order (k0, k2, k1, k3):
 // the half-wave that feeds MFMA k-parity p reads ONE float2 = (k_p, k_{p+2}) -- no per-MFMA select instructions, so the
@@ -38,7 +41,6 @@ constexpr int D = 256;
 #ifndef QV2X_ENC_LDS_PAD        // dev builds: extra LDS floats per workgroup (occupancy experiments)
 #define QV2X_ENC_LDS_PAD 0
 #endif
-constexpr int ENC_SMEM_FLOATS = 2 * ER * LDF + ER + 4 * ER + 8 * ER + ER + QV2X_ENC_LDS_PAD;
 
 struct EncArgs {
     const int8_t* in; const float* in_f32; uint8_t* codes;      // in_f32 != null: the rows come as fp32 (un-quantized model)
@@ -82,6 +84,7 @@ __device__ __forceinline__ GemmHead gemm_head(const float2* __restrict__ wp, con
     return h;
 }
 
+template <int ERT>
 __device__ __forceinline__ void gemm_rows_x32(const float* __restrict__ src, const float2* __restrict__ wp, const GemmHead& head,
                                               int wave, int lane, v16f (&acc)[ERT]) {
     const int par = lane >> 5, col = wave * 32 + (lane & 31);
@@ -136,6 +139,7 @@ __device__ __forceinline__ unsigned long long dist_key(float d, int code) {
 }
 
 // one step of the key-min reduction: combine with the lane `shift` positions up inside the 16-lane DPP row
+template <int ERT>
 __device__ __forceinline__ void store_tile(float* __restrict__ dst, int wave, int lane, const v16f (&acc)[ERT]) {
 #pragma unroll
     for (int i = 0; i < ERT; ++i)
@@ -144,7 +148,10 @@ __device__ __forceinline__ void store_tile(float* __restrict__ dst, int wave, in
             dst[(i * 32 + mfma32_row(r, lane)) * LDF + kpos(wave * 32 + (lane & 31))] = acc[i][r];
 }
 
-__global__ __launch_bounds__(512, 4) void codebook_encode_kernel(const EncArgs a) {
+template <int ER>
+__global__ __launch_bounds__(512, ER == 32 ? 4 : 2) void codebook_encode_kernel(const EncArgs a) {
+    constexpr int ERT = ER / 32;
+    constexpr int ENC_SMEM_FLOATS = 2 * ER * LDF + ER + 4 * ER + 8 * ER + ER + QV2X_ENC_LDS_PAD;
     // static LDS (67.8 KB; two workgroups per CU): no per-device hipFuncSetAttribute state to keep (include/qv2x.h:12)
     __shared__ __attribute__((aligned(16))) float smem[ENC_SMEM_FLOATS];
     float* bufA = smem;                       // x, then q, then next x
@@ -409,7 +416,10 @@ static int encode_launch(const qv2x_encode_desc* d, const int8_t* in, const floa
         a.lvl[l] = l < d->levels ? level_weights[l] : nullptr;
         if (l < d->levels && (!a.lvl[l] || ((uintptr_t)a.lvl[l] & 15))) return fail(QV2X_EALIGN, "qv2x_codebook_encode_f32: level %d weights null or unaligned", l);
     }
-    codebook_encode_kernel<<<(a.M + ER - 1) / ER, 512, 0, (hipStream_t)stream>>>(a);
+    static const int er_env = [] { const char* e = getenv("QV2X_ENC_ROWS"); return e ? atoi(e) : 0; }();      // dev knob: 32 | 64
+    const int er = er_env ? er_env : (a.M >= 98304 ? 64 : 32);        // from three V2X-Real frames on: the 64-row form (1 / 2 / 4 / 8 frames: 478 vs 518, 853 vs 856, 1580 vs 1499, 2991 vs 2906 us)
+    if (er == 64) codebook_encode_kernel<64><<<(a.M + 63) / 64, 512, 0, (hipStream_t)stream>>>(a);
+    else codebook_encode_kernel<32><<<(a.M + 31) / 32, 512, 0, (hipStream_t)stream>>>(a);
     return hip_check(hipGetLastError(), "qv2x_codebook_encode_f32 launch");
 }
 
