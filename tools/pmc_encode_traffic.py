@@ -9,15 +9,16 @@ def mean(d, counter):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if "codebook_encode_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
-                rows.append((int(r["Grid_Size"]), float(r["Counter_Value"])))
+                per_wg = 64 if "<64>" in r["Kernel_Name"] else 32          # rows per 512-thread workgroup (the kernel's template argument)
+                rows.append((int(r["Grid_Size"]) // 512 * per_wg, float(r["Counter_Value"]), int(r["Grid_Size"])))
     if not rows:
-        return None, 0, 0
-    g = max(r[0] for r in rows)
-    v = [c for (gs, c) in rows if gs == g]
-    return sum(v) / len(v), len(v), g
-f, nf, gf = mean(fetch_dir, "FETCH_SIZE")
-w, nw, gw = mean(write_dir, "WRITE_SIZE")
-res = {"kernel": "codebook_encode_kernel", "launches_averaged": [nf, nw], "grid_threads": gf, "agent_frames_per_launch": gf // 512 * 32 // 35200 if gf else None,
+        return None, 0, 0, 0
+    g = max(r[0] for r in rows)                                            # the launches with the most rows: the bench's own batch
+    v = [c for (nr, c, gs) in rows if nr == g]
+    return sum(v) / len(v), len(v), [gs for (nr, c, gs) in rows if nr == g][0], g
+f, nf, gf, rows_f = mean(fetch_dir, "FETCH_SIZE")
+w, nw, gw, rows_w = mean(write_dir, "WRITE_SIZE")
+res = {"kernel": "codebook_encode_kernel", "launches_averaged": [nf, nw], "grid_threads": gf, "agent_frames_per_launch": rows_f // 35200 if gf else None,
        "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
        "traffic_bytes_per_launch_raw": None if f is None or w is None else int((f + w) * 1024),
        "traffic_bytes_per_launch": None if f is None or w is None else int((2 * f + w) * 1024),
