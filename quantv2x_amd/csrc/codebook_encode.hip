@@ -148,12 +148,12 @@ __device__ __forceinline__ void store_tile(float* __restrict__ dst, int wave, in
             dst[(i * 32 + mfma32_row(r, lane)) * LDF + kpos(wave * 32 + (lane & 31))] = acc[i][r];
 }
 
+template <int ER> constexpr int enc_smem_floats() { return 2 * ER * LDF + ER + 4 * ER + 8 * ER + ER + QV2X_ENC_LDS_PAD; }
+
+// the whole encode of the ER rows [m0, m0 + ER) by one 8-wave workgroup; smem: enc_smem_floats<ER>() floats
 template <int ER>
-__global__ __launch_bounds__(512, ER == 32 ? 4 : 2) void codebook_encode_kernel(const EncArgs a) {
+__device__ __forceinline__ void encode_rows(const EncArgs& a, const int m0, float* __restrict__ smem) {
     constexpr int ERT = ER / 32;
-    constexpr int ENC_SMEM_FLOATS = 2 * ER * LDF + ER + 4 * ER + 8 * ER + ER + QV2X_ENC_LDS_PAD;
-    // static LDS (67.8 KB; two workgroups per CU): no per-device hipFuncSetAttribute state to keep (include/qv2x.h:12)
-    __shared__ __attribute__((aligned(16))) float smem[ENC_SMEM_FLOATS];
     float* bufA = smem;                       // x, then q, then next x
     float* bufB = smem + ER * LDF;            // z
     float* x2 = smem + 2 * ER * LDF;          // [64]
@@ -162,7 +162,6 @@ __global__ __launch_bounds__(512, ER == 32 ? 4 : 2) void codebook_encode_kernel(
     int* code_s = (int*)(pkey + 4 * ER);      // [ER]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * ER;
 #ifdef QV2X_ENC_TRACE
     const unsigned long long t_start = __builtin_readcyclecounter();
     unsigned hwid, xcc;
@@ -367,6 +366,22 @@ __global__ __launch_bounds__(512, ER == 32 ? 4 : 2) void codebook_encode_kernel(
 #endif
 }
 
+// static LDS (67.8 / 135.7 KB): no per-device hipFuncSetAttribute state to keep (include/qv2x.h:12)
+template <int ER>
+__global__ __launch_bounds__(512, ER == 32 ? 4 : 2) void codebook_encode_kernel(const EncArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[enc_smem_floats<ER>()];
+    encode_rows<ER>(a, blockIdx.x * ER, smem);
+}
+
+// Launches of one or two frames: whole rounds of 64-row workgroups (one per CU: n64 of them, a multiple of the CU count), then the rows
+// that would make a mostly empty round as 32-row workgroups -- which finish in 0.56 of a 64-row workgroup's time alone on their CU.
+// One V2X-Real frame: 512 x 64 + 76 x 32 rows, two full rounds and a short one (416 us) instead of 1100 x 32 on 512 slots (478 us).
+__global__ __launch_bounds__(512, 2) void codebook_encode_mixed_kernel(const EncArgs a, const int n64) {
+    __shared__ __attribute__((aligned(16))) float smem[enc_smem_floats<64>()];
+    if ((int)blockIdx.x < n64) encode_rows<64>(a, blockIdx.x * 64, smem);
+    else encode_rows<32>(a, n64 * 64 + ((int)blockIdx.x - n64) * 32, smem);
+}
+
 __global__ void codebook_c2_kernel(const float* __restrict__ cb, int kc, float* __restrict__ c2) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= kc) return;
@@ -417,8 +432,14 @@ static int encode_launch(const qv2x_encode_desc* d, const int8_t* in, const floa
         if (l < d->levels && (!a.lvl[l] || ((uintptr_t)a.lvl[l] & 15))) return fail(QV2X_EALIGN, "qv2x_codebook_encode_f32: level %d weights null or unaligned", l);
     }
     static const int er_env = [] { const char* e = getenv("QV2X_ENC_ROWS"); return e ? atoi(e) : 0; }();      // dev knob: 32 | 64
-    const int er = er_env ? er_env : (a.M >= 98304 ? 64 : 32);        // from three V2X-Real frames on: the 64-row form (1 / 2 / 4 / 8 frames: 478 vs 518, 853 vs 856, 1580 vs 1499, 2991 vs 2906 us)
+    // from three V2X-Real frames on: the 64-row form (1 / 2 / 4 / 8 frames: 478 vs 518, 853 vs 856, 1580 vs 1499, 2991 vs 2906 us);
+    // below: the mixed form when it has at least one full round of 64-row workgroups
+    int cus = 256, dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    const int n64 = (a.M / 64) / cus * cus;
+    const int er = er_env ? er_env : (a.M >= 98304 ? 64 : (n64 > 0 ? 96 : 32));
     if (er == 64) codebook_encode_kernel<64><<<(a.M + 63) / 64, 512, 0, (hipStream_t)stream>>>(a);
+    else if (er == 96 && n64 > 0) codebook_encode_mixed_kernel<<<n64 + (a.M - n64 * 64 + 31) / 32, 512, 0, (hipStream_t)stream>>>(a, n64);
     else codebook_encode_kernel<32><<<(a.M + 31) / 32, 512, 0, (hipStream_t)stream>>>(a);
     return hip_check(hipGetLastError(), "qv2x_codebook_encode_f32 launch");
 }
