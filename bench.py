@@ -510,7 +510,13 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     sharded_mode = world > 1 or args.force_sharded
+    saved_stdout = None
     if sharded_mode:
+        # RCCL writes a version banner to the C stdout of every rank: until the line is ready, fd 1 is stderr, so that the JSON line is the
+        # ONLY thing this job puts on stdout
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
@@ -661,10 +667,13 @@ def main():
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()     # RCCL prints its version banner around here: keep the JSON line last
+    import ctypes
+    ctypes.CDLL(None).fflush(None)       # RCCL's version banner sits in the C stdio buffer: push it out (to stderr, see above) first
+    sys.stdout.flush()
+    if saved_stdout is not None:
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     if line is not None:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)   # RCCL's version banner sits in the C stdio buffer: push it out before the JSON line
-        sys.stdout.flush()
         print(json.dumps(line), flush=True)
 
 
