@@ -35,12 +35,38 @@ sys.path.insert(0, ROOT)
 INT8_MFMA_PEAK_TOPS = 5000.0
 F32_MFMA_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
-SHAPE = "v2xreal"
+SHAPE = "v2xreal"                          # N = 1 default; main() re-binds SHAPE / N_POINTS from workload_for(world)
 N_POINTS = 60000
-ENCODE_GFLOP_PER_AGENT_FRAME = 43.84       # 21.92 GMAC fp32, reference op order
+ENCODE_GFLOP_PER_AGENT_FRAME = 43.84       # 21.92 GMAC fp32, reference op order (V2X-Real: 35 200 cells)
+ENCODE_GMAC_PER_CELL = 21.92e9 / 35200     # the same figure per feature-map cell (OPV2V: 65 536 cells -> 40.8 GMAC)
 
 
-def build_engine(n_threads):
+def workload_for(world):
+    """BASELINE.json ``configs`` -> the concrete synthetic workload of an N-GPU run:
+    N = 1 configs[1]; N = 2 configs[2] (V2X-Real, line layout); N = 3..4 configs[3] (V2X-Real VC, ring layout); both with
+    max_cav 5 and the multi-class (mc) heads of lidar_attfuse_stage3.yaml:12.  N >= 5 configs[4]: the OPV2V(-H) 512 x 512 grid
+    (opv2v/LiDAROnly/lidar_attfuse.yaml:17), max_cav raised to 8, single-class heads, sweeps dense enough for >= 40k pillars."""
+    if world == 1:
+        return {"index": 1, "shape": "v2xreal", "layout": "line", "n_points": 60000, "multiclass": True, "max_cav": 5,
+                "workload": "Single-agent int8 PointPillar + BEV backbone on 1xMI355X, synthetic V2X-Real point cloud (~60k pts, 0.4 m voxels)",
+                "grid": "704x200x1 voxels -> 256x100x352 feature map"}
+    if world == 2:
+        return {"index": 2, "shape": "v2xreal", "layout": "line", "n_points": 60000, "multiclass": True, "max_cav": 5,
+                "workload": "2-agent intermediate fusion with codebook-compressed BEV features, 2xMI355X, RCCL all-gather over xGMI "
+                            "(V2X-Real shape, line layout, max_cav 5, mc heads)",
+                "grid": "704x200x1 voxels -> 256x100x352 feature map"}
+    if world <= 4:
+        return {"index": 3, "shape": "v2xreal", "layout": "ring", "n_points": 60000, "multiclass": True, "max_cav": 5,
+                "workload": f"{world}-agent V2X-Real VC scenario, int8 attentive fusion + spatial transform, {world}xMI355X "
+                            "(ring layout, max_cav 5, mc heads)",
+                "grid": "704x200x1 voxels -> 256x100x352 feature map"}
+    return {"index": 4, "shape": "opv2v", "layout": "ring", "n_points": 70000, "multiclass": False, "max_cav": 8,
+            "workload": f"{world}-agent OPV2V-H dense scene, full int8 pipeline with codebook compressor, {world}xMI355X "
+                        "(512x512 grid, max_cav 8, single-class heads, >= 40k pillars per agent)",
+            "grid": "512x512x1 voxels -> 256x256x256 feature map"}
+
+
+def build_engine(n_threads, multiclass=True):
     import copy
     import torch
     from quantv2x_amd import synth
@@ -50,7 +76,7 @@ def build_engine(n_threads):
     torch.set_num_threads(n_threads)
     # the reference's flow: create_model -> load weights (seeded synthetic: no checkpoint exists here) -> QuantModel
     # -> weight quantizers -> one min-max observer pass (torch, on the host) -> freeze -> deploy on the HIP path
-    model = train_utils.create_model(copy.deepcopy(synth.make_hypes(SHAPE))).eval()
+    model = train_utils.create_model(copy.deepcopy(synth.make_hypes(SHAPE, multiclass=multiclass))).eval()
     synth.load_state_dict_numpy(model, synth.make_state_dict(model.state_dict(), seed=1))
     fp_model = copy.deepcopy(model)
     calib = synth.scene_to_torch(synth.make_scene(SHAPE, n_agents=1, seed=3, n_points=N_POINTS))
@@ -59,15 +85,15 @@ def build_engine(n_threads):
     return state, deploy(state=state), fp_model, qt
 
 
-def frame_batch(world, rank, frames, device):
+def frame_batch(world, rank, frames, device, layout=None, max_cav=None):
     """`frames` scenes of `world` agents (different sweeps, same poses).  Returns the numpy scene 0, the model input of a
     single-GPU batch (every agent of every frame, batch index = frame * world + agent), this rank's input (its own agent of every
     frame, batch index = frame) and the agents' world poses."""
     import numpy as np
     import torch
     from quantv2x_amd import synth
-    layout = "ring" if world > 2 else "line"
-    scenes = [synth.make_scene(SHAPE, n_agents=world, seed=3 + f, n_points=N_POINTS, layout=layout) for f in range(frames)]
+    layout = layout or ("ring" if world > 2 else "line")
+    scenes = [synth.make_scene(SHAPE, n_agents=world, seed=3 + f, n_points=N_POINTS, layout=layout, max_cav=max_cav) for f in range(frames)]
     full_parts, mine_parts = [], []
     for f, sc in enumerate(scenes):
         co = sc["inputs_m1"]["voxel_coords"]
@@ -136,8 +162,9 @@ def rooflines(eng, full, frames, iters):
           sum(2.0 * p[7] for p in de), "TFLOP/s", F32_MFMA_PEAK_TFLOPS, 1, f"{sum(2.0 * p[7] for p in de) / 1e9:.2f} GFLOP: 3 deblocks, one launch")
     stage("shrinker_convs_i8", lambda: eng.run_plan(n, only=lambda k, l: k == "conv" and l.name.startswith("shrinker")), "mfma-i8",
           sum(2.0 * p[7] for p in sh), "TOP/s", INT8_MFMA_PEAK_TOPS, len(sh), f"{sum(2.0 * p[7] for p in sh) / 1e9:.1f} GOP: 3x3 384->256 + 3x3 256->256")
-    stage("codebook_encode_f32", lambda: eng.encode_codes(n), "mfma-f32", ENCODE_GFLOP_PER_AGENT_FRAME * 1e9 * n, "TFLOP/s",
-          F32_MFMA_PEAK_TFLOPS, 1, f"{n} x {ENCODE_GFLOP_PER_AGENT_FRAME} GFLOP (11 chained 256-wide GEMMs per cell, reference op order)")
+    enc_gflop = round(2.0 * ENCODE_GMAC_PER_CELL * hw / 1e9, 2)          # 43.84 at V2X-Real (35 200 cells), 81.61 at OPV2V (65 536)
+    stage("codebook_encode_f32", lambda: eng.encode_codes(n), "mfma-f32", enc_gflop * 1e9 * n, "TFLOP/s",
+          F32_MFMA_PEAK_TFLOPS, 1, f"{n} x {enc_gflop} GFLOP (11 chained 256-wide GEMMs per cell, reference op order)")
     codes = eng._workspace(n)["codes"]
     pw = full["pairwise_t_matrix"].contiguous()
     fused = torch.empty((n, hw, 256), dtype=torch.float32, device=eng.dev)
@@ -146,7 +173,7 @@ def rooflines(eng, full, frames, iters):
     def fuse_all():                                  # as DeployedModel.forward does: every scene of the batch in one launch
         eng.fuse_scenes(C.c_void_p(codes.data_ptr()), hw, n * hw, None, pw, [f * hw for f in range(n)], [1] * n, fused)
     stage("decode_warp_attfuse", fuse_all, "hbm", n * (3 * hw + 3 * 128 * 1024 + hw * 1024), "GB/s", HBM_PEAK_GBS, 1,
-          f"{n} x (105.6 KB codes + 384 KiB LUT read, 36.0 MB fp32 fused map written), one launch for the batch's scenes")
+          f"{n} x ({3 * hw / 1e3:.1f} KB codes + 384 KiB LUT read, {hw * 1024 / 1e6:.1f} MB fp32 fused map written), one launch for the batch's scenes")
     heads_macs = hw * 256 * (eng.heads.cout + (eng.heads_single.cout if eng.heads_single is not None else 0))
     stage("heads_f32", lambda: eng._heads_pair(fused, n, codes, n), "mfma-f32", n * 2.0 * heads_macs, "TFLOP/s", F32_MFMA_PEAK_TFLOPS, 2 if getattr(eng, "single_by_tables", False) else 1,
           f"{n} x {heads_macs / 1e9:.3f} GMAC: the {eng.heads.cout}-channel heads on the fused map + the {eng.heads_single.cout if eng.heads_single is not None else 0}-channel "
@@ -154,19 +181,21 @@ def rooflines(eng, full, frames, iters):
           f"multiplies 96 padded columns)")
     enc = stages["codebook_encode_f32"]
     traffic, note = None, "no PMC profile committed for this round yet"
-    pmc = os.path.join(ROOT, "profiles", "r03_pmc_encode.json")
-    if os.path.exists(pmc):
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_encode.json")))     # the latest round's PMC passes
+    pmc = found[-1] if found else ""
+    if pmc:
         with open(pmc) as f:
             j = json.load(f)
         if j.get("agent_frames_per_launch") == n:        # (a stored figure only describes launches of the batch size it was taken at)
             traffic, note = j.get("traffic_bytes_per_launch"), j.get("note", "")
         else:
-            note = f"profiles/r03_pmc_encode.json was taken at {j.get('agent_frames_per_launch')} agent-frames per launch, this run has {n}"
+            note = f"profiles/{os.path.basename(pmc)} was taken at {j.get('agent_frames_per_launch')} agent-frames per launch, this run has {n}"
     roof = {"bound": "mfma", "achieved": enc["achieved"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": enc["frac"],
             "traffic": traffic, "traffic_note": "STORED figure, not measured by this run: " + note,
             "kernel": "codebook_encode_kernel (f32 MFMA v_mfma_f32_32x32x2_f32; the dominant kernel by time)", "launches_per_batch": 1,
             "avg_launch_us": enc["us_per_batch"], "agent_frames_per_launch": n,
-            "algorithmic_gflop_per_launch": round(ENCODE_GFLOP_PER_AGENT_FRAME * n, 2),
+            "algorithmic_gflop_per_launch": round(enc_gflop * n, 2),
             "share_of_batch_time": None}
     total = sum(s["us_per_batch"] for s in stages.values())
     roof["share_of_batch_time"] = round(enc["us_per_batch"] / total, 3)
@@ -393,59 +422,101 @@ def second_encoder_line(device):
                     "dense_window_gmac counts every window offset of every active output, occupied or not"}
 
 
-def cpu_baseline(state, sc_np, budget_s=12.0, max_frames=6):
-    """The CPU oracle (checker) on the same workload, on the host cores of this box."""
+def cpu_baseline(state, scenes_np, gpu_check=None, budget_s=20.0, max_frames=12):
+    """The CPU oracle (checker) on the same workload, on the host cores of this box: the frames of the bench's own batch, one at a time.
+    ``gpu_check(f, oracle_taps) -> (index_mismatches, u8_mismatches)`` compares what the oracle just computed for frame f with what the
+    timed HIP graphs left in the workspace (parity gates with every timing) -- the oracle is the checker here, never
+    the thing shipped; the comparison is outside the timed interval."""
     from oracle.spec import Oracle
     cores = os.cpu_count() or 1
     orc = Oracle(state)
-    orc.forward(sc_np)                      # warm-up (also builds the shared object if needed)
-    t0, frames = time.time(), 0
-    while frames < max_frames and (time.time() - t0) < budget_s:
-        orc.forward(sc_np)
+    orc.forward(scenes_np[0])               # warm-up (also builds the shared object if needed)
+    spent, frames, parity = 0.0, 0, {"index_mismatches": 0, "u8_mismatches": 0, "frames_checked": 0}
+    while frames < min(max_frames, len(scenes_np)) and spent < budget_s:
+        taps = {}
+        t0 = time.time()
+        orc.forward(scenes_np[frames], taps)
+        spent += time.time() - t0
+        if gpu_check is not None:
+            im, um = gpu_check(frames, taps)
+            parity["index_mismatches"] += im
+            parity["u8_mismatches"] += um
+            parity["frames_checked"] += 1
         frames += 1
-    dt = time.time() - t0
-    return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{frames} full single-agent V2X-Real frames (whole hot path) through oracle/ in {dt:.1f} s, OpenMP on {cores} threads"}
+    out = {"value": round(frames / spent, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": f"{frames} full single-agent V2X-Real frames of the bench's own batch (whole hot path) through oracle/ in {spent:.1f} s, "
+                     f"OpenMP on {cores} threads"}
+    return out, (parity if gpu_check is not None else None)
 
 
-def cpu_baseline_torch(fp_model, qt, sc_np, cores, budget_s=10.0):
-    """SURVEY.md §8(d) / BASELINE.md §4: the torch restatement of the reference (the plugin mirror: same modules, same torch
-    ops) on the host cores -- fp32, and W8A8 fake-quant (quantize -> dequantize in fp32 around fp32 F.conv2d, the reference's
-    only execution mode).  1 warm-up + up to 3 timed frames each."""
+def cpu_baseline_torch(fp_model, qt, sc_np, cores, warmup=3, timed=10):
+    """SURVEY.md §8(d) / BASELINE.md §4 protocol: the torch restatement of the reference (the plugin mirror: same modules, same torch
+    ops) on the host cores -- fp32, and W8A8 fake-quant (quantize -> dequantize in fp32 around fp32 F.conv2d, the reference's only
+    execution mode; quant_layer.py:391-410).  The thread count is swept over {32, 64, all host cores} with one fp32 frame each
+    (a count is skipped once the sweep has started to get slower: torch's CPU convolutions lose to oversubscription, 45 s per fp32
+    frame on 256 threads measured in round 3), then ``warmup`` + ``timed`` frames per mode at the best count, with the per-stage split
+    of BASELINE.md §2 (encoder / backbone / shrinker / codebook / fusion / heads) from forward hooks on the mirror's modules
+    (timing protocol of tools/profiler/params_calc.py:48-79)."""
     import torch
     from quantv2x_amd import synth
-    # torch's CPU convolutions lose to thread oversubscription on a 256-thread host (45 s per fp32 frame with 256 threads,
-    # measured): 32 threads is where the per-frame time bottoms out, so `cores` here is the thread count actually used
-    threads = min(cores, 32)
-    torch.set_num_threads(threads)
     dd = synth.scene_to_torch(sc_np)
-    out = {"cores": threads, "host_cores": cores, "unit": "frames/s", "kind": "torch restatement of the reference (plugin mirror)"}
-    for name, m in (("fp32", fp_model), ("w8a8_fake_quant", qt)):
+    out = {"host_cores": cores, "unit": "frames/s", "kind": "torch restatement of the reference (plugin mirror)", "warmup_frames": warmup,
+           "timed_frames": timed}
+
+    def run(m):
         with torch.no_grad():
             torch.manual_seed(0)
             m(dd)
-            t0, n = time.time(), 0
-            while n < 3 and (time.time() - t0) < budget_s:
-                m(dd)
-                n += 1
+
+    sweep, prev = {}, None
+    for th in sorted({min(32, cores), min(64, cores), cores}):
+        if prev is not None and len(sweep) >= 2 and prev > 1.15 * min(sweep.values()):
+            sweep[th] = None                                  # already getting slower: not worth a 45-s frame
+            continue
+        torch.set_num_threads(th)
+        run(fp_model)
+        t0 = time.time()
+        run(fp_model)
+        prev = sweep[th] = time.time() - t0
+    best = min((t, th) for th, t in sweep.items() if t is not None)[1]
+    out["thread_sweep_fp32_s_per_frame"] = {str(k): (None if v is None else round(v, 3)) for k, v in sweep.items()}
+    out["cores"] = best
+    torch.set_num_threads(best)
+
+    stage_of = (("encoder_m1", "encoder"), ("backbone_m1", "backbone"), ("shrinker_m1", "shrinker"), ("codebook", "codebook"),
+                ("fusion_net", "fusion"), ("cls_head", "heads"), ("reg_head", "heads"), ("dir_head", "heads"),
+                ("cls_head_single", "heads"), ("reg_head_single", "heads"), ("dir_head_single", "heads"))
+    for name, m in (("fp32", fp_model), ("w8a8_fake_quant", qt)):
+        inner = m.model if hasattr(m, "model") else m
+        acc, t_in, hooks = {}, {}, []
+        for attr, stage in stage_of:
+            mod = getattr(inner, attr, None)
+            if mod is None:
+                continue
+            hooks.append(mod.register_forward_pre_hook(lambda _m, _i, a=attr: t_in.__setitem__(a, time.perf_counter())))
+            hooks.append(mod.register_forward_hook(lambda _m, _i, _o, a=attr, st=stage: acc.__setitem__(st, acc.get(st, 0.0) + time.perf_counter() - t_in[a])))
+        for _ in range(warmup):
+            run(m)
+        acc.clear()
+        t0 = time.time()
+        for _ in range(timed):
+            run(m)
         dt = time.time() - t0
-        out[name] = round(n / dt, 4)
-        out[name + "_sample"] = f"{n} single-agent V2X-Real frames in {dt:.1f} s"
+        for h in hooks:
+            h.remove()
+        out[name] = round(timed / dt, 4)
+        out[name + "_sample"] = f"{timed} single-agent V2X-Real frames in {dt:.1f} s after {warmup} warm-up frames, {best} threads"
+        out[name + "_ms_per_stage"] = {k: round(v / timed * 1e3, 1) for k, v in acc.items()}
     return out
-
-
-def _free_port():
-    import socket
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        return so.getsockname()[1]
 
 
 def self_launch(n, argv, check_devices=True):
     """``python bench.py --gpus N`` without a launcher: start ``python -m torch.distributed.run --nproc-per-node N bench.py ...`` as a
     FRESH CHILD (this process has not touched a GPU: counting devices does not initialise one, and a process that did must never
     be replaced by exec), pass its output through (rank 0's JSON line is the last line of stdout) and return its exit code.
-    Reference analogue of the launch: opencood/tools/train_ddp.py:46-106, tools/multi_gpu_utils.py:16-38 (env:// rendezvous)."""
+    torchrun picks the rendezvous port itself (--standalone: a c10d store on a free port of 127.0.0.1 -- no bind / close / re-bind race
+    with another job on the node).  Reference analogue of the launch: opencood/tools/train_ddp.py:46-106,
+    tools/multi_gpu_utils.py:16-38 (env:// rendezvous)."""
     import subprocess
     if check_devices:
         import torch
@@ -454,16 +525,18 @@ def self_launch(n, argv, check_devices=True):
             print(f"bench.py: --gpus {n} but this node has {have} GPU(s); not printing a line for a job that did not run", file=sys.stderr)
             return 2
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(n),
+           os.path.abspath(__file__)] + list(argv)
     print("[bench] launching: " + " ".join(cmd), file=sys.stderr, flush=True)
     return subprocess.call(cmd, env=env)
 
 
 def dry_run_ranks(rank, world, args):
-    """The launcher path without GPUs: gloo group, one all-reduce, rank 0 prints a line carrying the world size."""
+    """The launcher path without GPUs: gloo group, one all-reduce, rank 0 prints a line carrying the world size and the workload
+    (BASELINE config, shape, heads, max_cav) a real run at this world size would execute."""
     import torch
     import torch.distributed as dist
+    from quantv2x_amd import synth
     dist.init_process_group("gloo")
     t = torch.tensor([float(rank + 1)])
     dist.all_reduce(t)
@@ -471,12 +544,20 @@ def dry_run_ranks(rank, world, args):
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
+        wl = workload_for(world)
+        lidar, vox, _, _ = synth.SHAPES[wl["shape"]]
+        gw, gh, _ = synth.grid_size(lidar, vox)
         print(json.dumps({"metric": "launcher dry run (no GPU work)", "n_gpus": world, "dry_run": True, "ranks_joined": ok,
-                          "steps": args.steps, "warmup": args.warmup}), flush=True)
+                          "steps": args.steps, "warmup": args.warmup, "ego_only": bool(args.ego_only),
+                          "config": {"workload": wl["workload"], "baseline_config_index": wl["index"], "shape": wl["shape"],
+                                     "voxel_grid": [gw, gh], "feature_map": [gh // 2, gw // 2], "layout": wl["layout"], "max_cav": wl["max_cav"],
+                                     "multiclass_heads": wl["multiclass"], "points_per_agent": wl["n_points"],
+                                     "agents_per_frame": world, "batch_per_rank": args.batch}}), flush=True)
     return 0 if ok else 1
 
 
 def main():
+    global SHAPE, N_POINTS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -486,13 +567,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra fields (fp32 path, multi-agent, Pyramid, SECOND, collapsed encode, "
                     "points -> boxes): the line's contract fields, roofline and roofline_stages only (profiling passes)")
-    ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path (two HIP graphs around the collective) with one rank")
+    ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path (HIP graphs around the collective) with one rank")
     ap.add_argument("--link", default="torch", choices=["torch", "rccl"], help="N>1 collective: torch.distributed or qv2x_allgather_codes")
+    ap.add_argument("--graph-link", action="store_true", help="with --link rccl: the all-gather is captured INSIDE the step's one HIP graph "
+                    "(pre + qv2x_allgather_codes + post = one replay per step) instead of sitting between two graphs")
+    ap.add_argument("--ego-only", action="store_true", help="N>1: only rank 0 fuses (SURVEY 8(e)(i), the parity configuration: its output equals "
+                    "the single-process model's); `value` then counts rank 0's frames only.  Without the flag every rank is the ego of its own "
+                    "view (8(e)(ii)) and the ego-only figure is reported beside it as `ego_only`")
     ap.add_argument("--dry-run-ranks", action="store_true",
                     help="launcher check (CPU, gloo): every rank joins the group, rank 0 prints a line with n_gpus = world size; no GPU work")
     args = ap.parse_args()
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.dry_run_ranks):
         # a bare `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU) and relay rank 0's line
         raise SystemExit(self_launch(args.gpus, sys.argv[1:], check_devices=not args.dry_run_ranks))
 
@@ -507,6 +593,10 @@ def main():
         raise SystemExit(dry_run_ranks(rank, world, args))
     if torch.cuda.device_count() < world:
         raise SystemExit(f"--gpus {args.gpus}: this node has {torch.cuda.device_count()} GPU(s)")
+    if args.graph_link and args.link != "rccl":
+        raise SystemExit("--graph-link needs --link rccl (the C ABI's own communicator: qv2x_allgather_codes is captured into the step's graph)")
+    wl = workload_for(world)
+    SHAPE, N_POINTS = wl["shape"], wl["n_points"]
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     sharded_mode = world > 1 or args.force_sharded
@@ -525,8 +615,9 @@ def main():
 
     cores = os.cpu_count() or 8
     B = max(1, args.batch)
-    state, eng, fp_model, qt = build_engine(max(1, min(32, cores // max(world, 1))))
-    sc_np, full, mine, poses = frame_batch(world, rank, B, device)
+    state, eng, fp_model, qt = build_engine(max(1, min(32, cores // max(world, 1))), multiclass=wl["multiclass"])
+    sc_np, full, mine, poses = frame_batch(world, rank, B, device, layout=wl["layout"], max_cav=wl["max_cav"])
+    ego_line = None
 
     if not sharded_mode:
         from quantv2x_amd.engine import deploy
@@ -555,23 +646,30 @@ def main():
         F = max(1, args.inflight)
         engines = [eng] + [deploy(state=state) for _ in range(F - 1)]
         streams = [torch.cuda.Stream() for _ in range(F)]
-        shardeds = [AgentShardedModel(e, frames=B, link=args.link, max_cav=5) for e in engines]
         pose = torch.from_numpy(poses[rank]).to(device)
-        for sh, st in zip(shardeds, streams):                         # capture (and the lazy one-off work) up front, slot by slot
-            with torch.cuda.stream(st):
-                sh.forward(mine, pose)
-            torch.cuda.synchronize()
-        it = [0]
 
-        def step():
-            i = it[0] % F
-            it[0] += 1
-            with torch.cuda.stream(streams[i]):
-                shardeds[i].forward(mine, pose)
-        launch = (f"per rank: hipGraph (a1-a6, {B} frames) -> all-gather of code planes + poses "
-                  f"({'torch.distributed nccl = RCCL' if args.link == 'torch' else 'qv2x_allgather_codes (RCCL)'}) -> hipGraph (a7-a11); "
-                  f"{F} batches in flight on {F} streams")
-        frames_per_step = B * world
+        def make_step(ego_only):
+            shardeds = [AgentShardedModel(e, frames=B, link=args.link, max_cav=wl["max_cav"], ego_only=ego_only, graph_link=args.graph_link)
+                        for e in engines]
+            for sh, st in zip(shardeds, streams):                     # capture (and the lazy one-off work) up front, slot by slot
+                with torch.cuda.stream(st):
+                    sh.forward(mine, pose)
+                torch.cuda.synchronize()
+            k = [0]
+
+            def step():
+                i = k[0] % F
+                k[0] += 1
+                with torch.cuda.stream(streams[i]):
+                    shardeds[i].forward(mine, pose)
+            return step, shardeds
+        step, shardeds = make_step(args.ego_only)
+        link_txt = "torch.distributed nccl = RCCL" if args.link == "torch" else "qv2x_allgather_codes (RCCL)"
+        launch = (f"per rank: ONE hipGraph per step (a1-a6, {B} frames -> all-gather of code planes + poses [{link_txt}, captured] -> a7-a11)"
+                  if args.graph_link else
+                  f"per rank: hipGraph (a1-a6, {B} frames) -> all-gather of code planes + poses ({link_txt}) -> hipGraph (a7-a11)") + \
+                 f"; {F} batches in flight on {F} streams"
+        frames_per_step = B if args.ego_only else B * world
         print(f"[bench] rank {rank}/{world} on cuda:{local}: RCCL world size {dist.get_world_size()}", file=sys.stderr, flush=True)
 
     def barrier():
@@ -579,18 +677,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(step_fn, warmup, steps):
+        for _ in range(warmup):
+            step_fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    dt = timed(step, args.warmup, args.steps)
+    if sharded_mode and not args.ego_only:
+        # the parity configuration of SURVEY 8(e)(i) beside the headline: only rank 0 fuses -- its output is the single-process model's
+        del shardeds
+        step_e, shardeds = make_step(True)
+        ke = max(5, args.steps // 4)
+        dte = timed(step_e, max(2, args.warmup // 4), ke)
+        ego_line = {"value": round(B * ke / dte, 2), "unit": "frames/s", "steps": ke, "ms_per_step": round(dte / ke * 1e3, 4),
+                    "frames_per_step": B, "note": "ego_only: every rank encodes and joins the all-gather, rank 0 alone runs a7-a11 (the reference's "
+                    "single-ego output, SURVEY 8(e)(i)); `value` above counts every rank's own ego view (8(e)(ii))"}
 
     # p50 latency of ONE frame run alone (device-synchronised), outside the timed region
     lat = []
@@ -598,8 +709,8 @@ def main():
         _, one, _, _ = frame_batch(1, 0, 1, device)
         solo = eng.capture(one)
     else:
-        _, _, mine1, _ = frame_batch(world, rank, 1, device)
-        sh1 = AgentShardedModel(eng, frames=1, link=args.link, max_cav=5)
+        _, _, mine1, _ = frame_batch(world, rank, 1, device, layout=wl["layout"], max_cav=wl["max_cav"])
+        sh1 = AgentShardedModel(eng, frames=1, link=args.link, max_cav=wl["max_cav"], ego_only=args.ego_only, graph_link=args.graph_link)
         solo = lambda: sh1.forward(mine1, pose)
     for _ in range(10):
         solo()
@@ -615,27 +726,33 @@ def main():
     for _ in range(50):
         solo()
     barrier()
-    one_at_a_time = 50 * (world if sharded_mode else 1) / (time.perf_counter() - ta)
+    one_at_a_time = 50 * (world if (sharded_mode and not args.ego_only) else 1) / (time.perf_counter() - ta)
 
     if rank == 0:
+        hw = eng.fh * eng.fw
         line = {
             "metric": "frames/sec/node (N-agent int8 BEV fusion)", "value": round(frames_per_step * args.steps / dt, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i8", "data": "synthetic",
-            "config": {"workload": "Single-agent int8 PointPillar + BEV backbone on 1xMI355X, synthetic V2X-Real point cloud "
-                                   "(~60k pts, 0.4 m voxels)" if world == 1 else
-                                   f"{world}-agent intermediate fusion with codebook-compressed BEV features, one agent per GPU",
+            "config": {"workload": wl["workload"], "baseline_config_index": wl["index"],
                        "stages": "pfn+scatter, 19 conv + 3 deconv backbone, shrinker, 3-level codebook encode, decode+warp+attention, heads (+ *_single heads)",
-                       "grid": "704x200x1 voxels -> 256x100x352 feature map", "agents_per_frame": world,
+                       "grid": wl["grid"], "agents_per_frame": world, "max_cav": wl["max_cav"], "layout": wl["layout"],
+                       "heads": "multi-class (mc, 72 channels)" if wl["multiclass"] else "single-class (20 channels)",
+                       "points_per_agent": N_POINTS,
                        "frames_per_step": frames_per_step, "batch_per_rank": B, "batches_in_flight": F,
                        "pillars_per_step_rank0": int((mine if sharded_mode else full["inputs_m1"])["voxel_features"].shape[0]),
-                       "frame_definition": "one ego-view fused detection frame; with N GPUs every rank is the ego of its own view",
+                       "frame_definition": ("one ego-view fused detection frame; ego_only: rank 0 is the ego, the other ranks only encode and send" if args.ego_only
+                                            else "one ego-view fused detection frame; with N GPUs every rank is the ego of its own view"),
+                       "ego_only": bool(args.ego_only),
                        "launch": launch, "quantization": "W8A8 min-max PTQ (reference QuantModel recipe), random He-init weights",
+                       "wire_bytes_per_agent_frame": 3 * hw,
                        "rccl_world_size": dist.get_world_size() if dist.is_initialized() else 1},
             "latency_ms_p50": round(lat[len(lat) // 2], 4), "latency_ms_p95": round(lat[int(len(lat) * 0.95) - 1], 4),
             "latency_note": "one frame run alone (batch 1, nothing else in flight), host-timed around launch + device sync",
             "value_one_frame_at_a_time": round(one_at_a_time, 2),
         }
+        if ego_line is not None:
+            line["ego_only"] = ego_line
         roof, stages = rooflines(eng, full if not sharded_mode else frame_batch(1, 0, B, device)[1], B, iters=max(10, args.steps // 5))
         line["roofline"], line["roofline_stages"] = roof, stages
         if world == 1 and not sharded_mode and not args.no_extras:
@@ -659,9 +776,33 @@ def main():
             line["second_encoder"] = second_encoder_line(device)
             line["collapsed_encode_opt_in"] = collapsed_encode_line(state, full, B, F, args.steps, device)
             line["points_to_boxes"] = points_to_boxes_line(state, device)
-        if not args.no_cpu_baseline and world == 1:       # reported on rank 0 at N = 1 only
-            line["cpu_baseline"] = cpu_baseline(state, frame_batch(1, 0, 1, "cpu")[0])
-            line["cpu_baseline_torch"] = cpu_baseline_torch(fp_model, qt, frame_batch(1, 0, 1, "cpu")[0], cores)
+        if not args.no_cpu_baseline and world == 1 and not sharded_mode:       # reported on rank 0 at N = 1 only
+            # the CPU checker on frames of THIS batch; each frame it finishes is compared with what the timed graphs computed (both
+            # engines' workspaces hold their last replay: same inputs, so the same bytes) -- the parity gate of SURVEY 8(d)
+            from quantv2x_amd import synth
+            for i in range(F):                                                  # one more replay each: the extras above reused engine 0's workspace
+                with torch.cuda.stream(streams[i]):
+                    reps[i]()
+            torch.cuda.synchronize()
+            scenes_np = [synth.make_scene(SHAPE, n_agents=1, seed=3 + f, n_points=N_POINTS, layout=wl["layout"], max_cav=wl["max_cav"]) for f in range(min(B, 12))]
+            wss = [e._workspace(B) for e in engines]
+
+            def gpu_check(f, taps):
+                import numpy as np
+                want_codes = taps["codes"].reshape(taps["codes"].shape[0], -1)                       # [levels, H*W] of one agent
+                want_u8 = taps["shrinker_m1.layers.0.double_conv.1"][0]                             # [H, W, 256] uint8
+                im = um = 0
+                for ws in wss:
+                    im += int((ws["codes"][:, f].cpu().numpy() != want_codes).sum())
+                    got = (ws["s1"][f, 1:-1, 1:-1, :].to(torch.int16) + 128).to(torch.uint8).cpu().numpy()
+                    um += int((got != want_u8).sum())
+                return im, um
+            line["cpu_baseline"], parity = cpu_baseline(state, scenes_np, gpu_check)
+            parity.update({"engines_checked": F, "indices_per_frame": 3 * hw, "u8_per_frame": hw * 256,
+                           "what": "codebook indices (3 levels) and the shrinker's uint8 output map of the batch's first frames, as left in the workspaces of "
+                                   "the timed HIP graphs, against oracle/ on the same frames; must be 0 / 0"})
+            line["parity"] = parity
+            line["cpu_baseline_torch"] = cpu_baseline_torch(fp_model, qt, scenes_np[0], cores)
     else:
         line = None
     if dist.is_initialized():

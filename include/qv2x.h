@@ -114,17 +114,6 @@ int qv2x_conv3x3_i8_pack_wide(const qv2x_conv_desc* desc /* host */, const int8_
 int qv2x_conv3x3_i8_wide(const qv2x_conv_desc* desc /* host */, const int8_t* in, const int8_t* w_wide,
                          const float* scale, const int32_t* corr, const int32_t* aw, const float* bias,
                          int8_t* out, void* stream);
-/* The same call with the kernel form named (qv2x_conv3x3_i8_wide = QV2X_WIDE_AUTO, chosen by launch size).  QV2X_WIDE_PINGPONG: one
- * 8-wave workgroup per CU holding 2 (128-channel) or 4 (64-channel) independent groups; the two waves of a SIMD are kept half an item
- * apart by workgroup barriers, so one multiplies while its partner requantizes and stores.  One input group, cout 64 | 128 | 256 k run
- * as 128-channel blocks where the launch is large enough.  Same bits in every form (the parity tests run all three). */
-#define QV2X_WIDE_AUTO 0
-#define QV2X_WIDE_PLAIN 1
-#define QV2X_WIDE_PINGPONG 2
-#define QV2X_WIDE_PIPE 3      /* 4 x 32 patches, two accumulator sets per wave: item i is requantized inside the K loop of item i + 1 (one input group of 64 | 128 | 256 channels) */
-int qv2x_conv3x3_i8_wide_form(const qv2x_conv_desc* desc /* host */, const int8_t* in, const int8_t* w_wide,
-                              const float* scale, const int32_t* corr, const int32_t* aw, const float* bias,
-                              int8_t* out, int form, void* stream);
 
 /* a3, one backbone level in ONE launch.  A chain of `depth` (1..4) such convolutions with 64 input and 64 output channels
  * each (level 0 of BaseBEVBackbone, base_bev_backbone.py:96-119 / quant_block.py:243-303): layer 0 has stride `stride0`

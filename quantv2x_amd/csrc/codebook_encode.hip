@@ -431,13 +431,22 @@ static int encode_launch(const qv2x_encode_desc* d, const int8_t* in, const floa
         a.lvl[l] = l < d->levels ? level_weights[l] : nullptr;
         if (l < d->levels && (!a.lvl[l] || ((uintptr_t)a.lvl[l] & 15))) return fail(QV2X_EALIGN, "qv2x_codebook_encode_f32: level %d weights null or unaligned", l);
     }
-    static const int er_env = [] { const char* e = getenv("QV2X_ENC_ROWS"); return e ? atoi(e) : 0; }();      // dev knob: 32 | 64
-    // from three V2X-Real frames on: the 64-row form (1 / 2 / 4 / 8 frames: 478 vs 518, 853 vs 856, 1580 vs 1499, 2991 vs 2906 us);
-    // below: the mixed form when it has at least one full round of 64-row workgroups
+    int er_env = 0;
+#ifdef QV2X_DEV_KNOBS                                                  // dev builds only: 32 | 64 | 96 (mixed) rows per workgroup, anything else is refused
+    static const int er_knob = [] { const char* e = getenv("QV2X_ENC_ROWS"); return e ? atoi(e) : 0; }();
+    if (er_knob != 0 && er_knob != 32 && er_knob != 64 && er_knob != 96) return fail(QV2X_EINVAL, "QV2X_ENC_ROWS=%d: 32, 64 or 96", er_knob);
+    er_env = er_knob;
+#endif
+    // from six rounds of 64-row workgroups on (three V2X-Real frames on 256 CUs): the 64-row form (1 / 2 / 4 / 8 frames: 478 vs 518, 853 vs 856,
+    // 1580 vs 1499, 2991 vs 2906 us); below: the mixed form when it has at least one full round of 64-row workgroups
+    static int cus_of[64];                                             // CU count per device, asked once (0 = not asked yet)
     int cus = 256, dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        if (cus_of[dev] == 0) cus_of[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+        cus = cus_of[dev];
+    }
     const int n64 = (a.M / 64) / cus * cus;
-    const int er = er_env ? er_env : (a.M >= 98304 ? 64 : (n64 > 0 ? 96 : 32));
+    const int er = er_env ? er_env : ((a.M / 64) >= 6 * cus ? 64 : (n64 > 0 ? 96 : 32));
     if (er == 64) codebook_encode_kernel<64><<<(a.M + 63) / 64, 512, 0, (hipStream_t)stream>>>(a);
     else if (er == 96 && n64 > 0) codebook_encode_mixed_kernel<<<n64 + (a.M - n64 * 64 + 31) / 32, 512, 0, (hipStream_t)stream>>>(a, n64);
     else codebook_encode_kernel<32><<<(a.M + 31) / 32, 512, 0, (hipStream_t)stream>>>(a);

@@ -37,6 +37,10 @@ __device__ __forceinline__ float q_code(float y, float delta, float zp) {
 // gap is < 4.7e-5, so the two round alike unless p lies within 1e-4 of a half-integer.
 //   r = fma(y, rdelta, zp + 2^23)    ONE rounding of the exact p + zp + 2^23 to an integer (ulp 1 in [2^23, 2^24)): r = code + 2^23
 //   e = fma(y, rdelta, (zp + 2^23) - r) = fl(p - k), k = r - zp - 2^23 exactly: how far p is from the integer it was rounded to
+// NaN / Inf contract: the callers' y are finite by construction (an exact i32 sum times a finite per-channel scale plus a finite bias; fp32
+// dot products of finite codes and finite weights) -- deploy refuses non-finite scales, biases and deltas (ptq_state.py).  An infinite y
+// clamps like any out-of-range value; a NaN y yields an UNSPECIFIED code (v_med3_f32 with a NaN operand), where q_code's fminf(fmaxf())
+// gave code 0: nothing on the parity path depends on it (tools/probes/q_pack4_probe.hip lists the behaviour).
 // One test per group of four: max |e| > 0.4999 on any lane sends the wave through the exact divisions (5 % of the groups).  Below code 0
 // (p + zp < 0) r falls under 2^23 where its ulp is 1/2 and k may be a half-integer: the clamp sets those to the lowest code, which is what
 // they are.  The clamped code is read from the low mantissa byte of r.  (Round 3: 5.25 instead of 7.25 instructions per output -- the

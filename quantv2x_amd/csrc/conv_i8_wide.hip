@@ -84,28 +84,21 @@ __device__ long long g_wide_fine[4096 * 16];
 //     its per-pixel channel sums into a 256-entry LDS table once (two 1 KiB pieces per wave) and an output's window sum is nine
 //     table entries at the group fold.  The loop body is one basic block; the fold needs no barrier.
 //
-// Round 3: NGRP > 1 = the PING-PONG form.  A workgroup holds NGRP independent groups of NW waves -- each group is what a whole
-// workgroup is at NGRP = 1: its own items, halo buffers, window-sum sets and constants -- and wave w shares its SIMD with wave w + 4,
-// i.e. group g with group g + NGRP / 2.  Every group runs the same slot sequence per item, {chunk 0, ..., chunk n-1, epilogue}, one
-// WORKGROUP barrier per slot, and the upper half of the groups starts (n + 1) / 2 slots late: while one wave of a SIMD multiplies
-// (matrix pipe), its partner requantizes and stores (VALU / memory), instead of both doing the same thing at the same time.  Measured
-// before (s_memtime stamps, batch of 32): a 64 -> 64 layer spent 5.1k cycles per item in the K loop and 7.5k in the epilogue with the
-// co-resident workgroups in lockstep; the barriers are what keeps the halves out of phase (left alone they drift back into step).
+// (Round 3 also built a PING-PONG form -- groups of waves half an item apart, held there by workgroup barriers -- and a SOFTWARE-
+// PIPELINED one -- the epilogue of item i woven into the K loop of item i + 1 over two accumulator sets.  Both were bit-exact and
+// neither was faster (profiles/r03_wide_forms.log, DESIGN_HISTORY.md); round 4 took them out of the product library: they are in the
+// history at commit 0601783.)
 // Round 3: S2 = the ZeroPad2d + stride-2 first convolution of a backbone level (base_bev_backbone.py:60-66) on the same kernel.  The input
 // is read as four PARITY PLANES (row parity, column parity of the padded input): tap (dy, dx) of output pixel (y, x) is pixel
 // (y + dy / 2, x + dx / 2) of plane (dy & 1, dx & 1), so a plane's halo tile is an ordinary 6 x 33 tile and a "chunk" becomes
 // (64 input channels, plane) with 4 / 2 / 2 / 1 taps -- the same nine K steps per 64 channels, the same fragment reads (base + immediate),
 // four halo tiles instead of one.  Only the DMA's source addresses know about the stride (the global side of an LDS-DMA is per lane).
-template <bool MULTI, int NW, int NT, int BN, int NGRP = 1, int MTP = 5, bool S2 = false>
-#ifdef QV2X_WIDE_W3     // dev variant: the plain four-wave form held to 168 VGPRs (three waves per SIMD, three workgroups per CU)
-#define QV2X_WIDE_BOUNDS(MULTI, NW, NGRP) ((NGRP) == 1 && !(MULTI) && (NW) == 4 ? 3 : (((NW) * (NGRP) >= 8 || ((MULTI) && (NW) == 4)) ? ((NGRP) > 1 ? 2 : 1) : 2))
-#else
-#define QV2X_WIDE_BOUNDS(MULTI, NW, NGRP) ((NW) * (NGRP) == 16 ? 4 : (((NW) * (NGRP) >= 8 || ((MULTI) && (NW) == 4)) ? ((NGRP) > 1 ? 2 : 1) : 2))
-#endif
-__global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) void conv3x3_i8_wide_kernel(const WideArgs a) {
+template <bool MULTI, int NW, int NT, int BN, int MTP = 5, bool S2 = false>
+// (second bound = waves per SIMD the registers must allow: 8-wave workgroups and the three-group 4-wave form sit alone on a CU)
+#define QV2X_WIDE_BOUNDS(MULTI, NW) (((NW) >= 8 || ((MULTI) && (NW) == 4)) ? 1 : 2)
+__global__ __launch_bounds__(NW * 64, QV2X_WIDE_BOUNDS(MULTI, NW)) void conv3x3_i8_wide_kernel(const WideArgs a) {
     static_assert(NW * NT * 32 == BN && WTILE % BN == 0, "wave layout");
-    static_assert(NGRP == 1 || ((NW * NGRP == 8 || NW * NGRP == 16) && NGRP % 2 == 0), "ping-pong: 8 or 16 waves, group g beside group g + NGRP / 2 on the SIMDs");
-    static_assert(!S2 || (NGRP == 1 && !MULTI), "the stride-2 form: plain workgroups, one input group");
+    static_assert(!S2 || !MULTI, "the stride-2 form: one input group");
     constexpr int NPL = S2 ? 4 : 1;                                    // window-sum tables per set: one per parity plane
     constexpr int MT = MTP, TH = MTP, HPIX = (TH + 2) * HWD;           // (shadow the file-scope values: patch height = M tiles per wave)
     static_assert(HPIX <= HPAD, "halo tile");
@@ -114,15 +107,11 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
     constexpr int NF = MULTI ? 16 : 1;
     static_assert(NT == 1, "the epilogue below is written for one 32-channel tile per wave");
     constexpr int NG = MULTI ? QV2X_MAX_GROUPS : 1;
-    constexpr int GLDS = 2 * HBUF + 3 * NG * NPL * HPAD * 4 + NG * BN * 16;  // per group
-    __shared__ __attribute__((aligned(16))) int8_t lds_all[NGRP * GLDS];
+    __shared__ __attribute__((aligned(16))) int8_t lds[2 * HBUF + 3 * NG * NPL * HPAD * 4 + NG * BN * 16];
     // window-sum tables [set][group][halo pixel]: item k of a workgroup uses set k % 3.  Its first tile is summed into the set by the
     // previous item's last tap 8, and item k's start clears set (k + 1) % 3 -- last read two items ago, i.e. before barriers every wave has
     // passed -- so an item starts without a barrier or a wait of its own.
-    const int lane = threadIdx.x & 63;
-    const int grp = NGRP == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) / NW;   // this wave's group
-    const int tid = (int)threadIdx.x - grp * (NW * 64), wave = tid >> 6;                          // thread / wave index INSIDE the group
-    int8_t* lds = lds_all + grp * GLDS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int8_t* hbuf = lds;
     int* psum = (int*)(lds + 2 * HBUF);
     v4i* ctab = (v4i*)(psum + 3 * NG * NPL * HPAD);                    // [group][BN] {aw, corr_g, scale_g (bits), bias (bits)} per channel
@@ -131,27 +120,12 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
     // blockIdx.x, + gridDim.x, ... -- the grid is a multiple of 8 * nblk, so its channel block (weights, constants) and its XCD never change.
     // While an item's epilogue runs, the first two halo tiles and the first two weight steps of the next item are already in flight.
     const int nblk = a.cout / BN, npatch = a.n * a.tiles_x * a.tiles_y;
-    const int vstride = NGRP * (int)gridDim.x;                         // group g of workgroup b is "virtual workgroup" g * gridDim.x + b
-    int item = grp * (int)gridDim.x + (int)blockIdx.x;
+    const int vstride = (int)gridDim.x;
+    int item = (int)blockIdx.x;
     auto patch_of = [&](int it) { return (it / (8 * nblk)) * 8 + (it & 7); };
     auto valid = [&](int it) { return it < a.items && patch_of(it) < npatch; };
-    // slots (= workgroup barriers) every group of this workgroup goes through: start offset + items x (chunks + 1), the longest group's
-    int my_slots = 0, all_slots = 0;
-    if (NGRP > 1) {
-#pragma unroll
-        for (int g2 = 0; g2 < NGRP; ++g2) {
-            int cnt = 0;
-            for (int it = g2 * (int)gridDim.x + (int)blockIdx.x; valid(it); it += vstride) ++cnt;
-            const int sl = cnt ? (g2 >= NGRP / 2 ? (a.nchunks + 2) / 2 : 0) + cnt * (a.nchunks + 1) : 0;
-            all_slots = sl > all_slots ? sl : all_slots;
-            if (g2 == grp) my_slots = sl;
-        }
-        if (all_slots == 0) return;                                    // (uniform over the workgroup)
-    } else if (!valid(item)) {
-        return;
-    }
-    const bool idle = NGRP > 1 && my_slots == 0;                       // a group without items only keeps the barrier count
-    const int cb = idle ? 0 : (item >> 3) % nblk, n0 = cb * BN;
+    if (!valid(item)) return;
+    const int cb = (item >> 3) % nblk, n0 = cb * BN;
     const int total = a.nsteps;
     WTRACE(0);
 #ifdef QV2X_WIDE_TRACE
@@ -242,7 +216,15 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
 
     // fragment of (M tile i, tap, K half ks): 16 bytes of halo pixel (lane & 31) + 34 (i + dy) + dx in plane ks * 2 + half:
     // lane part in one register, the rest an immediate
-    v4i fa[2][MT];
+    // FA1 (the three-group form: 80 fp32 partial results per lane live beside the 80 accumulators): ONE fragment set, each half step's
+    // reads issued after the MFMAs of the half before -- the SIMD's other wave multiplies meanwhile (measured on the one-group forms in
+    // round 3: no difference in time); with two sets that kernel needed 275 registers and spilled 28 bytes per lane.
+#ifdef QV2X_WIDE_NO_FA1
+    constexpr bool FA1 = false;
+#else
+    constexpr bool FA1 = MULTI;
+#endif
+    v4i fa[FA1 ? 1 : 2][MT];
     const int rlane = half * PLANE + (lane & 31) * 16;
     // (TAP = 3 oy + ox names the tile offset (oy, ox) of the step's pixels: the tap itself at stride 1, the plane-local offset at stride 2)
     auto read_half = [&](auto ks_c, auto tap_c, int chunk) __attribute__((always_inline)) {
@@ -252,7 +234,7 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
 #endif
         const int8_t* hb = hbuf + ((pb + chunk) & 1) * HBUF + rlane;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) fa[KS][i] = *(const v4i*)(hb + KS * 2 * PLANE + (HWD * (i + TAP / 3) + TAP % 3) * 16);
+        for (int i = 0; i < MT; ++i) fa[FA1 ? 0 : KS][i] = *(const v4i*)(hb + KS * 2 * PLANE + (HWD * (i + TAP / 3) + TAP % 3) * 16);
     };
 
     int g = 0;
@@ -302,11 +284,18 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
         constexpr int Q = decltype(q_c)::value;
         constexpr bool LAST = decltype(last_c)::value != 0;
         load_w(IC<(Q + 2) % 3>{}, step + 2);                           // slot of step - 1, which is done
-        read_half(IC<1>{}, off_c, chunk);
+        if (!FA1) read_half(IC<1>{}, off_c, chunk);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < MT; ++i) acc[i][0] = WMFMA(wr[Q % 3][0], fa[0][i], acc[i][0]);
         __builtin_amdgcn_sched_barrier(0);
+        if (FA1) {                                                     // K half 1 into the same registers, multiplied before anything else is read
+            read_half(IC<1>{}, off_c, chunk);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[i][0] = WMFMA(wr[Q % 3][1], fa[0][i], acc[i][0]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (!LAST) {
             read_half(IC<0>{}, noff_c, chunk);
         } else {
@@ -329,9 +318,11 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
             read_half(IC<0>{}, IC<0>{}, nxt);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (!FA1) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) acc[i][0] = WMFMA(wr[Q % 3][1], fa[1][i], acc[i][0]);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < MT; ++i) acc[i][0] = WMFMA(wr[Q % 3][1], fa[1][i], acc[i][0]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
     // One K step = (chunk, tap) of a stride-1 layer.  On entry the K-half-0 fragments of the step are in flight or landed.
     auto one_step = [&](auto tap_c, int chunk) __attribute__((always_inline)) {
@@ -354,10 +345,6 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
     };
 
     // ---- once per workgroup: the constants of its channel block, the first item's first tiles and weight steps ---------------
-    if (idle) {
-        for (int k = 0; k < all_slots + 1; ++k) __builtin_amdgcn_s_barrier();
-        return;
-    }
     {
         const int nx = item + vstride;
         has_next = valid(nx);
@@ -391,9 +378,6 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
     issue_halo(1);
     __builtin_amdgcn_s_barrier();
     add_psum(0, 0);
-    if (NGRP > 1 && grp >= NGRP / 2) {                                 // the late half: (chunks + 2) / 2 slots behind its SIMD partners
-        for (int k = 0; k < (a.nchunks + 2) / 2; ++k) __builtin_amdgcn_s_barrier();
-    }
 
     for (;;) {
         WFINE(0);
@@ -435,7 +419,6 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
 #if defined(QV2X_WABL) && QV2X_WABL == 4     // dev ablation: the K loop alone (no window sums, no epilogue, no stores)
 #pragma unroll
         for (int i = 0; i < MT; ++i) asm volatile("" :: "v"(acc[i][0]));
-        if (NGRP > 1) __builtin_amdgcn_s_barrier();
         if (!has_next) break;
         goto next_item;
 #endif
@@ -489,7 +472,6 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
         WFINE(8);
         WTRACE(4);
         WFINE(9);
-        if (NGRP > 1) __builtin_amdgcn_s_barrier();                    // end of the epilogue slot
         WFINE(10);
         ++nit;
         if (!has_next) break;
@@ -508,288 +490,9 @@ __global__ __launch_bounds__(NW * NGRP * 64, QV2X_WIDE_BOUNDS(MULTI, NW, NGRP)) 
         }
         if (a.nchunks == 1) issue_halo(1);                             // (a one-chunk layer's K loop only requested the next item's tile 0)
     }
-    if (NGRP > 1) {                                                    // keep the barrier count of the longest group
-        for (int k = my_slots; k < all_slots; ++k) __builtin_amdgcn_s_barrier();
-    }
 #ifdef QV2X_WIDE_TRACE
     if (tid == 0 && blockIdx.x < 8192) g_wide_trace[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime();
 #endif
-}
-
-// ---- Round 3: the SOFTWARE-PIPELINED form (one input group, NCH = 1 | 2 | 4 chunks) ------------------------------------------------
-// Measured on the form above (s_memtime stamps, batch of 32, two waves per SIMD): a 64 -> 64 layer spends 4.1k cycles of an item in its K
-// loop and 9.4k in the requantizing epilogue, a 128 -> 128 layer 9.7k and 8.1k -- and MFMA time + VALU time add up to the item time:
-// the two waves of a SIMD sit in the same phase at the same time (both multiply, then both requantize; left alone they drift into step,
-// and holding them apart with barriers -- the NGRP form -- leaves each phase to ONE wave, which issues a VALU instruction only every
-// 5-7 cycles).  The matrix pipe and the VALU do overlap when MFMA blocks and VALU blocks of ~200 cycles alternate in BOTH waves
-// (tools/probes/mfma_valu_overlap_probe.hip: 5 MFMAs + 30 epilogue instructions per loop run at 33 cycles per MFMA with two waves per
-// SIMD), so here the epilogue of item i is cut into 16 pieces of four outputs per lane and woven into the K loop of item i + 1: a wave
-// keeps TWO accumulator sets (4 x 32-pixel tiles each: 128 of its 256 registers), the MFMAs of a half step fill one set while a piece
-// requantizes four values of the other, and the piece's bytes leave with that item's own 16-byte stores.  The patch is 4 x 32 (not
-// 5 x 32) to pay for the second set.  Same integer sums, same fp32 epilogue: bit-identical to the other forms.
-constexpr int PMT = 4;                                                 // M tiles per wave = patch rows
-
-template <int NCH> struct PipeSched {
-    static constexpr int HS = NCH * 18, NP = PMT * 4;                  // half steps of an item's K loop; epilogue pieces (tile-major)
-    static constexpr int hs_of(int p) { return 1 + p * (HS - 2) / NP; }   // the half step whose MFMAs piece p follows (0: window sums)
-    static constexpr int piece_at(int hs) {
-        for (int p = 0; p < NP; ++p) if (hs_of(p) == hs) return p;
-        return -1;
-    }
-};
-
-template <int NW, int NCH, int WT>
-__global__ __launch_bounds__(NW * 64, 2) void conv3x3_i8_pipe_kernel(const WideArgs a) {
-    constexpr int BN = NW * 32, MT = PMT, TH = PMT, HPIX = (TH + 2) * HWD, LH = HBLK / NW;
-    static_assert(WT % BN == 0, "weight tile");
-    static_assert(HBLK % NW == 0 && HPIX <= HPAD, "halo tile");
-    using Sched = PipeSched<NCH>;
-    __shared__ __attribute__((aligned(16))) int8_t lds[2 * HBUF + 3 * HPAD * 4 + BN * 16];
-    int8_t* hbuf = lds;
-    int* psum = (int*)(lds + 2 * HBUF);                                // [set][halo pixel]: item k uses set k % 3 (see the form above)
-    v4i* ctab = (v4i*)(psum + 3 * HPAD);                               // [BN] {aw, corr, scale (bits), bias (bits)} per channel
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int nblk = a.cout / BN, npatch = a.n * a.tiles_x * a.tiles_y;
-    int item = blockIdx.x;
-    auto patch_of = [&](int it) { return (it / (8 * nblk)) * 8 + (it & 7); };
-    auto valid = [&](int it) { return it < a.items && patch_of(it) < npatch; };
-    if (!valid(item)) return;
-    const int cb = (item >> 3) % nblk, n0 = cb * BN;
-    constexpr int total = NCH * 9;
-
-    struct Where { int y0, x0, img; };
-    auto place = [&](int it) __attribute__((always_inline)) {
-        const int patch = patch_of(it);
-        const int txi = patch % a.tiles_x, tyi = (patch / a.tiles_x) % a.tiles_y, img = patch / (a.tiles_x * a.tiles_y);
-        return Where{tyi * TH, txi * TW, img};
-    };
-    auto src_of = [&](const Where& w, int j) __attribute__((always_inline)) {
-        const int blk = wave + NW * j;
-        int hpx = (blk & 3) * 64 + lane;
-        hpx = hpx < HPIX ? hpx : HPIX - 1;
-        const int hy = hpx / HWD, hx = hpx - hy * HWD;
-        const int yy = min(w.y0 + hy, a.hp - 1), xx = min(w.x0 + hx, a.wp - 1);
-        return (unsigned)(((w.img * a.hp + yy) * a.wp + xx) * a.cin_total + (blk >> 2) * 16);
-    };
-    Where cur = place(item), nxw = cur, prv = cur;                     // prv: the item whose epilogue is being woven in
-    bool has_next = false;
-    int pb = 0, pset = 0, eset = 0;                                    // halo buffer of chunk 0; window-sum set of cur / of prv
-
-    v16i acc[2][MT];
-    v4i fa[2][MT];
-    v4i wr[3][2];
-    int totv[MT], pk[4];
-
-    // (halo DMA as inline asm, per-pixel channel sums, weight ring, planar fragment reads: as in conv3x3_i8_wide_kernel)
-    auto issue_halo = [&](int c) __attribute__((always_inline)) {
-        const int k = c - NCH;
-        if (k >= 0 && (!has_next || k >= NCH)) return;
-        const int off = a.coff[k < 0 ? c : k];
-        int8_t* buf = hbuf + ((pb + c) & 1) * HBUF;
-        const unsigned ldsb = (unsigned)(uintptr_t)((__attribute__((address_space(3))) int8_t*)buf) + wave_u * 1024;
-#pragma unroll
-        for (int j = 0; j < LH; ++j)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                         :: "s"(ldsb + NW * j * 1024), "v"(src_of(k < 0 ? cur : nxw, j) + (unsigned)off), "s"(a.in) : "memory", "m0");
-    };
-    auto add_psum = [&](int chunk, int set) __attribute__((always_inline)) {
-        const int8_t* buf = hbuf + ((pb + chunk) & 1) * HBUF;
-        constexpr int B = LH > 4 ? 4 : LH;                             // (in batches of four pieces: 16 registers)
-#pragma unroll
-        for (int j0 = 0; j0 < LH; j0 += B) {
-            v4i v[B];
-#pragma unroll
-            for (int j = 0; j < B; ++j) v[j] = *(const v4i*)(buf + (wave + NW * (j0 + j)) * 1024 + lane * 16);
-#pragma unroll
-            for (int j = 0; j < B; ++j) {
-                const int blk = wave + NW * (j0 + j);
-                int sm = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) sm = __builtin_amdgcn_sdot4(v[j][q], 0x01010101, sm, false);
-                __hip_atomic_fetch_add(psum + set * HPAD + (blk & 3) * 64 + lane, sm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        }
-    };
-    // weights: buffer loads -- resource = the workgroup's slice of the pre-tiled weights, a SCALAR running offset for the step and the
-    // lane's constant 16-byte offset.  With plain pointers hipcc forms one 64-bit per-lane address per (step, K half) and, every step
-    // being a compile-time constant here, hoists all of them out of the item loop: 18-72 register pairs, i.e. spills (first version of
-    // this form).  An empty asm statement to pin a running pointer is worse: any inline asm in the loop makes the waitcnt pass put
-    // s_waitcnt vmcnt(0) lgkmcnt(0) in front of every MFMA group (second version).
-    constexpr int wstep = WT * 64;                                     // bytes of one step's weight tile (WT = min(cout, 256) rows)
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.wt + (size_t)(n0 / WT) * total * wstep + ((n0 % WT) / 32 + wave_u) * 2048), 0, total * wstep, 0x00020000);
-    int wnext = 0;                                                     // byte offset of the next step to request (uniform)
-    const int wlane = lane * 16;
-    auto load_w = [&](auto slot_c, auto last_c) __attribute__((always_inline)) {
-        constexpr int SLOT = decltype(slot_c)::value;
-        wr[SLOT][0] = (v4i)__builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, wnext, 0);
-        wr[SLOT][1] = (v4i)__builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + 1024, wnext, 0);
-        wnext = decltype(last_c)::value ? 0 : wnext + wstep;           // (past an item's last step: the next item's step 0)
-    };
-    const int rlane = half * PLANE + (lane & 31) * 16;
-    auto read_half = [&](auto ks_c, auto tap_c, int chunk) __attribute__((always_inline)) {
-        constexpr int KS = decltype(ks_c)::value, TAP = decltype(tap_c)::value;
-        const int8_t* hb = hbuf + ((pb + chunk) & 1) * HBUF + rlane;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) fa[KS][i] = *(const v4i*)(hb + KS * 2 * PLANE + (HWD * (i + TAP / 3) + TAP % 3) * 16);
-    };
-
-    // ---- the epilogue of item `prv` (accumulator set P), in pieces --------------------------------------------------------------
-    const float rd = 1.0f / a.out_delta, lowc = a.relu ? a.out_zp + 8388608.0f : 8388608.0f;
-    auto epi_begin = [&]() __attribute__((always_inline)) {           // window sums: nine entries of the item's set per output pixel
-        int rowsum[MT + 2];
-        const int* ps = psum + eset * HPAD + (lane & 31);
-#pragma unroll
-        for (int k = 0; k < MT + 2; ++k) rowsum[k] = ps[k * HWD] + ps[k * HWD + 1] + ps[k * HWD + 2];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) totv[i] = rowsum[i] + rowsum[i + 1] + rowsum[i + 2];
-    };
-    auto epi_piece = [&](auto set_c, auto piece_c) __attribute__((always_inline)) {
-        constexpr int P = decltype(set_c)::value, I = decltype(piece_c)::value / 4, G4 = decltype(piece_c)::value % 4;
-        float y[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const v4i c = ctab[wave * 32 + 8 * G4 + 4 * half + e];
-            const int T = acc[P][I][4 * G4 + e] + __mul24(c[0], totv[I]) + c[1];
-            const int sci = c[2], bsi = c[3];
-            y[e] = __int_as_float(bsi) + (float)T * __int_as_float(sci);
-        }
-        pk[G4] = q_pack4(y[0], y[1], y[2], y[3], a.out_delta, rd, a.out_zp, lowc);
-        if (G4 == 3) {                                                 // the tile's 32 channels: half-wave exchange, one 16-byte store per lane
-            const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
-            const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
-            v4i ob;
-            ob[0] = s02[0]; ob[1] = s02[1]; ob[2] = s13[0]; ob[3] = s13[1];
-            const int yo = prv.y0 + I, xo = prv.x0 + (lane & 31);
-            if (yo < a.ho && xo < a.wo)
-                *(v4i*)(a.out + ((size_t)(prv.img * (a.ho + 2) + yo + 1) * (a.wo + 2) + xo + 1) * a.out_ctotal + a.out_c0 + n0 + wave * 32 + half * 16) = ob;
-        }
-    };
-    auto epi_at = [&](auto set_c, auto hs_c) __attribute__((always_inline)) {   // what the epilogue does after half step HS of the K loop
-#if defined(QV2X_PIPE_ABL)      // dev ablations (timing only): 1 = no epilogue anywhere, 2 = the whole epilogue after the K loop instead of woven in
-        return;
-#endif
-        constexpr int HSI = decltype(hs_c)::value, PC = Sched::piece_at(HSI);
-        if constexpr (HSI == 0) epi_begin();
-        if constexpr (PC >= 0) epi_piece(set_c, IC<PC>{});
-    };
-
-    // One K step = (chunk C, tap), in two halves, into accumulator set P; WITH_E: pieces of the other set's epilogue after each half.
-    auto one_step = [&](auto set_c, auto with_e, auto chunk_c, auto tap_c) __attribute__((always_inline)) {
-        constexpr int P = decltype(set_c)::value, C = decltype(chunk_c)::value, TAP = decltype(tap_c)::value;
-        constexpr bool WE = decltype(with_e)::value != 0;
-        constexpr int step = C * 9 + TAP;
-        load_w(IC<(TAP + 2) % 3>{}, IC<(step + 2) % total == total - 1>{});   // requests step + 2 (of the next item past the end)
-        read_half(IC<1>{}, tap_c, C);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) acc[P][i] = WMFMA(wr[TAP % 3][0], fa[0][i], acc[P][i]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (TAP < 8) {
-            read_half(IC<0>{}, IC<(TAP + 1) % 9>{}, C);
-        } else {
-            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            constexpr int nxt = C + 1;
-            add_psum(nxt, nxt < NCH ? pset : (pset == 2 ? 0 : pset + 1));
-            issue_halo(C + 2);
-            read_half(IC<0>{}, IC<0>{}, nxt);
-        }
-        if constexpr (WE) epi_at(IC<1 - P>{}, IC<2 * step>{});         // (the set's window sums were read at half step 0: no later piece touches LDS state)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) acc[P][i] = WMFMA(wr[TAP % 3][1], fa[1][i], acc[P][i]);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (WE) epi_at(IC<1 - P>{}, IC<2 * step + 1>{});
-    };
-    auto one_chunk = [&](auto set_c, auto with_e, auto chunk_c) __attribute__((always_inline)) {
-        one_step(set_c, with_e, chunk_c, IC<0>{}); one_step(set_c, with_e, chunk_c, IC<1>{}); one_step(set_c, with_e, chunk_c, IC<2>{});
-        one_step(set_c, with_e, chunk_c, IC<3>{}); one_step(set_c, with_e, chunk_c, IC<4>{}); one_step(set_c, with_e, chunk_c, IC<5>{});
-        one_step(set_c, with_e, chunk_c, IC<6>{}); one_step(set_c, with_e, chunk_c, IC<7>{}); one_step(set_c, with_e, chunk_c, IC<8>{});
-    };
-    // the K loop of item `cur` into set P (+ the epilogue of `prv` out of the other set)
-    auto one_item = [&](auto set_c, auto with_e) __attribute__((always_inline)) {
-        constexpr int P = decltype(set_c)::value;
-        {
-            int* nz = psum + (pset == 2 ? 0 : pset + 1) * HPAD;        // the next item's window-sum set
-            for (int t = tid; t < HPAD; t += NW * 64) nz[t] = 0;
-        }
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[P][i][r] = 0;
-        read_half(IC<0>{}, IC<0>{}, 0);
-        one_chunk(set_c, with_e, IC<0>{});
-        if constexpr (NCH > 1) one_chunk(set_c, with_e, IC<1>{});
-        if constexpr (NCH > 2) { one_chunk(set_c, with_e, IC<2>{}); one_chunk(set_c, with_e, IC<3>{}); }
-    };
-    // rotate: the item just accumulated becomes `prv`, the next one `cur`; false when there is no next item
-    auto rotate = [&]() __attribute__((always_inline)) {
-#if defined(QV2X_PIPE_ABL) && QV2X_PIPE_ABL == 1
-#pragma unroll
-        for (int i = 0; i < MT; ++i) { asm volatile("" :: "v"(acc[0][i])); asm volatile("" :: "v"(acc[1][i])); }
-#endif
-        prv = cur; eset = pset;
-        if (!has_next) return false;
-        item += (int)gridDim.x;
-        cur = nxw;
-        pb = (pb + NCH) & 1;
-        pset = pset == 2 ? 0 : pset + 1;
-        const int nx = item + (int)gridDim.x;
-        has_next = valid(nx);
-        if (has_next) nxw = place(nx);
-        if (NCH == 1) issue_halo(1);
-        return true;
-    };
-    auto epi_alone = [&](auto set_c) __attribute__((always_inline)) {  // the last item's epilogue: nothing left to weave it into
-#if defined(QV2X_PIPE_ABL) && QV2X_PIPE_ABL == 1
-#pragma unroll
-        for (int i = 0; i < MT; ++i) asm volatile("" :: "v"(acc[decltype(set_c)::value][i]));
-        return;
-#endif
-        epi_begin();
-        epi_piece(set_c, IC<0>{}); epi_piece(set_c, IC<1>{}); epi_piece(set_c, IC<2>{}); epi_piece(set_c, IC<3>{});
-        epi_piece(set_c, IC<4>{}); epi_piece(set_c, IC<5>{}); epi_piece(set_c, IC<6>{}); epi_piece(set_c, IC<7>{});
-        epi_piece(set_c, IC<8>{}); epi_piece(set_c, IC<9>{}); epi_piece(set_c, IC<10>{}); epi_piece(set_c, IC<11>{});
-        epi_piece(set_c, IC<12>{}); epi_piece(set_c, IC<13>{}); epi_piece(set_c, IC<14>{}); epi_piece(set_c, IC<15>{});
-    };
-
-    // ---- once per workgroup ------------------------------------------------------------------------------------------------------
-    {
-        const int nx = item + (int)gridDim.x;
-        has_next = valid(nx);
-        if (has_next) nxw = place(nx);
-    }
-    issue_halo(0);
-    load_w(IC<0>{}, IC<total == 1>{});
-    load_w(IC<1>{}, IC<total == 2>{});
-    if (tid < BN) {
-        const int co = n0 + tid;
-        v4i c;
-        c[0] = a.aw[co]; c[1] = a.corr[co]; c[2] = __float_as_int(a.scale[co]); c[3] = __float_as_int(a.bias[co]);
-        ctab[tid] = c;
-    }
-    for (int t = tid; t < 3 * HPAD; t += NW * 64) psum[t] = 0;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    issue_halo(1);
-    __builtin_amdgcn_s_barrier();
-    add_psum(0, 0);
-
-    one_item(IC<0>{}, IC<0>{});                                        // the first item: nothing to requantize yet
-    for (;;) {
-        if (!rotate()) { epi_alone(IC<0>{}); break; }
-#if defined(QV2X_PIPE_ABL) && QV2X_PIPE_ABL == 2
-        epi_alone(IC<0>{});
-#endif
-        one_item(IC<1>{}, IC<1>{});
-        if (!rotate()) { epi_alone(IC<1>{}); break; }
-#if defined(QV2X_PIPE_ABL) && QV2X_PIPE_ABL == 2
-        epi_alone(IC<1>{});
-#endif
-        one_item(IC<0>{}, IC<1>{});
-    }
 }
 
 // [Cout][G][3][3][C_g] -> [Cout/wtile][chunk = (g, cc)][tap][wtile/32][K half][lane][16], wtile = min(Cout, 256)
@@ -875,9 +578,6 @@ static long long wide_patches(const qv2x_conv_desc* d) {
 
 static int wide_bn(const qv2x_conv_desc* d) {
     const long long patches = wide_patches(d);
-#ifdef QV2X_WIDE_FORCE_BN128
-    if (d->cout % 256 == 0) return 128;
-#endif
     if (d->cout % 256 == 0) return patches * (d->cout / 256) >= 192 ? 256 : 128;
     return d->cout;
 }
@@ -940,95 +640,26 @@ extern "C" int qv2x_conv3x3_i8_pack_wide(const qv2x_conv_desc* d, const int8_t* 
 
 extern "C" int qv2x_conv3x3_i8_wide(const qv2x_conv_desc* d, const int8_t* in, const int8_t* w_wide, const float* scale,
                                     const int32_t* corr, const int32_t* aw, const float* bias, int8_t* out, void* stream) {
-    return qv2x_conv3x3_i8_wide_form(d, in, w_wide, scale, corr, aw, bias, out, QV2X_WIDE_AUTO, stream);
-}
-
-extern "C" int qv2x_conv3x3_i8_wide_form(const qv2x_conv_desc* d, const int8_t* in, const int8_t* w_wide, const float* scale,
-                                         const int32_t* corr, const int32_t* aw, const float* bias, int8_t* out, int form, void* stream) {
     using namespace qv2x;
-    if (form != QV2X_WIDE_AUTO && form != QV2X_WIDE_PLAIN && form != QV2X_WIDE_PINGPONG && form != QV2X_WIDE_PIPE)
-        return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_wide_form: form %d (0 auto, 1 plain, 2 ping-pong, 3 pipelined)", form);
     if (!d || !in || !w_wide || !scale || !corr || !aw || !bias || !out) return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_wide: null pointer");
     if (((uintptr_t)in & 15) || ((uintptr_t)w_wide & 15) || ((uintptr_t)out & 15)) return fail(QV2X_EALIGN, "qv2x_conv3x3_i8_wide: in / w / out must be 16-byte aligned");
     WideArgs a{};
     if (int rc = fill_args(d, a)) return rc;
     a.in = in; a.wt = w_wide; a.scale = scale; a.corr = corr; a.aw = aw; a.bias = bias; a.out = out;
     hipStream_t st = (hipStream_t)stream;
-    // Pipelined form (epilogue of item i inside the K loop of item i + 1; 4 x 32 patches): one input group of 1, 2 or 4 chunks
-    const bool can_pipe = d->stride == 1 && d->ngroups == 1 && (a.nchunks == 1 || a.nchunks == 2 || a.nchunks == 4);
-    if (form == QV2X_WIDE_PIPE && !can_pipe)
-        return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_wide_form: the pipelined form takes one input group of 64, 128 or 256 channels");
-    if (form == QV2X_WIDE_PIPE) {
-        a.tiles_y = (a.ho + PMT - 1) / PMT;
-        const int p8 = (a.n * a.tiles_x * a.tiles_y + 7) / 8 * 8;
-        const int bn = d->cout % 256 == 0 ? (2LL * p8 * (d->cout / 256) >= 3 * 256 ? 256 : 128) : d->cout;   // 256-channel workgroups once they fill the chip
-        a.items = p8 * (a.cout / bn);
-        const int period = 8 * (a.cout / bn);
-        const int slots = 256 * (bn == 256 ? 1 : (bn == 128 ? 2 : 4)) / period * period;
-        const dim3 grid(a.items < slots ? a.items : slots);
-#define QV2X_PIPE_LAUNCH(NWV, WTV) do { \
-        if (a.nchunks == 1) conv3x3_i8_pipe_kernel<NWV, 1, WTV><<<grid, NWV * 64, 0, st>>>(a); \
-        else if (a.nchunks == 2) conv3x3_i8_pipe_kernel<NWV, 2, WTV><<<grid, NWV * 64, 0, st>>>(a); \
-        else conv3x3_i8_pipe_kernel<NWV, 4, WTV><<<grid, NWV * 64, 0, st>>>(a); } while (0)
-        if (bn == 256) QV2X_PIPE_LAUNCH(8, 256);
-        else if (bn == 128 && a.wtile == 256) QV2X_PIPE_LAUNCH(4, 256);
-        else if (bn == 128) QV2X_PIPE_LAUNCH(4, 128);
-        else QV2X_PIPE_LAUNCH(2, 64);
-#undef QV2X_PIPE_LAUNCH
-        return hip_check(hipGetLastError(), "qv2x_conv3x3_i8_wide launch");
-    }
     const int patches8 = (a.n * a.tiles_x * a.tiles_y + 7) / 8 * 8;   // block ids come in groups of 8 (one per XCD)
-    // Ping-pong form (NGRP groups per 8-wave workgroup, one workgroup per CU, 64- or 128-channel groups): pays once a group owns a few
-    // items in a row -- with one item per group the late half's start offset is pure loss.
-    // MEASURED (batch of 32, profiles/r03_wide_forms.log): the grouped form is bit-exact and never faster -- a 128 -> 128 layer 56 vs 49 us,
-    // a 64 -> 64 layer 69 vs 67 us: a phase left to ONE wave of a SIMD runs at that wave's own issue rate (a VALU instruction every 5-7
-    // cycles, a K step in 770 instead of 540 cycles), which costs what the overlap returns.  AUTO therefore never picks it; the form
-    // stays reachable by name for the ablation tools and the parity tests.
-    int pp_min_x2 = 0;                                                 // items per group x 2 from which AUTO would use the grouped form (0: never)
-#ifdef QV2X_DEV_KNOBS
-    if (const char* e = getenv("QV2X_WIDE_PP")) pp_min_x2 = atoi(e);   // 0: never; dev builds only
-#endif
-    const int bn_pp = d->cout % 256 == 0 ? 128 : d->cout, ngrp = bn_pp == 64 ? 4 : 2;
-    const bool can_pp = d->ngroups == 1 && d->stride == 1;
-    if (form == QV2X_WIDE_PINGPONG && !can_pp)
-        return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_wide_form: the ping-pong form takes one input group");
-    const bool pp = form == QV2X_WIDE_PINGPONG ||
-                    (form == QV2X_WIDE_AUTO && pp_min_x2 > 0 && can_pp &&
-                     2LL * patches8 * (a.cout / bn_pp) >= (long long)pp_min_x2 * ngrp * 256);
-    const int bn = pp ? bn_pp : wide_bn(d);
+    const int bn = wide_bn(d);
     a.items = patches8 * (a.cout / bn);
     // persistent workgroups: one round of what a CU holds (two waves per SIMD: 174-256 VGPRs; LDS 36-60 KB per workgroup), a multiple
     // of 8 * (cout / bn)
     const int period = 8 * (a.cout / bn);                              // ids `period` apart share the channel block and the XCD
-#ifdef QV2X_WIDE_W16    // dev variant: 16-wave workgroups (four 128-channel groups, four waves per SIMD at <= 128 VGPRs), patches of W16 x 32
-    if (pp && bn == 128) {
-        a.tiles_y = (a.ho + QV2X_WIDE_W16 - 1) / QV2X_WIDE_W16;
-        a.items = (a.n * a.tiles_x * a.tiles_y + 7) / 8 * 8 * (a.cout / bn);
-        const int want = (a.items + 3) / 4, cap = 256 / period * period;
-        const dim3 grid(want < cap ? (want + period - 1) / period * period : cap);
-        conv3x3_i8_wide_kernel<false, 4, 1, 128, 4, QV2X_WIDE_W16><<<grid, 1024, 0, st>>>(a);
-        return hip_check(hipGetLastError(), "qv2x_conv3x3_i8_wide launch");
-    }
-#endif
-    if (pp) {
-        const int want = (a.items + ngrp - 1) / ngrp, cap = 256 / period * period;
-        const dim3 grid(want < cap ? (want + period - 1) / period * period : cap);
-        if (bn == 128) conv3x3_i8_wide_kernel<false, 4, 1, 128, 2><<<grid, 512, 0, st>>>(a);
-        else conv3x3_i8_wide_kernel<false, 2, 1, 64, 4><<<grid, 512, 0, st>>>(a);
-        return hip_check(hipGetLastError(), "qv2x_conv3x3_i8_wide launch");
-    }
-#ifdef QV2X_WIDE_W3
-    const int per_cu128 = 3;
-#else
-    const int per_cu128 = 2;
-#endif
     // (stride 2: four window-sum tables per set -- 45 KB of LDS: three 64-channel workgroups per CU)
-    const int slots = 256 * (bn == 256 ? 1 : (bn == 128 ? (d->ngroups > 1 ? 1 : per_cu128) : (a.stride2 ? 3 : 4))) / period * period;
+    const int slots = 256 * (bn == 256 ? 1 : (bn == 128 ? (d->ngroups > 1 ? 1 : 2) : (a.stride2 ? 3 : 4))) / period * period;
     const dim3 grid(a.items < slots ? a.items : slots);
     if (a.stride2) {
-        if (bn == 256) conv3x3_i8_wide_kernel<false, 8, 1, 256, 1, 5, true><<<grid, 512, 0, st>>>(a);
-        else if (bn == 128) conv3x3_i8_wide_kernel<false, 4, 1, 128, 1, 5, true><<<grid, 256, 0, st>>>(a);
-        else conv3x3_i8_wide_kernel<false, 2, 1, 64, 1, 5, true><<<grid, 128, 0, st>>>(a);
+        if (bn == 256) conv3x3_i8_wide_kernel<false, 8, 1, 256, 5, true><<<grid, 512, 0, st>>>(a);
+        else if (bn == 128) conv3x3_i8_wide_kernel<false, 4, 1, 128, 5, true><<<grid, 256, 0, st>>>(a);
+        else conv3x3_i8_wide_kernel<false, 2, 1, 64, 5, true><<<grid, 128, 0, st>>>(a);
     } else if (d->ngroups > 1) {
         if (bn == 256) conv3x3_i8_wide_kernel<true, 8, 1, 256><<<grid, 512, 0, st>>>(a);
         else conv3x3_i8_wide_kernel<true, 4, 1, 128><<<grid, 256, 0, st>>>(a);

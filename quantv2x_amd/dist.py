@@ -59,7 +59,7 @@ class AgentShardedModel:
     ``pairwise_from_poses``, ``fuse_frames_and_heads``) with the agents of a scene sharded over ranks."""
 
     def __init__(self, engine, group=None, ego_only: bool = False, frames: int = 1, link: str = "torch", graphs: Optional[bool] = None,
-                 max_cav: Optional[int] = None):
+                 max_cav: Optional[int] = None, graph_link: bool = False):
         if not getattr(engine, "has_codebook", True):
             raise NotImplementedError("AgentShardedModel exchanges the codebook's uint8 code planes: the codebook-less model "
                                       "has no compressed wire format (run it single-process through DeployedModel.forward)")
@@ -72,6 +72,11 @@ class AgentShardedModel:
         self.levels, self.hw = engine.wire_shape()
         self.codes_bytes, self.pose_off, self.payload_bytes = payload_layout(self.levels, self.frames, self.hw)
         self.graphs = graphs
+        # graph_link: the all-gather is captured INSIDE the step's HIP graph (pre + collective + post = ONE replay per step, no host
+        # round trip between the stages).  Only for link="rccl": qv2x_allgather_codes is a plain ncclAllGather on the capturing stream.
+        if graph_link and link != "rccl":
+            raise ValueError("graph_link=True needs link='rccl' (the C ABI's own communicator)")
+        self.graph_link = bool(graph_link)
         self._dev = None
         self._comm = None
         self._captured = None
@@ -157,6 +162,8 @@ class AgentShardedModel:
             self._captured = (key,) + self._capture(my_inputs, skip_post)
         _, pre, post, out = self._captured
         pre.replay()
+        if self.graph_link:                                          # one graph: a1-a6, the captured all-gather, a7-a11
+            return out
         self._exchange()
         if post is not None:
             post.replay()
@@ -179,6 +186,16 @@ class AgentShardedModel:
                     self._post()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if self.graph_link:
+            # ONE graph per step.  Capturing records the RCCL kernel without running it, so this is still rank-local; every rank's graph
+            # holds exactly one all-gather, and the ranks replay in the same order.
+            whole, out = torch.cuda.CUDAGraph(), None
+            with torch.cuda.graph(whole):
+                self._pre(my_inputs)
+                self._exchange()
+                if not skip_post:
+                    out = self._post()
+            return whole, None, out
         pre = torch.cuda.CUDAGraph()
         with torch.cuda.graph(pre):
             self._pre(my_inputs)

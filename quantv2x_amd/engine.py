@@ -327,7 +327,6 @@ class DeployedModel(nn.Module):
         self._bufs: Dict[int, dict] = {}
         # launch-plan switches for the ablation tools (tools/bench_*_abl.py); the defaults are the shipped configuration
         self.use_wide_conv, self.batch_deconvs, self.use_chains = True, True, True
-        self.wide_form = 0                                             # QV2X_WIDE_AUTO; the ablation tools name a form
         self.chain_max_agents = 1
         # "exact": the reference's eleven chained GEMMs, bit-identical indices (the parity configuration).  "collapsed": opt-in, see collapse_encoder
         self.encode_mode, self._collapsed = "exact", None
@@ -418,9 +417,8 @@ class DeployedModel(nn.Module):
             if layer.w_wide is None:                                    # one-off re-tiling of the weights (not capturable)
                 layer.w_wide = torch.empty_like(layer.w)
                 L.check(self.lib.qv2x_conv3x3_i8_pack_wide(C.byref(d), L.ptr(layer.w), L.ptr(layer.w_wide), L.current_stream()), layer.name)
-            form = self.wide_form if (len(layer.groups) == 1 and layer.groups[0][1] in (64, 128, 256)) else 0
-            L.check(self.lib.qv2x_conv3x3_i8_wide_form(C.byref(d), L.ptr(x), L.ptr(layer.w_wide), L.ptr(layer.scale), L.ptr(layer.corr),
-                                                       L.ptr(layer.aw), L.ptr(layer.bias), L.ptr(out), form, L.current_stream()), layer.name)
+            L.check(self.lib.qv2x_conv3x3_i8_wide(C.byref(d), L.ptr(x), L.ptr(layer.w_wide), L.ptr(layer.scale), L.ptr(layer.corr),
+                                                  L.ptr(layer.aw), L.ptr(layer.bias), L.ptr(out), L.current_stream()), layer.name)
             return
         L.check(self.lib.qv2x_conv3x3_i8(C.byref(d), L.ptr(x), L.ptr(layer.w), L.ptr(layer.scale), L.ptr(layer.corr),
                                          L.ptr(layer.aw), L.ptr(layer.bias), L.ptr(out), L.current_stream()), layer.name)
@@ -614,7 +612,7 @@ class DeployedModel(nn.Module):
         try:
             self.run_plan(frames)
             self.clear_pillars(inputs, frames)
-        except Exception:
+        except BaseException:                                          # (KeyboardInterrupt too: a fill-less graph cannot see `canvas_clean`)
             self._restore_canvas(frames)
             raise
         return self.encode_codes(frames, out=codes_out)
@@ -660,7 +658,7 @@ class DeployedModel(nn.Module):
             if taps is not None:
                 taps["canvas"], taps["cat"] = canvas.clone(), b["cat"]     # (a copy: the canvas itself is handed back clean just below)
             self.clear_pillars(inputs, n_agents)
-        except Exception:
+        except BaseException:
             self._restore_canvas(n_agents)                             # never leave pillars behind (see pillars_to_canvas)
             raise
         if taps is not None:
@@ -809,7 +807,8 @@ class DeployedModel(nn.Module):
                 raise ValueError("record_len on the GPU cannot be read during HIP-graph capture: pass a CPU tensor")
             lens = [int(v) for v in (rl.tolist() if isinstance(rl, torch.Tensor) else rl)]
         hw = self.fh * self.fw
-        bufs = self._workspace(n_total)
+        # (no workspace of n_total agents here: a codebook model's post stage only needs the code planes it is handed -- the ego engine of a
+        #  heterogeneous scene never encodes n_total agents itself)
         feats = None if self.has_codebook else self._shared_features(enc, n_total)
         fused = torch.empty((nb, hw, 256), dtype=torch.float32, device=self.dev)
         starts = [sum(lens[:bi]) for bi in range(nb)]
@@ -897,6 +896,9 @@ class DeployedHeterModel(nn.Module):
             raise NotImplementedError(f"deployed heterogeneous path: no engine for modality {unknown}")
         slots = self._slots.get(tuple(agents))
         if slots is None:                                              # (built once per layout, outside any HIP-graph capture: capture() warms up first)
+            if torch.cuda.is_current_stream_capturing():
+                raise L.Qv2xError(f"DeployedHeterModel: agent layout {agents} is new and the stream is capturing -- its slot indices are an H2D copy; "
+                                  "run one eager forward of this layout first (DeployedHeterModel.capture does)")
             slots = {m: torch.as_tensor([i for i, a in enumerate(agents) if a == m], dtype=torch.int64, device=self.dev) for m in self.engines}
             self._slots[tuple(agents)] = slots
         enc = torch.empty((lv, n_total * hw), dtype=torch.uint8, device=self.dev)

@@ -218,7 +218,21 @@ def export_ptq_state(qt_model, modality: str = "m1") -> Dict[str, np.ndarray]:
                     out[p + tag + "_w"] = _np(lin.weight).astype(np.float32)
                     out[p + tag + "_b"] = _np(lin.bias).astype(np.float32)
         out["meta/codebook_levels"] = np.int64(len(cb._encoders))
-    return out
+    return check_finite(out)
+
+
+def check_finite(state: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """Every float of a frozen PTQ state must be finite and every ``*_delta`` positive: the kernels' requantizer (csrc/common.h q_pack4)
+    is specified on finite inputs only, and a finite state keeps every intermediate finite (exact i32 sums x finite scales + finite biases)."""
+    for k, v in state.items():
+        a = np.asarray(v)
+        if a.dtype.kind == "f":
+            if not np.isfinite(a).all():
+                raise ValueError(f"PTQ state: {k} holds a non-finite value; the deployed path is specified on finite quantizer parameters and weights")
+            off = k.endswith("/a_delta") and bool(state.get(k[:-len("a_delta")] + "a_off", False))     # (a disabled output quantizer's delta is unused)
+            if k.endswith("_delta") and not off and not (a > 0).all():
+                raise ValueError(f"PTQ state: {k} must be positive")
+    return state
 
 
 def save_ptq_state(path: str, state: Dict[str, np.ndarray]) -> None:
@@ -227,7 +241,7 @@ def save_ptq_state(path: str, state: Dict[str, np.ndarray]) -> None:
 
 def load_ptq_state(path: str) -> Dict[str, np.ndarray]:
     with np.load(path, allow_pickle=False) as z:
-        return {k: z[k] for k in z.files}
+        return check_finite({k: z[k] for k in z.files})
 
 
 def second_layers(enc):

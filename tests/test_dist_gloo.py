@@ -179,3 +179,41 @@ def test_bench_starts_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--dry-run-ranks"],
                        env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_bench_workload_follows_baseline_configs_per_world_size():
+    """`bench.py --gpus N` runs the configuration BASELINE.json names for N: 1 -> configs[1], 2 -> configs[2] (V2X-Real, line), 4 ->
+    configs[3] (V2X-Real VC, ring; max_cav 5, mc heads: lidar_attfuse_stage3.yaml:12), 8 -> configs[4] (OPV2V 512 x 512 grid,
+    opv2v/LiDAROnly/lidar_attfuse.yaml:17, max_cav 8, single-class heads, >= 40k pillars per agent).  The table itself, the synthetic
+    sweep it promises, and the launcher path at world 8 (gloo, no GPU) and at world 1 (used to die in init_process_group)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from quantv2x_amd import synth
+    want = {1: (1, "v2xreal", True, 5, "line"), 2: (2, "v2xreal", True, 5, "line"), 3: (3, "v2xreal", True, 5, "ring"), 4: (3, "v2xreal", True, 5, "ring"),
+            8: (4, "opv2v", False, 8, "ring")}
+    for n, (idx, shape, mc, cav, layout) in want.items():
+        wl = bench.workload_for(n)
+        assert (wl["index"], wl["shape"], wl["multiclass"], wl["max_cav"], wl["layout"]) == (idx, shape, mc, cav, layout), (n, wl)
+    w8 = bench.workload_for(8)
+    assert "8-agent OPV2V-H" in w8["workload"] and "8xMI355X" in w8["workload"]
+    sc = synth.make_scene(w8["shape"], n_agents=1, seed=3, n_points=w8["n_points"], max_cav=w8["max_cav"])
+    assert sc["inputs_m1"]["voxel_features"].shape[0] >= 40000 and sc["pairwise_t_matrix"].shape[1] == 8
+    hy = synth.make_hypes(w8["shape"], multiclass=False)
+    assert synth.grid_size(*synth.SHAPES["opv2v"][:2])[:2] == (512, 512)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run-ranks", "--ego-only"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    c = line["config"]
+    assert line["n_gpus"] == 8 and line["ranks_joined"] and line["ego_only"]
+    assert c["baseline_config_index"] == 4 and c["shape"] == "opv2v" and c["voxel_grid"] == [512, 512] and c["feature_map"] == [256, 256]
+    assert c["max_cav"] == 8 and c["multiclass_heads"] is False and c["agents_per_frame"] == 8 and "OPV2V-H" in c["workload"]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dry-run-ranks"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["config"]["baseline_config_index"] == 1 and line["config"]["shape"] == "v2xreal"

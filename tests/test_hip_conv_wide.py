@@ -80,15 +80,15 @@ def test_wide_matches_regular_and_oracle(n, h, w, groups, cout):
     d.out_delta, d.out_zp = layer.out_q[0], float(layer.out_q[1])
     st = L.current_stream()
     outs = []
-    # the regular kernel, then the wide one: auto, plain, ping-pong, software-pipelined (one input group of 1 | 2 | 4 chunks)
-    forms = [None, 0, 1] + ([2] if len(groups) == 1 else []) + ([3] if len(groups) == 1 and cin in (64, 128, 256) else [])
+    # the regular (im2col) kernel, then the halo-patch one
+    forms = [None, 0]
     for form in forms:
         out = torch.full((n, h + 2, w + 2, cout), -77, dtype=torch.int8, device=dev)
         if form is not None:
             w_wide = torch.empty_like(layer.w)
             L.check(lib.qv2x_conv3x3_i8_pack_wide(C.byref(d), L.ptr(layer.w), L.ptr(w_wide), st), "pack")
-            L.check(lib.qv2x_conv3x3_i8_wide_form(C.byref(d), L.ptr(xin), L.ptr(w_wide), L.ptr(layer.scale), L.ptr(layer.corr),
-                                                  L.ptr(layer.aw), L.ptr(layer.bias), L.ptr(out), form, st), "wide")
+            L.check(lib.qv2x_conv3x3_i8_wide(C.byref(d), L.ptr(xin), L.ptr(w_wide), L.ptr(layer.scale), L.ptr(layer.corr),
+                                             L.ptr(layer.aw), L.ptr(layer.bias), L.ptr(out), st), "wide")
         else:
             L.check(lib.qv2x_conv3x3_i8(C.byref(d), L.ptr(xin), L.ptr(layer.w), L.ptr(layer.scale), L.ptr(layer.corr),
                                         L.ptr(layer.aw), L.ptr(layer.bias), L.ptr(out), st), "regular")
@@ -141,8 +141,8 @@ def test_wide_stride2_matches_regular_and_oracle(n, h, w, cin, cout):
         if wide:
             w_wide = torch.empty_like(layer.w)
             L.check(lib.qv2x_conv3x3_i8_pack_wide(C.byref(d), L.ptr(layer.w), L.ptr(w_wide), st), "pack")
-            L.check(lib.qv2x_conv3x3_i8_wide_form(C.byref(d), L.ptr(xin), L.ptr(w_wide), L.ptr(layer.scale), L.ptr(layer.corr),
-                                                  L.ptr(layer.aw), L.ptr(layer.bias), L.ptr(out), 1, st), "wide")
+            L.check(lib.qv2x_conv3x3_i8_wide(C.byref(d), L.ptr(xin), L.ptr(w_wide), L.ptr(layer.scale), L.ptr(layer.corr),
+                                             L.ptr(layer.aw), L.ptr(layer.bias), L.ptr(out), st), "wide")
         else:
             L.check(lib.qv2x_conv3x3_i8(C.byref(d), L.ptr(xin), L.ptr(layer.w), L.ptr(layer.scale), L.ptr(layer.corr),
                                         L.ptr(layer.aw), L.ptr(layer.bias), L.ptr(out), st), "regular")
@@ -178,9 +178,7 @@ def test_wide_rejects_unsupported():
     d.stride = 3
     rc = lib.qv2x_conv3x3_i8_wide(C.byref(d), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), None)
     assert rc != 0 and b"stride" in lib.qv2x_last_error()
-    d.stride, d.ngroups, d.cin_total = 1, 2, 128
+    d.stride, d.ngroups, d.cin_total, d.cout = 2, 2, 128, 256
     d.group_c0[1], d.group_c[1] = 64, 64
-    rc = lib.qv2x_conv3x3_i8_wide_form(C.byref(d), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), 2, None)
-    assert rc != 0 and b"one input group" in lib.qv2x_last_error()      # the ping-pong form folds one group only
-    rc = lib.qv2x_conv3x3_i8_wide_form(C.byref(d), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), 7, None)
-    assert rc != 0 and b"form 7" in lib.qv2x_last_error()
+    rc = lib.qv2x_conv3x3_i8_wide(C.byref(d), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), L.ptr(x), None)
+    assert rc != 0 and b"one input group" in lib.qv2x_last_error()      # the stride-2 form folds one group only

@@ -107,7 +107,8 @@ def test_v2xreal_properties_four_agents(v2xreal):
 
 
 def test_v2xreal_batch_of_eight_frames_exact(v2xreal):
-    """The throughput configuration of bench.py: eight single-agent frames in one batch.  At this size every stride-1 layer of the
+    """Eight single-agent frames in one batch (rounds 1-2's throughput configuration; the bench's own batch of 32 is
+    test_bench_configuration_batch32_two_streams_exact below).  At this size every stride-1 layer of the
     backbone runs on the halo-patch kernel (64 / 128 output channels per workgroup, the 25 x 88 level split in two channel halves);
     every uint8 activation of the encode side and every codebook index against the oracle, frame by frame."""
     from quantv2x_amd import synth
@@ -132,3 +133,55 @@ def test_v2xreal_batch_of_eight_frames_exact(v2xreal):
         for n in names:
             np.testing.assert_array_equal(got[n][f], ot[n][0], err_msg=f"frame {f}: {n}")
         np.testing.assert_array_equal(codes[:, f].reshape(ot["codes"].shape[0], -1), ot["codes"].reshape(ot["codes"].shape[0], -1), err_msg=f"frame {f}: codes")
+
+
+def test_bench_configuration_batch32_two_streams_exact():
+    """bench.py's own configuration, built by bench.py's own functions: B = 32 single-agent V2X-Real frames per HIP
+    graph (``bench.build_engine`` + ``bench.frame_batch`` + ``eng.capture(full)``), TWO engines on TWO streams, replayed twice in the
+    bench's round-robin order.  288 MB canvases, 2-9 persistent items per conv workgroup, 9 M-thread grids: the codebook indices of all
+    32 frames of BOTH engines and the shrinker's uint8 map of 4 frames, bit for bit against the oracle; the predictions of the
+    graphs' output dict against it for the same 4 frames."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    from _common import head_lsb, interior_u8
+    from oracle.spec import Oracle
+    from quantv2x_amd import synth
+    from quantv2x_amd.engine import deploy
+    B, F = 32, 2
+    wl = bench.workload_for(1)
+    bench.SHAPE, bench.N_POINTS = wl["shape"], wl["n_points"]
+    state, eng, _, _ = bench.build_engine(min(32, os.cpu_count() or 8), multiclass=wl["multiclass"])
+    _, full, _, _ = bench.frame_batch(1, 0, B, torch.device("cuda"), layout=wl["layout"], max_cav=wl["max_cav"])
+    engines = [eng] + [deploy(state=state) for _ in range(F - 1)]
+    streams = [torch.cuda.Stream() for _ in range(F)]
+    reps = []
+    for e, st in zip(engines, streams):
+        with torch.cuda.stream(st):
+            reps.append(e.capture(full))
+    torch.cuda.synchronize()
+    outs = [None] * F
+    for i in range(2 * F):                               # bench.py's step(): graph i % F on stream i % F, nothing waits in between
+        with torch.cuda.stream(streams[i % F]):
+            outs[i % F] = reps[i % F]()
+    torch.cuda.synchronize()
+    orc = Oracle(state)
+    codes = [e._workspace(B)["codes"].cpu().numpy() for e in engines]               # [levels, B, H*W]
+    preds = [o["preds_tensor"].cpu().numpy() for o in outs]
+    lsb = head_lsb(state)
+    assert torch.equal(engines[0]._workspace(B)["s1"], engines[1]._workspace(B)["s1"])
+    for f in range(B):
+        sc = synth.make_scene(wl["shape"], n_agents=1, seed=3 + f, n_points=wl["n_points"], layout=wl["layout"], max_cav=wl["max_cav"])
+        ot = {}
+        want = orc.forward(sc, ot)
+        oc = ot["codes"].reshape(ot["codes"].shape[0], -1)
+        for k in range(F):
+            np.testing.assert_array_equal(codes[k][:, f], oc, err_msg=f"engine {k} frame {f}: codebook indices")
+        if f % 8 == 0:
+            for k in range(F):
+                got = interior_u8(engines[k]._workspace(B)["s1"][f:f + 1])[0]
+                np.testing.assert_array_equal(got, ot["shrinker_m1.layers.0.double_conv.1"][0], err_msg=f"engine {k} frame {f}: shrinker map")
+                d = np.abs(preds[k][f] - want["preds_tensor"][0])
+                assert d.max() <= lsb * 1.001 and (d > 1e-5).mean() < 1e-3, (k, f, d.max())

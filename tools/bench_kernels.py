@@ -16,8 +16,6 @@ eng = deploy(path=os.path.join(os.path.dirname(os.path.abspath(__file__)), "cach
 import bench
 dd = bench.frame_batch(1, 0, n, torch.device("cuda", 0))[1]          # n single-agent frames (a batch), as bench.py builds them
 eng.use_chains = chains
-if os.environ.get("QV2X_WIDE_FORM"):          # dev: name the wide kernel's form (include/qv2x.h QV2X_WIDE_*) for every layer that can take it
-    eng.wide_form = int(os.environ["QV2X_WIDE_FORM"])
 eng(dd); torch.cuda.synchronize()
 
 

@@ -1,9 +1,12 @@
 #!/bin/bash
 # Round evidence on the GPU box, in three separate gpurun calls (raw profiler output is deleted before the call ends: gpurun_out/ is capped at 64 MiB):
-#   gpurun --timeout 1500 -- 'bash tools/final_evidence.sh r03 tests'      GPU tests + the bench line
-#   gpurun --timeout 900  -- 'bash tools/final_evidence.sh r03 trace'      rocprofv3 --kernel-trace --stats of the bench command
-#   gpurun --timeout 1500 -- 'bash tools/final_evidence.sh r03 pmc'        FETCH_SIZE, WRITE_SIZE, MFMA-busy passes
-tag=${1:-r03}; what=${2:-tests}
+#   gpurun --timeout 1500 -- 'bash tools/final_evidence.sh r04 tests'      GPU tests + the bench line
+#   gpurun --timeout 900  -- 'bash tools/final_evidence.sh r04 trace'      rocprofv3 --kernel-trace --stats of the bench command
+#   gpurun --timeout 1500 -- 'bash tools/final_evidence.sh r04 pmc'        FETCH_SIZE, WRITE_SIZE, MFMA-busy passes
+# The trace runs the bench with ONE batch in flight (--inflight 1): with two streams the launches of one stream wait behind the other's
+# and the trace's average duration is not the kernel's time (17.6 ms "average" inside a 16.5 ms step).  A second trace at
+# the default two batches in flight is kept beside it.  The PMC passes run --steps 4 --warmup 1 (the counters are per launch).
+tag=${1:-r04}; what=${2:-tests}
 out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
 if [ $what = tests ]; then
@@ -11,11 +14,16 @@ if [ $what = tests ]; then
   python bench.py > $out/bench_n1.json 2> $out/bench_n1.err; tail -c 300 $out/bench_n1.json
 fi
 if [ $what = trace ]; then
+  rocprofv3 --kernel-trace --stats -d /tmp/prof1 -o bench -- python3 bench.py --no-cpu-baseline --no-extras --steps 30 --warmup 5 --inflight 1 > $out/bench_n1_under_rocprof_inflight1.json 2> $out/prof1.err
+  db=$(find /tmp/prof1 -name "*results.db" | head -1)
+  python tools/rocpd_stats.py $db > $out/bench_n1_kernel_stats_inflight1.txt 2>&1
+  python tools/prof_summary.py $db 60 > $out/bench_n1_kernel_stats_by_grid_inflight1.txt 2>&1
+  head -30 $out/bench_n1_kernel_stats_by_grid_inflight1.txt
+  rm -rf /tmp/prof1
   rocprofv3 --kernel-trace --stats -d /tmp/prof -o bench -- python3 bench.py --no-cpu-baseline --no-extras --steps 30 --warmup 5 > $out/bench_n1_under_rocprof.json 2> $out/prof.err
   db=$(find /tmp/prof -name "*results.db" | head -1)
   python tools/rocpd_stats.py $db > $out/bench_n1_kernel_stats.txt 2>&1
   python tools/prof_summary.py $db 60 > $out/bench_n1_kernel_stats_by_grid.txt 2>&1
-  head -30 $out/bench_n1_kernel_stats_by_grid.txt
 fi
 if [ $what = pmc ]; then
   for c in FETCH_SIZE WRITE_SIZE; do
