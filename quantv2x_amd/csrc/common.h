@@ -34,38 +34,46 @@ __device__ __forceinline__ float q_code(float y, float delta, float zp) {
 // Four outputs -> one dword of (code - 128) bytes (byte e = element e), the same values q_code gives.  `rdelta` = 1.0f / delta,
 // hoisted by the caller.  The product p = y * rdelta is within 1.2e-7 |p| of y / delta and fl(y / delta) within 6e-8 more; a code only
 // depends on rint(.) for |p| < 256.5 (0 <= zp <= 255: beyond that both values clamp to 0 or 255 even when they differ by one), where the
-// gap is < 4.7e-5, so the two round alike unless p lies within 1e-4 of a half-integer.
-//   r = fma(y, rdelta, zp + 2^23)    ONE rounding of the exact p + zp + 2^23 to an integer (ulp 1 in [2^23, 2^24)): r = code + 2^23
-//   e = fma(y, rdelta, (zp + 2^23) - r) = fl(p - k), k = r - zp - 2^23 exactly: how far p is from the integer it was rounded to
+// gap is < 4.7e-5.  Round 4: a SANDWICH instead of a residual test --
+//   tA = fma(y, rdelta, zp + 1e-4),  tB = fma(y, rdelta, zp - 1e-4)      (fp32: zp +- 1e-4 keeps >= 9.2e-5 of the offset at zp <= 255)
+//   cA = v_cvt_pk_u8_f32(tA), cB = v_cvt_pk_u8_f32(tB)                   (round to nearest even, saturate to 0..255, insert byte e:
+//                                                                          tools/probes/cvt_pk_u8_probe.hip, profiles/r04_cvt_pk_u8_probe.log)
+// fl, rint and the clamp are monotone and tB_exact < fl(y / delta) + zp < tA_exact, so cA == cB pins the exact code between two equal
+// values; where they differ (y / delta within ~1e-4 of a half-integer, exact ties included: 5 % of the groups of 256 outputs) the wave
+// takes the exact divisions.  6.25 -> 4.5 instructions per output (no v_med3, no v_perm: the conversion clamps and packs) -- the epilogues
+// are bound by the SIMD's VALU issue, DESIGN.md 3.
+// `lowc`: lowest code + 2^23 (the callers' convention since round 3): 8388608.0f (code 0) for the plain quantizer; zp + 2^23 folds a ReLU
+// in front of the quantizer into the clamp -- rint is monotone and rint(0) = 0, so q(max(y, 0)) = max(rint(y / delta), 0) + zp.  With
+// zp = 0 (every post-ReLU quantizer the reference's observers produce: the observed minimum is 0) the saturation IS that clamp.
 // NaN / Inf contract: the callers' y are finite by construction (an exact i32 sum times a finite per-channel scale plus a finite bias; fp32
-// dot products of finite codes and finite weights) -- deploy refuses non-finite scales, biases and deltas (ptq_state.py).  An infinite y
-// clamps like any out-of-range value; a NaN y yields an UNSPECIFIED code (v_med3_f32 with a NaN operand), where q_code's fminf(fmaxf())
-// gave code 0: nothing on the parity path depends on it (tools/probes/q_pack4_probe.hip lists the behaviour).
-// One test per group of four: max |e| > 0.4999 on any lane sends the wave through the exact divisions (5 % of the groups).  Below code 0
-// (p + zp < 0) r falls under 2^23 where its ulp is 1/2 and k may be a half-integer: the clamp sets those to the lowest code, which is what
-// they are.  The clamped code is read from the low mantissa byte of r.  (Round 3: 5.25 instead of 7.25 instructions per output -- the
-// epilogues are bound by the SIMD's VALU issue)
-// `lowc`: lowest code + 2^23.  8388608.0f (code 0) for the plain quantizer; zp + 2^23 folds a ReLU in front of the quantizer into the
-// clamp -- rint is monotone and rint(0) = 0, so q(max(y, 0)) = max(rint(y / delta), 0) + zp -- and saves the caller one fmaxf per output.
+// dot products of finite codes and finite weights) -- deploy refuses non-finite scales, biases and deltas (ptq_state.check_finite).  An
+// infinite y saturates like any out-of-range value; a NaN y converts to code 0 on both sides of the sandwich (v_cvt_pk_u8_f32(NaN) = 0), the
+// lowest code, as q_code's fminf(fmaxf()) gave (ReLU layers with zp > 0: zp, through the v_max below).
+// The sandwich in pieces, for epilogues that requantize ONE output between two MFMAs (conv_i8_ws.hip): add element e of a group of four ...
+__device__ __forceinline__ void q_sandwich_add(float y, int e, float rdelta, float za, float zb, unsigned& ca, unsigned& cb) {
+    ca = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(y, rdelta, za), e, ca);
+    cb = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(y, rdelta, zb), e, cb);
+}
+// ... and close the group: the four (code - 128) bytes.  `low` = lowest code (0, or zp under a folded ReLU: uniform).  A ReLU folded in
+// front of a quantizer with zp > 0 needs a lower clamp the conversion does not have: such a layer (none of the reference's post-ReLU
+// observers produces one: their minimum is 0) takes the exact path for every group -- correct, slower.
+__device__ __forceinline__ int q_sandwich_finish(unsigned ca, unsigned cb, float y0, float y1, float y2, float y3, float delta, float zp, float low) {
+    if ((__builtin_amdgcn_ballot_w64(ca != cb) != 0) | (low > 0.0f)) {
+        const float y[4] = {y0, y1, y2, y3};
+        ca = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ca = __builtin_amdgcn_cvt_pk_u8_f32(fmaxf(rintf(y[e] / delta) + zp, low), e, ca);   // (an integer: converts exactly)
+    }
+    return (int)(ca ^ 0x80808080u);
+}
 __device__ __forceinline__ int q_pack4(float y0, float y1, float y2, float y3, float delta, float rdelta, float zp, float lowc = 8388608.0f) {
-    const float y[4] = {y0, y1, y2, y3};
-    const float zm = zp + 8388608.0f;
-    float r[4], dmax = 0.0f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        r[e] = __builtin_fmaf(y[e], rdelta, zm);
-        dmax = fmaxf(dmax, fabsf(__builtin_fmaf(y[e], rdelta, zm - r[e])));
-    }
-    if (__builtin_amdgcn_ballot_w64(dmax > 0.4999f) != 0) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] = rintf(y[e] / delta) + zm;
-    }
-    unsigned b[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) b[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_fmed3f(r[e], lowc, 8388863.0f));   // ONE v_med3_f32 (fminf(fmaxf()) is two: NaN rules); r is never NaN here
-    const unsigned lo = __builtin_amdgcn_perm(b[1], b[0], 0x0c0c0400u);      // byte 0 of b0, byte 0 of b1
-    const unsigned hi = __builtin_amdgcn_perm(b[3], b[2], 0x0c0c0400u);
-    return (int)(__builtin_amdgcn_perm(hi, lo, 0x05040100u) ^ 0x80808080u);
+    const float za = zp + 1.0e-4f, zb = zp - 1.0e-4f;
+    unsigned ca = 0, cb = 0;
+    q_sandwich_add(y0, 0, rdelta, za, zb, ca, cb);
+    q_sandwich_add(y1, 1, rdelta, za, zb, ca, cb);
+    q_sandwich_add(y2, 2, rdelta, za, zb, ca, cb);
+    q_sandwich_add(y3, 3, rdelta, za, zb, ca, cb);
+    return q_sandwich_finish(ca, cb, y0, y1, y2, y3, delta, zp, lowc - 8388608.0f);
 }
 
 // C/D fragment row of register r for the 32x32 MFMA forms (cdna guide §3): row = (r&3) + 8*(r>>2) + 4*(lane>>5)

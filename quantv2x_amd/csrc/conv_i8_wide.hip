@@ -18,6 +18,11 @@
 
 namespace qv2x {
 
+// conv_i8_ws.hip: the weights-stationary form for layers with 64 input channels (same w_wide layout, same results)
+bool ws64_takes(const qv2x_conv_desc* d);
+int launch_ws64(const qv2x_conv_desc* d, const int8_t* in, const int8_t* w_wide, const float* scale, const int32_t* corr, const int32_t* aw,
+                const float* bias, int8_t* out, hipStream_t st);
+
 namespace {
 
 constexpr int TH = 5, TW = 32, HWD = TW + 2, HPIX = (TH + 2) * HWD;    // 238 halo pixels
@@ -647,6 +652,9 @@ extern "C" int qv2x_conv3x3_i8_wide(const qv2x_conv_desc* d, const int8_t* in, c
     if (int rc = fill_args(d, a)) return rc;
     a.in = in; a.wt = w_wide; a.scale = scale; a.corr = corr; a.aw = aw; a.bias = bias; a.out = out;
     hipStream_t st = (hipStream_t)stream;
+#ifndef QV2X_NO_WS64
+    if (ws64_takes(d)) return launch_ws64(d, in, w_wide, scale, corr, aw, bias, out, st);
+#endif
     const int patches8 = (a.n * a.tiles_x * a.tiles_y + 7) / 8 * 8;   // block ids come in groups of 8 (one per XCD)
     const int bn = wide_bn(d);
     a.items = patches8 * (a.cout / bn);

@@ -55,6 +55,11 @@ def _padded(x_u8, zx_per_channel):
     (64, 50, 96, [(0, 128)], 128),          # 1920 items on 512 four-wave groups: 3 or 4 each, two chunks (three slots per item)
     (24, 25, 88, [(0, 256)], 256),          # the 25 x 88 level: 360 patches x two 128-channel blocks on 512 groups, four chunks
     (2, 10, 40, [(0, 192)], 128),           # three chunks (odd): the late half starts two slots behind; most groups idle
+    # round 4: the weights-stationary form (conv_i8_ws.hip: 64 -> 64 channels, stride 1, from 1024 patches of 10 x 32 on)
+    (90, 33, 70, [(0, 64)], 64),            # 1080 patches, ragged on both axes (3 of 10 rows, 6 of 32 columns): 2 or 3 items per workgroup
+    (10, 100, 352, [(0, 64)], 64),          # the V2X-Real level-0 map: 10 x 11 exact patches per frame
+    (1100, 7, 20, [(0, 64)], 64),           # one mostly empty patch per image: the second row group stores two rows of five
+    (32, 101, 65, [(0, 64)], 64),           # 11 x 3 patches per image, one row and one column into the last patch
 ])
 def test_wide_matches_regular_and_oracle(n, h, w, groups, cout):
     from oracle.spec import Oracle

@@ -55,5 +55,15 @@ int main() {
         }
     }
     printf("q_pack4 vs clamp(rintf(y / delta) + zp): %lld mismatches of %lld\n", bad, total);
+    // the NaN / Inf contract of common.h: NaN -> the lowest code, +-Inf saturate
+    for (int relu = 0; relu < 2; ++relu) {
+        const float special[8] = {NAN, INFINITY, -INFINITY, 0.0f, NAN, 1e30f, -1e30f, -0.0f};
+        hipMemcpy(dy, special, sizeof(special), hipMemcpyHostToDevice);
+        run<<<1, 64>>>(dy, 8, 0.05f, 7.0f, relu, dout);
+        int o[2]; hipMemcpy(o, dout, 8, hipMemcpyDeviceToHost);
+        printf("relu=%d zp=7: q(NaN, +Inf, -Inf, 0) = %d %d %d %d | q(NaN, 1e30, -1e30, -0) = %d %d %d %d\n", relu,
+               ((o[0]) & 255) ^ 128, ((o[0] >> 8) & 255) ^ 128, ((o[0] >> 16) & 255) ^ 128, ((o[0] >> 24) & 255) ^ 128,
+               ((o[1]) & 255) ^ 128, ((o[1] >> 8) & 255) ^ 128, ((o[1] >> 16) & 255) ^ 128, ((o[1] >> 24) & 255) ^ 128);
+    }
     return bad != 0;
 }
