@@ -234,6 +234,16 @@ int qv2x_dequant_i8_f32(const int8_t* in, int n, int h, int w, int c, int zp, fl
 int qv2x_heads_f32(const float* x, int R, int hw, int cout, int cout_pad, const float* w, const float* bias,
                    const float* da, const float* za, float* out, void* stream);
 
+/* a7-a11 in ONE launch (round 4): qv2x_fuse_att_batch_f32 followed by qv2x_heads_f32 on the fused rows, tile by tile in LDS -- the fused
+ * fp32 map (36 MB per V2X-Real frame) is neither written nor read back (heter_model_baseline.py:237-260 over fusion_in_one.py:126-151).
+ * Same arithmetic as the two calls, bit for bit.  out f32 NCHW [n_scenes][cout][hw]; `fused_tap` (optional, may be null): receives the
+ * fused rows f32 [n_scenes][hw][256] as well (parity tests, debugging).  Pays from a few rounds of 32-cell tiles on (a batch of frames);
+ * one frame alone is faster as two launches. */
+int qv2x_fuse_heads_batch_f32(const qv2x_fuse_desc* desc /* host */, int n_scenes, const int64_t* scene_offset /* host */,
+                              const int32_t* scene_agents /* host */, const uint8_t* codes, const float* lut, const float* lut_bias,
+                              const float* feats, const double* pairwise, int cout, int cout_pad, const float* w, const float* bias,
+                              const float* da, const float* za, float* out, float* fused_tap, void* stream);
+
 /* *_preds_single (heter_model_baseline.py:224-230) in one launch: qv2x_decode_lut_f32 followed by qv2x_heads_f32 on
  * every agent's own decoded feature.  codes u8 [levels][R], rows agent-major (R = agents * hw); out f32 [agents][cout][hw]. */
 int qv2x_decode_heads_f32(const uint8_t* codes, int R, int hw, int levels, int kc, const float* lut, const float* lut_bias,

@@ -231,10 +231,10 @@ class Oracle:
         return outs
 
     # ---- whole path ----------------------------------------------------------------------------
-    def forward(self, scene, taps=None):
-        n_agents = len(scene["agent_modality_list"])
+    def canvas(self, scene, n_agents, taps=None):
+        """a1 + a2 (PointPillar) or a13 (SECOND: oracle/spec_second.py) on ``scene["inputs_m1"]``: the uint8 BEV canvas and its quantizer."""
         taps = {} if taps is None else taps
-        if "meta/encoder" in self.s and str(self.s["meta/encoder"]) == "second":      # a13 (oracle/spec_second.py) in front of the same 2-D path
+        if "meta/encoder" in self.s and str(self.s["meta/encoder"]) == "second":
             from .spec_second import OracleSecond
             sec = OracleSecond(self.s)
             last = f"second/{sec.n_layers - 1}/"
@@ -244,6 +244,12 @@ class Oracle:
         else:
             pcodes, canvas, cq = self.pfn_scatter(scene, n_agents)
             taps["pillar_code"], taps["canvas"] = pcodes, canvas
+        return canvas, cq
+
+    def forward(self, scene, taps=None):
+        n_agents = len(scene["agent_modality_list"])
+        taps = {} if taps is None else taps
+        canvas, cq = self.canvas(scene, n_agents, taps)
         cat, cat_q = self.backbone(canvas, cq, taps)
         shr, shr_q = self.shrinker(cat, cat_q, taps)
         taps["shrinker_q"] = shr_q

@@ -117,6 +117,10 @@ __device__ __forceinline__ float4 fuse_cell_n(const FuseArgs& a, int cell, int l
     return o;
 }
 
+// several scenes in one launch: scene s = `agents[s]` agents whose data starts `off[s]` bytes into the codes (floats into feats)
+constexpr int MAX_SCENES = 64;
+struct SceneList { long long off[MAX_SCENES]; int agents[MAX_SCENES]; };
+
 // host: smallest compiled bound that covers `agents`
 inline int fuse_bound(int agents) { return agents <= 1 ? 1 : (agents <= 2 ? 2 : (agents <= 4 ? 4 : MAXA)); }
 

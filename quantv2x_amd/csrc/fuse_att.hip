@@ -19,9 +19,7 @@ __global__ __launch_bounds__(256) void fuse_att_kernel(const FuseArgs a) {
     a.fused[(size_t)cell * 64 + lane] = fuse_cell_n<NA>(a, cell, lane);
 }
 
-// several scenes in one launch: blockIdx.y = scene
-constexpr int MAX_SCENES = 64;
-struct SceneList { long long off[MAX_SCENES]; int agents[MAX_SCENES]; };
+// several scenes in one launch: blockIdx.y = scene (SceneList: fuse_att.h)
 
 template <int NA>
 __global__ __launch_bounds__(256) void fuse_att_batch_kernel(FuseArgs a, const SceneList sl) {

@@ -18,7 +18,12 @@ namespace qv2x {
 // (Computing the FUSED rows in here as well -- fuse_cell() for 8 cells per wave, then the heads -- was measured slower than
 // the two launches: 62.8 vs 24.0 + 31.7 us at one agent, 198 vs 93 + 32 us at four; the gather-latency-bound fusion wants
 // one short-lived wave per cell and many of them per CU, which a 32-row GEMM tile does not give it.)
-enum { ROWS_GLOBAL = 0, ROWS_DECODE = 2 };
+//   ROWS_FUSE<NA> (round 4) the FUSED rows themselves -- decode + warp + attention (fuse_cell_n, fuse_att.h) for the wave's eight cells --
+//                so the 36 MB-per-frame fused map is neither written nor read back.  Rounds 1-2 measured this form at ONE frame (1100
+//                workgroups = one round of the chip: a launch lasts as long as one tile's dependent chain, 62.8 against 24.0 + 31.7 us) and
+//                dropped it; a batch of 32 frames is 27 rounds, where what counts is throughput and the 2.3 GB of map traffic.  Same
+//                arithmetic as the two launches, bit for bit.  `fused_tap` (optional) still receives the rows (debug / parity tests).
+enum { ROWS_GLOBAL = 0, ROWS_DECODE = 2, ROWS_FUSE = 3 };
 
 #ifdef QV2X_HEADS_TRACE     // dev build only (tools/heads_trace.py): s_memtime stamps of thread 0 of every workgroup
 __device__ long long g_heads_trace[32768 * 6];
@@ -32,8 +37,8 @@ struct HeadArgs {
     const float* w; const float* bias; const float* da; const float* za; float* out;
 };
 
-template <int SRC>
-__device__ __forceinline__ void rows_heads_tile(const HeadArgs& h, const FuseArgs& fa, const int tm, float* smem) {
+template <int SRC, int NA = 1>
+__device__ __forceinline__ void rows_heads_tile(const HeadArgs& h, const FuseArgs& fa, const int tm, float* smem, const SceneList* sl = nullptr) {
     float* rows = smem;
     HTRACE(0);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -48,6 +53,25 @@ __device__ __forceinline__ void rows_heads_tile(const HeadArgs& h, const FuseArg
             const int mc = m < h.R ? m : h.R - 1;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(h.x + (size_t)mc * 256 + ((lane ^ r) << 2)),
                                              (__attribute__((address_space(3))) void*)(rows + r * 256), 16, 0, 0);
+        }
+    } else if (SRC == ROWS_FUSE) {
+#pragma unroll 1
+        for (int j = 0; j < 8; ++j) {
+            const int r = wave * 8 + j;
+            int m = tm * 32 + r;
+            m = __builtin_amdgcn_readfirstlane(m);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < h.R) {
+                const int sc = m / h.hw, cell = m - sc * h.hw;
+                FuseArgs a = fa;                               // this row's scene: its agents, where their data starts, its pairwise block
+                a.agents = sl->agents[sc];
+                if (a.feats) a.feats = (const float4*)((const float*)a.feats + sl->off[sc]);
+                else a.codes += sl->off[sc];
+                a.pairwise += (size_t)sc * a.L * a.L * 16;
+                v = fuse_cell_n<NA>(a, cell, lane);
+                if (fa.fused) fa.fused[(size_t)m * 64 + lane] = v;
+            }
+            *(float4*)(rows + r * 256 + ((lane ^ r) << 2)) = v;
         }
     } else {
         // the wave's eight rows, four at a time: all their code bytes first, then all their table rows, then the sums in level order
@@ -181,6 +205,13 @@ __global__ __launch_bounds__(256) void rows_heads_kernel(const HeadArgs h, const
     rows_heads_tile<SRC>(h, fa, blockIdx.x, smem);
 }
 
+// a7-a11 in one launch: every 32-cell tile is fused (decode + warp + attention) and multiplied by the heads where it stands
+template <int NA>
+__global__ __launch_bounds__(256) void fuse_heads_kernel(const HeadArgs h, const FuseArgs fa, const SceneList sl) {
+    __shared__ __attribute__((aligned(16))) float smem[32 * 256];
+    rows_heads_tile<ROWS_FUSE, NA>(h, fa, blockIdx.x, smem, &sl);
+}
+
 // The fused-feature heads (rows from memory) and the *_single heads (rows decoded from the codes) of one frame in ONE
 // launch, blockIdx.y = job: two 1100-workgroup grids whose copy-in / GEMM / store phases interleave, one launch gap less.
 // (block id = 16 (tile / 8) + 8 job + tile % 8: block ids go round the eight XCDs, so the job bit sits above them -- every XCD and CU gets
@@ -293,6 +324,40 @@ extern "C" int qv2x_heads_f32(const float* x, int R, int hw, int cout, int cout_
     h.x = x;
     rows_heads_kernel<ROWS_GLOBAL><<<(R + 31) / 32, 256, 0, (hipStream_t)stream>>>(h, FuseArgs{});
     return hip_check(hipGetLastError(), "qv2x_heads_f32 launch");
+}
+
+extern "C" int qv2x_fuse_heads_batch_f32(const qv2x_fuse_desc* d, int n_scenes, const int64_t* scene_offset, const int32_t* scene_agents,
+                                         const uint8_t* codes, const float* lut, const float* lut_bias, const float* feats, const double* pairwise,
+                                         int cout, int cout_pad, const float* w, const float* bias, const float* da, const float* za,
+                                         float* out, float* fused_tap, void* stream) {
+    using namespace qv2x;
+    const char* who = "qv2x_fuse_heads_batch_f32";
+    if (!scene_offset || !scene_agents || !d) return fail(QV2X_EINVAL, "%s: null pointer", who);
+    if (n_scenes < 1 || n_scenes > MAX_SCENES) return fail(QV2X_EINVAL, "%s: 1..%d scenes, got %d", who, MAX_SCENES, n_scenes);
+    SceneList sl{};
+    int most = 1;
+    for (int s = 0; s < n_scenes; ++s) {
+        if (scene_offset[s] < 0 || (feats && scene_offset[s] % 4) || scene_agents[s] < 1 || scene_agents[s] > MAXA || scene_agents[s] > d->max_cav || d->ego >= scene_agents[s])
+            return fail(QV2X_EINVAL, "%s: scene %d: offset %lld, agents %d (1..%d, <= max_cav, > ego)", who, s, (long long)scene_offset[s], scene_agents[s], MAXA);
+        sl.off[s] = scene_offset[s]; sl.agents[s] = scene_agents[s];
+        most = scene_agents[s] > most ? scene_agents[s] : most;
+    }
+    qv2x_fuse_desc d1 = *d;
+    d1.agents = most;
+    FuseArgs a;
+    if (int rc = fuse_args_from_desc(&d1, codes, lut, lut_bias, feats, pairwise, who, a)) return rc;
+    a.fused = (float4*)fused_tap;
+    HeadArgs h;
+    if (int rc = head_args(who, n_scenes * a.hw, a.hw, cout, cout_pad, w, bias, da, za, out, h)) return rc;
+    const dim3 grid((h.R + 31) / 32);
+    hipStream_t st = (hipStream_t)stream;
+    switch (fuse_bound(most)) {
+        case 1: fuse_heads_kernel<1><<<grid, 256, 0, st>>>(h, a, sl); break;
+        case 2: fuse_heads_kernel<2><<<grid, 256, 0, st>>>(h, a, sl); break;
+        case 4: fuse_heads_kernel<4><<<grid, 256, 0, st>>>(h, a, sl); break;
+        default: fuse_heads_kernel<MAXA><<<grid, 256, 0, st>>>(h, a, sl); break;
+    }
+    return hip_check(hipGetLastError(), "qv2x_fuse_heads_batch_f32 launch");
 }
 
 extern "C" int qv2x_decode_heads_f32(const uint8_t* codes, int R, int hw, int levels, int kc, const float* lut, const float* lut_bias,

@@ -222,6 +222,12 @@ class _Heads:
 
 class DeployedModel(nn.Module):
     """The hot path as HIP kernels.  Same call contract as the reference's model."""
+    # a7-a11 as ONE launch (qv2x_fuse_heads_batch_f32: the fused map stays in LDS) from this many 32-cell tiles on -- four rounds of the
+    # chip's 1280 resident workgroups; below it (one frame: a single round) the two launches are faster.  Measured at a batch of 32
+    # V2X-Real frames (profiles/r04_fuse_heads_times.log): single-agent scenes 1160 against 1224 us; scenes of four agents 780 against
+    # 632 us (eight serial cells per wave, each a chain of dependent gathers per agent) -- so only scenes of ONE agent take it.
+    fuse_heads_min_tiles = 4 * 1280
+    fuse_heads_max_agents = 1
 
     def __init__(self, state: Dict[str, np.ndarray], device="cuda", emit_single_preds: Optional[bool] = None):
         super().__init__()
@@ -634,14 +640,20 @@ class DeployedModel(nn.Module):
         ``+ f * frame_stride``); ``pairwise`` f64 [frames, L, L, 4, 4].  With ``own_codes`` (u8 [levels, frames, H*W]) the
         ``*_single`` heads of this rank's own agent run in the same launch as the heads on the fused maps."""
         hw = self.fh * self.fw
-        fused = torch.empty((frames, hw, 256), dtype=torch.float32, device=self.dev)
-        self.fuse_scenes(L.ptr(gathered), agent_stride, level_stride, None, pairwise, [f * frame_stride for f in range(frames)],
-                         [n_agents] * frames, fused, ego)
         sp = None
-        if self.heads_single is not None and own_codes is not None:
-            preds, sp = self._heads_pair(fused, frames, own_codes, frames)
+        if frames * hw // 32 >= self.fuse_heads_min_tiles and n_agents <= self.fuse_heads_max_agents:    # one launch, no fused map in HBM (see finish)
+            preds = self.fuse_heads_scenes(L.ptr(gathered), agent_stride, level_stride, None, pairwise, [f * frame_stride for f in range(frames)],
+                                           [n_agents] * frames, ego)
+            if self.heads_single is not None and own_codes is not None:
+                sp = self._decode_heads_single(own_codes, frames)
         else:
-            preds = self._run_heads(self.heads, fused, frames, hw)
+            fused = torch.empty((frames, hw, 256), dtype=torch.float32, device=self.dev)
+            self.fuse_scenes(L.ptr(gathered), agent_stride, level_stride, None, pairwise, [f * frame_stride for f in range(frames)],
+                             [n_agents] * frames, fused, ego)
+            if self.heads_single is not None and own_codes is not None:
+                preds, sp = self._heads_pair(fused, frames, own_codes, frames)
+            else:
+                preds = self._run_heads(self.heads, fused, frames, hw)
         c, r, _ = self.heads.splits
         out = {"cls_preds": preds[:, :c], "reg_preds": preds[:, c:c + r], "dir_preds": preds[:, c + r:], "preds_tensor": preds}
         if sp is not None:
@@ -706,6 +718,25 @@ class DeployedModel(nn.Module):
             L.check(self.lib.qv2x_fuse_att_batch_f32(C.byref(d), s1 - s0, offs, cnts, codes_ptr, lut, lb,
                                                      L.ptr(feats) if feats is not None else None, L.ptr(pairwise[s0]), L.ptr(out[s0]),
                                                      L.current_stream()), "qv2x_fuse_att_batch_f32")
+
+    def fuse_heads_scenes(self, codes_ptr, agent_stride, level_stride, feats, pairwise, offsets, counts, ego=0, fused_tap=None):
+        """a7-a11 for several scenes in ONE launch per 64 scenes (qv2x_fuse_heads_batch_f32): predictions f32 [scenes, cout, H, W]; the
+        fused map only exists tile by tile in LDS (``fused_tap`` f32 [scenes, H*W, 256], optional, receives a copy)."""
+        hd, hw = self.heads, self.fh * self.fw
+        out = torch.empty((len(counts), hd.cout, self.fh, self.fw), dtype=torch.float32, device=self.dev)
+        for s0 in range(0, len(counts), 64):
+            s1 = min(len(counts), s0 + 64)
+            d = self._fuse_desc(agent_stride, level_stride, pairwise[s0], max(counts[s0:s1]), ego)
+            offs = (C.c_int64 * (s1 - s0))(*offsets[s0:s1])
+            cnts = (C.c_int32 * (s1 - s0))(*counts[s0:s1])
+            lut = L.ptr(self.lut) if self.has_codebook else None
+            lb = L.ptr(self.lut_bias) if self.has_codebook else None
+            L.check(self.lib.qv2x_fuse_heads_batch_f32(C.byref(d), s1 - s0, offs, cnts, codes_ptr, lut, lb,
+                                                       L.ptr(feats) if feats is not None else None, L.ptr(pairwise[s0]),
+                                                       hd.cout, hd.cout_pad, L.ptr(hd.w), L.ptr(hd.bias), L.ptr(hd.da), L.ptr(hd.za), L.ptr(out[s0]),
+                                                       L.ptr(fused_tap[s0]) if fused_tap is not None else None, L.current_stream()),
+                    "qv2x_fuse_heads_batch_f32")
+        return out
 
     def fuse_and_heads(self, codes, agent_stride, level_stride, pairwise_b, n_agents, ego=0) -> dict:
         """a7-a11 on an (all-gathered) code tensor for one scene; ``pairwise_b`` f64 [L, L, 4, 4] on the device."""
@@ -810,14 +841,23 @@ class DeployedModel(nn.Module):
         # (no workspace of n_total agents here: a codebook model's post stage only needs the code planes it is handed -- the ego engine of a
         #  heterogeneous scene never encodes n_total agents itself)
         feats = None if self.has_codebook else self._shared_features(enc, n_total)
-        fused = torch.empty((nb, hw, 256), dtype=torch.float32, device=self.dev)
         starts = [sum(lens[:bi]) for bi in range(nb)]
-        if self.has_codebook:                                            # every scene of the call in one launch
+        one_launch = taps is None and nb * hw // 32 >= self.fuse_heads_min_tiles and max(lens) <= self.fuse_heads_max_agents
+        fused = None if one_launch else torch.empty((nb, hw, 256), dtype=torch.float32, device=self.dev)
+        if one_launch:                                                   # decode + warp + fusion + heads, tile by tile: no fused map in HBM
+            if self.has_codebook:
+                preds = self.fuse_heads_scenes(L.ptr(enc), hw, n_total * hw, None, pairwise, [st * hw for st in starts], lens)
+            else:
+                preds = self.fuse_heads_scenes(None, 0, 0, feats, pairwise, [st * hw * 256 for st in starts], lens)
+        elif self.has_codebook:                                          # every scene of the call in one launch
             self.fuse_scenes(L.ptr(enc), hw, n_total * hw, None, pairwise, [st * hw for st in starts], lens, fused)
         else:
             self.fuse_scenes(None, 0, 0, feats, pairwise, [st * hw * 256 for st in starts], lens, fused)
         sp = None
-        if self.heads_single is not None and self.has_codebook:
+        if one_launch:
+            if self.heads_single is not None and self.has_codebook:
+                sp = self._decode_heads_single(enc, n_total)
+        elif self.heads_single is not None and self.has_codebook:
             # the heads on the fused map and the *_single heads on every agent's own decoded feature: one launch
             preds, sp = self._heads_pair(fused, nb, enc, n_total)
         else:

@@ -45,7 +45,9 @@ SECOND_SHAPES = {
     "second_tiny": ([-12.8, -6.4, -3.0, 12.8, 6.4, 1.0], [0.1, 0.1, 0.1], 4096),        # 256 x 128 x 40 -> 32 x 16 BEV map (= "tiny")
     "second_small": ([-25.6, -12.8, -3.0, 25.6, 12.8, 1.0], [0.1, 0.1, 0.1], 16384),    # 512 x 256 x 40 -> 64 x 32
     "second_full": ([-140.8, -40.0, -3.0, 140.8, 40.0, 1.0], [0.1, 0.1, 0.1], 70000),   # 2816 x 800 x 40 -> 352 x 100
+    "second_opv2v": ([-102.4, -102.4, -3.0, 102.4, 102.4, 1.0], [0.1, 0.1, 0.1], 70000),  # 2048 x 2048 x 40 -> 256 x 256 (= "opv2v")
 }
+SECOND_OF = {"tiny": "second_tiny", "small": "second_small", "v2xreal": "second_full", "opv2v": "second_opv2v"}
 
 
 def make_second_args(shape: str = "second_tiny", num_features_out: int = 128) -> dict:
@@ -82,12 +84,14 @@ def grid_size(lidar_range: Sequence[float], voxel_size: Sequence[float]) -> Tupl
 
 def make_hypes(shape: str = "v2xreal", multiclass: bool = True, codebook: bool = True,
                supervise_single: bool = True, dict_size: int = 128, seg_num: int = 1, fusion: str = "att", compress_ratio: int = 0,
-               encoder: str = "point_pillar", modalities: Sequence[str] = ("m1",)) -> dict:
+               encoder: str = "point_pillar", modalities: Sequence[str] = ("m1",), encoders: Optional[Dict[str, str]] = None) -> dict:
     """Return a ``hypes`` dict with the ``model`` section the reference's yaml would give.  ``modalities=("m1", "m2")``: a heterogeneous
     model (heter_model_baseline.py:41-75: one encoder / backbone / shrinker per modality; here both LiDAR PointPillar, same architecture,
     their own weights).  ``encoder="second"``: the m1 modality is the
     SECOND encoder over ``SECOND_SHAPES["second_" + shape]`` (same metric range, 0.1 m voxels); its 256-channel map is already at the
-    resolution PointPillar's first backbone level reaches, so the backbone starts with stride 1 and ``inplanes: 256``."""
+    resolution PointPillar's first backbone level reaches, so the backbone starts with stride 1 and ``inplanes: 256``.
+    ``encoders={"m3": "second"}``: the encoder per modality (heter_model_baseline.py:47-59 picks it by each modality's ``core_method``) --
+    a MIXED-encoder model, e.g. ``modalities=("m1", "m3")`` with PointPillar agents and SECOND agents in one scene."""
     lidar_range, voxel_size, max_voxels, max_cav = SHAPES[shape]
     args = {
         "ego_modality": "m1",
@@ -124,16 +128,22 @@ def make_hypes(shape: str = "v2xreal", multiclass: bool = True, codebook: bool =
         args["use_codebook"] = True
     if compress_ratio:                                # hypes_yaml/v2x_real/Naive_Compressor/*: `compressor: {input_dim: 256, compress_ratio: 16}`
         args["compressor"] = {"input_dim": 256, "compress_ratio": int(compress_ratio)}
-    if encoder == "second":
-        sname = {"tiny": "second_tiny", "small": "second_small", "v2xreal": "second_full"}[shape]
-        args["m1"]["core_method"] = "second"
-        args["m1"]["encoder_args"] = make_second_args(sname)
-        args["m1"]["backbone_args"].update({"layer_strides": [1, 2, 2], "inplanes": 256})
-    elif encoder != "point_pillar":
+    if encoder not in ("second", "point_pillar"):
         raise ValueError(encoder)
+    kinds = {m: encoder for m in modalities}
+    kinds.update(encoders or {})
+    pillar_cfg = copy.deepcopy(args["m1"])
     for m in modalities:
-        if m != "m1":
-            args[m] = copy.deepcopy(args["m1"])
+        args[m] = copy.deepcopy(pillar_cfg)
+        if kinds[m] == "second":
+            args[m]["core_method"] = "second"
+            args[m]["encoder_args"] = make_second_args(SECOND_OF[shape])
+            args[m]["backbone_args"].update({"layer_strides": [1, 2, 2], "inplanes": 256})
+        elif kinds[m] != "point_pillar":
+            raise ValueError(kinds[m])
+    if "m1" not in modalities:
+        del args["m1"]
+        args["ego_modality"] = modalities[0]
     core = "heter_baseline_collab_codebook" if codebook else "heter_model_baseline"
     if multiclass:
         core += "_mc"
@@ -415,7 +425,7 @@ def pairwise_t_matrix(poses: Sequence[np.ndarray], max_cav: int) -> np.ndarray:
 
 def make_scene(shape: str = "v2xreal", n_agents: int = 1, seed: int = 0, n_points: int = 60000,
                layout: str = "line", sigma_m: Optional[float] = None, max_cav: Optional[int] = None, encoder: str = "point_pillar",
-               modalities: Optional[Sequence[str]] = None) -> dict:
+               modalities: Optional[Sequence[str]] = None, encoders: Optional[Dict[str, str]] = None) -> dict:
     """Build the numpy form of ``batch_data['ego']`` for one frame (batch size 1).  ``encoder="second"``: ``inputs_m1`` holds the 0.1 m
     voxels of ``make_second_scene`` over the same range.  ``modalities``: one name per agent (default all ``m1``); every modality gets its
     own ``inputs_<m>`` whose ``voxel_coords[:, 0]`` counts that modality's agents (what the reference's collate gives its encoders)."""
@@ -442,7 +452,10 @@ def make_scene(shape: str = "v2xreal", n_agents: int = 1, seed: int = 0, n_point
         out["inputs_" + m] = {"voxel_features": np.concatenate(feats, axis=0), "voxel_coords": np.concatenate(coords, axis=0),
                               "voxel_num_points": np.concatenate(nums, axis=0)}
     if encoder == "second":
-        out["inputs_m1"] = make_second_scene({"tiny": "second_tiny", "small": "second_small", "v2xreal": "second_full"}[shape], n_agents, seed, n_points)
+        out["inputs_m1"] = make_second_scene(SECOND_OF[shape], n_agents, seed, n_points)
+    for m, kind in (encoders or {}).items():                          # a mixed scene: this modality's agents as 0.1 m voxels of their own sweeps
+        if kind == "second" and m in per:
+            out["inputs_" + m] = make_second_scene(SECOND_OF[shape], len(per[m][0]), seed * 7 + 1, n_points)
     out.update({
         "agent_modality_list": modalities,
         "record_len": np.asarray([n_agents], dtype=np.int64),

@@ -187,7 +187,7 @@ def heter_oracle_forward(states, sc_np, taps=None):
             continue
         orc = Oracle(st)
         sub = {"inputs_m1": sc_np["inputs_" + m], "agent_modality_list": ["m1"] * len(idx)}
-        pcodes, canvas, cq = orc.pfn_scatter(sub, len(idx))
+        canvas, cq = orc.canvas(sub, len(idx))                             # PointPillar or SECOND, as this modality's state says
         mt = {}
         cat, cat_q = orc.backbone(canvas, cq, mt)
         shr, shr_q = orc.shrinker(cat, cat_q, mt)
@@ -210,3 +210,20 @@ def heter_oracle_forward(states, sc_np, taps=None):
         s_cls, s_reg, s_dir = main.heads(feats, "_single")
         out.update({"cls_preds_single": s_cls, "reg_preds_single": s_reg, "dir_preds_single": s_dir})
     return out
+
+
+# ---- MIXED-encoder scenes (heter_model_baseline.py:47-59: the encoder class is picked per modality): m1 PointPillar + m3 SECOND -------
+MIXED_MODALITIES = ["m1", "m3", "m1"]
+MIXED_ENCODERS = {"m3": "second"}
+
+
+def mixed_scene_np(modalities=MIXED_MODALITIES, shape="tiny", seed=SEED_SCENE, n_points=N_POINTS, **kw):
+    return synth.make_scene(shape, n_agents=len(modalities), seed=seed, n_points=n_points, modalities=modalities, encoders=MIXED_ENCODERS, **kw)
+
+
+def calibrated_mixed_plugin(shape="tiny", n_points=N_POINTS, **kw):
+    """One PointPillar modality (m1) and one SECOND modality (m3) under the shared codebook / fusion / heads, W8A8 min-max, one EMA pass on
+    the [m1, m3, m1] scene, frozen."""
+    from quantv2x_amd.plugin.tools.inference_quant import calibrate_minmax
+    model = build_plugin(shape, modalities=("m1", "m3"), encoders=MIXED_ENCODERS, **kw)
+    return calibrate_minmax(quant_wrap(model), [synth.scene_to_torch(mixed_scene_np(shape=shape, n_points=n_points))])

@@ -143,3 +143,74 @@ def test_single_modality_engine_still_refuses_other_modalities(states):
     eng = deploy(state=states["m1"])
     with pytest.raises(NotImplementedError):
         eng(synth.scene_to_torch(heter_scene_np(), "cuda"))
+
+
+# ---- MIXED encoders: m1 = PointPillar, m3 = SECOND in one scene (heter_model_baseline.py:47-59, heter_encoders.py:52-81) ----
+@pytest.fixture(scope="module")
+def mixed():
+    from _common import calibrated_mixed_plugin
+    from quantv2x_amd.ptq_state import export_ptq_state
+    with one_thread():
+        qt = calibrated_mixed_plugin()
+    return qt, {m: export_ptq_state(qt, modality=m) for m in ("m1", "m3")}
+
+
+def test_mixed_encoder_model_mirror_export_and_oracle(mixed):
+    """The mirror builds the reference-shaped two-ENCODER model (PointPillar + SECOND by ``core_method``), QuantModel wraps both stacks,
+    every modality exports its own state (the SECOND one with its sparse convolutions and ``meta/encoder``), and the composed oracle --
+    each modality's agents through ITS encoder, code planes in agent order -- tracks the mirror's hard forward (spconv is absent from
+    /root/reference: the SECOND half is pinned on the mirror, not on the reference)."""
+    from _common import MIXED_MODALITIES, hard_forward_heter, heter_oracle_forward, mixed_scene_np
+    qt, states = mixed
+    model = qt.model
+    assert model.modality_name_list == ["m1", "m3"]
+    assert type(model.encoder_m1).__name__ == "QuantPointPillar" and type(model.encoder_m3).__name__ == "QuantSECOND"
+    assert "meta/encoder" not in states["m1"] or str(states["m1"]["meta/encoder"]) != "second"
+    assert str(states["m3"]["meta/encoder"]) == "second" and int(states["m3"]["meta/canvas_channels"]) == 256
+    assert list(states["m3"]["meta/layer_strides"]) == [1, 2, 2] and list(states["m1"]["meta/layer_strides"]) == [2, 2, 2]
+    np.testing.assert_array_equal(states["m1"]["codebook/1/codebook"], states["m3"]["codebook/1/codebook"])
+    sc = mixed_scene_np()
+    ot, mt = {}, {}
+    out = heter_oracle_forward(states, sc, ot)
+    with torch.no_grad(), one_thread():
+        hard_forward_heter(model, synth.scene_to_torch(sc), mt)
+    codes_m = mt["codes"].numpy().astype(np.uint8)
+    for a, m in enumerate(MIXED_MODALITIES):                          # free-running through 22 random-weight layers: statistical agreement ...
+        assert (ot["codes"][:, a] == codes_m[:, a]).mean() > 0.85, (a, m)
+    assert (ot["codes"][:, [1, 0, 2]][:, 0] == codes_m[:, 0]).mean() < 0.2      # ... against the yardstick of another agent's codes
+    assert out["preds_tensor"].shape == mt["preds_tensor"].shape
+    # the SECOND agent through the composed path == the same agent through the single-modality SECOND oracle
+    from oracle.spec import Oracle
+    one = {"inputs_m1": sc["inputs_m3"], "agent_modality_list": ["m1"], "record_len": np.asarray([1]), "pairwise_t_matrix": sc["pairwise_t_matrix"]}
+    t1 = {}
+    Oracle(states["m3"]).forward(one, t1)
+    np.testing.assert_array_equal(t1["codes"][:, 0], ot["codes"][:, 1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("modalities", [["m1", "m3", "m1"], ["m3", "m1"], ["m3"], ["m3", "m3", "m1", "m1"]])
+def test_deployed_mixed_encoder_scene_bit_exact_vs_oracle(mixed, modalities):
+    """PointPillar agents and SECOND agents in one deployed scene: every agent's wire indices equal to ITS modality's oracle, predictions
+    within the head-LSB rule; then the same frame as ONE HIP graph."""
+    from _common import heter_oracle_forward, mixed_scene_np
+    from quantv2x_amd.engine import DeployedHeterModel, deploy
+    qt, states = mixed
+    eng = deploy(qt)
+    assert isinstance(eng, DeployedHeterModel) and sorted(eng.engines) == ["m1", "m3"]
+    assert eng.engines["m3"].encoder_kind == "second" and eng.engines["m1"].encoder_kind == "point_pillar"
+    eng.engines["m3"].second_max_voxels = 4096
+    sc = mixed_scene_np(modalities)
+    otaps, gtaps = {}, {}
+    want = heter_oracle_forward(states, sc, otaps)
+    dd = synth.scene_to_torch(sc, "cuda")
+    got = {k: v.clone() for k, v in eng(dd, gtaps).items()}
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(gtaps["codes"].cpu().numpy().reshape(otaps["codes"].shape), otaps["codes"])
+    d = np.abs(got["preds_tensor"].cpu().numpy() - want["preds_tensor"])
+    assert d.max() <= head_lsb(states[modalities[0]]) * 1.001 and (d > 1e-5).mean() < 1e-3
+    replay = eng.capture(dd)
+    for _ in range(2):
+        out = replay()
+    torch.cuda.synchronize()
+    for k in got:
+        assert torch.equal(out[k], got[k]), k

@@ -185,3 +185,49 @@ def test_bench_configuration_batch32_two_streams_exact():
                 np.testing.assert_array_equal(got, ot["shrinker_m1.layers.0.double_conv.1"][0], err_msg=f"engine {k} frame {f}: shrinker map")
                 d = np.abs(preds[k][f] - want["preds_tensor"][0])
                 assert d.max() <= lsb * 1.001 and (d > 1e-5).mean() < 1e-3, (k, f, d.max())
+
+
+def _mixed(shape, modalities, layout, seed, n_points_calib=20000, **kw):
+    """A mixed-encoder model (m1 PointPillar + m3 SECOND: heter_model_baseline.py:47-59) calibrated and deployed at full size, one scene
+    through it and through the per-modality oracles."""
+    import copy
+    from _common import MIXED_ENCODERS, heter_oracle_forward
+    from quantv2x_amd import synth
+    from quantv2x_amd.engine import DeployedHeterModel, deploy
+    from quantv2x_amd.plugin.tools import inference_quant, train_utils
+    from quantv2x_amd.ptq_state import export_ptq_state
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    model = train_utils.create_model(copy.deepcopy(synth.make_hypes(shape, modalities=("m1", "m3"), encoders=MIXED_ENCODERS, **kw))).eval()
+    synth.load_state_dict_numpy(model, synth.make_state_dict(model.state_dict(), seed=1))
+    calib = synth.scene_to_torch(synth.make_scene(shape, n_agents=2, seed=3, n_points=n_points_calib, modalities=["m1", "m3"], encoders=MIXED_ENCODERS))
+    qt = inference_quant.calibrate_minmax(inference_quant.wrap(model), [calib])
+    states = {m: export_ptq_state(qt, modality=m) for m in ("m1", "m3")}
+    eng = deploy(qt)
+    assert isinstance(eng, DeployedHeterModel)
+    sc = synth.make_scene(shape, n_agents=len(modalities), seed=seed, n_points=60000, layout=layout, modalities=modalities, encoders=MIXED_ENCODERS,
+                          max_cav=max(5, len(modalities)))
+    otaps, gtaps = {}, {}
+    want = heter_oracle_forward(states, sc, otaps)
+    got = eng(synth.scene_to_torch(sc, "cuda"), gtaps)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(gtaps["codes"].cpu().numpy().reshape(otaps["codes"].shape), otaps["codes"])     # every agent's wire indices
+    h, w = otaps["fused"].shape[1:3]
+    from _common import FUSE_TOL
+    np.testing.assert_allclose(gtaps["fused"].cpu().numpy().reshape(-1, h, w, 256), otaps["fused"], **FUSE_TOL)
+    d = np.abs(got["preds_tensor"].cpu().numpy() - want["preds_tensor"])
+    assert d.max() <= head_lsb(states["m1"]) * 1.001 and (d > 1e-5).mean() < 1e-3
+    return otaps, got
+
+
+def test_v2xreal_mixed_encoder_scene_exact():
+    """One heterogeneous V2X-Real scene: a PointPillar agent and a SECOND agent (0.1 m voxels over the same range) under the shared codebook,
+    fusion and heads -- 2 x 3 x 35 200 wire indices against the per-modality oracles, bit for bit."""
+    otaps, got = _mixed("v2xreal", ["m1", "m3"], "line", seed=3)
+    assert otaps["codes"].shape == (3, 2, 100, 352) and got["preds_tensor"].shape == (1, 72, 100, 352)
+
+
+def test_opv2v_mixed_encoders_eight_agents_exact():
+    """BASELINE configs[4] is OPV2V-H -- H for heterogeneous: eight agents, four PointPillar and four SECOND, on the 512 x 512 grid
+    (SECOND: 2048 x 2048 x 40 voxels), max_cav 8, single-class heads."""
+    otaps, got = _mixed("opv2v", ["m1", "m3"] * 4, "ring", seed=7, multiclass=False)
+    assert otaps["codes"].shape == (3, 8, 256, 256) and got["preds_tensor"].shape == (1, 20, 256, 256) and got["cls_preds_single"].shape[0] == 8
