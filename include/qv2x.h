@@ -244,6 +244,17 @@ int qv2x_fuse_heads_batch_f32(const qv2x_fuse_desc* desc /* host */, int n_scene
                               const float* feats, const double* pairwise, int cout, int cout_pad, const float* w, const float* bias,
                               const float* da, const float* za, float* out, float* fused_tap, void* stream);
 
+/* Every 1x1 head of SINGLE-AGENT scenes by table look-up (round 4).  AttFusion over one agent is the identity (fusion_in_one.py:131-151 with
+ * record_len 1, T[0][0] = I), decode is a sum of per-level table rows (qv2x_decode_lut_f32) and a 1x1 head is linear, so cls | reg | dir on
+ * the fused map (heter_model_baseline.py:242-260) and the *_single heads (:224-230) are
+ *     y[co] = bias[co] + sum_l tables[l][code_l][co],    out = (clamp(rint(y / da[co]) + za[co], 0, 255) - za[co]) * da[co]   (da <= 0: no quantizer)
+ * for co < c0 + c1: the first c0 channels go to out0 f32 NCHW [R / hw][c0][hw], the next c1 to out1 [R / hw][c1][hw] (either set may be empty:
+ * c = 0 and a null pointer).  codes u8 [levels][R], rows agent-major; tables f32 [levels][kc][c0 + c1] = decode table x head weights, made by
+ * the caller in float64 (engine.py); levels * kc * (c0 + c1) floats must fit the 160 KB of LDS.  A different fp32 association than
+ * decode-then-GEMM: equal to ~1e-6 relative before the output quantizer (bounded in the tests like every head). */
+int qv2x_table_heads_f32(const uint8_t* codes, int R, int hw, int levels, int kc, int c0, int c1, const float* tables,
+                         const float* bias, const float* da, const float* za, float* out0, float* out1, void* stream);
+
 /* *_preds_single (heter_model_baseline.py:224-230) in one launch: qv2x_decode_lut_f32 followed by qv2x_heads_f32 on
  * every agent's own decoded feature.  codes u8 [levels][R], rows agent-major (R = agents * hw); out f32 [agents][cout][hw]. */
 int qv2x_decode_heads_f32(const uint8_t* codes, int R, int hw, int levels, int kc, const float* lut, const float* lut_bias,

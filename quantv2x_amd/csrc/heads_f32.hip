@@ -288,6 +288,63 @@ __global__ __launch_bounds__(256) void single_heads_lut_kernel(const uint8_t* __
     }
 }
 
+// Round 4: the same identity for EVERY head of a single-agent scene, all channels in one pass.  AttFusion over one agent returns that agent's
+// own feature (fusion_in_one.py:131-151 with record_len 1: the softmax of a single score is 1; T[0][0] = I samples every cell at its own
+// centre), so cls / reg / dir on the "fused" map AND the *_single heads are 1x1 heads on decode(codes): CT = c0 + c1 stacked channels,
+//     y[co] = b'[co] + T'_0[c_0][co] + T'_1[c_1][co] + T'_2[c_2][co]        (level order; tables made in float64 on the host, engine.py)
+// -- no 36 MB fused map, no 3 KB of decode gathers per cell, no GEMM.  The tables (levels x kc x CT floats, 141 KB for 3 x 128 x 92) live in
+// LDS for the lifetime of a persistent workgroup (one per CU, eight waves); row stride ST floats with ST / 4 odd, so the ds_read_b128 of 64
+// lanes with 64 different codes spread over the 64 banks.  A wave takes runs of 64 cells (lane = cell: every NCHW store is 256 contiguous
+// bytes per channel), four channels per step: three ds_read_b128, twelve adds, four output quantizers, four stores.
+__global__ __launch_bounds__(512, 1) void table_heads_kernel(const uint8_t* __restrict__ codes, int R, int hw, int levels, int kc, int CT, int ST, int c0, int c1,
+                                                             const float* __restrict__ tables, const float* __restrict__ bias, const float* __restrict__ da,
+                                                             const float* __restrict__ za, float* __restrict__ out0, float* __restrict__ out1) {
+    extern __shared__ __attribute__((aligned(16))) float tab[];       // [levels * kc][ST], then bias [CT4], da [CT4], za [CT4]
+    const int CT4 = (CT + 3) & ~3, rows = levels * kc;
+    float* cst = tab + (size_t)rows * ST;
+    for (int i = threadIdx.x; i < rows * (ST / 4); i += blockDim.x) {
+        const int row = i / (ST / 4), q = i - row * (ST / 4);
+        v4f v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * q + e < CT) v[e] = tables[(size_t)row * CT + 4 * q + e];
+        *(v4f*)(tab + (size_t)row * ST + 4 * q) = v;
+    }
+    for (int i = threadIdx.x; i < CT4; i += blockDim.x) {
+        cst[i] = i < CT ? bias[i] : 0.f; cst[CT4 + i] = i < CT ? da[i] : -1.f; cst[2 * CT4 + i] = i < CT ? za[i] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int runs = (R + 63) / 64;
+    for (int run = blockIdx.x * nw + wave; run < runs; run += gridDim.x * nw) {
+        const int m = run * 64 + lane;
+        const int mc = m < R ? m : R - 1;
+        const int agent = mc / hw, cell = mc - agent * hw;
+        const float* rp[4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) rp[l] = tab + (size_t)(l < levels ? l * kc + codes[(size_t)l * R + mc] : 0) * ST;
+        float* o0 = out0 ? out0 + (size_t)agent * c0 * hw + cell : nullptr;
+        float* o1 = out1 ? out1 + (size_t)agent * c1 * hw + cell : nullptr;
+        for (int g = 0; g < CT4 / 4; ++g) {
+            v4f y = *(const v4f*)(cst + 4 * g);
+            const v4f d4 = *(const v4f*)(cst + CT4 + 4 * g), z4 = *(const v4f*)(cst + 2 * CT4 + 4 * g);
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+                if (l < levels) { const v4f t = *(const v4f*)(rp[l] + 4 * g); y[0] += t[0]; y[1] += t[1]; y[2] += t[2]; y[3] += t[3]; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 4 * g + e;
+                float v = y[e];
+                if (d4[e] > 0.0f) v = (q_code(v, d4[e], z4[e]) - z4[e]) * d4[e];
+                if (m < R && c < CT) {
+                    if (c < c0) { if (o0) o0[(size_t)c * hw] = v; }
+                    else if (o1) o1[(size_t)(c - c0) * hw] = v;
+                }
+            }
+        }
+    }
+}
+
 // interior of a padded i8 BEV tensor -> fp32 rows [N*H*W][C]: x = (code - zp) * delta  (models without the codebook)
 __global__ __launch_bounds__(256) void dequant_i8_kernel(const int8_t* __restrict__ in, int n, int h, int w, int c, int ax, float delta,
                                                          float* __restrict__ out) {
@@ -388,6 +445,26 @@ extern "C" int qv2x_single_heads_lut_f32(const uint8_t* codes, int R, int hw, in
     const int groups = runs <= 1024 ? 1 : (runs + 1023) / 1024;
     single_heads_lut_kernel<<<(runs + groups - 1) / groups, 256, lds, (hipStream_t)stream>>>(codes, R, hw, levels, kc, cout, groups, tables, bias, da, za, out);
     return hip_check(hipGetLastError(), "qv2x_single_heads_lut_f32 launch");
+}
+
+extern "C" int qv2x_table_heads_f32(const uint8_t* codes, int R, int hw, int levels, int kc, int c0, int c1, const float* tables,
+                                    const float* bias, const float* da, const float* za, float* out0, float* out1, void* stream) {
+    using namespace qv2x;
+    const char* who = "qv2x_table_heads_f32";
+    if (!codes || !tables || !bias || !da || !za || (!out0 && !out1)) return fail(QV2X_EINVAL, "%s: null pointer", who);
+    const int CT = c0 + c1;
+    if (R <= 0 || hw <= 0 || R % hw || levels < 1 || levels > 4 || kc < 1 || kc > 256 || c0 < 0 || c1 < 0 || CT < 1 || (c0 > 0) != (out0 != nullptr) || (c1 > 0) != (out1 != nullptr))
+        return fail(QV2X_EINVAL, "%s: R=%d hw=%d levels=%d kc=%d c0=%d c1=%d (an output per non-empty channel set)", who, R, hw, levels, kc, c0, c1);
+    const int CT4 = (CT + 3) & ~3;
+    const int ST = (CT4 / 4) % 2 ? CT4 : CT4 + 4;                     // row stride in floats, ST / 4 odd: 64 different rows start in 16 different bank quads
+    const size_t lds = ((size_t)levels * kc * ST + 3 * CT4) * sizeof(float);
+    if (lds > 160 * 1024) return fail(QV2X_EINVAL, "%s: tables of %zu bytes do not fit the 160 KB of LDS", who, lds);
+    if (int rc = hip_check(hipFuncSetAttribute((const void*)table_heads_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), who)) return rc;
+    int dev = 0, cus = 256, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    const int runs = (R + 63) / 64, want = (runs + 7) / 8;
+    table_heads_kernel<<<want < cus ? want : cus, 512, lds, (hipStream_t)stream>>>(codes, R, hw, levels, kc, CT, ST, c0, c1, tables, bias, da, za, out0, out1);
+    return hip_check(hipGetLastError(), "qv2x_table_heads_f32 launch");
 }
 
 extern "C" int qv2x_decode_lut_f32(const uint8_t* codes, int R, int levels, int kc, const float* lut, const float* lut_bias,

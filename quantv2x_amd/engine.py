@@ -228,6 +228,9 @@ class DeployedModel(nn.Module):
     # 632 us (eight serial cells per wave, each a chain of dependent gathers per agent) -- so only scenes of ONE agent take it.
     fuse_heads_min_tiles = 4 * 1280
     fuse_heads_max_agents = 1
+    # scenes of ONE agent: every head by table look-up on the agent's own codes (qv2x_table_heads_f32; see __init__)
+    single_agent_tables = True
+    table_heads = None                                                   # (engines that build their own heads -- the fp32 ones -- keep the general path)
 
     def __init__(self, state: Dict[str, np.ndarray], device="cuda", emit_single_preds: Optional[bool] = None):
         super().__init__()
@@ -330,6 +333,20 @@ class DeployedModel(nn.Module):
         self.single_by_tables = self.heads_single is not None and self.has_codebook and self.levels * self.kc * self.heads_single.cout * 4 <= 60 * 1024
         if self.single_by_tables:
             self.heads_single.collapse_over_decode(lut, lut_bias, dev)
+        # single-agent scenes (round 4): AttFusion over one agent is the identity, so EVERY head is a table look-up on the agent's own codes
+        # (qv2x_table_heads_f32): cls | reg | dir [+ the *_single heads] stacked, tables = decode table x head weights in float64
+        self.table_heads = None
+        if self.has_codebook and self.fusion == 0:
+            sets = [self.heads] + ([self.heads_single] if self.heads_single is not None else [])
+            ct = sum(h.cout for h in sets)
+            ct4 = (ct + 3) // 4 * 4
+            st = ct4 if (ct4 // 4) % 2 else ct4 + 4
+            if (self.levels * self.kc * st + 3 * ct4) * 4 <= 160 * 1024:
+                t = np.concatenate([np.einsum("lkd,cd->lkc", lut.astype(np.float64), h._w_np) for h in sets], axis=2)
+                b = np.concatenate([lut_bias.astype(np.float64) @ h._w_np.T + h._b_np for h in sets])
+                cat = lambda name: torch.cat([getattr(h, name)[:h.cout] for h in sets]).contiguous()
+                self.table_heads = (_dev(t.astype(np.float32), dev), _dev(b.astype(np.float32), dev), cat("da"), cat("za"),
+                                    self.heads.cout, self.heads_single.cout if self.heads_single is not None else 0)
         self._bufs: Dict[int, dict] = {}
         # launch-plan switches for the ablation tools (tools/bench_*_abl.py); the defaults are the shipped configuration
         self.use_wide_conv, self.batch_deconvs, self.use_chains = True, True, True
@@ -641,6 +658,8 @@ class DeployedModel(nn.Module):
         ``*_single`` heads of this rank's own agent run in the same launch as the heads on the fused maps."""
         hw = self.fh * self.fw
         sp = None
+        if n_agents == 1 and self.table_heads is not None and self.single_agent_tables and own_codes is not None and frame_stride == hw:
+            return self._table_heads_out(own_codes, frames)                # a world of one agent: the own code planes ARE the scene
         if frames * hw // 32 >= self.fuse_heads_min_tiles and n_agents <= self.fuse_heads_max_agents:    # one launch, no fused map in HBM (see finish)
             preds = self.fuse_heads_scenes(L.ptr(gathered), agent_stride, level_stride, None, pairwise, [f * frame_stride for f in range(frames)],
                                            [n_agents] * frames, ego)
@@ -718,6 +737,22 @@ class DeployedModel(nn.Module):
             L.check(self.lib.qv2x_fuse_att_batch_f32(C.byref(d), s1 - s0, offs, cnts, codes_ptr, lut, lb,
                                                      L.ptr(feats) if feats is not None else None, L.ptr(pairwise[s0]), L.ptr(out[s0]),
                                                      L.current_stream()), "qv2x_fuse_att_batch_f32")
+
+    def _table_heads_out(self, codes, n: int) -> dict:
+        """The model's output dict for ``n`` single-agent scenes from their code planes u8 [levels, n * H*W] (qv2x_table_heads_f32).
+        Relies on the contract ``pairwise_t_matrix[b, 0, 0] = I`` (``T[i, j] = T_j^-1 T_i``, transformation_utils.py:21-66)."""
+        tab, tb, da, za, c0, c1 = self.table_heads
+        hw = self.fh * self.fw
+        preds = torch.empty((n, c0, self.fh, self.fw), dtype=torch.float32, device=self.dev)
+        sp = torch.empty((n, c1, self.fh, self.fw), dtype=torch.float32, device=self.dev) if c1 else None
+        L.check(self.lib.qv2x_table_heads_f32(L.ptr(codes), n * hw, hw, self.levels, self.kc, c0, c1, L.ptr(tab), L.ptr(tb), L.ptr(da), L.ptr(za),
+                                              L.ptr(preds), L.ptr(sp) if sp is not None else None, L.current_stream()), "qv2x_table_heads_f32")
+        c, r, _ = self.heads.splits
+        out = {"cls_preds": preds[:, :c], "reg_preds": preds[:, c:c + r], "dir_preds": preds[:, c + r:], "preds_tensor": preds}
+        if sp is not None:
+            c, r, _ = self.heads_single.splits
+            out.update({"cls_preds_single": sp[:, :c], "reg_preds_single": sp[:, c:c + r], "dir_preds_single": sp[:, c + r:]})
+        return out
 
     def fuse_heads_scenes(self, codes_ptr, agent_stride, level_stride, feats, pairwise, offsets, counts, ego=0, fused_tap=None):
         """a7-a11 for several scenes in ONE launch per 64 scenes (qv2x_fuse_heads_batch_f32): predictions f32 [scenes, cout, H, W]; the
@@ -842,6 +877,8 @@ class DeployedModel(nn.Module):
         #  heterogeneous scene never encodes n_total agents itself)
         feats = None if self.has_codebook else self._shared_features(enc, n_total)
         starts = [sum(lens[:bi]) for bi in range(nb)]
+        if taps is None and self.table_heads is not None and self.single_agent_tables and all(n == 1 for n in lens):
+            return self._table_heads_out(enc, nb)                         # every scene is one agent: all heads straight from its code planes
         one_launch = taps is None and nb * hw // 32 >= self.fuse_heads_min_tiles and max(lens) <= self.fuse_heads_max_agents
         fused = None if one_launch else torch.empty((nb, hw, 256), dtype=torch.float32, device=self.dev)
         if one_launch:                                                   # decode + warp + fusion + heads, tile by tile: no fused map in HBM

@@ -31,6 +31,7 @@ def test_one_launch_equals_two_launches(counts):
     from quantv2x_amd.ptq_state import export_ptq_state
     state = export_ptq_state(calibrated_plugin("tiny", n_agents=2))
     eng = deploy(state=state)
+    eng.single_agent_tables = False                        # (single-agent scenes would take the table look-up: test_single_agent_scenes_by_tables)
     dd = _batch([scene_np(n, seed=11 + i) for i, n in enumerate(counts)])
     eng.fuse_heads_min_tiles = 1 << 30                     # the two launches
     want = {k: v.clone() for k, v in eng(dd).items()}
@@ -66,3 +67,44 @@ def test_one_launch_max_fusion_and_no_codebook():
     torch.cuda.synchronize()
     for k in want:
         assert torch.equal(got[k], want[k]), k
+
+
+@pytest.mark.parametrize("shape,frames,n_points", [("tiny", 1, 3000), ("tiny", 5, 3000), ("small", 3, 8000)])
+def test_single_agent_scenes_by_tables(shape, frames, n_points):
+    """qv2x_table_heads_f32: scenes of ONE agent -- AttFusion over one agent is the identity, so every head (cls | reg | dir and the *_single
+    ones) is three table rows per cell.  Against the general path (decode + warp + attention, then the GEMM heads) and against the oracle:
+    a different fp32 association before the heads' output quantizers, so equal up to rare +-1 LSB flips (the rule every head is held to)."""
+    from _common import head_lsb
+    from oracle.spec import Oracle
+    from quantv2x_amd.engine import deploy
+    from quantv2x_amd.ptq_state import export_ptq_state
+    state = export_ptq_state(calibrated_plugin(shape, n_agents=2, n_points=n_points))
+    eng = deploy(state=state)
+    assert eng.table_heads is not None
+    scenes = [scene_np(1, shape=shape, seed=21 + i, n_points=n_points) for i in range(frames)]
+    dd = _batch(scenes)
+    eng.single_agent_tables, eng.fuse_heads_min_tiles = False, 1 << 30
+    want = {k: v.clone() for k, v in eng(dd).items()}
+    eng.single_agent_tables = True
+    got = eng(dd)
+    torch.cuda.synchronize()
+    assert set(got) == set(want)
+    orc = Oracle(state)
+    for k in want:
+        lsb = head_lsb(state, "_single" if k.endswith("_single") else "")
+        d = (got[k] - want[k]).abs()
+        assert float(d.max()) <= lsb * 1.001 and float((d > 1e-5).float().mean()) < 1e-3, (k, float(d.max()))
+    for f, sc in enumerate(scenes):
+        o = orc.forward(sc)
+        for k in ("preds_tensor", "cls_preds_single", "reg_preds_single"):
+            lsb = head_lsb(state, "_single" if k.endswith("_single") else "")
+            d = np.abs(got[k][f:f + 1].cpu().numpy() - o[k])
+            assert d.max() <= lsb * 1.001 and (d > 1e-5).mean() < 1e-3, (f, k, d.max())
+    # a scene of two agents in the batch: the general path takes the whole call
+    mixed = _batch([scene_np(1, shape=shape, seed=5, n_points=n_points), scene_np(2, shape=shape, seed=6, n_points=n_points)])
+    a = {k: v.clone() for k, v in eng(mixed).items()}
+    eng.single_agent_tables = False
+    b = eng(mixed)
+    torch.cuda.synchronize()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
