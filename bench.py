@@ -167,18 +167,37 @@ def rooflines(eng, full, frames, iters):
           F32_MFMA_PEAK_TFLOPS, 1, f"{n} x {enc_gflop} GFLOP (11 chained 256-wide GEMMs per cell, reference op order)")
     codes = eng._workspace(n)["codes"]
     pw = full["pairwise_t_matrix"].contiguous()
-    fused = torch.empty((n, hw, 256), dtype=torch.float32, device=eng.dev)
     import ctypes as C
+    general = {}                                      # the multi-agent path (decode + warp + attention, then the GEMM heads): not what single-agent scenes run
 
-    def fuse_all():                                  # as DeployedModel.forward does: every scene of the batch in one launch
-        eng.fuse_scenes(C.c_void_p(codes.data_ptr()), hw, n * hw, None, pw, [f * hw for f in range(n)], [1] * n, fused)
-    stage("decode_warp_attfuse", fuse_all, "hbm", n * (3 * hw + 3 * 128 * 1024 + hw * 1024), "GB/s", HBM_PEAK_GBS, 1,
-          f"{n} x ({3 * hw / 1e3:.1f} KB codes + 384 KiB LUT read, {hw * 1024 / 1e6:.1f} MB fp32 fused map written), one launch for the batch's scenes")
+    def stage_into(dst, name, fn, bound, work, unit, peak, launches, note):
+        keep = stages.get(name)
+        stage(name, fn, bound, work, unit, peak, launches, note)
+        dst[name] = stages.pop(name)
+        if keep is not None:
+            stages[name] = keep
     heads_macs = hw * 256 * (eng.heads.cout + (eng.heads_single.cout if eng.heads_single is not None else 0))
-    stage("heads_f32", lambda: eng._heads_pair(fused, n, codes, n), "mfma-f32", n * 2.0 * heads_macs, "TFLOP/s", F32_MFMA_PEAK_TFLOPS, 2 if getattr(eng, "single_by_tables", False) else 1,
-          f"{n} x {heads_macs / 1e9:.3f} GMAC: the {eng.heads.cout}-channel heads on the fused map + the {eng.heads_single.cout if eng.heads_single is not None else 0}-channel "
-          f"*_single heads on the decoded own feature (round 3: three table rows per cell, no GEMM; rounds 1-2 priced both at 2 x 0.649 GMAC; the fused-map kernel "
-          f"multiplies 96 padded columns)")
+    by_tables = getattr(eng, "table_heads", None) is not None and getattr(eng, "single_agent_tables", False)
+    if by_tables:
+        ct = eng.heads.cout + (eng.heads_single.cout if eng.heads_single is not None else 0)
+        stage("all_heads_by_tables", lambda: eng._table_heads_out(codes, n), "hbm", n * (3 * hw + ct * hw * 4), "GB/s", HBM_PEAK_GBS, 1,
+              f"what a single-agent scene runs for a7-a11 (round 4): AttFusion over ONE agent is the identity, so cls | reg | dir and the *_single heads are "
+              f"three table rows per cell (qv2x_table_heads_f32, {ct} channels, tables in LDS): {n} x ({3 * hw / 1e3:.1f} KB codes read + "
+              f"{ct * hw * 4 / 1e6:.1f} MB of predictions written); replaces decode_warp_attfuse + heads_f32 below for these scenes")
+    fused = torch.empty((n, hw, 256), dtype=torch.float32, device=eng.dev)
+
+    def fuse_all():                                  # as DeployedModel.forward does for multi-agent scenes: every scene of the batch in one launch
+        eng.fuse_scenes(C.c_void_p(codes.data_ptr()), hw, n * hw, None, pw, [f * hw for f in range(n)], [1] * n, fused)
+    dst = general if by_tables else stages
+    stage_into(dst, "decode_warp_attfuse", fuse_all, "hbm", n * (3 * hw + 3 * 128 * 1024 + hw * 1024), "GB/s", HBM_PEAK_GBS, 1,
+               f"{n} x ({3 * hw / 1e3:.1f} KB codes + 384 KiB LUT read, {hw * 1024 / 1e6:.1f} MB fp32 fused map written), one launch for the batch's scenes")
+    stage_into(dst, "heads_f32", lambda: eng._heads_pair(fused, n, codes, n), "mfma-f32", n * 2.0 * heads_macs, "TFLOP/s", F32_MFMA_PEAK_TFLOPS,
+               2 if getattr(eng, "single_by_tables", False) else 1,
+               f"{n} x {heads_macs / 1e9:.3f} GMAC: the {eng.heads.cout}-channel heads on the fused map + the {eng.heads_single.cout if eng.heads_single is not None else 0}-channel "
+               f"*_single heads on the decoded own feature (three table rows per cell, no GEMM); the fused-map kernel multiplies 96 padded columns")
+    if by_tables:
+        general["note"] = ("the GENERAL path of a7-a11 (scenes of 2+ agents; every rank of an N-GPU run), timed here on the same single-agent batch for "
+                           "reference -- not part of this line's step")
     enc = stages["codebook_encode_f32"]
     traffic, note = None, "no PMC profile committed for this round yet"
     import glob
@@ -197,8 +216,10 @@ def rooflines(eng, full, frames, iters):
             "avg_launch_us": enc["us_per_batch"], "agent_frames_per_launch": n,
             "algorithmic_gflop_per_launch": round(enc_gflop * n, 2),
             "share_of_batch_time": None}
-    total = sum(s["us_per_batch"] for s in stages.values())
+    total = sum(s["us_per_batch"] for s in stages.values() if "us_per_batch" in s)
     roof["share_of_batch_time"] = round(enc["us_per_batch"] / total, 3)
+    if general:
+        stages["general_path_multi_agent"] = general
     int8_us = stages["backbone_convs_i8"]["us_per_batch"] + stages["shrinker_convs_i8"]["us_per_batch"]
     int8_ops = sum(2.0 * p[7] for p in bb + sh)
     stages["int8_conv_stack_total"] = {"bound": "mfma-i8", "us_per_batch": round(int8_us, 2), "achieved": round(int8_ops / (int8_us * 1e-6) / 1e12, 1),
