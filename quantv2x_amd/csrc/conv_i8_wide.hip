@@ -89,6 +89,8 @@ __device__ long long g_wide_fine[4096 * 16];
 //     its per-pixel channel sums into a 256-entry LDS table once (two 1 KiB pieces per wave) and an output's window sum is nine
 //     table entries at the group fold.  The loop body is one basic block; the fold needs no barrier.
 //
+// (Round 4 tried the epilogue woven at HALF-output granularity behind every MFMA of the next item -- bit-exact, a tie again:
+// profiles/r04_woven_conv_experiment.log.)
 // (Round 3 also built a PING-PONG form -- groups of waves half an item apart, held there by workgroup barriers -- and a SOFTWARE-
 // PIPELINED one -- the epilogue of item i woven into the K loop of item i + 1 over two accumulator sets.  Both were bit-exact and
 // neither was faster (profiles/r03_wide_forms.log, DESIGN_HISTORY.md); round 4 took them out of the product library: they are in the
@@ -500,258 +502,6 @@ __global__ __launch_bounds__(NW * 64, QV2X_WIDE_BOUNDS(MULTI, NW)) void conv3x3_
 #endif
 }
 
-// ---- Round 4: the WOVEN form (one input group of NCH = 2 | 4 chunks, 4 x 32 patches) ---------------------------------------------------------
-// What the probes of round 4 say about gfx950 (tools/probes/mfma_valu_roles_probe.hip, mfma_valu_weave_probe.hip): the matrix pipe and the VALU
-// of a SIMD overlap ONLY inside one wave's own instruction stream -- a wave issuing back-to-back MFMAs stalls its SIMD-mate's VALU completely --
-// and there about six VALU instructions per v_mfma_i32_32x32x32_i8 are free (cycles per MFMA = 32 + 4.2 x max(0, K - 6)).  The form above runs
-// K loop, then epilogue: MFMA time + VALU time.  Round 3's software-pipelined form wove the epilogue of item i into the K loop of item i + 1 in
-// pieces of FOUR outputs (~60 instructions behind every ~18th MFMA): everything past the sixth instruction of a piece cost full time, a tie.
-// Here the same two accumulator sets, but HALF an output (4-5 instructions) behind EVERY MFMA of the next item's first 128: 660 requantizing
-// instructions spread over 144 (128 -> 128 layers) or 288 (256 -> 256) MFMAs.  Same integer sums, same fp32 epilogue: bit-identical.
-constexpr int PMT = 4;                                                 // M tiles per wave = patch rows (two accumulator sets: 128 of the 256 registers)
-
-template <int NW, int NCH, int WT>
-__global__ __launch_bounds__(NW * 64, 2) void conv3x3_i8_woven_kernel(const WideArgs a) {
-    constexpr int BN = NW * 32, MT = PMT, TH = PMT, HPIX = (TH + 2) * HWD, LH = HBLK / NW;
-    static_assert(WT % BN == 0, "weight tile");
-    static_assert(HBLK % NW == 0 && HPIX <= HPAD, "halo tile");
-    static_assert(NCH * 72 >= 2 * MT * 16, "half an output per MFMA: the K loop must be at least 128 MFMAs long");
-    __shared__ __attribute__((aligned(16))) int8_t lds[2 * HBUF + 3 * HPAD * 4 + BN * 16];
-    int8_t* hbuf = lds;
-    int* psum = (int*)(lds + 2 * HBUF);                                // [set][halo pixel]: item k uses set k % 3 (see the form above)
-    v4i* ctab = (v4i*)(psum + 3 * HPAD);                               // [BN] {aw, corr, scale (bits), bias (bits)} per channel
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int nblk = a.cout / BN, npatch = a.n * a.tiles_x * a.tiles_y;
-    int item = blockIdx.x;
-    auto patch_of = [&](int it) { return (it / (8 * nblk)) * 8 + (it & 7); };
-    auto valid = [&](int it) { return it < a.items && patch_of(it) < npatch; };
-    if (!valid(item)) return;
-    const int cb = (item >> 3) % nblk, n0 = cb * BN;
-    constexpr int total = NCH * 9;
-
-    struct Where { int y0, x0, img; };
-    auto place = [&](int it) __attribute__((always_inline)) {
-        const int patch = patch_of(it);
-        const int txi = patch % a.tiles_x, tyi = (patch / a.tiles_x) % a.tiles_y, img = patch / (a.tiles_x * a.tiles_y);
-        return Where{tyi * TH, txi * TW, img};
-    };
-    auto src_of = [&](const Where& w, int j) __attribute__((always_inline)) {
-        const int blk = wave + NW * j;
-        int hpx = (blk & 3) * 64 + lane;
-        hpx = hpx < HPIX ? hpx : HPIX - 1;
-        const int hy = hpx / HWD, hx = hpx - hy * HWD;
-        const int yy = min(w.y0 + hy, a.hp - 1), xx = min(w.x0 + hx, a.wp - 1);
-        return (unsigned)(((w.img * a.hp + yy) * a.wp + xx) * a.cin_total + (blk >> 2) * 16);
-    };
-    Where cur = place(item), nxw = cur, prv = cur;                     // prv: the item whose epilogue is being woven in
-    bool has_next = false;
-    int pb = 0, pset = 0, eset = 0;                                    // halo buffer of chunk 0; window-sum set of cur / of prv
-
-    v16i acc[2][MT];
-    v4i fa[2][MT];
-    v4i wr[3][2];
-    int totv[MT], pk[4];
-
-    // (halo DMA as inline asm, per-pixel channel sums, weight ring, planar fragment reads: as in conv3x3_i8_wide_kernel)
-    auto issue_halo = [&](int c) __attribute__((always_inline)) {
-        const int k = c - NCH;
-        if (k >= 0 && (!has_next || k >= NCH)) return;
-        const int off = a.coff[k < 0 ? c : k];
-        int8_t* buf = hbuf + ((pb + c) & 1) * HBUF;
-        const unsigned ldsb = (unsigned)(uintptr_t)((__attribute__((address_space(3))) int8_t*)buf) + wave_u * 1024;
-#pragma unroll
-        for (int j = 0; j < LH; ++j)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                         :: "s"(ldsb + NW * j * 1024), "v"(src_of(k < 0 ? cur : nxw, j) + (unsigned)off), "s"(a.in) : "memory", "m0");
-    };
-    auto add_psum = [&](int chunk, int set) __attribute__((always_inline)) {
-        const int8_t* buf = hbuf + ((pb + chunk) & 1) * HBUF;
-        v4i v[LH];
-#pragma unroll
-        for (int j = 0; j < LH; ++j) v[j] = *(const v4i*)(buf + (wave + NW * j) * 1024 + lane * 16);
-#pragma unroll
-        for (int j = 0; j < LH; ++j) {
-            const int blk = wave + NW * j;
-            int sm = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) sm = __builtin_amdgcn_sdot4(v[j][q], 0x01010101, sm, false);
-            __hip_atomic_fetch_add(psum + set * HPAD + (blk & 3) * 64 + lane, sm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    };
-    // weights: buffer loads -- resource = the workgroup's slice of the pre-tiled weights, a SCALAR running offset for the step and the
-    // lane's constant 16-byte offset (with plain pointers hipcc forms one 64-bit per-lane address per (step, K half) and, every step
-    // being a compile-time constant here, hoists all of them out of the item loop: spills)
-    constexpr int wstep = WT * 64;                                     // bytes of one step's weight tile (WT = min(cout, 256) rows)
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.wt + (size_t)(n0 / WT) * total * wstep + ((n0 % WT) / 32 + wave_u) * 2048), 0, total * wstep, 0x00020000);
-    int wnext = 0;                                                     // byte offset of the next step to request (uniform)
-    const int wlane = lane * 16;
-    auto load_w = [&](auto slot_c, auto last_c) __attribute__((always_inline)) {
-        constexpr int SLOT = decltype(slot_c)::value;
-        wr[SLOT][0] = (v4i)__builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, wnext, 0);
-        wr[SLOT][1] = (v4i)__builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane + 1024, wnext, 0);
-        wnext = decltype(last_c)::value ? 0 : wnext + wstep;           // (past an item's last step: the next item's step 0)
-    };
-    const int rlane = half * PLANE + (lane & 31) * 16;
-    auto read_half = [&](auto ks_c, auto tap_c, int chunk) __attribute__((always_inline)) {
-        constexpr int KS = decltype(ks_c)::value, TAP = decltype(tap_c)::value;
-        const int8_t* hb = hbuf + ((pb + chunk) & 1) * HBUF + rlane;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) fa[KS][i] = *(const v4i*)(hb + KS * 2 * PLANE + (HWD * (i + TAP / 3) + TAP % 3) * 16);
-    };
-
-    // ---- the epilogue of item `prv` (accumulator set P), HALF an output per slice ---------------------------------------------------
-    const float rd = 1.0f / a.out_delta;
-    const float za = a.out_zp + 1.0e-4f, zb = a.out_zp - 1.0e-4f, qlow = a.relu ? a.out_zp : 0.0f;
-    unsigned qa = 0, qb = 0;
-    float yq[4];
-    v4i cq;                                                            // the output's channel constants, read in the first half, used in both
-    auto epi_begin = [&]() __attribute__((always_inline)) {           // window sums: nine entries of the item's set per output pixel
-        int rowsum[MT + 2];
-        const int* ps = psum + eset * HPAD + (lane & 31);
-#pragma unroll
-        for (int k = 0; k < MT + 2; ++k) rowsum[k] = ps[k * HWD] + ps[k * HWD + 1] + ps[k * HWD + 2];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) totv[i] = rowsum[i] + rowsum[i + 1] + rowsum[i + 2];
-    };
-    // slice S = 2 * output + half; output = 16 * tile + register
-    auto epi_slice = [&](auto set_c, auto s_c) __attribute__((always_inline)) {
-        constexpr int P = decltype(set_c)::value, S = decltype(s_c)::value;
-        if constexpr (S >= 0 && S < 2 * MT * 16) {
-            constexpr int O = S >> 1, H = S & 1, I = O >> 4, R = O & 15, G4 = R >> 2, E = R & 3;
-            if constexpr (H == 0) {
-                cq = ctab[wave * 32 + 8 * G4 + 4 * half + E];
-                const int T = acc[P][I][R] + __mul24(cq[0], totv[I]) + cq[1];
-                const int sci = cq[2], bsi = cq[3];
-                yq[E] = __int_as_float(bsi) + (float)T * __int_as_float(sci);
-            } else {
-                if (E == 0) { qa = 0; qb = 0; }
-                q_sandwich_add(yq[E], E, rd, za, zb, qa, qb);
-                if (E == 3) pk[G4] = q_sandwich_finish(qa, qb, yq[0], yq[1], yq[2], yq[3], a.out_delta, a.out_zp, qlow);
-                if (R == 15) {                                         // the tile's 32 channels: half-wave exchange, one 16-byte store per lane
-                    const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
-                    const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
-                    v4i ob;
-                    ob[0] = s02[0]; ob[1] = s02[1]; ob[2] = s13[0]; ob[3] = s13[1];
-                    const int yo = prv.y0 + I, xo = prv.x0 + (lane & 31);
-                    if (yo < a.ho && xo < a.wo)
-                        *(v4i*)(a.out + ((size_t)(prv.img * (a.ho + 2) + yo + 1) * (a.wo + 2) + xo + 1) * a.out_ctotal + a.out_c0 + n0 + wave * 32 + half * 16) = ob;
-                }
-            }
-        }
-    };
-
-    // One K step = (chunk C, tap), in two halves, into accumulator set P; WITH_E: a slice of the other set's epilogue behind every MFMA.
-    auto one_step = [&](auto set_c, auto with_e, auto chunk_c, auto tap_c) __attribute__((always_inline)) {
-        constexpr int P = decltype(set_c)::value, C = decltype(chunk_c)::value, TAP = decltype(tap_c)::value;
-        constexpr bool WE = decltype(with_e)::value != 0;
-        constexpr int step = C * 9 + TAP;
-        load_w(IC<(TAP + 2) % 3>{}, IC<(step + 2) % total == total - 1>{});   // requests step + 2 (of the next item past the end)
-        read_half(IC<1>{}, tap_c, C);
-        __builtin_amdgcn_sched_barrier(0);
-        auto mm = [&](auto ks_c, auto i_c) __attribute__((always_inline)) {
-            constexpr int KS = decltype(ks_c)::value, I = decltype(i_c)::value;
-            acc[P][I] = WMFMA(wr[TAP % 3][KS], fa[KS][I], acc[P][I]);
-            if constexpr (WE) epi_slice(IC<1 - P>{}, IC<(2 * step + KS) * MT + I>{});
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        mm(IC<0>{}, IC<0>{}); mm(IC<0>{}, IC<1>{}); mm(IC<0>{}, IC<2>{}); mm(IC<0>{}, IC<3>{});
-        if (TAP < 8) {
-            read_half(IC<0>{}, IC<(TAP + 1) % 9>{}, C);
-        } else {
-            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            constexpr int nxt = C + 1;
-            add_psum(nxt, nxt < NCH ? pset : (pset == 2 ? 0 : pset + 1));
-            issue_halo(C + 2);
-            read_half(IC<0>{}, IC<0>{}, nxt);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        mm(IC<1>{}, IC<0>{}); mm(IC<1>{}, IC<1>{}); mm(IC<1>{}, IC<2>{}); mm(IC<1>{}, IC<3>{});
-    };
-    auto one_chunk = [&](auto set_c, auto with_e, auto chunk_c) __attribute__((always_inline)) {
-        one_step(set_c, with_e, chunk_c, IC<0>{}); one_step(set_c, with_e, chunk_c, IC<1>{}); one_step(set_c, with_e, chunk_c, IC<2>{});
-        one_step(set_c, with_e, chunk_c, IC<3>{}); one_step(set_c, with_e, chunk_c, IC<4>{}); one_step(set_c, with_e, chunk_c, IC<5>{});
-        one_step(set_c, with_e, chunk_c, IC<6>{}); one_step(set_c, with_e, chunk_c, IC<7>{}); one_step(set_c, with_e, chunk_c, IC<8>{});
-    };
-    // the K loop of item `cur` into set P (+ the epilogue of `prv` out of the other set, in the first 128 MFMAs)
-    auto one_item = [&](auto set_c, auto with_e) __attribute__((always_inline)) {
-        constexpr int P = decltype(set_c)::value;
-        {
-            int* nz = psum + (pset == 2 ? 0 : pset + 1) * HPAD;        // the next item's window-sum set
-            for (int t = tid; t < HPAD; t += NW * 64) nz[t] = 0;
-        }
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[P][i][r] = 0;
-        if constexpr (decltype(with_e)::value != 0) epi_begin();
-        read_half(IC<0>{}, IC<0>{}, 0);
-        one_chunk(set_c, with_e, IC<0>{});
-        one_chunk(set_c, with_e, IC<1>{});
-        if constexpr (NCH > 2) { one_chunk(set_c, IC<0>{}, IC<2>{}); one_chunk(set_c, IC<0>{}, IC<3>{}); }     // (slices 144 .. are empty)
-    };
-    // rotate: the item just accumulated becomes `prv`, the next one `cur`; false when there is no next item
-    auto rotate = [&]() __attribute__((always_inline)) {
-        prv = cur; eset = pset;
-        if (!has_next) return false;
-        item += (int)gridDim.x;
-        cur = nxw;
-        pb = (pb + NCH) & 1;
-        pset = pset == 2 ? 0 : pset + 1;
-        const int nx = item + (int)gridDim.x;
-        has_next = valid(nx);
-        if (has_next) nxw = place(nx);
-        return true;
-    };
-    auto epi_alone = [&](auto set_c) __attribute__((always_inline)) {  // the last item's epilogue: nothing left to weave it into
-        epi_begin();
-        auto tile = [&](auto i_c) __attribute__((always_inline)) {
-            constexpr int B = decltype(i_c)::value * 32;
-            epi_slice(set_c, IC<B + 0>{}); epi_slice(set_c, IC<B + 1>{}); epi_slice(set_c, IC<B + 2>{}); epi_slice(set_c, IC<B + 3>{});
-            epi_slice(set_c, IC<B + 4>{}); epi_slice(set_c, IC<B + 5>{}); epi_slice(set_c, IC<B + 6>{}); epi_slice(set_c, IC<B + 7>{});
-            epi_slice(set_c, IC<B + 8>{}); epi_slice(set_c, IC<B + 9>{}); epi_slice(set_c, IC<B + 10>{}); epi_slice(set_c, IC<B + 11>{});
-            epi_slice(set_c, IC<B + 12>{}); epi_slice(set_c, IC<B + 13>{}); epi_slice(set_c, IC<B + 14>{}); epi_slice(set_c, IC<B + 15>{});
-            epi_slice(set_c, IC<B + 16>{}); epi_slice(set_c, IC<B + 17>{}); epi_slice(set_c, IC<B + 18>{}); epi_slice(set_c, IC<B + 19>{});
-            epi_slice(set_c, IC<B + 20>{}); epi_slice(set_c, IC<B + 21>{}); epi_slice(set_c, IC<B + 22>{}); epi_slice(set_c, IC<B + 23>{});
-            epi_slice(set_c, IC<B + 24>{}); epi_slice(set_c, IC<B + 25>{}); epi_slice(set_c, IC<B + 26>{}); epi_slice(set_c, IC<B + 27>{});
-            epi_slice(set_c, IC<B + 28>{}); epi_slice(set_c, IC<B + 29>{}); epi_slice(set_c, IC<B + 30>{}); epi_slice(set_c, IC<B + 31>{});
-        };
-        tile(IC<0>{}); tile(IC<1>{}); tile(IC<2>{}); tile(IC<3>{});
-    };
-
-    // ---- once per workgroup ------------------------------------------------------------------------------------------------------
-    {
-        const int nx = item + (int)gridDim.x;
-        has_next = valid(nx);
-        if (has_next) nxw = place(nx);
-    }
-    issue_halo(0);
-    load_w(IC<0>{}, IC<total == 1>{});
-    load_w(IC<1>{}, IC<total == 2>{});
-    if (tid < BN) {
-        const int co = n0 + tid;
-        v4i c;
-        c[0] = a.aw[co]; c[1] = a.corr[co]; c[2] = __float_as_int(a.scale[co]); c[3] = __float_as_int(a.bias[co]);
-        ctab[tid] = c;
-    }
-    for (int t = tid; t < 3 * HPAD; t += NW * 64) psum[t] = 0;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    issue_halo(1);
-    __builtin_amdgcn_s_barrier();
-    add_psum(0, 0);
-
-    one_item(IC<0>{}, IC<0>{});                                        // the first item: nothing to requantize yet
-    for (;;) {
-        if (!rotate()) { epi_alone(IC<0>{}); break; }
-        one_item(IC<1>{}, IC<1>{});
-        if (!rotate()) { epi_alone(IC<1>{}); break; }
-        one_item(IC<0>{}, IC<1>{});
-    }
-}
-
 // [Cout][G][3][3][C_g] -> [Cout/wtile][chunk = (g, cc)][tap][wtile/32][K half][lane][16], wtile = min(Cout, 256)
 __global__ void pack_wide_kernel(const int8_t* __restrict__ w, int8_t* __restrict__ wt, int cout, int ktot, int nchunks,
                                  WideArgs a) {
@@ -906,29 +656,6 @@ extern "C" int qv2x_conv3x3_i8_wide(const qv2x_conv_desc* d, const int8_t* in, c
     hipStream_t st = (hipStream_t)stream;
 #ifndef QV2X_NO_WS64
     if (ws64_takes(d)) return launch_ws64(d, in, w_wide, scale, corr, aw, bias, out, st);
-#endif
-#ifdef QV2X_WOVEN
-    // the woven form: one input group of 128 or 256 channels, stride 1, enough 4 x 32 patches to keep every workgroup busy for several items
-    if (d->stride == 1 && d->ngroups == 1 && (a.nchunks == 2 || a.nchunks == 4) && (d->cout == 128 || d->cout % 256 == 0)) {
-        const int ty = (a.ho + PMT - 1) / PMT;
-        const int p8 = (a.n * a.tiles_x * ty + 7) / 8 * 8;
-        const int bnw = d->cout % 256 == 0 ? (2LL * p8 * (d->cout / 256) >= 3 * 256 ? 256 : 128) : d->cout;
-        const int periodw = 8 * (a.cout / bnw);
-        const int slotsw = 256 * (bnw == 256 ? 1 : 2) / periodw * periodw;
-        if ((long long)p8 * (a.cout / bnw) >= 2LL * slotsw) {
-            a.tiles_y = ty;
-            a.items = p8 * (a.cout / bnw);
-            const dim3 gridw(a.items < slotsw ? a.items : slotsw);
-#define QV2X_WOVEN_LAUNCH(NWV, WTV) do { \
-            if (a.nchunks == 2) conv3x3_i8_woven_kernel<NWV, 2, WTV><<<gridw, NWV * 64, 0, st>>>(a); \
-            else conv3x3_i8_woven_kernel<NWV, 4, WTV><<<gridw, NWV * 64, 0, st>>>(a); } while (0)
-            if (bnw == 256) QV2X_WOVEN_LAUNCH(8, 256);
-            else if (a.wtile == 256) QV2X_WOVEN_LAUNCH(4, 256);
-            else QV2X_WOVEN_LAUNCH(4, 128);
-#undef QV2X_WOVEN_LAUNCH
-            return hip_check(hipGetLastError(), "qv2x_conv3x3_i8_wide (woven form) launch");
-        }
-    }
 #endif
     const int patches8 = (a.n * a.tiles_x * a.tiles_y + 7) / 8 * 8;   // block ids come in groups of 8 (one per XCD)
     const int bn = wide_bn(d);
