@@ -756,7 +756,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i8", "data": "synthetic",
             "config": {"workload": wl["workload"], "baseline_config_index": wl["index"],
-                       "stages": "pfn+scatter, 19 conv + 3 deconv backbone, shrinker, 3-level codebook encode, decode+warp+attention, heads (+ *_single heads)",
+                       "stages": ("pfn+scatter, 19 conv + 3 deconv backbone, shrinker, 3-level codebook encode, " +
+                                  ("every head by table look-up on the agent's own codes (single-agent scenes: AttFusion over one agent is the identity)"
+                                   if world == 1 and not sharded_mode else "decode+warp+attention, heads (+ *_single heads)")),
                        "grid": wl["grid"], "agents_per_frame": world, "max_cav": wl["max_cav"], "layout": wl["layout"],
                        "heads": "multi-class (mc, 72 channels)" if wl["multiclass"] else "single-class (20 channels)",
                        "points_per_agent": N_POINTS,

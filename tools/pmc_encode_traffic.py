@@ -22,7 +22,7 @@ res = {"kernel": "codebook_encode_kernel", "launches_averaged": [nf, nw], "grid_
        "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
        "traffic_bytes_per_launch_raw": None if f is None or w is None else int((f + w) * 1024),
        "traffic_bytes_per_launch": None if f is None or w is None else int((2 * f + w) * 1024),
-       "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline`; "
+       "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras` (tools/final_evidence.sh); "
                "the launches of the bench's own batch only; traffic_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1 KiB (gfx950: FETCH_SIZE counts "
                "64 B per 128-B request, MI355X_MICROARCH.md), _raw = the counters as reported"}
 json.dump(res, open(out, "w"), indent=1)
