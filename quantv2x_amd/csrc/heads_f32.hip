@@ -25,7 +25,7 @@ namespace qv2x {
 //                arithmetic as the two launches, bit for bit.  `fused_tap` (optional) still receives the rows (debug / parity tests).
 enum { ROWS_GLOBAL = 0, ROWS_DECODE = 2, ROWS_FUSE = 3 };
 
-#ifdef QV2X_HEADS_TRACE     // dev build only (tools/heads_trace.py): s_memtime stamps of thread 0 of every workgroup
+#ifdef QV2X_HEADS_TRACE     // dev build only (s_memtime stamps, round 2): s_memtime stamps of thread 0 of every workgroup
 __device__ long long g_heads_trace[32768 * 6];
 #define HTRACE(k) do { const int hb_ = ((blockIdx.x >> 3) & 1) * (gridDim.x >> 1) + (blockIdx.x >> 4) * 8 + (blockIdx.x & 7); if (threadIdx.x == 0 && hb_ < 32768) g_heads_trace[hb_ * 6 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -77,7 +77,7 @@ __device__ __forceinline__ void rows_heads_tile(const HeadArgs& h, const FuseArg
         // the wave's eight rows, four at a time: all their code bytes first, then all their table rows, then the sums in level order
         // (tap_value's arithmetic).  Row by row and level by level -- and with a run-time level count, which makes every load
         // conditional and hipcc wait for each code byte before it requests the next -- this was 48 dependent L2 round trips per wave:
-        // 20k of the 36k cycles a *_single workgroup lived (tools/heads_trace.py).  Three levels (every model of the reference) take
+        // 20k of the 36k cycles a *_single workgroup lived (s_memtime stamps, round 2).  Three levels (every model of the reference) take
         // the unrolled form; other counts the row-by-row one.
         if (fa.levels == 3) {
             constexpr int LV = 3;
@@ -293,10 +293,10 @@ __global__ __launch_bounds__(256) void single_heads_lut_kernel(const uint8_t* __
 // centre), so cls / reg / dir on the "fused" map AND the *_single heads are 1x1 heads on decode(codes): CT = c0 + c1 stacked channels,
 //     y[co] = b'[co] + T'_0[c_0][co] + T'_1[c_1][co] + T'_2[c_2][co]        (level order; tables made in float64 on the host, engine.py)
 // -- no 36 MB fused map, no 3 KB of decode gathers per cell, no GEMM.  The tables (levels x kc x CT floats, 141 KB for 3 x 128 x 92) live in
-// LDS for the lifetime of a persistent workgroup (one per CU, eight waves); row stride ST floats with ST / 4 odd, so the ds_read_b128 of 64
+// LDS for the lifetime of a persistent workgroup (one per CU, eight or sixteen waves); row stride ST floats with ST / 4 odd, so the ds_read_b128 of 64
 // lanes with 64 different codes spread over the 64 banks.  A wave takes runs of 64 cells (lane = cell: every NCHW store is 256 contiguous
 // bytes per channel), four channels per step: three ds_read_b128, twelve adds, four output quantizers, four stores.
-__global__ __launch_bounds__(512, 1) void table_heads_kernel(const uint8_t* __restrict__ codes, int R, int hw, int levels, int kc, int CT, int ST, int c0, int c1,
+__global__ __launch_bounds__(1024, 1) void table_heads_kernel(const uint8_t* __restrict__ codes, int R, int hw, int levels, int kc, int CT, int ST, int c0, int c1,
                                                              const float* __restrict__ tables, const float* __restrict__ bias, const float* __restrict__ da,
                                                              const float* __restrict__ za, float* __restrict__ out0, float* __restrict__ out1) {
     extern __shared__ __attribute__((aligned(16))) float tab[];       // [levels * kc][ST], then bias [CT4], da [CT4], za [CT4]
@@ -462,8 +462,11 @@ extern "C" int qv2x_table_heads_f32(const uint8_t* codes, int R, int hw, int lev
     if (int rc = hip_check(hipFuncSetAttribute((const void*)table_heads_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), who)) return rc;
     int dev = 0, cus = 256, v = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    const int runs = (R + 63) / 64, want = (runs + 7) / 8;
-    table_heads_kernel<<<want < cus ? want : cus, 512, lds, (hipStream_t)stream>>>(codes, R, hw, levels, kc, CT, ST, c0, c1, tables, bias, da, za, out0, out1);
+    // sixteen waves per workgroup (four per SIMD: the kernel is bound by instruction issue -- 153 against 206 us per batch of 32 frames with
+    // eight) once every wave has a run of 64 cells to take; below that (one frame: 550 runs) eight, whose table copy-in is over sooner
+    const int runs = (R + 63) / 64;
+    const int nwav = runs >= 16 * cus ? 16 : 8, want = (runs + nwav - 1) / nwav;
+    table_heads_kernel<<<want < cus ? want : cus, nwav * 64, lds, (hipStream_t)stream>>>(codes, R, hw, levels, kc, CT, ST, c0, c1, tables, bias, da, za, out0, out1);
     return hip_check(hipGetLastError(), "qv2x_table_heads_f32 launch");
 }
 
