@@ -209,16 +209,19 @@ __global__ __launch_bounds__(NW * 64, QV2X_WIDE_BOUNDS(MULTI, NW)) void conv3x3_
     // this lane's 2 x 16 bytes of the weight tile of step `st`: row = its output channel (wave, lane & 31), piece ks * 2 + half of the row's 64 bytes
     const int wstep = a.wtile * 64;                                    // bytes of one step's weight tile
     // (the tile is stored in fragment order -- [32-row block][K half][lane][16 B] -- so each load instruction reads 1 KiB contiguous)
-    const int8_t* wdir = a.wt + (size_t)(n0 / a.wtile) * total * wstep + ((n0 % a.wtile) / 32 + wave) * 2048 + lane * 16;
     v4i wr[3][2];
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.wt + (size_t)(n0 / a.wtile) * total * wstep + ((n0 % a.wtile) / 32 + wave_u) * 2048), 0, total * wstep, 0x00020000);
     auto load_w = [&](auto slot_c, int st) __attribute__((always_inline)) {
         constexpr int SLOT = decltype(slot_c)::value;
 #if defined(QV2X_WABL) && QV2X_WABL == 3
         if (st > 1) return;
 #endif
-        const int8_t* p = wdir + (size_t)(st < total ? st : st - total) * wstep;   // past the end: steps 0, 1 again -- the next item's
-        wr[SLOT][0] = *(const v4i*)p;
-        wr[SLOT][1] = *(const v4i*)(p + 1024);
+        // Round 4: buffer loads -- the workgroup's weight slice as a resource, a SCALAR step offset, the lane's constant 16-byte offset: no
+        // 64-bit per-lane address arithmetic in the loop (2 % on the 256-channel layers and the shrinker, bit-identical)
+        const int so = (st < total ? st : st - total) * wstep;       // past the end: steps 0, 1 again -- the next item's
+        wr[SLOT][0] = (v4i)__builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16, so, 0);
+        wr[SLOT][1] = (v4i)__builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16 + 1024, so, 0);
     };
 
     // fragment of (M tile i, tap, K half ks): 16 bytes of halo pixel (lane & 31) + 34 (i + dy) + dx in plane ks * 2 + half:
