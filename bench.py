@@ -85,14 +85,25 @@ def build_engine(n_threads, multiclass=True):
     return state, deploy(state=state), fp_model, qt
 
 
-def frame_batch(world, rank, frames, device, layout=None, max_cav=None):
+def frame_batch(world, rank, frames, device, layout=None, max_cav=None, own_only=False):
     """`frames` scenes of `world` agents (different sweeps, same poses).  Returns the numpy scene 0, the model input of a
     single-GPU batch (every agent of every frame, batch index = frame * world + agent), this rank's input (its own agent of every
-    frame, batch index = frame) and the agents' world poses."""
+    frame, batch index = frame) and the agents' world poses.  ``own_only`` (the ranks of an N-GPU run): only this rank's agent is
+    generated -- the same sweeps ``synth.make_scene`` gives it (seed = scene seed * 1000 + agent) -- and the first two results are None."""
     import numpy as np
     import torch
     from quantv2x_amd import synth
     layout = layout or ("ring" if world > 2 else "line")
+    cat = lambda parts: {k: torch.from_numpy(np.concatenate([p[k] for p in parts])).to(device) for k in parts[0]}
+    if own_only:
+        lidar_range, voxel_size, max_voxels, _ = synth.SHAPES[SHAPE]
+        sigma = {"v2xreal": 35.0, "opv2v": 45.0}[SHAPE]
+        mine_parts = []
+        for f in range(frames):
+            vf, co, nump = synth.voxelize(synth.make_points(lidar_range, N_POINTS, (3 + f) * 1000 + rank, sigma), lidar_range, voxel_size, 32, max_voxels)
+            mine_parts.append({"voxel_features": vf, "voxel_coords": np.concatenate([np.full((co.shape[0], 1), f, dtype=np.int32), co], axis=1),
+                               "voxel_num_points": nump})
+        return None, None, cat(mine_parts), synth.agent_poses(world, layout)
     scenes = [synth.make_scene(SHAPE, n_agents=world, seed=3 + f, n_points=N_POINTS, layout=layout, max_cav=max_cav) for f in range(frames)]
     full_parts, mine_parts = [], []
     for f, sc in enumerate(scenes):
@@ -104,7 +115,6 @@ def frame_batch(world, rank, frames, device, layout=None, max_cav=None):
         m = {k: v[sel].copy() for k, v in sc["inputs_m1"].items()}
         m["voxel_coords"][:, 0] = f
         mine_parts.append(m)
-    cat = lambda parts: {k: torch.from_numpy(np.concatenate([p[k] for p in parts])).to(device) for k in parts[0]}
     full = {"inputs_m1": cat(full_parts), "agent_modality_list": ["m1"] * (world * frames),
             "record_len": torch.full((frames,), world, dtype=torch.int64),
             "pairwise_t_matrix": torch.from_numpy(np.concatenate([sc["pairwise_t_matrix"] for sc in scenes])).to(device)}
@@ -637,7 +647,7 @@ def main():
     cores = os.cpu_count() or 8
     B = max(1, args.batch)
     state, eng, fp_model, qt = build_engine(max(1, min(32, cores // max(world, 1))), multiclass=wl["multiclass"])
-    sc_np, full, mine, poses = frame_batch(world, rank, B, device, layout=wl["layout"], max_cav=wl["max_cav"])
+    sc_np, full, mine, poses = frame_batch(world, rank, B, device, layout=wl["layout"], max_cav=wl["max_cav"], own_only=world > 1)
     ego_line = None
 
     if not sharded_mode:
@@ -730,7 +740,7 @@ def main():
         _, one, _, _ = frame_batch(1, 0, 1, device)
         solo = eng.capture(one)
     else:
-        _, _, mine1, _ = frame_batch(world, rank, 1, device, layout=wl["layout"], max_cav=wl["max_cav"])
+        _, _, mine1, _ = frame_batch(world, rank, 1, device, layout=wl["layout"], max_cav=wl["max_cav"], own_only=world > 1)
         sh1 = AgentShardedModel(eng, frames=1, link=args.link, max_cav=wl["max_cav"], ego_only=args.ego_only, graph_link=args.graph_link)
         solo = lambda: sh1.forward(mine1, pose)
     for _ in range(10):

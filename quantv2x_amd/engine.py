@@ -336,7 +336,7 @@ class DeployedModel(nn.Module):
         # single-agent scenes (round 4): AttFusion over one agent is the identity, so EVERY head is a table look-up on the agent's own codes
         # (qv2x_table_heads_f32): cls | reg | dir [+ the *_single heads] stacked, tables = decode table x head weights in float64
         self.table_heads = None
-        if self.has_codebook and self.fusion == 0:
+        if self.has_codebook:                                            # (AttFusion or MaxFusion: either is the identity on one agent)
             sets = [self.heads] + ([self.heads_single] if self.heads_single is not None else [])
             ct = sum(h.cout for h in sets)
             ct4 = (ct + 3) // 4 * 4
