@@ -162,7 +162,11 @@ int qv2x_deconv_i8_batch(const qv2x_deconv_desc* descs /* host */, int n, const 
  *   weights: one f32 blob per level, laid out by the host as
  *       stage [64][256][4] | stage_b [256] | qhead [64][256][4] | qhead_b [256] | lhead [64][256][4] | lhead_b [256]
  *       | cb_packed [64][Kc][4] | cb [Kc][256] | c2 [Kc]
- *     ([K/4][cols][4] = four consecutive k innermost, stored in the order k0, k2, k1, k3); lhead* unused on the last level
+ *     ([K/4][cols][4] = four consecutive k innermost, stored in the order k0, k2, k1, k3); lhead* unused on the last level;
+ *     then the same four matrices once more in MFMA A-operand order for the wave-per-32-cells form that launches of many frames take,
+ *       stage [4][32][2][64][4] | qhead [4][32][2][64][4] | cb [ceil(Kc/64)][32][2][64][4] | lhead [4][32][2][64][4] | 4096 floats of padding
+ *     ([pair][group][tile][lane = 32 h + c][s] = W[64 pair + 32 tile + c][8 group + 2 s + h], rows past Kc zero: one linear stream of
+ *     1 KiB groups)
  *   codes: u8 [levels][N*H*W]. */
 typedef struct {
     int32_t n, h, w;
@@ -177,6 +181,10 @@ int qv2x_codebook_c2_f32(const float* codebook, int kc, float* c2, void* stream)
 int qv2x_codebook_encode_f32(const qv2x_encode_desc* desc /* host */, const int8_t* in,
                              const float* const* level_weights /* host array of device pointers */,
                              uint8_t* codes, void* stream);
+/* The same with the wave-per-32-cells form forced (qv2x_codebook_encode_f32 / _f32in pick it by launch size; the codes are identical).
+ * Exactly one of `in` (padded i8 BEV) and `in_f32` (padded fp32 BEV, as qv2x_codebook_encode_f32in) is non-null. */
+int qv2x_codebook_encode_wave_f32(const qv2x_encode_desc* desc /* host */, const int8_t* in, const float* in_f32,
+                                  const float* const* level_weights /* host array */, uint8_t* codes, void* stream);
 
 /* OPT-IN, not the parity configuration: qv2x_codebook_encode_f32 with the encoder's affine heads collapsed on the host
  * (quantv2x_amd/engine.py: collapse_encoder).  distance_l[k] - |q_l|^2 = G_l[k] . x + g_l[k] + sum_{j<l} T_lj[code_j][k] with x the shared

@@ -1,0 +1,25 @@
+// Shared by the two forms of a6 (codebook_encode.hip: a workgroup per 32 / 64 cells; codebook_encode_wave.hip: a wave per 32 cells).
+#pragma once
+#include "common.h"
+
+namespace qv2x {
+
+constexpr int ENC_D = 256;
+constexpr int ENC_WAVE_PAD = 16 * 256;      // floats behind the wave-form section: its weight ring reads 16 groups (1 KiB each) ahead
+
+struct EncArgs {
+    const int8_t* in; const float* in_f32; uint8_t* codes;      // in_f32 != null: the rows come as fp32 (un-quantized model)
+    const float* lvl[4];
+    int n, h, w, levels, kc, ax, M;
+    float dx;
+};
+
+// A level blob (include/qv2x.h): the workgroup form's section, then the wave form's.
+__device__ __host__ __forceinline__ int64_t level_floats_wg(int kc) { return 3LL * (ENC_D * ENC_D + ENC_D) + (int64_t)ENC_D * kc + (int64_t)kc * ENC_D + kc; }
+__device__ __host__ __forceinline__ int64_t level_floats(int kc) { return level_floats_wg(kc) + 3LL * ENC_D * ENC_D + (int64_t)((kc + 63) / 64 * 64) * ENC_D + ENC_WAVE_PAD; }
+
+// codebook_encode_wave.hip
+bool encode_wave_takes(const EncArgs& a, int cus);
+int encode_wave_launch(const EncArgs& a, hipStream_t st);
+
+}  // namespace qv2x

@@ -13,7 +13,7 @@
 // index, then a 4-way combine across waves through LDS.
 #include <cstdlib>
 
-#include "common.h"
+#include "codebook_encode.h"
 
 namespace qv2x {
 
@@ -42,13 +42,6 @@ constexpr int D = 256;
 #define QV2X_ENC_LDS_PAD 0
 #endif
 
-struct EncArgs {
-    const int8_t* in; const float* in_f32; uint8_t* codes;      // in_f32 != null: the rows come as fp32 (un-quantized model)
-    const float* lvl[4];
-    int n, h, w, levels, kc, ax, M;
-    float dx;
-};
-
 // Workgroup barrier for LDS hand-offs only.  __syncthreads() is fence + barrier, and the fence drains vmcnt: the next phase's weight
 // k-quads, requested ahead of the barrier on purpose, would have to land before the barrier instead of behind it.  Nothing in this
 // kernel passes data between waves through global memory, so ordering the LDS traffic is all a barrier has to do here.
@@ -57,8 +50,6 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 
-__device__ __forceinline__ size_t off_stage_w() { return 0; }
-__device__ __host__ __forceinline__ int64_t level_floats(int kc) { return 3LL * (D * D + D) + (int64_t)D * kc + (int64_t)kc * D + kc; }
 
 // out[64 rows][cols 32*wave .. +32) = in[64][256] . W^T, acc0 = bias.  W packed [64][256][4].  Eight waves split
 // the 256 output columns, so every weight element is fetched by exactly one wave of the workgroup; two waves share
@@ -405,7 +396,15 @@ extern "C" int qv2x_codebook_c2_f32(const float* codebook, int kc, float* c2, vo
 
 extern "C" int64_t qv2x_codebook_level_floats(int kc) { return qv2x::level_floats(kc); }
 
-static int encode_launch(const qv2x_encode_desc* d, const int8_t* in, const float* in_f32, const float* const* level_weights, uint8_t* codes, void* stream);
+static int encode_launch(const qv2x_encode_desc* d, const int8_t* in, const float* in_f32, const float* const* level_weights, uint8_t* codes, void* stream,
+                         int form = 0);
+
+// the wave-per-32-cells form whatever the launch size (qv2x_codebook_encode_f32 takes it from three rounds of the chip on): same codes
+extern "C" int qv2x_codebook_encode_wave_f32(const qv2x_encode_desc* d, const int8_t* in, const float* in_f32, const float* const* level_weights,
+                                             uint8_t* codes, void* stream) {
+    if (!in && !in_f32) return qv2x::fail(QV2X_EINVAL, "qv2x_codebook_encode_wave_f32: null pointer");
+    return encode_launch(d, in_f32 ? (const int8_t*)in_f32 : in, in_f32, level_weights, codes, stream, 1);
+}
 
 extern "C" int qv2x_codebook_encode_f32(const qv2x_encode_desc* d, const int8_t* in, const float* const* level_weights,
                                         uint8_t* codes, void* stream) {
@@ -418,7 +417,8 @@ extern "C" int qv2x_codebook_encode_f32in(const qv2x_encode_desc* d, const float
     return encode_launch(d, (const int8_t*)in, in, level_weights, codes, stream);
 }
 
-static int encode_launch(const qv2x_encode_desc* d, const int8_t* in, const float* in_f32, const float* const* level_weights, uint8_t* codes, void* stream) {
+static int encode_launch(const qv2x_encode_desc* d, const int8_t* in, const float* in_f32, const float* const* level_weights, uint8_t* codes, void* stream,
+                         int form) {
     using namespace qv2x;
     if (!d || !in || !level_weights || !codes) return fail(QV2X_EINVAL, "qv2x_codebook_encode_f32: null pointer");
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->levels < 1 || d->levels > 4) return fail(QV2X_EINVAL, "qv2x_codebook_encode_f32: bad shape");
@@ -445,6 +445,7 @@ static int encode_launch(const qv2x_encode_desc* d, const int8_t* in, const floa
         if (cus_of[dev] == 0) cus_of[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
         cus = cus_of[dev];
     }
+    if (form == 1 || (er_env == 0 && encode_wave_takes(a, cus))) return encode_wave_launch(a, (hipStream_t)stream);
     const int n64 = (a.M / 64) / cus * cus;
     const int er = er_env ? er_env : ((a.M / 64) >= 6 * cus ? 64 : (n64 > 0 ? 96 : 32));
     if (er == 64) codebook_encode_kernel<64><<<(a.M + 63) / 64, 512, 0, (hipStream_t)stream>>>(a);

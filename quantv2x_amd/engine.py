@@ -103,6 +103,26 @@ def _pack_k4p(w: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(_pack_k4(w)[:, :, [0, 2, 1, 3]])
 
 
+def _pack_wave(w: np.ndarray) -> np.ndarray:
+    """[J, 256] row-major -> [J/64 tile pairs][32 groups][2 tiles][64 lanes][4] float32 (J zero-padded to a multiple of 64), the A-operand
+    order of codebook_encode_wave.hip: lane ``32 h + c`` of group ``g`` of tile ``t`` of pair ``P`` holds ``w[64 P + 32 t + c, 8 g + 2 s + h]``
+    for the four MFMA steps s."""
+    j, k = w.shape
+    assert k == 256
+    if j % 64:
+        w = np.concatenate([w, np.zeros((64 - j % 64, k), w.dtype)])
+    return np.ascontiguousarray(w.reshape(-1, 2, 32, 32, 4, 2).transpose(0, 3, 1, 5, 2, 4), dtype=np.float32)
+
+
+ENC_WAVE_PAD = 16 * 256          # floats behind a level blob's wave section (codebook_encode.h)
+
+
+def wave_section(stage_w, qhead_w, lhead_w, cb) -> np.ndarray:
+    """The second half of a level blob (include/qv2x.h): stage | qhead | codebook | lhead in A-operand order -- one linear stream."""
+    return np.concatenate([_pack_wave(stage_w).reshape(-1), _pack_wave(qhead_w).reshape(-1), _pack_wave(cb).reshape(-1),
+                           _pack_wave(lhead_w).reshape(-1), np.zeros(ENC_WAVE_PAD, np.float32)])
+
+
 class _ConvLayer:
     """Device-side constants of one 3x3 QuantModule convolution."""
 
@@ -353,6 +373,7 @@ class DeployedModel(nn.Module):
         self.chain_max_agents = 1
         # "exact": the reference's eleven chained GEMMs, bit-identical indices (the parity configuration).  "collapsed": opt-in, see collapse_encoder
         self.encode_mode, self._collapsed = "exact", None
+        self.encode_form = "auto"                                      # "wave": force the wave-per-32-cells encode kernel (same codes)
 
     # ------------------------------------------------------------------------------------------------------
     def _level_blob(self, l: int) -> torch.Tensor:
@@ -365,11 +386,13 @@ class DeployedModel(nn.Module):
                  zeros_w if last else _pack_k4p(g("lhead_w")), zeros_b if last else g("lhead_b"),
                  _pack_k4p(cb), cb, np.zeros(kc, np.float32)]
         flat = np.concatenate([p.reshape(-1) for p in parts])
+        wg = flat.size                                                 # the workgroup form's section ends with c2
+        flat = np.concatenate([flat, wave_section(g("stage_w"), g("qhead_w"), np.zeros((256, 256), np.float32) if last else g("lhead_w"), cb)])
         assert flat.size == self.lib.qv2x_codebook_level_floats(kc)
         blob = _dev(flat, self.dev)
-        cb_off = flat.size - kc - kc * 256
+        cb_off = wg - kc - kc * 256
         L.check(self.lib.qv2x_codebook_c2_f32(C.c_void_p(blob.data_ptr() + 4 * cb_off), kc,
-                                              C.c_void_p(blob.data_ptr() + 4 * (flat.size - kc)), L.current_stream()),
+                                              C.c_void_p(blob.data_ptr() + 4 * (wg - kc)), L.current_stream()),
                 "qv2x_codebook_c2_f32")
         return blob
 
@@ -619,6 +642,10 @@ class DeployedModel(nn.Module):
             return codes
         if self.encode_mode != "exact":
             raise ValueError(f"encode_mode {self.encode_mode!r}: 'exact' (the reference's op order, the default) or 'collapsed'")
+        if self.encode_form == "wave":                                # tests: the many-frames form at any size (the library picks by launch size)
+            L.check(self.lib.qv2x_codebook_encode_wave_f32(C.byref(d), L.ptr(b["s1"]), None, self.level_ptrs, L.ptr(codes),
+                                                           L.current_stream()), "qv2x_codebook_encode_wave_f32")
+            return codes
         L.check(self.lib.qv2x_codebook_encode_f32(C.byref(d), L.ptr(b["s1"]), self.level_ptrs, L.ptr(codes),
                                                   L.current_stream()), "qv2x_codebook_encode_f32")
         return codes

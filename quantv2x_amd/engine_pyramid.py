@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import lib as L
-from .engine import _ConvLayer, _DeconvLayer, _Heads, _dev, _pack_k4p, decode_tables
+from .engine import _ConvLayer, _DeconvLayer, _Heads, _dev, _pack_k4p, decode_tables, wave_section
 
 
 def _q(state, name):
@@ -244,12 +244,18 @@ class DeployedPyramidModel(nn.Module):
                  np.zeros((W // 4, W, 4), np.float32) if last else pw(g("lhead_w")), np.zeros(W, np.float32) if last else pb(g("lhead_b")),
                  _pack_k4p(cb), cb, np.zeros(kc, np.float32)]
         flat = np.concatenate([p.reshape(-1) for p in parts])
+        wg = flat.size
+        if not self.native64:                                              # the 256-wide kernel's blob carries the wave form's section too
+
+            def full(w):
+                out = np.zeros((W, W), np.float32); out[:D, :D] = w; return out
+            flat = np.concatenate([flat, wave_section(full(g("stage_w")), full(g("qhead_w")), np.zeros((W, W), np.float32) if last else full(g("lhead_w")), cb)])
         floats, c2fn = ((self.lib.qv2x_codebook64_level_floats, self.lib.qv2x_codebook64_c2_f32) if self.native64
                         else (self.lib.qv2x_codebook_level_floats, self.lib.qv2x_codebook_c2_f32))
         assert flat.size == floats(kc)
         blob = _dev(flat, self.dev)
-        cb_off = flat.size - kc - kc * W
-        L.check(c2fn(C.c_void_p(blob.data_ptr() + 4 * cb_off), kc, C.c_void_p(blob.data_ptr() + 4 * (flat.size - kc)), L.current_stream()), "codebook c2")
+        cb_off = wg - kc - kc * W
+        L.check(c2fn(C.c_void_p(blob.data_ptr() + 4 * cb_off), kc, C.c_void_p(blob.data_ptr() + 4 * (wg - kc)), L.current_stream()), "codebook c2")
         return blob
 
     def _padded(self, n, h, w, c, zp):

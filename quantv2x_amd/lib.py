@@ -15,7 +15,7 @@ MAX_GROUPS = 4
 SYMBOLS = [
     "qv2x_last_error", "qv2x_version", "qv2x_fill_i8", "qv2x_pfn_scatter_i8", "qv2x_pfn_unscatter_i8", "qv2x_conv3x3_i8",
     "qv2x_conv3x3_i8_wide_ok", "qv2x_conv3x3_i8_pack_wide", "qv2x_conv3x3_i8_wide", "qv2x_conv3x3_i8_chain64",
-    "qv2x_deconv_i8", "qv2x_deconv_i8_batch", "qv2x_codebook_level_floats", "qv2x_codebook_c2_f32", "qv2x_codebook_encode_f32", "qv2x_fuse_att_f32", "qv2x_fuse_att_batch_f32", "qv2x_fuse_heads_batch_f32",
+    "qv2x_deconv_i8", "qv2x_deconv_i8_batch", "qv2x_codebook_level_floats", "qv2x_codebook_c2_f32", "qv2x_codebook_encode_f32", "qv2x_codebook_encode_wave_f32", "qv2x_fuse_att_f32", "qv2x_fuse_att_batch_f32", "qv2x_fuse_heads_batch_f32",
     "qv2x_decode_lut_f32", "qv2x_single_heads_lut_f32", "qv2x_table_heads_f32", "qv2x_dequant_i8_f32", "qv2x_heads_f32", "qv2x_decode_heads_f32", "qv2x_heads_pair_f32", "qv2x_voxelize_workspace_bytes", "qv2x_voxelize_f32",
     "qv2x_postprocess_workspace_bytes", "qv2x_postprocess_f32", "qv2x_postprocess_late_workspace_bytes", "qv2x_postprocess_late_f32",
     "qv2x_conv3x3_f32", "qv2x_deconv_f32", "qv2x_pfn_scatter_f32", "qv2x_codebook_encode_f32in",
@@ -145,6 +145,7 @@ def load() -> C.CDLL:
     lib.qv2x_codebook_level_floats.restype = C.c_int64
     lib.qv2x_codebook_c2_f32.argtypes = [vp, C.c_int, vp, vp]
     lib.qv2x_codebook_encode_f32.argtypes = [C.POINTER(EncodeDesc), vp, C.POINTER(vp), vp, vp]
+    lib.qv2x_codebook_encode_wave_f32.argtypes = [C.POINTER(EncodeDesc), vp, vp, C.POINTER(vp), vp, vp]
     lib.qv2x_fuse_att_f32.argtypes = [C.POINTER(FuseDesc), vp, vp, vp, vp, vp, vp, vp]
     lib.qv2x_fuse_att_batch_f32.argtypes = [C.POINTER(FuseDesc), C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int32), vp, vp, vp, vp, vp, vp, vp]
     lib.qv2x_decode_lut_f32.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]

@@ -49,7 +49,8 @@ def test_argument_errors_without_gpu():
     assert l.qv2x_codebook_encode_f32(C.byref(d), lib.ptr(buf), ptrs, lib.ptr(buf), None) == -1
     assert b"dict_size" in l.qv2x_last_error()
     assert l.qv2x_heads_f32(lib.ptr(buf), 10, 3, 72, 96, lib.ptr(buf), lib.ptr(buf), lib.ptr(buf), lib.ptr(buf), lib.ptr(buf), None) == -1
-    assert l.qv2x_codebook_level_floats(128) == 3 * (65536 + 256) + 256 * 128 * 2 + 128
+    # the workgroup form's section (three heads + biases, the codebook twice, |C|^2) + the wave form's (the four matrices again + padding)
+    assert l.qv2x_codebook_level_floats(128) == (3 * (65536 + 256) + 256 * 128 * 2 + 128) + (3 * 65536 + 128 * 256 + 4096)
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
