@@ -114,8 +114,14 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
         const float* cb = lhead_b + D + (size_t)D * a.kc;              // [kc][256]
         const float* c2 = cb + (size_t)a.kc * D;                        // [kc]
         // the wave section: stage | qhead | codebook | lhead, each [tile pair][32 groups][2 tiles][64 lanes][4 steps] -- ONE linear stream
-        const char* wb = (const char*)(W + level_floats_wg(a.kc));     // (uniform: the loads below are saddr + lane offset + immediate)
-        const unsigned loff = (unsigned)lane * 16u;
+        // (buffer loads: the section as a resource, a SCALAR running offset, the lane's constant 16-byte offset -- no per-lane 64-bit address
+        // arithmetic between the MFMAs)
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)(W + level_floats_wg(a.kc)), 0, 0x7fffffff, 0x00020000);
+        int wo = 0;                                                     // bytes into the section: one tile pair = 64 KiB
+        const int loff = lane * 16;
+        auto wload = [&](int grp) __attribute__((always_inline)) {
+            return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, wo + grp * 1024, 0));
+        };
         const bool last = l + 1 == a.levels;
         const int npair = (a.kc + 63) >> 6;                             // (an odd number of 32-code tiles: the last pair's second tile is zeros)
 
@@ -137,7 +143,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
         __builtin_amdgcn_sched_barrier(0);
         v4f ring[2 * NPF];
 #pragma unroll
-        for (int i = 0; i < 2 * NPF; ++i) ring[i] = *(const v4f*)(wb + loff + i * 1024);
+        for (int i = 0; i < 2 * NPF; ++i) ring[i] = wload(i);
         __builtin_amdgcn_sched_barrier(0);
 
         // two 32-channel tiles at once: acc0 = bn (BIAS) or 0, 2 x 128 MFMAs against the operand registers `m` -- TWO dependent chains, so
@@ -172,13 +178,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
                 if (g == 15) WFINE2(3);
                 if (g == 23) WFINE2(4);
 #ifndef QV2X_ENCW_ABL_NOLOAD                                              // (dev ablation: the ring is never refilled)
-                ring[(2 * g) % (2 * NPF)] = *(const v4f*)(wb + loff + (2 * (g + NPF)) * 1024);
-                ring[(2 * g + 1) % (2 * NPF)] = *(const v4f*)(wb + loff + (2 * (g + NPF) + 1) * 1024);
+                ring[(2 * g) % (2 * NPF)] = wload(2 * (g + NPF));
+                ring[(2 * g + 1) % (2 * NPF)] = wload(2 * (g + NPF) + 1);
 #endif
                 __builtin_amdgcn_sched_barrier(0);                      // (hipcc otherwise sinks every load to its first use)
             }
 #ifndef QV2X_ENCW_ABL_SAMEW                                               // (dev ablation: every pair streams the same 64 KiB -- L1 / L2 latency out of the picture)
-            wb += 64 * 1024;
+            wo += 64 * 1024;
 #endif
             WFINE2(5);
         };
@@ -280,8 +286,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
 }
 
 bool encode_wave_takes(const EncArgs& a, int cus) {
-    // from three rounds of the chip's 4 x CUs wave slots on; below that the workgroup form's 64- / 32-row mix balances better
-    return (a.M + 31) / 32 >= 3 * 4 * cus;
+    // from six rounds of the chip's 4 x CUs wave slots on (V2X-Real: 4 frames 1560 against 1473 us for the workgroup form, 8 frames 2779
+    // against 2912, 16: 5530, 32: 10 770 against 11 140); below that the workgroup form's 64- / 32-row mix balances better
+    return (a.M + 31) / 32 >= 6 * 4 * cus;
 }
 
 int encode_wave_launch(const EncArgs& a, hipStream_t st) {

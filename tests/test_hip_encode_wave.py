@@ -94,14 +94,14 @@ def test_wave_form_on_the_reference_rows(golden):
 
 
 def test_many_frames_launch_takes_the_wave_form_and_is_exact():
-    """Four V2X-Real frames in one launch (140 800 cells: above the library's threshold): codes == one frame at a time (the workgroup form)."""
+    """Six V2X-Real frames in one launch (211 200 cells: above the library's threshold): codes == one frame at a time (the workgroup form)."""
     import torch
     from quantv2x_amd import synth
     from quantv2x_amd.engine import deploy
     state = copy.copy(_state())
     state["meta/grid"] = np.array(synth.grid_size(*synth.SHAPES["v2xreal"][:2]), dtype=np.int64)
     eng = deploy(state=state)
-    n = 4
+    n = 6
     b = eng._workspace(n)
     rng = np.random.default_rng(5)
     b["s1"][:, 1:-1, 1:-1, :] = torch.from_numpy(rng.integers(-128, 128, size=(n, 100, 352, 256), dtype=np.int8)).cuda()
