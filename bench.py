@@ -17,7 +17,7 @@ all-gather moves the code planes + poses, and every rank fuses as the ego of its
 N-agent frames; ``value`` = N * B * K / (max-over-ranks time).  Per-GPU work is fixed as N grows: ``"scaling": "weak"``.
 
 Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line (contract in the task prompt) with
-  roofline         the dominant kernel by time (codebook_encode_kernel: f32 MFMA), launch duration from HIP events
+  roofline         the dominant kernel by time (codebook_encode_wave_kernel: f32 MFMA), launch duration from HIP events
   roofline_stages  every stage of the frame against its own bound (int8 MFMA / f32 MFMA / HBM), same method
   cpu_baseline     the CPU oracle (``oracle/``, the checker -- never the product) on the host cores; and
   cpu_baseline_torch  the torch restatement of the reference (plugin mirror) in fp32 and W8A8 fake-quant, all host cores
@@ -222,7 +222,7 @@ def rooflines(eng, full, frames, iters):
             note = f"profiles/{os.path.basename(pmc)} was taken at {j.get('agent_frames_per_launch')} agent-frames per launch, this run has {n}"
     roof = {"bound": "mfma", "achieved": enc["achieved"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": enc["frac"],
             "traffic": traffic, "traffic_note": "STORED figure, not measured by this run: " + note,
-            "kernel": "codebook_encode_kernel (f32 MFMA v_mfma_f32_32x32x2_f32; the dominant kernel by time)", "launches_per_batch": 1,
+            "kernel": "codebook_encode_wave_kernel (f32 MFMA v_mfma_f32_32x32x2_f32; the dominant kernel by time; a wave per 32 cells)", "launches_per_batch": 1,
             "avg_launch_us": enc["us_per_batch"], "agent_frames_per_launch": n,
             "algorithmic_gflop_per_launch": round(enc_gflop * n, 2),
             "share_of_batch_time": None}

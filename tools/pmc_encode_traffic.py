@@ -1,5 +1,5 @@
-"""HBM-side traffic of the dominant kernel (codebook_encode_kernel) from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the
-bench command -> profiles/r03_pmc_encode.json (the figure bench.py's roofline.traffic quotes).  FETCH_SIZE / WRITE_SIZE are in KiB.
+"""HBM-side traffic of the dominant kernel (codebook_encode_wave_kernel at the bench's batch) from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the
+bench command -> profiles/rNN_pmc_encode.json (the figure bench.py's roofline.traffic quotes).  FETCH_SIZE / WRITE_SIZE are in KiB.
 Only the launches of the bench's own batch (the largest grid) are averaged.  MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports half
 the bytes of wide coalesced streaming reads -- the corrected figure doubles it; WRITE_SIZE is taken as reported."""
 import csv, glob, json, sys
@@ -8,9 +8,12 @@ def mean(d, counter):
     rows = []
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "codebook_encode_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
-                per_wg = 64 if "<64>" in r["Kernel_Name"] else 32          # rows per 512-thread workgroup (the kernel's template argument)
-                rows.append((int(r["Grid_Size"]) // 512 * per_wg, float(r["Counter_Value"]), int(r["Grid_Size"])))
+            if "codebook_encode" in r["Kernel_Name"] and "_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                if "codebook_encode_wave_kernel" in r["Kernel_Name"]:        # the many-frames form: one 64-thread wave per 32 rows
+                    nrows = int(r["Grid_Size"]) // 64 * 32
+                else:                                                       # rows per 512-thread workgroup (the kernel's template argument)
+                    nrows = int(r["Grid_Size"]) // 512 * (64 if "<64>" in r["Kernel_Name"] else 32)
+                rows.append((nrows, float(r["Counter_Value"]), int(r["Grid_Size"])))
     if not rows:
         return None, 0, 0, 0
     g = max(r[0] for r in rows)                                            # the launches with the most rows: the bench's own batch
@@ -18,7 +21,7 @@ def mean(d, counter):
     return sum(v) / len(v), len(v), [gs for (nr, c, gs) in rows if nr == g][0], g
 f, nf, gf, rows_f = mean(fetch_dir, "FETCH_SIZE")
 w, nw, gw, rows_w = mean(write_dir, "WRITE_SIZE")
-res = {"kernel": "codebook_encode_kernel", "launches_averaged": [nf, nw], "grid_threads": gf, "agent_frames_per_launch": rows_f // 35200 if gf else None,
+res = {"kernel": "codebook_encode_wave_kernel (launches of the bench's batch; the workgroup form below six rounds of the chip)", "launches_averaged": [nf, nw], "grid_threads": gf, "agent_frames_per_launch": rows_f // 35200 if gf else None,
        "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
        "traffic_bytes_per_launch_raw": None if f is None or w is None else int((f + w) * 1024),
        "traffic_bytes_per_launch": None if f is None or w is None else int((2 * f + w) * 1024),
