@@ -12,6 +12,7 @@ struct EncArgs {
     const float* lvl[4];
     int n, h, w, levels, kc, ax, M;
     float dx;
+    int m_lo, m_hi;             // the rows [m_lo, m_hi) of the M = n h w cells this launch encodes (a launch may be split between the two forms)
 };
 
 // A level blob (include/qv2x.h): the workgroup form's section, then the wave form's.
@@ -19,7 +20,6 @@ __device__ __host__ __forceinline__ int64_t level_floats_wg(int kc) { return 3LL
 __device__ __host__ __forceinline__ int64_t level_floats(int kc) { return level_floats_wg(kc) + 3LL * ENC_D * ENC_D + (int64_t)((kc + 63) / 64 * 64) * ENC_D + ENC_WAVE_PAD; }
 
 // codebook_encode_wave.hip
-bool encode_wave_takes(const EncArgs& a, int cus);
-int encode_wave_launch(const EncArgs& a, hipStream_t st);
+int encode_wave_launch(const EncArgs& a, hipStream_t st);      // rows [a.m_lo, a.m_hi): one wave per 32
 
 }  // namespace qv2x

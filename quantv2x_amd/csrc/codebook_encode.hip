@@ -325,7 +325,7 @@ __device__ __forceinline__ void encode_rows(const EncArgs& a, const int m0, floa
             }
             const int bi = (int)(unsigned)bk;
             code_s[tid] = bi;
-            if (m0 + tid < a.M) a.codes[(size_t)l * a.M + m0 + tid] = (uint8_t)bi;
+            if (m0 + tid < a.m_hi) a.codes[(size_t)l * a.M + m0 + tid] = (uint8_t)bi;
         }
         lds_barrier();
         EFINE(9);
@@ -361,7 +361,7 @@ __device__ __forceinline__ void encode_rows(const EncArgs& a, const int m0, floa
 template <int ER>
 __global__ __launch_bounds__(512, ER == 32 ? 4 : 2) void codebook_encode_kernel(const EncArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[enc_smem_floats<ER>()];
-    encode_rows<ER>(a, blockIdx.x * ER, smem);
+    encode_rows<ER>(a, a.m_lo + blockIdx.x * ER, smem);
 }
 
 // Launches of one or two frames: whole rounds of 64-row workgroups (one per CU: n64 of them, a multiple of the CU count), then the rows
@@ -369,8 +369,8 @@ __global__ __launch_bounds__(512, ER == 32 ? 4 : 2) void codebook_encode_kernel(
 // One V2X-Real frame: 512 x 64 + 76 x 32 rows, two full rounds and a short one (416 us) instead of 1100 x 32 on 512 slots (478 us).
 __global__ __launch_bounds__(512, 2) void codebook_encode_mixed_kernel(const EncArgs a, const int n64) {
     __shared__ __attribute__((aligned(16))) float smem[enc_smem_floats<64>()];
-    if ((int)blockIdx.x < n64) encode_rows<64>(a, blockIdx.x * 64, smem);
-    else encode_rows<32>(a, n64 * 64 + ((int)blockIdx.x - n64) * 32, smem);
+    if ((int)blockIdx.x < n64) encode_rows<64>(a, a.m_lo + blockIdx.x * 64, smem);
+    else encode_rows<32>(a, a.m_lo + n64 * 64 + ((int)blockIdx.x - n64) * 32, smem);
 }
 
 __global__ void codebook_c2_kernel(const float* __restrict__ cb, int kc, float* __restrict__ c2) {
@@ -426,7 +426,7 @@ static int encode_launch(const qv2x_encode_desc* d, const int8_t* in, const floa
     if ((uintptr_t)in & 15) return fail(QV2X_EALIGN, "qv2x_codebook_encode_f32: in must be 16-byte aligned");
     EncArgs a;
     a.in = in; a.in_f32 = in_f32; a.codes = codes; a.n = d->n; a.h = d->h; a.w = d->w; a.levels = d->levels; a.kc = d->kc;
-    a.ax = 128 - d->in_zx; a.dx = d->in_delta; a.M = d->n * d->h * d->w;
+    a.ax = 128 - d->in_zx; a.dx = d->in_delta; a.M = d->n * d->h * d->w; a.m_lo = 0; a.m_hi = a.M;
     for (int l = 0; l < 4; ++l) {
         a.lvl[l] = l < d->levels ? level_weights[l] : nullptr;
         if (l < d->levels && (!a.lvl[l] || ((uintptr_t)a.lvl[l] & 15))) return fail(QV2X_EALIGN, "qv2x_codebook_encode_f32: level %d weights null or unaligned", l);
@@ -445,12 +445,29 @@ static int encode_launch(const qv2x_encode_desc* d, const int8_t* in, const floa
         if (cus_of[dev] == 0) cus_of[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
         cus = cus_of[dev];
     }
-    if (form == 1 || (er_env == 0 && encode_wave_takes(a, cus))) return encode_wave_launch(a, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    if (form == 1) return encode_wave_launch(a, st);
+    // The wave form (codebook_encode_wave.hip: a wave per 32 cells, one wave per SIMD) runs whole rounds of the chip's 4 x CUs wave slots
+    // at 0.88 of the f32 peak; a remainder of up to two workgroups per CU is the workgroup form's (32 cells per 8-wave workgroup: the same
+    // cells in a third of a wave's time), a larger one is one more round of waves.  One V2X-Real frame = 1100 waves: one round of 1024 +
+    // 76 workgroups, 410 us against 449 for the workgroup form alone; two frames 704 against 801, five 1643 against 1787
+    // (profiles/r04_encode_by_frames.log).  Launches of less than one round keep the workgroup form's 64- / 32-row mix below.
+    const int slots = 4 * cus, waves = (a.M + 31) / 32;
+    const int rounds = waves / slots, rest = waves - rounds * slots;
+    if (er_env == 0 && rounds >= 1) {
+        if (rest == 0 || rest > 2 * cus) return encode_wave_launch(a, st);
+        EncArgs main = a, tail = a;
+        main.m_hi = rounds * slots * 32;
+        tail.m_lo = main.m_hi;
+        if (int rc = encode_wave_launch(main, st)) return rc;
+        codebook_encode_kernel<32><<<rest, 512, 0, st>>>(tail);
+        return hip_check(hipGetLastError(), "qv2x_codebook_encode_f32 launch");
+    }
     const int n64 = (a.M / 64) / cus * cus;
     const int er = er_env ? er_env : ((a.M / 64) >= 6 * cus ? 64 : (n64 > 0 ? 96 : 32));
-    if (er == 64) codebook_encode_kernel<64><<<(a.M + 63) / 64, 512, 0, (hipStream_t)stream>>>(a);
-    else if (er == 96 && n64 > 0) codebook_encode_mixed_kernel<<<n64 + (a.M - n64 * 64 + 31) / 32, 512, 0, (hipStream_t)stream>>>(a, n64);
-    else codebook_encode_kernel<32><<<(a.M + 31) / 32, 512, 0, (hipStream_t)stream>>>(a);
+    if (er == 64) codebook_encode_kernel<64><<<(a.M + 63) / 64, 512, 0, st>>>(a);
+    else if (er == 96 && n64 > 0) codebook_encode_mixed_kernel<<<n64 + (a.M - n64 * 64 + 31) / 32, 512, 0, st>>>(a, n64);
+    else codebook_encode_kernel<32><<<(a.M + 31) / 32, 512, 0, st>>>(a);
     return hip_check(hipGetLastError(), "qv2x_codebook_encode_f32 launch");
 }
 

@@ -71,7 +71,7 @@ template <bool F32IN>
 __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(1, 1))) void codebook_encode_wave_kernel(const EncArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[32 * RS];
     const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
-    const int m0 = (int)blockIdx.x * 32;
+    const int m0 = a.m_lo + (int)blockIdx.x * 32;
     float* const row = smem + j * RS;
 
     float xq[128], z[128];              // B operands: x, then q, then the next x | z (read by qhead and by lhead)
@@ -260,7 +260,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
             const int oc = __shfl_xor(bc, 32);
             if (od < best || (od == best && oc < bc)) bc = oc;
         }
-        if (h == 0 && m0 + j < a.M) a.codes[(size_t)l * a.M + m0 + j] = (uint8_t)bc;
+        if (h == 0 && m0 + j < a.m_hi) a.codes[(size_t)l * a.M + m0 + j] = (uint8_t)bc;
         WFINE(5);
         if (last) break;
         // ---- x <- lhead(z) - C[code] ------------------------------------------------------------------------------------------
@@ -285,14 +285,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
     }
 }
 
-bool encode_wave_takes(const EncArgs& a, int cus) {
-    // from six rounds of the chip's 4 x CUs wave slots on (V2X-Real: 4 frames 1560 against 1473 us for the workgroup form, 8 frames 2779
-    // against 2912, 16: 5530, 32: 10 770 against 11 140); below that the workgroup form's 64- / 32-row mix balances better
-    return (a.M + 31) / 32 >= 6 * 4 * cus;
-}
-
 int encode_wave_launch(const EncArgs& a, hipStream_t st) {
-    const unsigned grid = (unsigned)((a.M + 31) / 32);
+    const unsigned grid = (unsigned)((a.m_hi - a.m_lo + 31) / 32);
     if (a.in_f32) codebook_encode_wave_kernel<true><<<grid, 64, 0, st>>>(a);
     else codebook_encode_wave_kernel<false><<<grid, 64, 0, st>>>(a);
     return hip_check(hipGetLastError(), "qv2x_codebook_encode_f32 (wave form) launch");

@@ -1,5 +1,5 @@
-"""a6, the wave-per-32-cells form of the encode kernel (codebook_encode_wave.hip; launches of many frames take it): the SAME codes as the
-oracle and as the workgroup form -- on the reference's 35 200 golden rows, on ragged launches, on fp32 rows, at every dictionary size."""
+"""a6, the wave-per-32-cells form of the encode kernel (codebook_encode_wave.hip; whole rounds of the chip's wave slots take it, the remainder
+of a launch and launches of less than a round the workgroup form): the SAME codes as the oracle and as the workgroup form -- on the reference's 35 200 golden rows, on ragged launches, on fp32 rows, at every dictionary size."""
 import copy
 import ctypes as C
 
@@ -94,7 +94,8 @@ def test_wave_form_on_the_reference_rows(golden):
 
 
 def test_many_frames_launch_takes_the_wave_form_and_is_exact():
-    """Six V2X-Real frames in one launch (211 200 cells: above the library's threshold): codes == one frame at a time (the workgroup form)."""
+    """Six V2X-Real frames in one launch (6 600 waves: six rounds of waves + a remainder of 456 workgroups) == one frame at a time (one round
+    of waves + 76 workgroups): the library's split between the two kernel forms is invisible in the codes."""
     import torch
     from quantv2x_amd import synth
     from quantv2x_amd.engine import deploy
