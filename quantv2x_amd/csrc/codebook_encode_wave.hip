@@ -1,4 +1,5 @@
-// a6, the form for launches of many frames: ONE WAVE owns 32 BEV cells through every level; nothing is shared between waves.
+// a6, the form that whole rounds of the chip's wave slots take (encode_launch, codebook_encode.hip): ONE WAVE owns 32 BEV cells through
+// every level; nothing is shared between waves.
 //
 // The workgroup form (codebook_encode.hip) computes out[cells][channels] = in . W^T with the eight waves of a workgroup splitting the
 // output channels, so every GEMM of the chain ends with a tile store, a workgroup barrier and a re-read, and the |q|^2 / argmin phases
@@ -6,12 +7,12 @@
 // (profiles/r04_enc_fine_b32.log), and weaving them into the GEMMs does not pay with two waves per SIMD.
 //
 // Here the product is transposed: D[channel][cell] = W[channel][k] . act[k][cell].  The weights are the MFMA's A operand, streamed from
-// L2 in fragment order (one 16-byte load per lane feeds four MFMAs); the activations of the wave's 32 cells are the B operand and stay in
+// L2 in fragment order (one 16-byte buffer load per lane feeds four MFMAs); the activations of the wave's 32 cells are the B operand and stay in
 // 128 registers per matrix; a pair of 32-channel output tiles (two 16-register accumulators, two dependent chains of 128 MFMAs) goes through the wave's
 // own 33 KB of LDS to come back in B-operand order -- no workgroup barrier, no other wave involved.  In the C layout a lane holds ONE cell
 // (lane & 31) and 16 channels / codes per tile, so the argmin over the codes is a running minimum inside the lane plus one exchange
-// between the two half-waves, and |q|^2 is two 64-long chains per lane read back from the wave's LDS rows.  One wave per SIMD (~400
-// VGPRs), four single-wave workgroups per CU (LDS), 32-cell scheduling granularity.
+// between the two half-waves, and |q|^2 is two 64-long chains per lane read back from the wave's LDS rows.  One wave per SIMD (256
+// VGPRs + ~220 AGPRs, no scratch), four single-wave workgroups per CU (LDS), 32-cell scheduling granularity.  Measured: DESIGN.md §3.
 //
 // Bit-exactness: every dot product is the same ascending-k fp32 fma chain with acc0 = bias (v_mfma_f32_32x32x2_f32 adds k = 2t from
 // lanes 0-31, then k = 2t + 1 from lanes 32-63; a . b commutes), |q|^2 and the distance use the workgroup form's op order, ties go to
@@ -60,9 +61,11 @@ __device__ __forceinline__ void tile_vec(const float* __restrict__ p, int h, int
 __device__ long long g_encw_fine[4096][32];
 #define WFINE(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_encw_fine[blockIdx.x][8 * l + (k)] = __builtin_readcyclecounter(); } while (0)
 #define WFINE2(k) do { if (fine2 && threadIdx.x == 0 && blockIdx.x < 4096) g_encw_fine[blockIdx.x][24 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define WFINE2_ARM(v) fine2 = (v)
 #else
 #define WFINE(k) do { } while (0)
 #define WFINE2(k) do { } while (0)
+#define WFINE2_ARM(v) do { } while (0)
 #endif
 
 }  // namespace
@@ -150,7 +153,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
         // that the matrix pipe never waits for a result (one chain of v_mfma_f32_32x32x2_f32 on a lone wave: 0.875 of the rate,
         // tools/probes/mfma_f32_chain_probe.hip); the ring slots a group leaves are refilled at once; `hook` = the requests for the next pair
         v16f acc[2];
+#ifdef QV2X_ENCW_FINE
         bool fine2 = false;
+#endif
         auto tile2 = [&](const float (&m)[128], const bool biased, auto&& hook) __attribute__((always_inline)) {
             WFINE2(0);
 #pragma unroll
@@ -193,12 +198,12 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
         // ---- z = stage(x) -------------------------------------------------------------------------------------------------
 #pragma unroll 1
         for (int P = 0; P < 4; ++P) {
-            fine2 = l == 1 && P == 1;
+            WFINE2_ARM(l == 1 && P == 1);                               // (dev stamps: one pair of the stage GEMM of level 1 in detail)
             tile2(xq, true, [&]() __attribute__((always_inline)) { next_vec(P < 3 ? stage_b : qhead_b, P < 3 ? P + 1 : 0); });
             tile_to_lds(row, h, 2 * P, acc[0]);
             tile_to_lds(row, h, 2 * P + 1, acc[1]);
             WFINE2(6);
-            fine2 = false;
+            WFINE2_ARM(false);
         }
         WFINE(1);
         lds_to_operand(row, h, z);
