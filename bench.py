@@ -587,6 +587,55 @@ def dry_run_ranks(rank, world, args):
     return 0 if ok else 1
 
 
+def rehearse(args, device):
+    """--rehearse-world W (see its help): rank 0's step of the W-GPU line on one GPU, its two stages timed with HIP events."""
+    global SHAPE, N_POINTS
+    import numpy as np
+    import torch
+    from quantv2x_amd.dist import AgentShardedModel
+    W = args.rehearse_world
+    wl = workload_for(W)
+    SHAPE, N_POINTS = wl["shape"], wl["n_points"]
+    torch.cuda.set_device(device)
+    B = max(1, args.batch)
+    state, eng, _, _ = build_engine(max(1, min(32, os.cpu_count() or 8)), multiclass=wl["multiclass"])
+    _, _, mine, poses = frame_batch(W, 0, B, device, layout=wl["layout"], max_cav=wl["max_cav"], own_only=True)
+    pose_t = torch.from_numpy(np.stack(poses)).to(device)
+    sh = AgentShardedModel(eng, frames=B, max_cav=wl["max_cav"], emulate_world=W, emulate_poses=pose_t)
+    out = sh.forward(mine, pose_t[0])
+    torch.cuda.synchronize()
+    _, pre, post, _ = sh._captured
+
+    def step():
+        sh.forward(mine, pose_t[0])
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    pre_us = event_time_us(pre.replay, max(5, args.steps // 5))
+    post_us = event_time_us(post.replay, max(5, args.steps // 5))
+    hw = eng.fh * eng.fw
+    line = {"metric": "frames/sec of ONE rank's step (rehearsal of an N-GPU run on one GPU; NOT a multi-GPU measurement)",
+            "value": round(B * args.steps / dt, 2), "unit": "frames/s", "n_gpus": 1, "rehearsal_of_n_gpus": W, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "dtype": "i8", "data": "synthetic",
+            "config": {"workload": wl["workload"], "baseline_config_index": wl["index"], "grid": wl["grid"], "agents_per_frame": W,
+                       "max_cav": wl["max_cav"], "layout": wl["layout"], "points_per_agent": N_POINTS, "batch_per_rank": B,
+                       "heads": "multi-class (mc, 72 channels)" if wl["multiclass"] else "single-class (20 channels)",
+                       "pillars_per_step_rank0": int(mine["voxel_features"].shape[0]), "wire_bytes_per_agent_frame": 3 * hw,
+                       "launch": "hipGraph (a1-a6 on the own agent's frames) -> the own payload copied into every agent slot, the agents' poses "
+                                 "written beside it (stands in for the all-gather) -> hipGraph (pairwise matrices, a7-a11 over W agents)"},
+            "stage_us": {"pre_a1_to_a6": round(pre_us, 1), "post_a7_to_a11": round(post_us, 1)},
+            "note": f"what every rank of `bench.py --gpus {W}` executes per step, with the collective replaced by a device copy; with a free "
+                    f"link the {W}-GPU line would read {W} x value (every rank the ego of its own view)",
+            "output_shapes": {k: list(v.shape) for k, v in out.items() if hasattr(v, "shape")}}
+    print(json.dumps(line), flush=True)
+    return 0
+
+
 def main():
     global SHAPE, N_POINTS
     ap = argparse.ArgumentParser()
@@ -605,6 +654,11 @@ def main():
     ap.add_argument("--ego-only", action="store_true", help="N>1: only rank 0 fuses (SURVEY 8(e)(i), the parity configuration: its output equals "
                     "the single-process model's); `value` then counts rank 0's frames only.  Without the flag every rank is the ego of its own "
                     "view (8(e)(ii)) and the ego-only figure is reported beside it as `ego_only`")
+    ap.add_argument("--rehearse-world", type=int, default=0, metavar="W",
+                    help="ONE GPU plays rank 0 of a W-GPU run: the workload BASELINE.json names for W (workload_for), the own agent's frames "
+                         "encoded, every other agent slot of the gathered payload filled with the own code planes + that agent's pose, the "
+                         "fusion of W agents and the heads -- the per-rank step of the W-GPU line with its true shapes, WITHOUT the link. "
+                         "Prints its own line (n_gpus 1, rehearsal_of_n_gpus W): not a multi-GPU measurement")
     ap.add_argument("--dry-run-ranks", action="store_true",
                     help="launcher check (CPU, gloo): every rank joins the group, rank 0 prints a line with n_gpus = world size; no GPU work")
     args = ap.parse_args()
@@ -626,6 +680,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus}: this node has {torch.cuda.device_count()} GPU(s)")
     if args.graph_link and args.link != "rccl":
         raise SystemExit("--graph-link needs --link rccl (the C ABI's own communicator: qv2x_allgather_codes is captured into the step's graph)")
+    if args.rehearse_world:
+        if world != 1 or args.rehearse_world < 2 or args.rehearse_world > 8:
+            raise SystemExit("--rehearse-world W: one process, 2 <= W <= 8")
+        raise SystemExit(rehearse(args, torch.device("cuda", local)))
     wl = workload_for(world)
     SHAPE, N_POINTS = wl["shape"], wl["n_points"]
     torch.cuda.set_device(local)

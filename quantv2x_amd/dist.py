@@ -59,7 +59,8 @@ class AgentShardedModel:
     ``pairwise_from_poses``, ``fuse_frames_and_heads``) with the agents of a scene sharded over ranks."""
 
     def __init__(self, engine, group=None, ego_only: bool = False, frames: int = 1, link: str = "torch", graphs: Optional[bool] = None,
-                 max_cav: Optional[int] = None, graph_link: bool = False):
+                 max_cav: Optional[int] = None, graph_link: bool = False, emulate_world: Optional[int] = None,
+                 emulate_poses: Optional[torch.Tensor] = None):
         if not getattr(engine, "has_codebook", True):
             raise NotImplementedError("AgentShardedModel exchanges the codebook's uint8 code planes: the codebook-less model "
                                       "has no compressed wire format (run it single-process through DeployedModel.forward)")
@@ -68,6 +69,14 @@ class AgentShardedModel:
         self.engine, self.group, self.ego_only, self.frames, self.link = engine, group, ego_only, int(frames), link
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # REHEARSAL (bench.py --rehearse-world W): one process plays rank 0 of a world of W -- its own payload fills every agent slot, the
+        # other agents' poses come from ``emulate_poses`` [W, 4, 4] -- so that the per-rank kernels of a W-GPU step run with their true
+        # shapes on one GPU.  Not a multi-GPU run: no collective, and the "other agents" are copies of the own code planes.
+        self.emulate = None
+        if emulate_world is not None:
+            if self.world != 1 or link != "torch" or emulate_poses is None or tuple(emulate_poses.shape) != (emulate_world, 4, 4):
+                raise ValueError("emulate_world: one process, link='torch', emulate_poses [W, 4, 4]")
+            self.world, self.emulate = int(emulate_world), emulate_poses.to(torch.float64)
         self.max_cav = max(self.world, max_cav or 0)
         self.levels, self.hw = engine.wire_shape()
         self.codes_bytes, self.pose_off, self.payload_bytes = payload_layout(self.levels, self.frames, self.hw)
@@ -122,6 +131,11 @@ class AgentShardedModel:
         self.my_poses.copy_(my_pose.to(torch.float64).expand(self.frames, 4, 4))
 
     def _exchange(self):
+        if self.emulate is not None:
+            self.gathered.copy_(self.payload.unsqueeze(0).expand(self.world, -1))
+            self.gathered[:, self.pose_off:].view(torch.float64).view(self.world, self.frames, 4, 4).copy_(
+                self.emulate.to(self.gathered.device)[:, None].expand(self.world, self.frames, 4, 4))
+            return
         if self.link == "rccl":
             from . import lib as L
             L.check(self._lib.qv2x_allgather_codes(self._comm, L.ptr(self.payload), L.ptr(self.gathered), self.payload_bytes,

@@ -158,6 +158,35 @@ def test_exchange_world_one_is_a_copy():
         dist.destroy_process_group()
 
 
+def test_rehearsal_of_a_world_of_three_on_one_process():
+    """``emulate_world`` (bench.py --rehearse-world): one process plays rank 0 of a world of W -- every agent slot holds the own code planes,
+    the other agents' poses come from the caller -- so the post stage sees W agents, the ego at slot 0, and the pairwise matrices of the
+    given poses.  No process group is needed."""
+    from quantv2x_amd import synth
+    from quantv2x_amd.dist import AgentShardedModel, POSE_BYTES
+    from quantv2x_amd.ptq_state import export_ptq_state
+    from oracle import geometry
+    state = export_ptq_state(calibrated_plugin())
+    eng = _OracleEngine(state)
+    W = 3
+    poses = torch.from_numpy(np.stack(synth.agent_poses(W, "ring")))
+    sc = scene_np(1)
+    mine = {k: torch.from_numpy(v) for k, v in sc["inputs_m1"].items()}
+    sh = AgentShardedModel(eng, frames=1, max_cav=5, emulate_world=W, emulate_poses=poses)
+    out = sh.forward(mine, poses[0])
+    assert sh.world == W and sh.gathered.shape[0] == W
+    shape, agent_stride, level_stride, frame_stride, n_agents, ego = eng.calls[-1]
+    assert (n_agents, ego) == (W, 0) and agent_stride == sh.payload_bytes
+    for a in range(W):                                              # the own code planes in every slot, that agent's pose beside them
+        assert torch.equal(sh.gathered[a, :sh.codes_bytes], sh.payload[:sh.codes_bytes])
+        got = sh.gathered[a, sh.pose_off:sh.pose_off + POSE_BYTES].numpy().view(np.float64).reshape(4, 4)
+        np.testing.assert_array_equal(got, poses[a].numpy())
+    np.testing.assert_array_equal(sh.pairwise[0].numpy(), geometry.pairwise_from_poses([p.numpy() for p in poses], 5))
+    assert np.isfinite(out["preds_tensor"].numpy()).all()
+    with pytest.raises(ValueError):
+        AgentShardedModel(eng, emulate_world=W, emulate_poses=poses[:2])
+
+
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it starts two ranks through torch.distributed.run (a fresh child) and
     relays rank 0's line; the dry-run flag keeps the ranks on gloo / CPU.  Without two GPUs the real bench refuses instead of
