@@ -454,8 +454,13 @@ static int encode_launch(const qv2x_encode_desc* d, const int8_t* in, const floa
     // (profiles/r04_encode_by_frames.log).  Launches of less than one round keep the workgroup form's 64- / 32-row mix below.
     const int slots = 4 * cus, waves = (a.M + 31) / 32;
     const int rounds = waves / slots, rest = waves - rounds * slots;
+    int tail_max = 2 * cus;                                            // most workgroups a remainder may have
+#ifdef QV2X_DEV_KNOBS
+    static const int tail_knob = [] { const char* e = getenv("QV2X_ENC_TAIL"); return e ? atoi(e) : -1; }();   // 0: every remainder as waves
+    if (tail_knob >= 0) tail_max = tail_knob;
+#endif
     if (er_env == 0 && rounds >= 1) {
-        if (rest == 0 || rest > 2 * cus) return encode_wave_launch(a, st);
+        if (rest == 0 || rest > tail_max) return encode_wave_launch(a, st);
         EncArgs main = a, tail = a;
         main.m_hi = rounds * slots * 32;
         tail.m_lo = main.m_hi;

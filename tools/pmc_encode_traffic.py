@@ -21,7 +21,7 @@ def mean(d, counter):
     return sum(v) / len(v), len(v), [gs for (nr, c, gs) in rows if nr == g][0], g
 f, nf, gf, rows_f = mean(fetch_dir, "FETCH_SIZE")
 w, nw, gw, rows_w = mean(write_dir, "WRITE_SIZE")
-res = {"kernel": "codebook_encode_wave_kernel (launches of the bench's batch; the workgroup form below six rounds of the chip)", "launches_averaged": [nf, nw], "grid_threads": gf, "agent_frames_per_launch": rows_f // 35200 if gf else None,
+res = {"kernel": "codebook_encode_wave_kernel: the whole rounds of waves of the bench's batch (34 816 of its 35 200 waves' worth of rows; the remainder runs as 384 workgroups of codebook_encode_kernel<32>, not counted here)", "launches_averaged": [nf, nw], "grid_threads": gf, "rows_per_launch": rows_f, "agent_frames_per_launch": round(rows_f / 35200, 3) if gf else None,
        "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
        "traffic_bytes_per_launch_raw": None if f is None or w is None else int((f + w) * 1024),
        "traffic_bytes_per_launch": None if f is None or w is None else int((2 * f + w) * 1024),
