@@ -15,6 +15,8 @@ such batches are in flight on two streams (the next batch's PFN / backbone fill 
 With N GPUs, rank r owns agent r (one process per GPU): every step each rank encodes B frames of its agent, ONE RCCL
 all-gather moves the code planes + poses, and every rank fuses as the ego of its own view, so a step yields N x B fused
 N-agent frames; ``value`` = N * B * K / (max-over-ranks time).  Per-GPU work is fixed as N grows: ``"scaling": "weak"``.
+``--rehearse-world W`` (one GPU): rank 0's step of the W-GPU line with the all-gather replaced by a device copy -- its own line, not a
+multi-GPU measurement.
 
 Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line (contract in the task prompt) with
   roofline         the dominant kernel by time (codebook_encode_wave_kernel: f32 MFMA), launch duration from HIP events
