@@ -68,6 +68,37 @@ def test_wave_form_equals_workgroup_form_on_random_heads(levels, kc, n, h, w):
     np.testing.assert_array_equal(codes.cpu().numpy(), ref.cpu().numpy())
 
 
+@pytest.mark.parametrize("h,w,what", [(128, 256, "exactly one round of waves, no remainder"),
+                                      (100, 328, "one round + a remainder of ONE workgroup"),
+                                      (128, 384, "one round + a remainder of 512 workgroups (the most a remainder may have)"),
+                                      (116, 424, "one round + 513: the remainder is a second round of waves"),
+                                      (97, 331, "ragged: the last workgroup of the remainder is partly past the end")])
+def test_split_launch_boundaries(h, w, what):
+    """qv2x_codebook_encode_f32 splits a launch into whole rounds of the chip's 1 024 wave slots (wave form) + a remainder of up to 512
+    32-cell workgroups: at the boundaries of that rule the codes equal the wave form forced over the whole launch."""
+    import torch
+    from quantv2x_amd import lib as L
+    lib = L.load()
+    dev = torch.device("cuda", 0)
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip("the boundaries are those of a 256-CU part")
+    rng = np.random.default_rng(h * 1000 + w)
+    levels, kc = 2, 64
+    blobs = _blobs(rng, levels, kc, dev)
+    ptrs = (C.c_void_p * levels)(*[b.data_ptr() for b in blobs])
+    x = torch.from_numpy(rng.integers(-128, 128, size=(1, h + 2, w + 2, 256), dtype=np.int8)).to(dev)
+    d = L.EncodeDesc()
+    d.n, d.h, d.w, d.levels, d.kc, d.in_zx, d.in_delta = 1, h, w, levels, kc, 131, 0.021
+    M = h * w
+    a = torch.full((levels, M), 255, dtype=torch.uint8, device=dev)
+    b = torch.full((levels, M), 255, dtype=torch.uint8, device=dev)
+    L.check(lib.qv2x_codebook_encode_f32(C.byref(d), L.ptr(x), ptrs, L.ptr(a), L.current_stream()), "split")
+    L.check(lib.qv2x_codebook_encode_wave_f32(C.byref(d), L.ptr(x), None, ptrs, L.ptr(b), L.current_stream()), "wave")
+    a, b = a.cpu().numpy(), b.cpu().numpy()
+    assert a.max() < kc, what
+    np.testing.assert_array_equal(a, b, err_msg=what)
+
+
 def test_wave_form_on_the_reference_rows(golden):
     """35 200 real rows x 3 levels: the wave form == the oracle == the workgroup form; against the REFERENCE no index outside its own ties."""
     import torch
