@@ -606,7 +606,7 @@ def rehearse(args, device):
     sh = AgentShardedModel(eng, frames=B, max_cav=wl["max_cav"], emulate_world=W, emulate_poses=pose_t)
     out = sh.forward(mine, pose_t[0])
     torch.cuda.synchronize()
-    _, pre, post, _ = sh._captured
+    pre, post = sh.stage_graphs()
 
     def step():
         sh.forward(mine, pose_t[0])

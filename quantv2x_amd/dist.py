@@ -183,6 +183,13 @@ class AgentShardedModel:
             post.replay()
         return out
 
+    def stage_graphs(self):
+        """(pre, post) HIP graphs of the captured step (post is None on a non-ego rank of ``ego_only`` and with ``graph_link``), for stage
+        timing; None before the first ``forward``."""
+        if self._captured is None:
+            return None
+        return self._captured[1], self._captured[2]
+
     def _capture(self, my_inputs, skip_post):
         """Two HIP graphs around the collective.  The pillar count and the input addresses are baked in: refresh the input
         tensors in place between steps (pad unused pillar rows with agent index -1).
