@@ -101,5 +101,9 @@ int main() {
     run<8, 1, 6>(w, wbytes, out, cyc, "32 channels x 192 pixels per wave, two waves per SIMD");
     run<8, 1, 4>(w, wbytes, out, cyc, "32 channels x 128 pixels per wave, two waves per SIMD");
     run<16, 1, 4>(w, wbytes, out, cyc, "32 channels x 128 pixels per wave, four waves per SIMD");
+    run<16, 1, 3>(w, wbytes, out, cyc, "32 channels x 96 pixels per wave, four waves per SIMD");
+    run<16, 1, 2>(w, wbytes, out, cyc, "32 channels x 64 pixels per wave, four waves per SIMD");
+    run<12, 1, 3>(w, wbytes, out, cyc, "32 channels x 96 pixels per wave, three waves per SIMD");
+    run<12, 1, 5>(w, wbytes, out, cyc, "32 channels x 160 pixels per wave, three waves per SIMD");
     return 0;
 }
