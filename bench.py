@@ -736,6 +736,11 @@ def main():
         # same round-robin order, so the F all-gathers in flight on one communicator cannot cross
         F = max(1, args.inflight)
         engines = [eng] + [deploy(state=state) for _ in range(F - 1)]
+        if world == 1:
+            # --force-sharded at world 1 times "the N>1 code path": the post stage must be the GENERAL a7-a11 kernels a real rank runs
+            # (decode + warp + attention + GEMM heads), not the single-agent table look-up a world of one would take
+            for e in engines:
+                e.single_agent_tables = False
         streams = [torch.cuda.Stream() for _ in range(F)]
         pose = torch.from_numpy(poses[rank]).to(device)
 

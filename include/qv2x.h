@@ -24,6 +24,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libqv2x.so is built with -fvisibility=hidden: the entry points declared in this header are its whole dynamic symbol table
+ * (tests/test_cabi_cpu.py checks `nm -D` against it). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define QV2X_OK 0
 #define QV2X_EINVAL (-1)     /* bad argument (shape not supported, null pointer ...) */
@@ -556,6 +561,9 @@ int qv2x_pairwise_from_poses_f64(const uint8_t* gathered, int world, int64_t age
 int qv2x_pairwise_from_poses_batch_f64(const uint8_t* gathered, int world, int64_t agent_stride_bytes, int64_t pose_offset_bytes,
                                        int frames, int64_t frame_stride_bytes, int max_cav, double* pairwise, void* stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

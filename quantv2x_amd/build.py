@@ -16,7 +16,7 @@ OBJDIR = os.path.join(HERE, "build")
 # a separate multiply and add (oracle/qv2x_oracle.c is built the same way).
 # -Wno-inline-asm: conv_i8_wide.hip issues its LDS-DMA as inline asm that writes M0 (see the comment there); hipcc warns that M0 is a
 # reserved register -- the kernel has no other M0 user (no builtin LDS-DMA, no ds_*_addtid, no GWS / sendmsg).
-CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=default", "-Wno-inline-asm"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-Wno-inline-asm"]
 FLAGS = CFLAGS + ["-shared"]            # one-shot form (tools that build a variant library use it with SOURCES)
 
 
@@ -48,7 +48,12 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
         subprocess.check_call(cmd)
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as pool:
         list(pool.map(compile_one, todo))
-    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + [_obj(s) for s in SOURCES]
+    # the dynamic symbol table = the C entry points of include/qv2x.h (-fvisibility=hidden + the header's visibility pragma) and nothing
+    # else: hipcc keeps every __global__ kernel's host-side handle at default visibility, the version script makes those local too
+    vmap = os.path.join(OBJDIR, "exports.map")
+    with open(vmap, "w") as f:
+        f.write("{ global: qv2x_*; local: *; };\n")
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + vmap, "-o", OUT] + [_obj(s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -13,6 +13,8 @@
 // index, then a 4-way combine across waves through LDS.
 #include <cstdlib>
 
+#include <atomic>
+
 #include "codebook_encode.h"
 
 namespace qv2x {
@@ -437,13 +439,15 @@ static int encode_launch(const qv2x_encode_desc* d, const int8_t* in, const floa
     if (er_knob != 0 && er_knob != 32 && er_knob != 64 && er_knob != 96) return fail(QV2X_EINVAL, "QV2X_ENC_ROWS=%d: 32, 64 or 96", er_knob);
     er_env = er_knob;
 #endif
-    // from six rounds of 64-row workgroups on (three V2X-Real frames on 256 CUs): the 64-row form (1 / 2 / 4 / 8 frames: 478 vs 518, 853 vs 856,
-    // 1580 vs 1499, 2991 vs 2906 us); below: the mixed form when it has at least one full round of 64-row workgroups
-    static int cus_of[64];                                             // CU count per device, asked once (0 = not asked yet)
+    static std::atomic<int> cus_of[64];                                // CU count per device, asked once (0 = not asked yet); relaxed atomics: every
+                                                                       // thread that finds 0 asks and stores the same value (reentrant per stream)
     int cus = 256, dev = 0, v = 0;
     if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
-        if (cus_of[dev] == 0) cus_of[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-        cus = cus_of[dev];
+        cus = cus_of[dev].load(std::memory_order_relaxed);
+        if (cus == 0) {
+            cus = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+            cus_of[dev].store(cus, std::memory_order_relaxed);
+        }
     }
     hipStream_t st = (hipStream_t)stream;
     if (form == 1) return encode_wave_launch(a, st);
@@ -468,8 +472,10 @@ static int encode_launch(const qv2x_encode_desc* d, const int8_t* in, const floa
         codebook_encode_kernel<32><<<rest, 512, 0, st>>>(tail);
         return hip_check(hipGetLastError(), "qv2x_codebook_encode_f32 launch");
     }
+    // Below one round of waves (a.M < 128 cells per CU): the mixed form when it has at least one full round of 64-row workgroups, else
+    // 32-row workgroups.  (A whole launch of 64-row workgroups is a dev knob only since the split rule above: QV2X_ENC_ROWS=64.)
     const int n64 = (a.M / 64) / cus * cus;
-    const int er = er_env ? er_env : ((a.M / 64) >= 6 * cus ? 64 : (n64 > 0 ? 96 : 32));
+    const int er = er_env ? er_env : (n64 > 0 ? 96 : 32);
     if (er == 64) codebook_encode_kernel<64><<<(a.M + 63) / 64, 512, 0, st>>>(a);
     else if (er == 96 && n64 > 0) codebook_encode_mixed_kernel<<<n64 + (a.M - n64 * 64 + 31) / 32, 512, 0, st>>>(a, n64);
     else codebook_encode_kernel<32><<<(a.M + 31) / 32, 512, 0, st>>>(a);
@@ -477,12 +483,12 @@ static int encode_launch(const qv2x_encode_desc* d, const int8_t* in, const floa
 }
 
 #ifdef QV2X_ENC_FINE
-extern "C" int qv2x_debug_encode_fine(long long* host, int n) {
+extern "C" __attribute__((visibility("default"))) int qv2x_debug_encode_fine(long long* host, int n) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(qv2x::g_enc_fine), (size_t)n * 40 * sizeof(long long)) == hipSuccess ? 0 : -1;
 }
 #endif
 #ifdef QV2X_ENC_TRACE
-extern "C" int qv2x_debug_encode_blocks(unsigned long long* host, int n) {
+extern "C" __attribute__((visibility("default"))) int qv2x_debug_encode_blocks(unsigned long long* host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(qv2x::g_enc_blk), (size_t)n * 4 * sizeof(unsigned long long));
 }
 #endif

@@ -300,7 +300,7 @@ int encode_wave_launch(const EncArgs& a, hipStream_t st) {
 }  // namespace qv2x
 
 #ifdef QV2X_ENCW_FINE
-extern "C" int qv2x_debug_encw_fine(long long* host, int n) {
+extern "C" __attribute__((visibility("default"))) int qv2x_debug_encw_fine(long long* host, int n) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(qv2x::g_encw_fine), (size_t)n * 32 * sizeof(long long)) == hipSuccess ? 0 : -1;
 }
 #endif

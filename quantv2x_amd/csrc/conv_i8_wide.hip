@@ -593,11 +593,11 @@ static int wide_bn(const qv2x_conv_desc* d) {
 }
 
 #ifdef QV2X_WIDE_FINE
-extern "C" int qv2x_debug_wide_fine(long long* host_out, int nblocks) {
+extern "C" __attribute__((visibility("default"))) int qv2x_debug_wide_fine(long long* host_out, int nblocks) {
     using namespace qv2x;
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wide_fine), (size_t)nblocks * 16 * sizeof(long long));
 }
-extern "C" int qv2x_debug_wide_fine_clear() {
+extern "C" __attribute__((visibility("default"))) int qv2x_debug_wide_fine_clear() {
     using namespace qv2x;
     void* p = nullptr;
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_wide_fine)) != hipSuccess) return -1;
@@ -606,11 +606,11 @@ extern "C" int qv2x_debug_wide_fine_clear() {
 #endif
 
 #ifdef QV2X_WIDE_TRACE
-extern "C" int qv2x_debug_wide_trace(long long* host_out, int nblocks) {
+extern "C" __attribute__((visibility("default"))) int qv2x_debug_wide_trace(long long* host_out, int nblocks) {
     using namespace qv2x;
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wide_trace), (size_t)nblocks * 8 * sizeof(long long));
 }
-extern "C" int qv2x_debug_wide_trace_clear() {
+extern "C" __attribute__((visibility("default"))) int qv2x_debug_wide_trace_clear() {
     using namespace qv2x;
     void* p = nullptr;
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_wide_trace)) != hipSuccess) return -1;

@@ -284,10 +284,10 @@ __global__ __launch_bounds__(NCB * RG * 64, NCB * RG == 4 ? 2 : 1) void conv3x3_
 }  // namespace
 
 #ifdef QV2X_WS_FINE
-extern "C" int qv2x_debug_ws_fine(long long* host_out, int nblocks) {
+extern "C" __attribute__((visibility("default"))) int qv2x_debug_ws_fine(long long* host_out, int nblocks) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ws_fine), (size_t)nblocks * 16 * sizeof(long long));
 }
-extern "C" int qv2x_debug_ws_fine_clear() {
+extern "C" __attribute__((visibility("default"))) int qv2x_debug_ws_fine_clear() {
     void* p = nullptr;
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_ws_fine)) != hipSuccess) return -1;
     return (int)hipMemset(p, 0, sizeof(g_ws_fine));

@@ -480,7 +480,7 @@ extern "C" int qv2x_decode_lut_f32(const uint8_t* codes, int R, int levels, int 
 }
 
 #ifdef QV2X_HEADS_TRACE
-extern "C" int qv2x_debug_heads_trace(long long* host_out, int nblocks) {
+extern "C" __attribute__((visibility("default"))) int qv2x_debug_heads_trace(long long* host_out, int nblocks) {
     using namespace qv2x;
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_heads_trace), (size_t)nblocks * 6 * sizeof(long long));
 }

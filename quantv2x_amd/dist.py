@@ -116,6 +116,13 @@ class AgentShardedModel:
         comm = C.c_void_p()
         L.check(lib.qv2x_comm_init(uid, self.world, self.rank, C.byref(comm)), "qv2x_comm_init")
         self._comm, self._lib = comm, lib
+        # The communicator's FIRST collective runs here, eagerly: RCCL sets up its channels and proxy connections lazily on a
+        # communicator's first collective -- host-side allocations and synchronisations that must not happen under stream capture
+        # (graph_link=True captures the step's all-gather).  Every rank is here together (the broadcast above), so the ranks stay in
+        # phase; the gathered buffer it fills is overwritten by the first step.
+        L.check(lib.qv2x_allgather_codes(comm, L.ptr(self.payload), L.ptr(self.gathered), self.payload_bytes, L.current_stream()),
+                "qv2x_allgather_codes (communicator warm-up)")
+        torch.cuda.current_stream().synchronize()
 
     def close(self):
         if self._comm is not None:

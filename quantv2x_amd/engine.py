@@ -217,7 +217,7 @@ class _Heads:
             bs.append(state[n + "/bias"].astype(np.float32))
             off = bool(state[n + "/a_off"])
             das.append(np.full(w.shape[0], -1.0 if off else float(np.float32(state[n + "/a_delta"])), np.float32))
-            zas.append(np.full(w.shape[0], float(state[n + "/a_zp"]), np.float32))
+            zas.append(np.full(w.shape[0], 0.0 if off else float(state[n + "/a_zp"]), np.float32))   # (a disabled quantizer's parameters are never read)
         self.splits = [w.shape[0] for w in ws]
         self.cout = sum(self.splits)
         self.cout_pad = (self.cout + 31) // 32 * 32
@@ -686,7 +686,9 @@ class DeployedModel(nn.Module):
         hw = self.fh * self.fw
         sp = None
         if n_agents == 1 and self.table_heads is not None and self.single_agent_tables and own_codes is not None and frame_stride == hw:
-            return self._table_heads_out(own_codes, frames)                # a world of one agent: the own code planes ARE the scene
+            # a world of one agent: the own code planes ARE the scene (pairwise here comes from qv2x_pairwise_from_poses_*: T[0][0] of a
+            # world of one is the identity by construction, so the shortcut's contract holds without a read-back)
+            return self._table_heads_out(own_codes, frames)
         if frames * hw // 32 >= self.fuse_heads_min_tiles and n_agents <= self.fuse_heads_max_agents:    # one launch, no fused map in HBM (see finish)
             preds = self.fuse_heads_scenes(L.ptr(gathered), agent_stride, level_stride, None, pairwise, [f * frame_stride for f in range(frames)],
                                            [n_agents] * frames, ego)
@@ -764,6 +766,27 @@ class DeployedModel(nn.Module):
             L.check(self.lib.qv2x_fuse_att_batch_f32(C.byref(d), s1 - s0, offs, cnts, codes_ptr, lut, lb,
                                                      L.ptr(feats) if feats is not None else None, L.ptr(pairwise[s0]), L.ptr(out[s0]),
                                                      L.current_stream()), "qv2x_fuse_att_batch_f32")
+
+    def _self_transforms_are_identity(self, pairwise: torch.Tensor) -> bool:
+        """The table look-up for single-agent scenes skips the warp: it is only the model's result when ``pairwise[b, 0, 0] = I`` (what
+        ``get_pairwise_transformation`` produces, transformation_utils.py:21-66).  The reference warps with whatever it is handed
+        (AttFusion -> warp_affine_simple, fusion_in_one.py:142-143), so a non-identity self-transform (pose-noise experiments, a caller's
+        bug) must take the general path.  Checked on the host whenever the matrix can be read: a CPU tensor always; a device tensor unless
+        the stream is capturing (the verdict is cached per tensor version, so a replayed input costs one read-back).  During capture of a
+        device tensor the contract cannot be verified and is assumed -- ``capture()`` runs an eager forward first, which does check."""
+        if pairwise.is_cuda:
+            if torch.cuda.is_current_stream_capturing():
+                return True
+            key = (pairwise.data_ptr(), pairwise._version, tuple(pairwise.shape))
+            if getattr(self, "_ident_key", None) == key:
+                return self._ident_val
+            t00 = pairwise[:, 0, 0].cpu()
+        else:
+            key, t00 = None, pairwise[:, 0, 0]
+        ok = bool((t00 == torch.eye(4, dtype=t00.dtype)).all())
+        if key is not None:
+            self._ident_key, self._ident_val = key, ok
+        return ok
 
     def _table_heads_out(self, codes, n: int) -> dict:
         """The model's output dict for ``n`` single-agent scenes from their code planes u8 [levels, n * H*W] (qv2x_table_heads_f32).
@@ -904,8 +927,13 @@ class DeployedModel(nn.Module):
         #  heterogeneous scene never encodes n_total agents itself)
         feats = None if self.has_codebook else self._shared_features(enc, n_total)
         starts = [sum(lens[:bi]) for bi in range(nb)]
-        if taps is None and self.table_heads is not None and self.single_agent_tables and all(n == 1 for n in lens):
+        if (taps is None and self.table_heads is not None and self.single_agent_tables and all(n == 1 for n in lens)
+                and self._self_transforms_are_identity(pairwise)):
             return self._table_heads_out(enc, nb)                         # every scene is one agent: all heads straight from its code planes
+        if not pairwise.is_cuda:                                         # a host tensor (the reference's collate output before to_device): copied here
+            if torch.cuda.is_current_stream_capturing():
+                raise ValueError("pairwise_t_matrix on the host cannot be uploaded during HIP-graph capture: pass a device tensor")
+            pairwise = pairwise.to(self.dev)
         one_launch = taps is None and nb * hw // 32 >= self.fuse_heads_min_tiles and max(lens) <= self.fuse_heads_max_agents
         fused = None if one_launch else torch.empty((nb, hw, 256), dtype=torch.float32, device=self.dev)
         if one_launch:                                                   # decode + warp + fusion + heads, tile by tile: no fused map in HBM

@@ -227,10 +227,15 @@ def check_finite(state: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
     for k, v in state.items():
         a = np.asarray(v)
         if a.dtype.kind == "f":
+            # a DISABLED output quantizer's delta / zero point are never read by a kernel (e.g. an uninitialised delta of a layer with
+            # disable_act_quant=True): exempt from both tests
+            stem = k[:-len("a_delta")] if k.endswith("/a_delta") else (k[:-len("a_zp")] if k.endswith("/a_zp") else None)
+            off = stem is not None and bool(state.get(stem + "a_off", False))
+            if off:
+                continue
             if not np.isfinite(a).all():
                 raise ValueError(f"PTQ state: {k} holds a non-finite value; the deployed path is specified on finite quantizer parameters and weights")
-            off = k.endswith("/a_delta") and bool(state.get(k[:-len("a_delta")] + "a_off", False))     # (a disabled output quantizer's delta is unused)
-            if k.endswith("_delta") and not off and not (a > 0).all():
+            if k.endswith("_delta") and not (a > 0).all():
                 raise ValueError(f"PTQ state: {k} must be positive")
     return state
 

@@ -27,6 +27,20 @@ def test_library_exports_every_declared_symbol():
     assert l.qv2x_version() == 1
 
 
+def test_dynamic_symbol_table_is_the_header_only():
+    """-fvisibility=hidden + the header's visibility pragma: `nm -D` shows the declared C entry points and nothing else of ours
+    (no mangled qv2x:: helpers, no kernel stubs)."""
+    import subprocess
+    from quantv2x_amd import lib
+    _lib()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH], text=True)
+    names = [ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-2] in ("T", "t", "W", "w", "B", "D", "V")]
+    ours = [n for n in names if "qv2x" in n.lower()]
+    assert sorted(ours) == sorted(lib.SYMBOLS), sorted(set(ours) ^ set(lib.SYMBOLS))
+    leaked = [n for n in names if n.startswith("_ZN4qv2x") or "__device_stub__" in n]
+    assert not leaked, leaked[:5]
+
+
 def test_struct_layouts_match_header():
     from quantv2x_amd import lib
     assert C.sizeof(lib.PfnParams) == (640 + 64 + 4 + 6) * 4

@@ -108,3 +108,35 @@ def test_single_agent_scenes_by_tables(shape, frames, n_points):
     torch.cuda.synchronize()
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_single_agent_shortcut_honours_a_non_identity_self_transform():
+    """the table look-up skips the warp, so it is only taken when pairwise[b, 0, 0] = I.  A caller that hands a shifted / rotated
+    self-transform (pose-noise experiments) gets what the reference computes -- AttFusion warps with t_matrix[0] whatever it is
+    (fusion_in_one.py:142-143): the general path, equal to the oracle, for a device tensor and for a CPU tensor."""
+    from _common import head_lsb
+    from oracle.spec import Oracle
+    from quantv2x_amd import synth
+    from quantv2x_amd.engine import deploy
+    from quantv2x_amd.ptq_state import export_ptq_state
+    state = export_ptq_state(calibrated_plugin("tiny", n_agents=2))
+    eng = deploy(state=state)
+    assert eng.table_heads is not None and eng.single_agent_tables
+    sc = scene_np(1, seed=31)
+    sc["pairwise_t_matrix"] = sc["pairwise_t_matrix"].copy()
+    sc["pairwise_t_matrix"][0, 0, 0] = synth.pose_matrix(1.3, -0.7, 0.2)          # NOT the identity
+    want = Oracle(state).forward(sc)
+    ident = scene_np(1, seed=31)
+    plain = Oracle(state).forward(ident)
+    assert np.abs(want["preds_tensor"] - plain["preds_tensor"]).max() > 1e-3       # the warp matters for this scene
+    for on_cpu in (False, True):
+        dd = _batch([sc])
+        if on_cpu:
+            dd["pairwise_t_matrix"] = dd["pairwise_t_matrix"].cpu()
+        got = eng(dd)
+        torch.cuda.synchronize()
+        lsb = head_lsb(state, "")
+        d = np.abs(got["preds_tensor"].cpu().numpy() - want["preds_tensor"])
+        assert d.max() <= lsb * 1.001 and (d > 1e-5).mean() < 1e-3, (on_cpu, d.max())
+    # and the identity still takes the shortcut
+    assert eng._self_transforms_are_identity(_batch([ident])["pairwise_t_matrix"])
