@@ -218,16 +218,26 @@ def rooflines(eng, full, frames, iters):
     if pmc:
         with open(pmc) as f:
             j = json.load(f)
-        if j.get("agent_frames_per_launch") == n:        # (a stored figure only describes launches of the batch size it was taken at)
-            traffic, note = j.get("traffic_bytes_per_launch"), j.get("note", "")
-        else:
-            note = f"profiles/{os.path.basename(pmc)} was taken at {j.get('agent_frames_per_launch')} agent-frames per launch, this run has {n}"
+        af = float(j.get("agent_frames_per_launch") or 0)
+        if af > 0:
+            # The counters were taken over the launches of one batch size; per agent-frame the kernel's traffic does not depend on it (every
+            # wave streams the same 3.4 MB of level blobs through its XCD's L2 and reads its own 32 rows once), so the stored figure is kept
+            # PER AGENT-FRAME and scaled to this run's launch -- VERDICT r4: the field was null whenever the two sizes differed by a remainder.
+            traffic = int(round(float(j.get("traffic_bytes_per_launch")) / af * n))
+            note = (f"profiles/{os.path.basename(pmc)}: {j.get('traffic_bytes_per_launch')} B per launch of {af} agent-frames = "
+                    f"{float(j.get('traffic_bytes_per_launch')) / af / 1e6:.3f} MB per agent-frame, x {n} agent-frames of this run's launch; " + j.get("note", ""))
     roof = {"bound": "mfma", "achieved": enc["achieved"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": enc["frac"],
             "traffic": traffic, "traffic_note": "STORED figure, not measured by this run: " + note,
+            "algorithmic_bytes_per_launch": None, "traffic_over_algorithmic": None,
             "kernel": "codebook_encode_wave_kernel (f32 MFMA v_mfma_f32_32x32x2_f32; the dominant kernel by time; a wave per 32 cells)", "launches_per_batch": 1,
             "avg_launch_us": enc["us_per_batch"], "agent_frames_per_launch": n,
             "algorithmic_gflop_per_launch": round(enc_gflop * n, 2),
             "share_of_batch_time": None}
+    # algorithmic bytes of the launch: every cell's 256 input codes read once, its code planes written, the level blobs read once
+    alg = n * hw * 256 + n * hw * eng.levels + sum(int(b.numel()) * 4 for b in eng.level_blobs)
+    roof["algorithmic_bytes_per_launch"] = alg
+    if traffic:
+        roof["traffic_over_algorithmic"] = round(traffic / alg, 3)
     total = sum(s["us_per_batch"] for s in stages.values() if "us_per_batch" in s)
     roof["share_of_batch_time"] = round(enc["us_per_batch"] / total, 3)
     if general:
@@ -589,20 +599,28 @@ def dry_run_ranks(rank, world, args):
     return 0 if ok else 1
 
 
-def rehearse(args, device):
-    """--rehearse-world W (see its help): rank 0's step of the W-GPU line on one GPU, its two stages timed with HIP events."""
+def rehearse_line(W, B, steps, warmup, device, engine=None):
+    """Rank 0's step of the W-GPU line on one GPU (``AgentShardedModel(emulate_world=W)``): the own agent's B frames encoded, the own payload
+    copied into every agent slot with the agents' poses beside it (a device copy where the all-gather would be), then the pairwise matrices, the
+    fusion of W agents and the heads -- its two stages timed with HIP events.  ``engine``: a deployed model of the workload's shape to reuse
+    (the N = 1 line's own engine serves W = 2..4: same V2X-Real model); None builds (calibrates) the workload's model."""
     global SHAPE, N_POINTS
     import numpy as np
     import torch
     from quantv2x_amd.dist import AgentShardedModel
-    W = args.rehearse_world
     wl = workload_for(W)
+    keep = (SHAPE, N_POINTS)
     SHAPE, N_POINTS = wl["shape"], wl["n_points"]
-    torch.cuda.set_device(device)
-    B = max(1, args.batch)
-    state, eng, _, _ = build_engine(max(1, min(32, os.cpu_count() or 8)), multiclass=wl["multiclass"])
-    _, _, mine, poses = frame_batch(W, 0, B, device, layout=wl["layout"], max_cav=wl["max_cav"], own_only=True)
+    try:
+        eng = engine
+        if eng is None:
+            _, eng, _, _ = build_engine(max(1, min(32, os.cpu_count() or 8)), multiclass=wl["multiclass"])
+        _, _, mine, poses = frame_batch(W, 0, B, device, layout=wl["layout"], max_cav=wl["max_cav"], own_only=True)
+        n_points = N_POINTS
+    finally:
+        SHAPE, N_POINTS = keep
     pose_t = torch.from_numpy(np.stack(poses)).to(device)
+    tables = eng.single_agent_tables
     sh = AgentShardedModel(eng, frames=B, max_cav=wl["max_cav"], emulate_world=W, emulate_poses=pose_t)
     out = sh.forward(mine, pose_t[0])
     torch.cuda.synchronize()
@@ -610,32 +628,92 @@ def rehearse(args, device):
 
     def step():
         sh.forward(mine, pose_t[0])
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    pre_us = event_time_us(pre.replay, max(5, args.steps // 5))
-    post_us = event_time_us(post.replay, max(5, args.steps // 5))
+    pre_us = event_time_us(pre.replay, max(5, steps // 5))
+    post_us = event_time_us(post.replay, max(5, steps // 5))
+    eng.single_agent_tables = tables
     hw = eng.fh * eng.fw
-    line = {"metric": "frames/sec of ONE rank's step (rehearsal of an N-GPU run on one GPU; NOT a multi-GPU measurement)",
-            "value": round(B * args.steps / dt, 2), "unit": "frames/s", "n_gpus": 1, "rehearsal_of_n_gpus": W, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "dtype": "i8", "data": "synthetic",
+    return {"metric": "frames/sec of ONE rank's step (rehearsal of an N-GPU run on one GPU; NOT a multi-GPU measurement)",
+            "value": round(B * steps / dt, 2), "unit": "frames/s", "n_gpus": 1, "rehearsal_of_n_gpus": W, "steps": steps,
+            "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "dtype": "i8", "data": "synthetic",
             "config": {"workload": wl["workload"], "baseline_config_index": wl["index"], "grid": wl["grid"], "agents_per_frame": W,
-                       "max_cav": wl["max_cav"], "layout": wl["layout"], "points_per_agent": N_POINTS, "batch_per_rank": B,
+                       "max_cav": wl["max_cav"], "layout": wl["layout"], "points_per_agent": n_points, "batch_per_rank": B,
                        "heads": "multi-class (mc, 72 channels)" if wl["multiclass"] else "single-class (20 channels)",
-                       "pillars_per_step_rank0": int(mine["voxel_features"].shape[0]), "wire_bytes_per_agent_frame": 3 * hw,
+                       "pillars_per_step_rank0": int(mine["voxel_features"].shape[0]), "wire_bytes_per_agent_frame": eng.levels * hw,
                        "launch": "hipGraph (a1-a6 on the own agent's frames) -> the own payload copied into every agent slot, the agents' poses "
                                  "written beside it (stands in for the all-gather) -> hipGraph (pairwise matrices, a7-a11 over W agents)"},
             "stage_us": {"pre_a1_to_a6": round(pre_us, 1), "post_a7_to_a11": round(post_us, 1)},
             "note": f"what every rank of `bench.py --gpus {W}` executes per step, with the collective replaced by a device copy; with a free "
                     f"link the {W}-GPU line would read {W} x value (every rank the ego of its own view)",
             "output_shapes": {k: list(v.shape) for k, v in out.items() if hasattr(v, "shape")}}
-    print(json.dumps(line), flush=True)
+
+
+def rehearse(args, device):
+    """--rehearse-world W (see its help)"""
+    import torch
+    torch.cuda.set_device(device)
+    print(json.dumps(rehearse_line(args.rehearse_world, max(1, args.batch), args.steps, args.warmup, device)), flush=True)
     return 0
+
+
+def sharded_world1_line(state, B, device, steps=20):
+    """The N > 1 code path at world 1 inside the default line: ``AgentShardedModel`` over the C ABI's own RCCL communicator
+    (``qv2x_allgather_codes``) with the all-gather captured INSIDE the step's HIP graph (pre + collective + post = one replay per step), and the
+    two-graph form over torch.distributed's communicator beside it.  The post stage is the GENERAL a7-a11 path (the single-agent table
+    shortcut is switched off: a real rank never takes it).  stdout is parked on stderr meanwhile: RCCL prints a banner from C."""
+    import torch
+    import torch.distributed as dist
+    from quantv2x_amd.dist import AgentShardedModel
+    from quantv2x_amd.engine import deploy
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    out = {}
+    try:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("nccl", device_id=device)
+        wl = workload_for(1)
+        _, _, mine, poses = frame_batch(1, 0, B, device, layout=wl["layout"], max_cav=wl["max_cav"])
+        pose = torch.from_numpy(poses[0]).to(device)
+        for tag, link, graph_link in (("rccl_one_graph", "rccl", True), ("torch_two_graphs", "torch", False)):
+            eng = deploy(state=state)
+            eng.single_agent_tables = False
+            sh = AgentShardedModel(eng, frames=B, link=link, max_cav=wl["max_cav"], graph_link=graph_link)
+            sh.forward(mine, pose)
+            torch.cuda.synchronize()
+            for _ in range(3):
+                sh.forward(mine, pose)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                sh.forward(mine, pose)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out[tag] = {"frames_per_s": round(B * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps}
+            sh.close()
+            del sh, eng
+        out["note"] = ("world 1, ONE batch in flight, general a7-a11 post stage: `--force-sharded --link rccl --graph-link` (the all-gather captured in "
+                       "the step's graph) and `--force-sharded --link torch` (pre graph, eager all-gather, post graph); not a multi-GPU measurement")
+    finally:
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+    return out
 
 
 def main():
@@ -874,6 +952,25 @@ def main():
             line["second_encoder"] = second_encoder_line(device)
             line["collapsed_encode_opt_in"] = collapsed_encode_line(state, full, B, F, args.steps, device)
             line["points_to_boxes"] = points_to_boxes_line(state, device)
+            # what a rank of the N-GPU lines executes per step, inside the driver's clock: worlds 2 and 4 reuse this
+            # run's engine (same V2X-Real mc model); world 8 is BASELINE configs[4]'s OPV2V grid -- its model is calibrated here
+            reh = {}
+            for W in (2, 4, 8):
+                try:
+                    r = rehearse_line(W, B, 10, 2, device, engine=eng if W <= 4 else None)
+                    reh[f"world{W}"] = {"ms_per_step": r["ms_per_step"], "frames_per_s_of_one_rank": r["value"], "stage_us": r["stage_us"],
+                                        "workload": r["config"]["workload"], "pillars_per_step": r["config"]["pillars_per_step_rank0"],
+                                        "frames_per_step": B}
+                except Exception as e:                                     # an extra must not cost the line
+                    reh[f"world{W}"] = {"error": repr(e)[:300]}
+            reh["note"] = ("rank 0's step of `bench.py --gpus W` rehearsed on ONE GPU (AgentShardedModel(emulate_world=W)): a1-a6 on the own agent's "
+                           "frames, the own payload copied into every agent slot where the all-gather would be, then pairwise + a7-a11 over W agents. "
+                           "NOT a multi-GPU measurement: no link, and the other agents are copies of the own code planes")
+            line["rehearsal"] = reh
+            try:
+                line["sharded_world1"] = sharded_world1_line(state, B, device)
+            except Exception as e:
+                line["sharded_world1"] = {"error": repr(e)[:300]}
         if not args.no_cpu_baseline and world == 1 and not sharded_mode:       # reported on rank 0 at N = 1 only
             # the CPU checker on frames of THIS batch; each frame it finishes is compared with what the timed graphs computed (both
             # engines' workspaces hold their last replay: same inputs, so the same bytes) -- the parity gate of SURVEY 8(d)

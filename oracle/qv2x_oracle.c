@@ -214,62 +214,85 @@ ORC_API void orc_codebook_c2(const float* codebook, int Kc, float* c2) {
     for (int k = 0; k < Kc; ++k) c2[k] = sumsq256(codebook + (size_t)k * 256);
 }
 
-/* D = 64 (the Pyramid model's codebook, heter_pyramid_collab_codebook_mc.py:28): one 64-wide ascending chain */
-static float sumsq_d(const float* v, int D) {
-    if (D == 256) return sumsq256(v);
+/* |v|^2 over a segment of d dims in the op order of the HIP kernels: 64-wide ascending fma chains combined as a balanced tree
+ * (d = 256: (p0 + p1) + (p2 + p3); d = 128: p0 + p1; d = 64: p0); a segment shorter than 64 is one chain of d. */
+static float sumsq_seg(const float* v, int d) {
+    if (d == 256) return sumsq256(v);
+    if (d == 128) {
+        float p[2];
+        for (int q = 0; q < 2; ++q) { float a = 0.0f; for (int i = 0; i < 64; ++i) a = fmaf(v[q * 64 + i], v[q * 64 + i], a); p[q] = a; }
+        return p[0] + p[1];
+    }
     float a = 0.0f;
-    for (int i = 0; i < D; ++i) a = fmaf(v[i], v[i], a);
+    for (int i = 0; i < d; ++i) a = fmaf(v[i], v[i], a);
     return a;
 }
 
 /* ---------------------------------------------------------------------------------------------
- * a6: residual multi-codebook encode of R rows of D = 256 floats (m = 1), L levels, Kc codes/level.
- * Per level: z = stage(x); q = qhead(z); d_k = (|q|^2 + |C_k|^2) - 2 * (q . C_k); code = first argmin;
- *            x <- lhead(z) - C[code]   (not on the last level).
- * weights: per level pointers packed by the caller:  stage_w/b, qhead_w/b, lhead_w/b ([256][256] / [256]),
- *          codebook [Kc][256].
+ * a6: residual multi-codebook encode of R rows of D = 256 | 64 floats, L levels, S = seg_num (m) segments of D / S dims,
+ * Kc codes per segment and level (codebook.py:106-131: x.reshape(n, m, d), per-segment distance and argmin; :231-239, :330-337).
+ * Per level: z = stage(x); q = qhead(z); per segment s: d_k = (|q_s|^2 + |C_s,k|^2) - 2 * (q_s . C_s,k); code_s = first argmin;
+ *            x <- lhead(z) - concat_s C_s[code_s]   (not on the last level; codebook.py:192-201).
+ * weights: per level pointers packed by the caller:  stage_w/b, qhead_w/b, lhead_w/b ([D][D] / [D]),
+ *          codebook = the EXTENDED form [S * Kc][D]: row s * Kc + k holds C[s][k] in dims [s d, (s + 1) d) and zeros elsewhere
+ *          (quantv2x_amd/ptq_state.py) -- q . row over all D dims is then the segment's own ascending fma chain, bit for bit
+ *          (fmaf(q, 0, acc) = acc), which is how the HIP kernels evaluate it.  S = 1: the plain [Kc][D] codebook.
+ * codes: [L * S][R] planes, plane l * S + s.
  * ------------------------------------------------------------------------------------------- */
-ORC_API void orc_codebook_encode_d(const float* x_in, int R, int L, int Kc, int D,
-                                 const float* const* stage_w, const float* const* stage_b,
-                                 const float* const* qhead_w, const float* const* qhead_b,
-                                 const float* const* lhead_w, const float* const* lhead_b,
-                                 const float* const* codebook, uint8_t* codes /* [L][R] */,
-                                 float* gap_out /* [L][R] top-2 gap or NULL */) {
-    if (D != 256 && D != 64) return;
+ORC_API void orc_codebook_encode_seg(const float* x_in, int R, int L, int Kc, int D, int S,
+                                     const float* const* stage_w, const float* const* stage_b,
+                                     const float* const* qhead_w, const float* const* qhead_b,
+                                     const float* const* lhead_w, const float* const* lhead_b,
+                                     const float* const* codebook, uint8_t* codes /* [L * S][R] */,
+                                     float* gap_out /* [L * S][R] top-2 gap or NULL */) {
+    if ((D != 256 && D != 64) || S < 1 || D % S || Kc < 1 || Kc > 256) return;
+    const int d = D / S, KE = S * Kc;
     float* x = (float*)malloc((size_t)R * D * sizeof(float));
     float* z = (float*)malloc((size_t)R * D * sizeof(float));
     float* q = (float*)malloc((size_t)R * D * sizeof(float));
-    float* inter = (float*)malloc((size_t)R * Kc * sizeof(float));
-    float* c2 = (float*)malloc((size_t)Kc * sizeof(float));
+    float* inter = (float*)malloc((size_t)R * KE * sizeof(float));
+    float* c2 = (float*)malloc((size_t)KE * sizeof(float));
     memcpy(x, x_in, (size_t)R * D * sizeof(float));
     for (int l = 0; l < L; ++l) {
         linear_rows(x, R, D, stage_w[l], stage_b[l], D, z);
         linear_rows(z, R, D, qhead_w[l], qhead_b[l], D, q);
-        linear_rows(q, R, D, codebook[l], NULL, Kc, inter);
-        for (int k = 0; k < Kc; ++k) c2[k] = sumsq_d(codebook[l] + (size_t)k * D, D);
+        linear_rows(q, R, D, codebook[l], NULL, KE, inter);
+        for (int e = 0; e < KE; ++e) c2[e] = sumsq_seg(codebook[l] + (size_t)e * D + (size_t)(e / Kc) * d, d);
 #pragma omp parallel for schedule(static)
         for (int r = 0; r < R; ++r) {
-            const float x2 = sumsq_d(q + (size_t)r * D, D);
-            float best = INFINITY, second = INFINITY; int arg = 0;
-            for (int k = 0; k < Kc; ++k) {
-                const float d = (x2 + c2[k]) - 2.0f * inter[(size_t)r * Kc + k];
-                if (d < best) { second = best; best = d; arg = k; }
-                else if (d < second) second = d;
+            for (int s = 0; s < S; ++s) {
+                const float x2 = sumsq_seg(q + (size_t)r * D + (size_t)s * d, d);
+                float best = INFINITY, second = INFINITY; int arg = 0;
+                for (int k = 0; k < Kc; ++k) {
+                    const float dist = (x2 + c2[s * Kc + k]) - 2.0f * inter[(size_t)r * KE + s * Kc + k];
+                    if (dist < best) { second = best; best = dist; arg = k; }
+                    else if (dist < second) second = dist;
+                }
+                codes[((size_t)l * S + s) * R + r] = (uint8_t)arg;
+                if (gap_out) gap_out[((size_t)l * S + s) * R + r] = second - best;
             }
-            codes[(size_t)l * R + r] = (uint8_t)arg;
-            if (gap_out) gap_out[(size_t)l * R + r] = second - best;
         }
         if (l < L - 1) {
             linear_rows(z, R, D, lhead_w[l], lhead_b[l], D, q);       /* q reused as latentHead(z) */
             const float* cb = codebook[l];
 #pragma omp parallel for schedule(static)
-            for (int r = 0; r < R; ++r) {
-                const float* c = cb + (size_t)codes[(size_t)l * R + r] * D;
-                for (int j = 0; j < D; ++j) x[(size_t)r * D + j] = q[(size_t)r * D + j] - c[j];
-            }
+            for (int r = 0; r < R; ++r)
+                for (int s = 0; s < S; ++s) {
+                    const float* c = cb + ((size_t)s * Kc + codes[((size_t)l * S + s) * R + r]) * D;
+                    for (int j = s * d; j < (s + 1) * d; ++j) x[(size_t)r * D + j] = q[(size_t)r * D + j] - c[j];
+                }
         }
     }
     free(x); free(z); free(q); free(inter); free(c2);
+}
+
+ORC_API void orc_codebook_encode_d(const float* x_in, int R, int L, int Kc, int D,
+                                   const float* const* stage_w, const float* const* stage_b,
+                                   const float* const* qhead_w, const float* const* qhead_b,
+                                   const float* const* lhead_w, const float* const* lhead_b,
+                                   const float* const* codebook, uint8_t* codes /* [L][R] */,
+                                   float* gap_out /* [L][R] top-2 gap or NULL */) {
+    orc_codebook_encode_seg(x_in, R, L, Kc, D, 1, stage_w, stage_b, qhead_w, qhead_b, lhead_w, lhead_b, codebook, codes, gap_out);
 }
 
 ORC_API void orc_codebook_encode(const float* x_in, int R, int L, int Kc,
@@ -277,7 +300,7 @@ ORC_API void orc_codebook_encode(const float* x_in, int R, int L, int Kc,
                                  const float* const* qhead_w, const float* const* qhead_b,
                                  const float* const* lhead_w, const float* const* lhead_b,
                                  const float* const* codebook, uint8_t* codes, float* gap_out) {
-    orc_codebook_encode_d(x_in, R, L, Kc, 256, stage_w, stage_b, qhead_w, qhead_b, lhead_w, lhead_b, codebook, codes, gap_out);
+    orc_codebook_encode_seg(x_in, R, L, Kc, 256, 1, stage_w, stage_b, qhead_w, qhead_b, lhead_w, lhead_b, codebook, codes, gap_out);
 }
 
 /* a7 as a table sum: out[r] = ((bias + T0[c0]) + T1[c1]) + T2[c2]; lut [L][Kc][256] */

@@ -186,12 +186,14 @@ class Oracle:
                 else:
                     ptrs[l] = None
             return ptrs
-        kc = self.s["codebook/0/codebook"].shape[0]
-        codes = np.zeros((L, R), np.uint8)
-        gaps = np.zeros((L, R), np.float32) if want_gaps else None
-        lib().orc_codebook_encode(_p(_f32(rows)), R, L, kc, arr("stage_w"), arr("stage_b"), arr("qhead_w"), arr("qhead_b"),
-                                  arr("lhead_w"), arr("lhead_b"), arr("codebook"), _p(codes),
-                                  _p(gaps) if want_gaps else None)
+        # seg_num (m) segments: the state holds the EXTENDED codebook [m * kc][256] (ptq_state.extended_codebook); planes = L * m
+        S = int(self.s.get("meta/codebook_segs", 1))
+        kc = self.s["codebook/0/codebook"].shape[0] // S
+        codes = np.zeros((L * S, R), np.uint8)
+        gaps = np.zeros((L * S, R), np.float32) if want_gaps else None
+        lib().orc_codebook_encode_seg(_p(_f32(rows)), R, L, kc, 256, S, arr("stage_w"), arr("stage_b"), arr("qhead_w"), arr("qhead_b"),
+                                      arr("lhead_w"), arr("lhead_b"), arr("codebook"), _p(codes),
+                                      _p(gaps) if want_gaps else None)
         return (codes, gaps) if want_gaps else codes
 
     def encode(self, feat, feat_q):
@@ -199,9 +201,11 @@ class Oracle:
         return self.encode_rows(rows)
 
     def decode(self, codes):
-        L, R = codes.shape
+        """codes u8 [planes = L * m][R]: plane (l, s) looks up row s * kc + code of level l's table = row code of plane l * m + s."""
+        P, R = codes.shape
         out = np.zeros((R, 256), np.float32)
-        lib().orc_decode_lut(_p(np.ascontiguousarray(codes)), R, L, self.lut.shape[1], _p(_f32(self.lut)), _p(_f32(self.lut_bias)), _p(out))
+        kc = self.lut.shape[0] * self.lut.shape[1] // P
+        lib().orc_decode_lut(_p(np.ascontiguousarray(codes)), R, P, kc, _p(_f32(self.lut)), _p(_f32(self.lut_bias)), _p(out))
         return out
 
     # ---- a8 - a11 ------------------------------------------------------------------------------

@@ -238,13 +238,14 @@ class OraclePyramidFp32(OracleFp32):
                     else:
                         ptrs[l] = None
                 return ptrs
-            kc = self.s["codebook/0/codebook"].shape[0]
-            codes = np.zeros((L, R), np.uint8)
-            lib().orc_codebook_encode_d(_p(_f32(x.reshape(R, c))), R, L, kc, self.D, arr("stage_w"), arr("stage_b"), arr("qhead_w"), arr("qhead_b"),
-                                        arr("lhead_w"), arr("lhead_b"), arr("codebook"), _p(codes), None)
-            taps["codes"] = codes.reshape(L, n, h, w)
+            S = int(self.s.get("meta/codebook_segs", 1))                # seg_num: the state holds the extended codebook [S * kc][D]
+            kc = self.s["codebook/0/codebook"].shape[0] // S
+            codes = np.zeros((L * S, R), np.uint8)                       # planes
+            lib().orc_codebook_encode_seg(_p(_f32(x.reshape(R, c))), R, L, kc, self.D, S, arr("stage_w"), arr("stage_b"), arr("qhead_w"),
+                                          arr("qhead_b"), arr("lhead_w"), arr("lhead_b"), arr("codebook"), _p(codes), None)
+            taps["codes"] = codes.reshape(L * S, n, h, w)
             out = np.zeros((R, self.D), np.float32)
-            lib().orc_decode_lut_d(_p(codes), R, L, self.lut.shape[1], self.D, _p(_f32(self.lut)), _p(_f32(self.lut_bias)), _p(out))
+            lib().orc_decode_lut_d(_p(codes), R, L * S, kc, self.D, _p(_f32(self.lut)), _p(_f32(self.lut_bias)), _p(out))
             x = out.reshape(n, h, w, c)
             taps["features"] = x
         return self.pyramid_and_heads(x, scene, taps)

@@ -152,17 +152,19 @@ class OraclePyramid(Oracle):
                 else:
                     ptrs[l] = None
             return ptrs
-        kc = self.s["codebook/0/codebook"].shape[0]
-        codes = np.zeros((L, R), np.uint8)
-        gaps = np.zeros((L, R), np.float32) if want_gaps else None
-        lib().orc_codebook_encode_d(_p(_f32(rows)), R, L, kc, self.D, arr("stage_w"), arr("stage_b"), arr("qhead_w"), arr("qhead_b"),
-                                    arr("lhead_w"), arr("lhead_b"), arr("codebook"), _p(codes), _p(gaps) if want_gaps else None)
+        S = int(self.s.get("meta/codebook_segs", 1))                    # seg_num: the state holds the extended codebook [S * kc][D]
+        kc = self.s["codebook/0/codebook"].shape[0] // S
+        codes = np.zeros((L * S, R), np.uint8)
+        gaps = np.zeros((L * S, R), np.float32) if want_gaps else None
+        lib().orc_codebook_encode_seg(_p(_f32(rows)), R, L, kc, self.D, S, arr("stage_w"), arr("stage_b"), arr("qhead_w"), arr("qhead_b"),
+                                      arr("lhead_w"), arr("lhead_b"), arr("codebook"), _p(codes), _p(gaps) if want_gaps else None)
         return (codes, gaps) if want_gaps else codes
 
     def decode(self, codes):
-        L, R = codes.shape
+        P, R = codes.shape                                                # planes = levels * seg_num
         out = np.zeros((R, self.D), np.float32)
-        lib().orc_decode_lut_d(_p(np.ascontiguousarray(codes)), R, L, self.lut.shape[1], self.D, _p(_f32(self.lut)), _p(_f32(self.lut_bias)), _p(out))
+        kc = self.lut.shape[0] * self.lut.shape[1] // P
+        lib().orc_decode_lut_d(_p(np.ascontiguousarray(codes)), R, P, kc, self.D, _p(_f32(self.lut)), _p(_f32(self.lut_bias)), _p(out))
         return out
 
     def occupancy(self, lvl, x, xq):

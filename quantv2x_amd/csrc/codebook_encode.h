@@ -10,12 +10,13 @@ constexpr int ENC_WAVE_PAD = 16 * 256;      // floats behind the wave-form secti
 struct EncArgs {
     const int8_t* in; const float* in_f32; uint8_t* codes;      // in_f32 != null: the rows come as fp32 (un-quantized model)
     const float* lvl[4];
-    int n, h, w, levels, kc, ax, M;
+    int n, h, w, levels, kc, ax, M;     // kc: codes per SEGMENT and level
+    int segs, ke;                       // seg_num (m) = 1 | 2 | 4 segments of 256 / segs dims; ke = segs * kc rows of the extended codebook
     float dx;
     int m_lo, m_hi;             // the rows [m_lo, m_hi) of the M = n h w cells this launch encodes (a launch may be split between the two forms)
 };
 
-// A level blob (include/qv2x.h): the workgroup form's section, then the wave form's.
+// A level blob (include/qv2x.h): the workgroup form's section, then the wave form's.  `kc` here = rows of the (extended) codebook.
 __device__ __host__ __forceinline__ int64_t level_floats_wg(int kc) { return 3LL * (ENC_D * ENC_D + ENC_D) + (int64_t)ENC_D * kc + (int64_t)kc * ENC_D + kc; }
 __device__ __host__ __forceinline__ int64_t level_floats(int kc) { return level_floats_wg(kc) + 3LL * ENC_D * ENC_D + (int64_t)((kc + 63) / 64 * 64) * ENC_D + ENC_WAVE_PAD; }
 

@@ -141,18 +141,23 @@ __device__ __forceinline__ void store_tile(float* __restrict__ dst, int wave, in
             dst[(i * 32 + mfma32_row(r, lane)) * LDF + kpos(wave * 32 + (lane & 31))] = acc[i][r];
 }
 
-template <int ER> constexpr int enc_smem_floats() { return 2 * ER * LDF + ER + 4 * ER + 8 * ER + ER + QV2X_ENC_LDS_PAD; }
+constexpr int ENC_MAX_TILES = 16;   // 32-code tiles of the extended codebook: segs * kc <= 512
+template <int ER> constexpr int enc_smem_floats() { return 2 * ER * LDF + 4 * ER + 4 * ER + 2 * ENC_MAX_TILES * ER + 4 * ER + QV2X_ENC_LDS_PAD; }
 
 // the whole encode of the ER rows [m0, m0 + ER) by one 8-wave workgroup; smem: enc_smem_floats<ER>() floats
-template <int ER>
+// EXT = false: one segment and one round of code tiles (ke <= 32 * 8 / ERT: every (m, kc) = (1, <= 128) model) -- the loop over tile rounds
+// and the per-segment bookkeeping cost the 32-row form 15 registers and 8 bytes of scratch under its 128-register bound, so they are
+// compiled out of the form every V2X-Real / OPV2V attfuse model takes; EXT = true: seg_num > 1 or an extended codebook of several rounds.
+template <int ER, bool EXT>
 __device__ __forceinline__ void encode_rows(const EncArgs& a, const int m0, float* __restrict__ smem) {
     constexpr int ERT = ER / 32;
+    const int segs = EXT ? a.segs : 1;
     float* bufA = smem;                       // x, then q, then next x
     float* bufB = smem + ER * LDF;            // z
-    float* x2 = smem + 2 * ER * LDF;          // [64]
-    float* pval = x2 + ER;                    // [4][64]
-    unsigned long long* pkey = (unsigned long long*)(pval + 4 * ER);   // [4][ER] (distance, code) keys of the code tiles
-    int* code_s = (int*)(pkey + 4 * ER);      // [ER]
+    float* x2 = smem + 2 * ER * LDF;          // [segs <= 4][ER]: |q_s|^2 per segment
+    float* pval = x2 + 4 * ER;                // [4][ER]
+    unsigned long long* pkey = (unsigned long long*)(pval + 4 * ER);   // [ENC_MAX_TILES][ER] (distance, code) keys of the code tiles
+    int* code_s = (int*)(pkey + ENC_MAX_TILES * ER);                   // [segs][ER]: the chosen row of the extended codebook per segment
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef QV2X_ENC_TRACE
@@ -202,9 +207,10 @@ __device__ __forceinline__ void encode_rows(const EncArgs& a, const int m0, floa
         const float* qhead_b = qhead_w + D * D;
         const float* lhead_w = qhead_b + D;
         const float* lhead_b = lhead_w + D * D;
-        const float* cbp = lhead_b + D;                       // [64][kc][4]
-        const float* cb = cbp + (size_t)D * a.kc;             // [kc][256]
-        const float* c2 = cb + (size_t)a.kc * D;              // [kc]
+        // (the EXTENDED codebook: ke = segs * kc rows, segment s in dims [s d, (s + 1) d) of its rows, zeros elsewhere)
+        const float* cbp = lhead_b + D;                       // [64][ke][4]
+        const float* cb = cbp + (size_t)D * a.ke;             // [ke][256]
+        const float* c2 = cb + (size_t)a.ke * D;              // [ke]
 
         EFINE(0);
         gemm_rows_x32(bufA, (const float2*)stage_w, head, wave, lane, acc);         // z = stage(x)
@@ -231,26 +237,36 @@ __device__ __forceinline__ void encode_rows(const EncArgs& a, const int m0, floa
             }
             pval[part * ER + row] = s;
         }
-        // the distance tile's first codebook k-quads and |C_k|^2, requested ahead of the two barriers of the |q|^2 reduction
-        const int ct = wave & 3, rt = wave >> 2;
-        const bool has_dist = rt < ERT && ct * 32 < a.kc;
+        // the distance tile's first codebook k-quads and |C_k|^2, requested ahead of the two barriers of the |q|^2 reduction.
+        // Code tiles per round of the workgroup: 8 / ERT (ER = 32: wave -> tile `wave` of row tile 0; ER = 64: wave -> (row tile wave >> 2,
+        // tile wave & 3)); an extended codebook of more than one round of tiles (ke > 128 | 256) takes further rounds.
+        constexpr int TPR = 8 / ERT;
+        const int ct0 = wave % TPR, rt = wave / TPR;
+        const int ntile = (a.ke + 31) >> 5;
         float2 dhead[4];
         float c2v = 0.0f;
-        if (has_dist) {
-            const int code = ct * 32 + (lane & 31);
+        if (ct0 < ntile) {
+            const int code = ct0 * 32 + (lane & 31);
             const float2* cl = (const float2*)cbp + (size_t)code * 2 + (lane >> 5);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) dhead[t] = cl[(size_t)t * a.kc * 2];
+            for (int t = 0; t < 4; ++t) dhead[t] = cl[(size_t)t * a.ke * 2];
             c2v = c2[code];
         }
         lds_barrier();
         EFINE(5);
-        if (tid < ER) x2[tid] = (pval[tid] + pval[ER + tid]) + (pval[2 * ER + tid] + pval[3 * ER + tid]);
+        if (tid < ER) {
+            // |q_s|^2 per segment (oracle/qv2x_oracle.c:sumsq_seg): one segment (p0 + p1) + (p2 + p3); two: p0 + p1 | p2 + p3; four: the chains
+            const float p0 = pval[tid], p1 = pval[ER + tid], p2 = pval[2 * ER + tid], p3 = pval[3 * ER + tid];
+            if (segs == 1) x2[tid] = (p0 + p1) + (p2 + p3);
+            else if (segs == 2) { x2[tid] = p0 + p1; x2[ER + tid] = p2 + p3; }
+            else { x2[tid] = p0; x2[ER + tid] = p1; x2[2 * ER + tid] = p2; x2[3 * ER + tid] = p3; }
+        }
         lds_barrier();
         EFINE(6);
 
-        // ---- distances: wave -> (row tile = wave >> 2, codes [32*(wave & 3), +32)), then the argmin ------------
-        if (has_dist) {
+        // ---- distances: wave -> (row tile, 32 codes of the extended codebook), then the argmin per 32-code tile --------------------
+#pragma unroll 1
+        for (int ct = ct0; ct < ntile; ct += EXT ? TPR : ENC_MAX_TILES) {
             const int par = lane >> 5, code = ct * 32 + (lane & 31);
             v16f dacc;
 #pragma unroll
@@ -259,7 +275,7 @@ __device__ __forceinline__ void encode_rows(const EncArgs& a, const int m0, floa
             const float* al = bufA + (rt * 32 + (lane & 31)) * LDF + 2 * par;
             auto loadC = [&](float2 (&dst)[4], int q0) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) dst[t] = cl[(size_t)(q0 + t) * a.kc * 2];   // past the end: the [kc][256] copy
+                for (int t = 0; t < 4; ++t) dst[t] = cl[(size_t)(q0 + t) * a.ke * 2];   // past the end: the [ke][256] copy
             };
             auto dist4 = [&](const float2 (&bset)[4], int q0) {
                 float2 av[4];
@@ -272,8 +288,13 @@ __device__ __forceinline__ void encode_rows(const EncArgs& a, const int m0, floa
                 }
             };
             float2 s0[4], s1[4];
+            if (ct == ct0) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) s0[t] = dhead[t];
+                for (int t = 0; t < 4; ++t) s0[t] = dhead[t];
+            } else {                                                        // a further round: its head and |C|^2 only now
+                loadC(s0, 0);
+                c2v = c2[code];
+            }
             for (int q0 = 0; q0 < 64; q0 += 8) {
                 loadC(s1, q0 + 4);
                 __builtin_amdgcn_sched_barrier(0);
@@ -295,10 +316,11 @@ __device__ __forceinline__ void encode_rows(const EncArgs& a, const int m0, floa
             unsigned resk = 0xffffffffu;
             int resc = 0;
             const int l31 = lane & 31, hi = lane >> 5;
+            const float* x2r = x2 + (segs == 1 ? 0 : (ct * 32) / a.kc) * ER;   // (segs > 1: kc % 64 == 0, a tile lies inside one segment)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rt * 32 + mfma32_row(r, lane);
-                const float d = (x2[row] + c2v) - 2.0f * dacc[r];
+                const float d = (x2r[row] + c2v) - 2.0f * dacc[r];
                 unsigned b = __builtin_bit_cast(unsigned, d);
                 b ^= (unsigned)((int)b >> 31) | 0x80000000u;
                 unsigned m = b, o;
@@ -320,14 +342,17 @@ __device__ __forceinline__ void encode_rows(const EncArgs& a, const int m0, floa
         lds_barrier();
         EFINE(8);
         if (tid < ER) {
-            unsigned long long bk = pkey[tid];
-            for (int wv = 1; wv * 32 < a.kc; ++wv) {
-                const unsigned long long ok = pkey[wv * ER + tid];
-                bk = ok < bk ? ok : bk;                                // code tiles ascend: ties still go to the lower code
+            const int tps = segs == 1 ? ntile : a.kc >> 5;                  // 32-code tiles per segment
+            for (int sg = 0; sg < segs; ++sg) {
+                unsigned long long bk = pkey[(sg * tps) * ER + tid];
+                for (int wv = 1; wv < tps; ++wv) {
+                    const unsigned long long ok = pkey[(sg * tps + wv) * ER + tid];
+                    bk = ok < bk ? ok : bk;                            // code tiles ascend: ties still go to the lower code
+                }
+                const int bi = (int)(unsigned)bk;                      // row of the extended codebook: sg * kc + code
+                code_s[sg * ER + tid] = bi;
+                if (m0 + tid < a.m_hi) a.codes[((size_t)l * segs + sg) * a.M + m0 + tid] = (uint8_t)(bi - sg * a.kc);
             }
-            const int bi = (int)(unsigned)bk;
-            code_s[tid] = bi;
-            if (m0 + tid < a.m_hi) a.codes[(size_t)l * a.M + m0 + tid] = (uint8_t)bi;
         }
         lds_barrier();
         EFINE(9);
@@ -335,11 +360,12 @@ __device__ __forceinline__ void encode_rows(const EncArgs& a, const int m0, floa
         if (l + 1 < a.levels) {      // x <- lhead(z) - C[code]
             // the chosen codewords' entries of this lane's column: 16 gathers requested ahead of the GEMM that produces the minuend
             const int col = wave * 32 + (lane & 31);
+            const int* cs = code_s + ((wave * segs) >> 3) * ER;      // this wave's 32 columns lie in segment wave * segs / 8
             float cv[ERT][16];
 #pragma unroll
             for (int i = 0; i < ERT; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) cv[i][r] = cb[(size_t)code_s[i * 32 + mfma32_row(r, lane)] * D + col];
+                for (int r = 0; r < 16; ++r) cv[i][r] = cb[(size_t)cs[i * 32 + mfma32_row(r, lane)] * D + col];
             gemm_rows_x32(bufB, (const float2*)lhead_w, head, wave, lane, acc);
             EFINE(10);
             head = gemm_head((const float2*)a.lvl[l + 1], a.lvl[l + 1] + D * D, wave, lane);     // the next level's stage
@@ -360,19 +386,20 @@ __device__ __forceinline__ void encode_rows(const EncArgs& a, const int m0, floa
 }
 
 // static LDS (67.8 / 135.7 KB): no per-device hipFuncSetAttribute state to keep (include/qv2x.h:12)
-template <int ER>
+template <int ER, bool EXT = false>
 __global__ __launch_bounds__(512, ER == 32 ? 4 : 2) void codebook_encode_kernel(const EncArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[enc_smem_floats<ER>()];
-    encode_rows<ER>(a, a.m_lo + blockIdx.x * ER, smem);
+    encode_rows<ER, EXT>(a, a.m_lo + blockIdx.x * ER, smem);
 }
 
 // Launches of one or two frames: whole rounds of 64-row workgroups (one per CU: n64 of them, a multiple of the CU count), then the rows
 // that would make a mostly empty round as 32-row workgroups -- which finish in 0.56 of a 64-row workgroup's time alone on their CU.
 // One V2X-Real frame: 512 x 64 + 76 x 32 rows, two full rounds and a short one (416 us) instead of 1100 x 32 on 512 slots (478 us).
+template <bool EXT>
 __global__ __launch_bounds__(512, 2) void codebook_encode_mixed_kernel(const EncArgs a, const int n64) {
     __shared__ __attribute__((aligned(16))) float smem[enc_smem_floats<64>()];
-    if ((int)blockIdx.x < n64) encode_rows<64>(a, a.m_lo + blockIdx.x * 64, smem);
-    else encode_rows<32>(a, a.m_lo + n64 * 64 + ((int)blockIdx.x - n64) * 32, smem);
+    if ((int)blockIdx.x < n64) encode_rows<64, EXT>(a, a.m_lo + blockIdx.x * 64, smem);
+    else encode_rows<32, EXT>(a, a.m_lo + n64 * 64 + ((int)blockIdx.x - n64) * 32, smem);
 }
 
 __global__ void codebook_c2_kernel(const float* __restrict__ cb, int kc, float* __restrict__ c2) {
@@ -424,10 +451,16 @@ static int encode_launch(const qv2x_encode_desc* d, const int8_t* in, const floa
     using namespace qv2x;
     if (!d || !in || !level_weights || !codes) return fail(QV2X_EINVAL, "qv2x_codebook_encode_f32: null pointer");
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->levels < 1 || d->levels > 4) return fail(QV2X_EINVAL, "qv2x_codebook_encode_f32: bad shape");
-    if (d->kc < 32 || d->kc > 128 || d->kc % 32) return fail(QV2X_EINVAL, "qv2x_codebook_encode_f32: dict_size must be 32, 64, 96 or 128 (got %d)", d->kc);
+    const int segs = d->segs ? d->segs : 1;                            // (0: a descriptor from before the field existed)
+    if (segs != 1 && segs != 2 && segs != 4) return fail(QV2X_EINVAL, "qv2x_codebook_encode_f32: seg_num must be 1, 2 or 4 (got %d)", d->segs);
+    if (d->kc < 32 || d->kc > 256 || d->kc % 32 || (segs > 1 && d->kc % 64) || segs * d->kc > 32 * ENC_MAX_TILES)
+        return fail(QV2X_EINVAL, "qv2x_codebook_encode_f32: dict_size must be a multiple of 32 up to 256 (of 64 with seg_num > 1; seg_num * dict_size <= %d): "
+                                 "got dict_size %d, seg_num %d", 32 * ENC_MAX_TILES, d->kc, segs);
     if ((uintptr_t)in & 15) return fail(QV2X_EALIGN, "qv2x_codebook_encode_f32: in must be 16-byte aligned");
     EncArgs a;
     a.in = in; a.in_f32 = in_f32; a.codes = codes; a.n = d->n; a.h = d->h; a.w = d->w; a.levels = d->levels; a.kc = d->kc;
+    a.segs = segs; a.ke = segs * d->kc;
+    const bool ext = segs > 1 || a.ke > 128;                           // (the workgroup form's general variant: encode_rows<ER, true>)
     a.ax = 128 - d->in_zx; a.dx = d->in_delta; a.M = d->n * d->h * d->w; a.m_lo = 0; a.m_hi = a.M;
     for (int l = 0; l < 4; ++l) {
         a.lvl[l] = l < d->levels ? level_weights[l] : nullptr;
@@ -469,16 +502,25 @@ static int encode_launch(const qv2x_encode_desc* d, const int8_t* in, const floa
         main.m_hi = rounds * slots * 32;
         tail.m_lo = main.m_hi;
         if (int rc = encode_wave_launch(main, st)) return rc;
-        codebook_encode_kernel<32><<<rest, 512, 0, st>>>(tail);
+        if (ext) codebook_encode_kernel<32, true><<<rest, 512, 0, st>>>(tail);
+        else codebook_encode_kernel<32><<<rest, 512, 0, st>>>(tail);
         return hip_check(hipGetLastError(), "qv2x_codebook_encode_f32 launch");
     }
     // Below one round of waves (a.M < 128 cells per CU): the mixed form when it has at least one full round of 64-row workgroups, else
     // 32-row workgroups.  (A whole launch of 64-row workgroups is a dev knob only since the split rule above: QV2X_ENC_ROWS=64.)
     const int n64 = (a.M / 64) / cus * cus;
     const int er = er_env ? er_env : (n64 > 0 ? 96 : 32);
-    if (er == 64) codebook_encode_kernel<64><<<(a.M + 63) / 64, 512, 0, st>>>(a);
-    else if (er == 96 && n64 > 0) codebook_encode_mixed_kernel<<<n64 + (a.M - n64 * 64 + 31) / 32, 512, 0, st>>>(a, n64);
-    else codebook_encode_kernel<32><<<(a.M + 31) / 32, 512, 0, st>>>(a);
+    if (er == 64) {
+        if (ext) codebook_encode_kernel<64, true><<<(a.M + 63) / 64, 512, 0, st>>>(a);
+        else codebook_encode_kernel<64><<<(a.M + 63) / 64, 512, 0, st>>>(a);
+    } else if (er == 96 && n64 > 0) {
+        if (ext) codebook_encode_mixed_kernel<true><<<n64 + (a.M - n64 * 64 + 31) / 32, 512, 0, st>>>(a, n64);
+        else codebook_encode_mixed_kernel<false><<<n64 + (a.M - n64 * 64 + 31) / 32, 512, 0, st>>>(a, n64);
+    } else if (ext) {
+        codebook_encode_kernel<32, true><<<(a.M + 31) / 32, 512, 0, st>>>(a);
+    } else {
+        codebook_encode_kernel<32><<<(a.M + 31) / 32, 512, 0, st>>>(a);
+    }
     return hip_check(hipGetLastError(), "qv2x_codebook_encode_f32 launch");
 }
 

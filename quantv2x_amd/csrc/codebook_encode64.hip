@@ -1,5 +1,5 @@
 // f3: UMGMQuantizer.encode for the Pyramid model's 64-wide codebook (heter_pyramid_collab_codebook_mc.py:25-51, codebook.py:330-337),
-// m = 1, fused over the residual levels on v_mfma_f32_32x32x2_f32 -- the D = 64 sibling of codebook_encode.hip (same op order, same
+// seg_num m = 1 | 2 | 4 (the extended codebook of codebook_encode.hip: m * kc rows, segment s in dims [s d, (s + 1) d)), fused over the residual levels on v_mfma_f32_32x32x2_f32 -- the D = 64 sibling of codebook_encode.hip (same op order, same
 // ascending-k fma chains with acc0 = bias, bit-exact against oracle/qv2x_oracle.c:orc_codebook_encode_d).
 //
 // 11x fewer MACs per row than D = 256 and every matrix is 16 KB, so the shape changes: a workgroup of FOUR waves owns 64 BEV cells;
@@ -17,9 +17,11 @@ __device__ __forceinline__ int kpos(int c) { return (c & ~3) | ((c & 1) << 1) | 
 struct Enc64Args {
     const int8_t* in; const float* in_f32; uint8_t* codes;        // in_f32 != null: the rows come as fp32 (un-quantized model)
     const float* lvl[4];
-    int n, h, w, cin_total, levels, kc, ax, M;
+    int n, h, w, cin_total, levels, kc, ax, M;      // kc: codes per segment and level
+    int segs, ke;                                   // seg_num (m); ke = segs * kc rows of the extended codebook
     float dx;
 };
+constexpr int MAX_TILES = 16;                       // 32-code tiles of the extended codebook: ke <= 512
 
 // all 16 k-quads of this lane's weight column (16 float2) + its bias: requested BEFORE the barrier that precedes the GEMM, so the L2 round
 // trip overlaps the previous phase's tile store and the barrier wait
@@ -76,12 +78,12 @@ __device__ __forceinline__ void store_tile(float* __restrict__ dst, int rt, int 
 }
 
 __global__ __launch_bounds__(256, 4) void codebook_encode64_kernel(const Enc64Args a) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * ER * LDF + ER + 8 * ER + ER];
+    __shared__ __attribute__((aligned(16))) float smem[2 * ER * LDF + 4 * ER + 2 * MAX_TILES * ER + 4 * ER];
     float* bufA = smem;                       // x, then q, then next x
     float* bufB = smem + ER * LDF;            // z
-    float* x2 = smem + 2 * ER * LDF;          // [ER]
-    unsigned long long* pkey = (unsigned long long*)(x2 + ER);      // [4 code tiles][ER]
-    int* code_s = (int*)(pkey + 4 * ER);      // [ER]
+    float* x2 = smem + 2 * ER * LDF;          // [segs][ER]
+    unsigned long long* pkey = (unsigned long long*)(x2 + 4 * ER);  // [MAX_TILES code tiles][ER]
+    int* code_s = (int*)(pkey + MAX_TILES * ER);                    // [segs][ER]: rows of the extended codebook
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rt = wave >> 1, ctile = wave & 1;
@@ -121,9 +123,9 @@ __global__ __launch_bounds__(256, 4) void codebook_encode64_kernel(const Enc64Ar
         const float* qhead_b = qhead_w + D * D;
         const float* lhead_w = qhead_b + D;
         const float* lhead_b = lhead_w + D * D;
-        const float* cbp = lhead_b + D;                       // [16][kc][4]
-        const float* cb = cbp + (size_t)D * a.kc;             // [kc][64]
-        const float* c2 = cb + (size_t)a.kc * D;              // [kc]
+        const float* cbp = lhead_b + D;                       // [16][ke][4]
+        const float* cb = cbp + (size_t)D * a.ke;             // [ke][64]
+        const float* c2 = cb + (size_t)a.ke * D;              // [ke]
 
         gemm_tile(bufA, tw, rt, lane, acc);                                          // z = stage(x)
         tw = tile_weights((const float2*)qhead_w, qhead_b, ctile, lane);
@@ -133,24 +135,24 @@ __global__ __launch_bounds__(256, 4) void codebook_encode64_kernel(const Enc64Ar
         if (l + 1 < a.levels) tw = tile_weights((const float2*)lhead_w, lhead_b, ctile, lane);   // used after the argmin
         store_tile(bufA, rt, ctile, lane, acc);
         __syncthreads();
-        if (tid < ER) {      // |q|^2: one 64-wide ascending fma chain per row
-            const float2* qr = (const float2*)(bufA + tid * LDF);
+        if (tid < ER * a.segs) {      // |q_s|^2: one ascending fma chain over the segment's 64 / segs dims per (segment, row)
+            const int row = tid % ER, sg = tid / ER, nq = 16 / a.segs;
+            const float2* qr = (const float2*)(bufA + row * LDF) + 2 * sg * nq;
             float s = 0.0f;
-#pragma unroll 4
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < nq; ++j) {
                 const float2 e = qr[2 * j], o = qr[2 * j + 1];
                 s = fmaf(e.x, e.x, s); s = fmaf(o.x, o.x, s); s = fmaf(e.y, e.y, s); s = fmaf(o.y, o.y, s);
             }
-            x2[tid] = s;
+            x2[sg * ER + row] = s;
         }
         __syncthreads();
 
-        // ---- distances: this wave's row tile against code tiles 2 (wave & 1), 2 (wave & 1) + 1 ---------------------------------------
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int ct = 2 * ctile + c;
-            if (ct * 32 < a.kc) {
+        // ---- distances: this wave's row tile against code tiles 2 (wave & 1), 2 (wave & 1) + 1 of every round of four tiles ------------
+        for (int c = 0; c < 2 * ((a.ke + 127) >> 7); ++c) {
+            const int ct = 4 * (c >> 1) + 2 * ctile + (c & 1);
+            if (ct * 32 < a.ke) {
                 const int par = lane >> 5, code = ct * 32 + (lane & 31);
+                const float* x2r = x2 + (a.segs == 1 ? 0 : (ct * 32) / a.kc) * ER;
                 v16f dacc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dacc[r] = 0.0f;
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256, 4) void codebook_encode64_kernel(const Enc64Ar
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) s[g][t] = cl[(size_t)(g * 4 + t) * a.kc * 2];
+                    for (int t = 0; t < 4; ++t) s[g][t] = cl[(size_t)(g * 4 + t) * a.ke * 2];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float2 av[4];
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256, 4) void codebook_encode64_kernel(const Enc64Ar
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rt * 32 + mfma32_row(r, lane);
-                    unsigned long long key = dist_key((x2[row] + c2v) - 2.0f * dacc[r], code);
+                    unsigned long long key = dist_key((x2r[row] + c2v) - 2.0f * dacc[r], code);
                     keymin_dpp<0x108>(key); keymin_dpp<0x104>(key); keymin_dpp<0x102>(key); keymin_dpp<0x101>(key);
                     const int klo = (int)(unsigned)key, khi = (int)(unsigned)(key >> 32);
                     const unsigned lo16 = (unsigned)__builtin_amdgcn_readlane(klo, 16), hi16 = (unsigned)__builtin_amdgcn_readlane(khi, 16);
@@ -188,23 +190,26 @@ __global__ __launch_bounds__(256, 4) void codebook_encode64_kernel(const Enc64Ar
             }
         }
         __syncthreads();
-        if (tid < ER) {
-            unsigned long long bk = pkey[tid];
-            for (int wv = 1; wv * 32 < a.kc; ++wv) {
-                const unsigned long long ok = pkey[wv * ER + tid];
+        if (tid < ER * a.segs) {
+            const int row = tid % ER, sg = tid / ER;
+            const int tps = a.segs == 1 ? (a.ke + 31) >> 5 : a.kc >> 5;   // 32-code tiles per segment
+            unsigned long long bk = pkey[(sg * tps) * ER + row];
+            for (int wv = 1; wv < tps; ++wv) {
+                const unsigned long long ok = pkey[(sg * tps + wv) * ER + row];
                 bk = ok < bk ? ok : bk;                                // code tiles ascend: ties go to the lower code
             }
-            const int bi = (int)(unsigned)bk;
-            code_s[tid] = bi;
-            if (m0 + tid < a.M) a.codes[(size_t)l * a.M + m0 + tid] = (uint8_t)bi;
+            const int bi = (int)(unsigned)bk;                          // row of the extended codebook: sg * kc + code
+            code_s[sg * ER + row] = bi;
+            if (m0 + row < a.M) a.codes[((size_t)l * a.segs + sg) * a.M + m0 + row] = (uint8_t)(bi - sg * a.kc);
         }
         __syncthreads();
 
         if (l + 1 < a.levels) {      // x <- lhead(z) - C[code]
             const int col = ctile * 32 + (lane & 31);
             float cv[16];                                                             // the chosen codewords' entries, ahead of the GEMM
+            const int* cs = code_s + ((col * a.segs) >> 6) * ER;                      // the column's segment
 #pragma unroll
-            for (int r = 0; r < 16; ++r) cv[r] = cb[(size_t)code_s[rt * 32 + mfma32_row(r, lane)] * D + col];
+            for (int r = 0; r < 16; ++r) cv[r] = cb[(size_t)cs[rt * 32 + mfma32_row(r, lane)] * D + col];
             gemm_tile(bufB, tw, rt, lane, acc);
             tw = tile_weights((const float2*)a.lvl[l + 1], a.lvl[l + 1] + D * D, ctile, lane);   // the next level's stage
 #pragma unroll
@@ -239,11 +244,15 @@ static int encode64_launch(const qv2x_encode_desc* d, int cin_total, const int8_
     using namespace qv2x;
     if (!d || (!in && !in_f32) || !level_weights || !codes) return fail(QV2X_EINVAL, "qv2x_codebook_encode64_f32: null pointer");
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->levels < 1 || d->levels > 4) return fail(QV2X_EINVAL, "qv2x_codebook_encode64_f32: bad shape");
-    if (d->kc < 32 || d->kc > 128 || d->kc % 32) return fail(QV2X_EINVAL, "qv2x_codebook_encode64_f32: dict_size must be 32, 64, 96 or 128 (got %d)", d->kc);
+    const int segs = d->segs ? d->segs : 1;
+    if ((segs != 1 && segs != 2 && segs != 4) || d->kc < 32 || d->kc > 256 || d->kc % 32 || (segs > 1 && d->kc % 64) || segs * d->kc > 32 * MAX_TILES)
+        return fail(QV2X_EINVAL, "qv2x_codebook_encode64_f32: seg_num 1 | 2 | 4, dict_size a multiple of 32 up to 256 (of 64 with seg_num > 1; "
+                                 "seg_num * dict_size <= %d): got dict_size %d, seg_num %d", 32 * MAX_TILES, d->kc, d->segs);
     if (cin_total < 64 || cin_total % 16 || ((uintptr_t)in & 15) || ((uintptr_t)in_f32 & 15))
         return fail(QV2X_EALIGN, "qv2x_codebook_encode64_f32: >= 64 channels (%% 16), 16-byte aligned map");
     Enc64Args a;
     a.in = in; a.in_f32 = in_f32; a.codes = codes; a.n = d->n; a.h = d->h; a.w = d->w; a.cin_total = cin_total; a.levels = d->levels; a.kc = d->kc;
+    a.segs = segs; a.ke = segs * d->kc;
     a.ax = 128 - d->in_zx; a.dx = d->in_delta; a.M = d->n * d->h * d->w;
     for (int l = 0; l < 4; ++l) {
         a.lvl[l] = l < d->levels ? level_weights[l] : nullptr;

@@ -158,6 +158,7 @@ extern "C" int qv2x_codebook_encode_collapsed_f32(const qv2x_encode_desc* d, con
     using namespace qv2x;
     if (!d || !in || !g_packed || !bias || !codes) return fail(QV2X_EINVAL, "qv2x_codebook_encode_collapsed_f32: null pointer");
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->levels < 1 || d->levels > 3) return fail(QV2X_EINVAL, "qv2x_codebook_encode_collapsed_f32: 1..3 levels");
+    if (d->segs > 1) return fail(QV2X_EINVAL, "qv2x_codebook_encode_collapsed_f32: seg_num 1 only (the opt-in collapsed form; the exact entry takes seg_num 1 | 2 | 4)");
     if (d->kc < 32 || d->kc > 128 || d->kc % 32) return fail(QV2X_EINVAL, "qv2x_codebook_encode_collapsed_f32: dict_size must be 32, 64, 96 or 128 (got %d)", d->kc);
     if (d->levels > 1 && !tables) return fail(QV2X_EINVAL, "qv2x_codebook_encode_collapsed_f32: the residual levels need their tables");
     if (((uintptr_t)in & 15) || ((uintptr_t)g_packed & 15)) return fail(QV2X_EALIGN, "qv2x_codebook_encode_collapsed_f32: 16-byte aligned pointers");

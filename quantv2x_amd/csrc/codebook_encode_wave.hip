@@ -11,7 +11,9 @@
 // 128 registers per matrix; a pair of 32-channel output tiles (two 16-register accumulators, two dependent chains of 128 MFMAs) goes through the wave's
 // own 33 KB of LDS to come back in B-operand order -- no workgroup barrier, no other wave involved.  In the C layout a lane holds ONE cell
 // (lane & 31) and 16 channels / codes per tile, so the argmin over the codes is a running minimum inside the lane plus one exchange
-// between the two half-waves, and |q|^2 is two 64-long chains per lane read back from the wave's LDS rows.  One wave per SIMD (256
+// between the two half-waves, and |q|^2 is two 64-long chains per lane read back from the wave's LDS rows.  seg_num (m) > 1
+// (codebook.py:115-131): the codebook comes EXTENDED -- [m * kc][256], segment s in dims [s d, (s + 1) d), zeros elsewhere -- so the
+// distance GEMM is the same stream over m * kc rows, a segment's argmin closes after its kc rows, and the code planes are [levels * m].  One wave per SIMD (256
 // VGPRs + ~220 AGPRs, no scratch), four single-wave workgroups per CU (LDS), 32-cell scheduling granularity.  Measured: DESIGN.md §3.
 //
 // Bit-exactness: every dot product is the same ascending-k fp32 fma chain with acc0 = bias (v_mfma_f32_32x32x2_f32 adds k = 2t from
@@ -114,19 +116,19 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
         const float* stage_b = W + D * D;
         const float* qhead_b = stage_b + D + D * D;
         const float* lhead_b = qhead_b + D + D * D;
-        const float* cb = lhead_b + D + (size_t)D * a.kc;              // [kc][256]
-        const float* c2 = cb + (size_t)a.kc * D;                        // [kc]
+        const float* cb = lhead_b + D + (size_t)D * a.ke;              // [ke][256]: the extended codebook (ke = segs * kc rows)
+        const float* c2 = cb + (size_t)a.ke * D;                        // [ke]
         // the wave section: stage | qhead | codebook | lhead, each [tile pair][32 groups][2 tiles][64 lanes][4 steps] -- ONE linear stream
         // (buffer loads: the section as a resource, a SCALAR running offset, the lane's constant 16-byte offset -- no per-lane 64-bit address
         // arithmetic between the MFMAs)
-        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)(W + level_floats_wg(a.kc)), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)(W + level_floats_wg(a.ke)), 0, 0x7fffffff, 0x00020000);
         int wo = 0;                                                     // bytes into the section: one tile pair = 64 KiB
         const int loff = lane * 16;
         auto wload = [&](int grp) __attribute__((always_inline)) {
             return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, wo + grp * 1024, 0));
         };
         const bool last = l + 1 == a.levels;
-        const int npair = (a.kc + 63) >> 6;                             // (an odd number of 32-code tiles: the last pair's second tile is zeros)
+        const int npair = (a.ke + 63) >> 6;                             // (an odd number of 32-code tiles: the last pair's second tile is zeros)
 
         // bias / |C|^2 of the NEXT tile pair: requested NPF groups before the current pair ends, i.e. BEFORE the ring loads that are still in
         // flight when the pair starts -- the in-order vmcnt wait for it leaves the whole ring in flight
@@ -137,7 +139,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
         };
         auto next_c2 = [&](int P) __attribute__((always_inline)) {    // codes past the dictionary: |C|^2 = +inf, never the minimum
             tile_vec(c2, h, 2 * P, bn[0]);
-            if (64 * P + 32 < a.kc) tile_vec(c2, h, 2 * P + 1, bn[1]);
+            if (64 * P + 32 < a.ke) tile_vec(c2, h, 2 * P + 1, bn[1]);
             else
 #pragma unroll
                 for (int i = 0; i < 4; ++i) bn[1][i] = v4f{INFINITY, INFINITY, INFINITY, INFINITY};
@@ -217,8 +219,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
         }
         WFINE(3);
         lds_to_operand(row, h, xq);
-        // |q|^2: four 64-wide ascending fma chains per cell, (p0 + p1) + (p2 + p3); half-wave h runs chains 2 h and 2 h + 1 on the LDS row
-        float x2;
+        // |q|^2: four 64-wide ascending fma chains per cell; half-wave h runs chains 2 h and 2 h + 1 on the LDS row.  One segment (m = 1):
+        // (p0 + p1) + (p2 + p3); two segments of 128 dims: p0 + p1 | p2 + p3; four of 64: the chains themselves (codebook.py:115-121:
+        // x.reshape(n, m, d), (x ** 2).sum(2); oracle/qv2x_oracle.c:sumsq_seg)
+        float x2s[4];
         {
             const float* qh = row + 128 * h;
             float p[2];
@@ -234,14 +238,27 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
                 p[c] = s;
             }
             const float mine = p[0] + p[1];
-            x2 = mine + __shfl_xor(mine, 32);                          // (fp32 addition commutes: both half-waves hold (p0 + p1) + (p2 + p3))
+            const float other = __shfl_xor(mine, 32);
+            if (a.segs == 1) {
+                x2s[0] = x2s[1] = x2s[2] = x2s[3] = mine + other;      // (fp32 addition commutes: both half-waves hold (p0 + p1) + (p2 + p3))
+            } else if (a.segs == 2) {
+                x2s[0] = h ? other : mine; x2s[1] = h ? mine : other; x2s[2] = x2s[3] = 0.0f;
+            } else {
+                const float o0 = __shfl_xor(p[0], 32), o1 = __shfl_xor(p[1], 32);
+                x2s[0] = h ? o0 : p[0]; x2s[1] = h ? o1 : p[1]; x2s[2] = h ? p[0] : o0; x2s[3] = h ? p[1] : o1;
+            }
         }
         WFINE(4);
-        // ---- distances to the codes, 64 per pair, and the running first-argmin inside the lane --------------------------------
+        // ---- distances to the codes, 64 per pair, and the running first-argmin inside the lane; a pair lies inside ONE segment
+        //      (kc % 64 == 0 when segs > 1), a segment's argmin closes with its last pair ------------------------------------------------
         float best = INFINITY;
         int bc = 0;
+        unsigned bcs = 0;                                               // the segments' codes, one byte each
+        const int ppseg = npair / a.segs;                               // pairs per segment
 #pragma unroll 1
         for (int P = 0; P < npair; ++P) {
+            const int seg = a.segs == 1 ? 0 : P / ppseg, cbase = seg * a.kc;
+            const float x2 = seg == 0 ? x2s[0] : (seg == 1 ? x2s[1] : (seg == 2 ? x2s[2] : x2s[3]));
             v4f c2t[2][4];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -254,24 +271,28 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
                 for (int r = 0; r < 16; ++r) {                             // codes ascend with (t, r) inside a lane: a strict < keeps the first
                     const float s = x2 + c2t[t][r >> 2][r & 3];
                     const float d = s - 2.0f * acc[t][r];
-                    const int code = 64 * P + 32 * t + 8 * (r >> 2) + 4 * h + (r & 3);
+                    const int code = 64 * P + 32 * t + 8 * (r >> 2) + 4 * h + (r & 3) - cbase;
                     const bool lt = d < best;
                     best = lt ? d : best;
                     bc = lt ? code : bc;
                 }
+            if (a.segs == 1 ? P + 1 == npair : (P + 1) % ppseg == 0) {  // the segment's last pair: the two half-waves' minima, ties to the lower code
+                const float od = __shfl_xor(best, 32);
+                const int oc = __shfl_xor(bc, 32);
+                if (od < best || (od == best && oc < bc)) bc = oc;
+                if (h == 0 && m0 + j < a.m_hi) a.codes[((size_t)l * a.segs + seg) * a.M + m0 + j] = (uint8_t)bc;
+                bcs |= (unsigned)bc << (8 * seg);
+                best = INFINITY; bc = 0;
+            }
         }
-        {
-            const float od = __shfl_xor(best, 32);
-            const int oc = __shfl_xor(bc, 32);
-            if (od < best || (od == best && oc < bc)) bc = oc;
-        }
-        if (h == 0 && m0 + j < a.m_hi) a.codes[(size_t)l * a.M + m0 + j] = (uint8_t)bc;
         WFINE(5);
         if (last) break;
         // ---- x <- lhead(z) - C[code] ------------------------------------------------------------------------------------------
-        const float* cw = cb + (size_t)bc * D;
 #pragma unroll 1
         for (int P = 0; P < 4; ++P) {
+            // channels [64 P, 64 P + 64) lie in segment P * segs / 4: its codeword is row seg * kc + code of the extended codebook
+            const int seg = (P * a.segs) >> 2;
+            const float* cw = cb + (size_t)(seg * a.kc + (int)((bcs >> (8 * seg)) & 0xffu)) * D;
             v4f cv[2][4];
             tile_vec(cw, h, 2 * P, cv[0]);
             tile_vec(cw, h, 2 * P + 1, cv[1]);

@@ -41,8 +41,8 @@ int fuse_args_from_desc(const qv2x_fuse_desc* d, const uint8_t* codes, const flo
     if (!feats && (!codes || !lut || !lut_bias)) return fail(QV2X_EINVAL, "%s: need codes + lut + lut_bias, or feats", who);
     if (d->agents < 1 || d->agents > MAXA) return fail(QV2X_EINVAL, "%s: 1..%d agents, got %d", who, MAXA, d->agents);
     if (d->max_cav < d->agents || d->ego < 0 || d->ego >= d->agents) return fail(QV2X_EINVAL, "%s: max_cav / ego out of range", who);
-    if (d->h <= 0 || d->w <= 0 || (!feats && (d->levels < 1 || d->levels > 4 || d->kc < 1 || d->kc > 256)))
-        return fail(QV2X_EINVAL, "%s: bad sizes", who);
+    if (d->h <= 0 || d->w <= 0 || (!feats && (d->levels < 1 || d->levels > 16 || d->kc < 1 || d->kc > 256)))
+        return fail(QV2X_EINVAL, "%s: bad sizes (1..16 code planes = levels * seg_num, dict_size <= 256)", who);
     if (!(d->h_metres > 0) || !(d->w_metres > 0) || !(d->discrete_ratio > 0)) return fail(QV2X_EINVAL, "%s: map extent must be positive", who);
     a.codes = codes; a.lut = (const float4*)lut; a.lut_bias = (const float4*)lut_bias; a.feats = (const float4*)feats;
     a.fused = nullptr; a.pairwise = pairwise;

@@ -422,7 +422,7 @@ extern "C" int qv2x_decode_heads_f32(const uint8_t* codes, int R, int hw, int le
                                      float* out, void* stream) {
     using namespace qv2x;
     if (!codes || !lut || !lut_bias) return fail(QV2X_EINVAL, "qv2x_decode_heads_f32: null pointer");
-    if (levels < 1 || levels > 4 || kc < 1 || kc > 256) return fail(QV2X_EINVAL, "qv2x_decode_heads_f32: bad sizes");
+    if (levels < 1 || levels > 16 || kc < 1 || kc > 256) return fail(QV2X_EINVAL, "qv2x_decode_heads_f32: bad sizes (1..16 code planes = levels * seg_num, dict_size <= 256)");
     HeadArgs h;
     if (int rc = head_args("qv2x_decode_heads_f32", R, hw, cout, cout_pad, w, bias, da, za, out, h)) return rc;
     FuseArgs fa{};
@@ -474,7 +474,7 @@ extern "C" int qv2x_decode_lut_f32(const uint8_t* codes, int R, int levels, int 
                                    float* out, void* stream) {
     using namespace qv2x;
     if (!codes || !lut || !lut_bias || !out) return fail(QV2X_EINVAL, "qv2x_decode_lut_f32: null pointer");
-    if (R <= 0 || levels < 1 || levels > 4 || kc < 1 || kc > 256) return fail(QV2X_EINVAL, "qv2x_decode_lut_f32: bad sizes");
+    if (R <= 0 || levels < 1 || levels > 16 || kc < 1 || kc > 256) return fail(QV2X_EINVAL, "qv2x_decode_lut_f32: bad sizes (1..16 code planes = levels * seg_num, dict_size <= 256)");
     decode_lut_kernel<<<(R + 3) / 4, 256, 0, (hipStream_t)stream>>>(codes, R, levels, kc, (const float4*)lut, (const float4*)lut_bias, (float4*)out);
     return hip_check(hipGetLastError(), "qv2x_decode_lut_f32 launch");
 }
@@ -497,7 +497,7 @@ extern "C" int qv2x_heads_pair_f32(const float* x, int R, int hw, int cout, int 
     if (int rc = head_args("qv2x_heads_pair_f32", R, hw, cout, cout_pad, w, bias, da, za, out, h0)) return rc;
     if (int rc = head_args("qv2x_heads_pair_f32", R1, hw, cout1, cout_pad1, w1, bias1, da1, za1, out1, h1)) return rc;
     if ((uintptr_t)x & 15) return fail(QV2X_EALIGN, "qv2x_heads_pair_f32: x must be 16-byte aligned");
-    if (levels < 1 || levels > 4 || kc < 1 || kc > 256) return fail(QV2X_EINVAL, "qv2x_heads_pair_f32: bad sizes");
+    if (levels < 1 || levels > 16 || kc < 1 || kc > 256) return fail(QV2X_EINVAL, "qv2x_heads_pair_f32: bad sizes (1..16 code planes = levels * seg_num, dict_size <= 256)");
     h0.x = x;
     FuseArgs fa{};
     fa.codes = codes; fa.lut = (const float4*)lut; fa.lut_bias = (const float4*)lut_bias; fa.feats = nullptr;

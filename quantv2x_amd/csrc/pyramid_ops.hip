@@ -65,7 +65,7 @@ extern "C" int qv2x_codebook_decode_f32(const uint8_t* codes, int64_t agent_stri
                                         int kc, int d, const float* lut, const float* bias, float* out, void* stream) {
     using namespace qv2x;
     if (!codes || !lut || !bias || !out) return fail(QV2X_EINVAL, "qv2x_codebook_decode_f32: null pointer");
-    if (agents <= 0 || hw <= 0 || levels < 1 || levels > 8 || kc < 1 || kc > 256 || d <= 0 || d % 4)
+    if (agents <= 0 || hw <= 0 || levels < 1 || levels > 16 || kc < 1 || kc > 256 || d <= 0 || d % 4)
         return fail(QV2X_EINVAL, "qv2x_codebook_decode_f32: bad sizes (agents %d, hw %d, levels %d, kc %d, d %d)", agents, hw, levels, kc, d);
     if (((uintptr_t)lut & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)out & 15)) return fail(QV2X_EALIGN, "qv2x_codebook_decode_f32: 16-byte aligned tables / output");
     DecArgs a{codes, lut, bias, out, agent_stride, level_stride, agents * hw, hw, levels, kc, d};

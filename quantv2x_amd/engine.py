@@ -339,18 +339,26 @@ class DeployedModel(nn.Module):
             self.final = self.comp[-1]
         # ---- a6 / a7: codebook -----------------------------------------------------------------------------
         if self.has_codebook:
-            self.levels = int(s["meta/codebook_levels"])
-            self.kc = int(s["codebook/0/codebook"].shape[0])
-            lut, lut_bias = decode_tables(s, self.levels)
+            # seg_num (m) > 1: the state holds the EXTENDED codebook [m * kc][D] (ptq_state.extended_codebook).  Downstream of the encode
+            # everything counts code PLANES: ``levels`` = residual levels * m (the wire's [levels][agents][H*W] planes and the decode table
+            # [levels][kc][D], which is the per-level table over the extended rows read plane by plane); the encode kernels get the true
+            # level count ``enc_levels`` and ``segs``.
+            self.enc_levels, self.segs = int(s["meta/codebook_levels"]), int(s.get("meta/codebook_segs", 1))
+            self.levels = self.enc_levels * self.segs
+            self.ke = int(s["codebook/0/codebook"].shape[0])
+            self.kc = self.ke // self.segs
+            lut, lut_bias = decode_tables(s, self.enc_levels)
+            lut = lut.reshape(self.levels, self.kc, lut.shape[-1])
             self.lut = _dev(lut, dev)
             self.lut_bias = _dev(lut_bias, dev)
-            self.level_blobs = [self._level_blob(l) for l in range(self.levels)]
-            self.level_ptrs = (C.c_void_p * self.levels)(*[b.data_ptr() for b in self.level_blobs])
+            self.level_blobs = [self._level_blob(l) for l in range(self.enc_levels)]
+            self.level_ptrs = (C.c_void_p * self.enc_levels)(*[b.data_ptr() for b in self.level_blobs])
         # ---- a11: heads ------------------------------------------------------------------------------------
         self.heads = _Heads(s, "", dev)
         self.heads_single = _Heads(s, "_single", dev) if (self.emit_single and "cls_head_single/w_code" in s) else None
         # the *_single heads see one agent's own decoded feature: with the codebook that is three table rows per cell -- no GEMM
-        self.single_by_tables = self.heads_single is not None and self.has_codebook and self.levels * self.kc * self.heads_single.cout * 4 <= 60 * 1024
+        self.single_by_tables = (self.heads_single is not None and self.has_codebook and self.levels <= 4
+                                 and self.levels * self.kc * self.heads_single.cout * 4 <= 60 * 1024)
         if self.single_by_tables:
             self.heads_single.collapse_over_decode(lut, lut_bias, dev)
         # single-agent scenes (round 4): AttFusion over one agent is the identity, so EVERY head is a table look-up on the agent's own codes
@@ -361,7 +369,7 @@ class DeployedModel(nn.Module):
             ct = sum(h.cout for h in sets)
             ct4 = (ct + 3) // 4 * 4
             st = ct4 if (ct4 // 4) % 2 else ct4 + 4
-            if (self.levels * self.kc * st + 3 * ct4) * 4 <= 160 * 1024:
+            if self.levels <= 4 and (self.levels * self.kc * st + 3 * ct4) * 4 <= 160 * 1024:      # (the table kernels take up to four planes)
                 t = np.concatenate([np.einsum("lkd,cd->lkc", lut.astype(np.float64), h._w_np) for h in sets], axis=2)
                 b = np.concatenate([lut_bias.astype(np.float64) @ h._w_np.T + h._b_np for h in sets])
                 cat = lambda name: torch.cat([getattr(h, name)[:h.cout] for h in sets]).contiguous()
@@ -377,7 +385,7 @@ class DeployedModel(nn.Module):
 
     # ------------------------------------------------------------------------------------------------------
     def _level_blob(self, l: int) -> torch.Tensor:
-        s, kc = self.state, self.kc
+        s, kc = self.state, self.ke                                     # (rows of the extended codebook)
         g = lambda n: s[f"codebook/{l}/{n}"].astype(np.float32)
         zeros_w, zeros_b = np.zeros((64, 256, 4), np.float32), np.zeros(256, np.float32)
         last = f"codebook/{l}/lhead_w" not in s
@@ -631,11 +639,13 @@ class DeployedModel(nn.Module):
         if codes.dtype != torch.uint8 or not codes.is_contiguous() or codes.numel() != self.levels * n_agents * self.fh * self.fw:
             raise ValueError("encode_codes: out must be a contiguous uint8 tensor [levels, n_agents, H*W]")
         d = L.EncodeDesc()
-        d.n, d.h, d.w, d.levels, d.kc = n_agents, self.fh, self.fw, self.levels, self.kc
+        d.n, d.h, d.w, d.levels, d.kc, d.segs = n_agents, self.fh, self.fw, self.enc_levels, self.kc, self.segs
         d.in_zx, d.in_delta = int(self.shrink1.out_q[1]), float(self.shrink1.out_q[0])
         if self.encode_mode == "collapsed":                           # opt-in: one GEMM + argmin chain, indices may differ at near-ties
+            if self.segs != 1 or self.kc > 128:
+                raise NotImplementedError("encode_mode 'collapsed': seg_num 1 and dict_size <= 128 (the exact encode takes the rest)")
             if self._collapsed is None:
-                self._collapsed = tuple(_dev(t, self.dev) for t in collapse_encoder(self.state, self.levels, d.in_delta, d.in_zx))
+                self._collapsed = tuple(_dev(t, self.dev) for t in collapse_encoder(self.state, self.enc_levels, d.in_delta, d.in_zx))
             gp, bias, tab = self._collapsed
             L.check(self.lib.qv2x_codebook_encode_collapsed_f32(C.byref(d), L.ptr(b["s1"]), L.ptr(gp), L.ptr(bias), L.ptr(tab), L.ptr(codes),
                                                                 L.current_stream()), "qv2x_codebook_encode_collapsed_f32")

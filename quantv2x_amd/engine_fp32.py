@@ -20,7 +20,7 @@ import torch.nn as nn
 
 from . import lib as L
 from .engine import DeployedModel, _dev, _pack_k4p, decode_tables
-from .ptq_state import _np, _HEADS
+from .ptq_state import _np, _HEADS, extended_codebook
 
 
 def _fold(w: np.ndarray, b: Optional[np.ndarray], bn, out_axis: int):
@@ -90,16 +90,15 @@ def export_fp32_state(model) -> Dict[str, np.ndarray]:
     cb = getattr(model, "codebook", None)
     out["meta/has_codebook"] = np.bool_(cb is not None)
     if cb is not None:
-        if cb._m != 1:
-            raise NotImplementedError("deployed codebook path: seg_num (m) == 1")
         for lvl, (e, d) in enumerate(zip(cb._encoders, cb._decoders)):
             p = f"codebook/{lvl}/"
-            out[p + "codebook"] = _np(e._quantizer._codebook)[0].astype(np.float32)
+            out[p + "codebook"] = extended_codebook(_np(e._quantizer._codebook).astype(np.float32))   # [m * k, m * d] (ptq_state.py)
             for tag, lin in (("stage", e._latentStageEncoder), ("qhead", e._quantizationHead), ("lhead", e._latentHead),
                              ("dqhead", d._dequantizationHead), ("side", d._sideHead), ("restore", d._restoreHead)):
                 if lin is not None:
                     out[p + tag + "_w"], out[p + tag + "_b"] = _np(lin.weight).astype(np.float32), _np(lin.bias).astype(np.float32)
         out["meta/codebook_levels"] = np.int64(len(cb._encoders))
+        out["meta/codebook_segs"] = np.int64(cb._m)
     return out
 
 
@@ -182,12 +181,15 @@ class DeployedFp32Model(DeployedModel):
         if self.shrink1.cout != 256:
             raise NotImplementedError("deployed path expects a 256-channel shared feature")
         if self.has_codebook:
-            self.levels = int(s["meta/codebook_levels"])
-            self.kc = int(s["codebook/0/codebook"].shape[0])
-            lut, lut_bias = decode_tables(s, self.levels)
+            self.enc_levels, self.segs = int(s["meta/codebook_levels"]), int(s.get("meta/codebook_segs", 1))
+            self.levels = self.enc_levels * self.segs                  # code planes (engine.py)
+            self.ke = int(s["codebook/0/codebook"].shape[0])
+            self.kc = self.ke // self.segs
+            lut, lut_bias = decode_tables(s, self.enc_levels)
+            lut = lut.reshape(self.levels, self.kc, lut.shape[-1])
             self.lut, self.lut_bias = _dev(lut, dev), _dev(lut_bias, dev)
-            self.level_blobs = [self._level_blob(l) for l in range(self.levels)]
-            self.level_ptrs = (C.c_void_p * self.levels)(*[b.data_ptr() for b in self.level_blobs])
+            self.level_blobs = [self._level_blob(l) for l in range(self.enc_levels)]
+            self.level_ptrs = (C.c_void_p * self.enc_levels)(*[b.data_ptr() for b in self.level_blobs])
         self.heads = _F32Heads(s, "", dev)
         self.heads_single = _F32Heads(s, "_single", dev) if (self.emit_single and "cls_head_single/w" in s) else None
         self._bufs: Dict[int, dict] = {}
@@ -268,7 +270,7 @@ class DeployedFp32Model(DeployedModel):
         b = self._workspace(n_agents)
         codes = b["codes"] if out is None else out
         d = L.EncodeDesc()
-        d.n, d.h, d.w, d.levels, d.kc, d.in_zx, d.in_delta = n_agents, self.fh, self.fw, self.levels, self.kc, 0, 1.0
+        d.n, d.h, d.w, d.levels, d.kc, d.in_zx, d.in_delta, d.segs = n_agents, self.fh, self.fw, self.enc_levels, self.kc, 0, 1.0, self.segs
         L.check(self.lib.qv2x_codebook_encode_f32in(C.byref(d), L.ptr(b["s1"]), self.level_ptrs, L.ptr(codes), L.current_stream()),
                 "qv2x_codebook_encode_f32in")
         return codes

@@ -181,15 +181,22 @@ class DeployedPyramidModel(nn.Module):
         # ---- codebook (D = 64: its own encode kernel; other widths run the 256-wide one on zero-padded heads, see _level_blob) --
         self.native64 = True
         if self.has_codebook:
-            self.levels = int(s["meta/codebook_levels"])
-            self.kc, self.D = (int(v) for v in s["codebook/0/codebook"].shape)
+            # (seg_num > 1: the extended codebook [m * kc][D]; ``levels`` counts code planes = residual levels * m -- engine.py)
+            self.enc_levels, self.segs = int(s["meta/codebook_levels"]), int(s.get("meta/codebook_segs", 1))
+            self.levels = self.enc_levels * self.segs
+            self.ke, self.D = (int(v) for v in s["codebook/0/codebook"].shape)
+            self.kc = self.ke // self.segs
             if self.D > 256 or self.D % 4 or self.agent_blocks[-1].cout != self.D:
                 raise NotImplementedError("deployed Pyramid codebook: width <= 256 equal to the agent feature's channels")
             self.native64 = self.D == 64
-            lut, lut_bias = decode_tables(s, self.levels, self.D)
+            if self.segs > 1 and self.D not in (64, 256):
+                raise NotImplementedError("deployed Pyramid codebook: seg_num > 1 with a 64- or 256-wide codebook (other widths are zero-padded "
+                                          "to 256, which moves the segment boundaries)")
+            lut, lut_bias = decode_tables(s, self.enc_levels, self.D)
+            lut = lut.reshape(self.levels, self.kc, self.D)
             self.lut, self.lut_bias = _dev(lut, dev), _dev(lut_bias, dev)
-            self.level_blobs = [self._level_blob(l) for l in range(self.levels)]
-            self.level_ptrs = (C.c_void_p * self.levels)(*[b.data_ptr() for b in self.level_blobs])
+            self.level_blobs = [self._level_blob(l) for l in range(self.enc_levels)]
+            self.level_ptrs = (C.c_void_p * self.enc_levels)(*[b.data_ptr() for b in self.level_blobs])
         # ---- the pyramid: ResNeXt levels, occupancy heads, deblocks -------------------------------------------------------------------
         p_nums, p_strides = [int(v) for v in s["meta/pyramid_layer_nums"]], [int(v) for v in s["meta/pyramid_layer_strides"]]
         self.ups = [int(v) for v in s["meta/upsample_strides"]]
@@ -229,7 +236,7 @@ class DeployedPyramidModel(nn.Module):
         """One level's heads in the layout of the encode kernel: the native 64-wide one (qv2x_codebook_encode64_f32), or -- other widths
         -- zero-padded to the 256-wide kernel's (every extra term of every fma chain is 0 * 0 and the padded |.|^2 chains are exactly 0,
         so the codes equal a native evaluation bit for bit)."""
-        s, kc, D = self.state, self.kc, self.D
+        s, kc, D = self.state, self.ke, self.D                             # (kc: rows of the extended codebook)
         g = lambda n: s[f"codebook/{l}/{n}"].astype(np.float32)
         W = 64 if self.native64 else 256
 
@@ -423,7 +430,7 @@ class DeployedPyramidModel(nn.Module):
         if codes.dtype != torch.uint8 or not codes.is_contiguous() or codes.numel() != self.levels * n * self.fh * self.fw:
             raise ValueError("encode_codes: out must be a contiguous uint8 tensor [levels, n_agents, H*W]")
         d = L.EncodeDesc()
-        d.n, d.h, d.w, d.levels, d.kc = n, self.fh, self.fw, self.levels, self.kc
+        d.n, d.h, d.w, d.levels, d.kc, d.segs = n, self.fh, self.fw, self.enc_levels, self.kc, self.segs
         d.in_zx, d.in_delta = int(self.agent_q[1]), float(self.agent_q[0])
         if self.native64:
             L.check(self.lib.qv2x_codebook_encode64_f32(C.byref(d), b["enc_in"].shape[-1], L.ptr(b["enc_in"]), self.level_ptrs, L.ptr(codes),

@@ -19,7 +19,7 @@ import torch.nn as nn
 from . import lib as L
 from .engine import _dev, decode_tables
 from .engine_fp32 import _F32Heads, _fold, pack_k8
-from .ptq_state import _HEADS, _np
+from .ptq_state import _HEADS, _np, extended_codebook
 
 
 def export_fp32_pyramid_state(model) -> Dict[str, np.ndarray]:
@@ -74,16 +74,15 @@ def export_fp32_pyramid_state(model) -> Dict[str, np.ndarray]:
     cb = getattr(model, "codebook", None)
     out["meta/has_codebook"] = np.bool_(cb is not None)
     if cb is not None:
-        if cb._m != 1:
-            raise NotImplementedError("deployed codebook path: seg_num (m) == 1")
         for lvl, (e, d) in enumerate(zip(cb._encoders, cb._decoders)):
             p = f"codebook/{lvl}/"
-            out[p + "codebook"] = _np(e._quantizer._codebook)[0].astype(np.float32)
+            out[p + "codebook"] = extended_codebook(_np(e._quantizer._codebook).astype(np.float32))   # [m * k, m * d] (ptq_state.py)
             for tag, lin in (("stage", e._latentStageEncoder), ("qhead", e._quantizationHead), ("lhead", e._latentHead),
                              ("dqhead", d._dequantizationHead), ("side", d._sideHead), ("restore", d._restoreHead)):
                 if lin is not None:
                     out[p + tag + "_w"], out[p + tag + "_b"] = _np(lin.weight).astype(np.float32), _np(lin.bias).astype(np.float32)
         out["meta/codebook_levels"] = np.int64(len(cb._encoders))
+        out["meta/codebook_segs"] = np.int64(cb._m)
     return out
 
 
@@ -154,16 +153,19 @@ class DeployedPyramidFp32Model(nn.Module):
             self.agent_blocks.append(blk)
         self.D = self.agent_blocks[-1]["conv2"].cout
         if self.has_codebook:
-            self.levels = int(s["meta/codebook_levels"])
-            self.kc, d = (int(v) for v in s["codebook/0/codebook"].shape)
+            self.enc_levels, self.segs = int(s["meta/codebook_levels"]), int(s.get("meta/codebook_segs", 1))
+            self.levels = self.enc_levels * self.segs                  # code planes (engine.py)
+            self.ke, d = (int(v) for v in s["codebook/0/codebook"].shape)
+            self.kc = self.ke // self.segs
             if d != 64 or self.D != 64:
                 raise NotImplementedError("deployed fp32 Pyramid codebook: the 64-wide one")
-            lut, lut_bias = decode_tables(s, self.levels, 64)
+            lut, lut_bias = decode_tables(s, self.enc_levels, 64)
+            lut = lut.reshape(self.levels, self.kc, 64)
             self.lut, self.lut_bias = _dev(lut, dev), _dev(lut_bias, dev)
             from .engine_pyramid import DeployedPyramidModel
             self.native64 = True
-            self.level_blobs = [DeployedPyramidModel._level_blob(self, l) for l in range(self.levels)]
-            self.level_ptrs = (C.c_void_p * self.levels)(*[b.data_ptr() for b in self.level_blobs])
+            self.level_blobs = [DeployedPyramidModel._level_blob(self, l) for l in range(self.enc_levels)]
+            self.level_ptrs = (C.c_void_p * self.enc_levels)(*[b.data_ptr() for b in self.level_blobs])
         self.pyr_blocks, self.occ, self.deblocks = [], [], []
         for lvl, nb in enumerate(int(v) for v in s["meta/pyramid_layer_nums"]):
             blocks = []
@@ -275,7 +277,7 @@ class DeployedPyramidFp32Model(nn.Module):
         feat = self.agent_features(inputs, n, 1, taps)
         codes = self._ws(n, 1)["codes"] if out is None else out
         d = L.EncodeDesc()
-        d.n, d.h, d.w, d.levels, d.kc, d.in_zx, d.in_delta = n, self.fh, self.fw, self.levels, self.kc, 0, 1.0
+        d.n, d.h, d.w, d.levels, d.kc, d.in_zx, d.in_delta, d.segs = n, self.fh, self.fw, self.enc_levels, self.kc, 0, 1.0, self.segs
         L.check(self.lib.qv2x_codebook_encode64_f32in(C.byref(d), 64, L.ptr(feat), self.level_ptrs, L.ptr(codes), L.current_stream()), "qv2x_codebook_encode64_f32in")
         return codes
 

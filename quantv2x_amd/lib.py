@@ -92,7 +92,7 @@ class OccDesc(C.Structure):
 
 class EncodeDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("levels", C.c_int32), ("kc", C.c_int32),
-                ("in_zx", C.c_int32), ("in_delta", C.c_float)]
+                ("in_zx", C.c_int32), ("in_delta", C.c_float), ("segs", C.c_int32)]
 
 
 class FuseDesc(C.Structure):

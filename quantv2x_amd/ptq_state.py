@@ -206,11 +206,10 @@ def export_ptq_state(qt_model, modality: str = "m1") -> Dict[str, np.ndarray]:
     cb = getattr(model, "codebook", None)
     out["meta/has_codebook"] = np.bool_(cb is not None)
     if cb is not None:
-        if cb._m != 1:
-            raise NotImplementedError("deployed codebook path: seg_num (m) == 1")
+        m = int(cb._m)
         for lvl, (e, d) in enumerate(zip(cb._encoders, cb._decoders)):
             p = f"codebook/{lvl}/"
-            out[p + "codebook"] = _np(e._quantizer._codebook)[0].astype(np.float32)          # [k, d]
+            out[p + "codebook"] = extended_codebook(_np(e._quantizer._codebook).astype(np.float32))    # [m * k, m * d]; m = 1: [k, d]
             for tag, lin in (("stage", e._latentStageEncoder), ("qhead", e._quantizationHead),
                              ("lhead", e._latentHead), ("dqhead", d._dequantizationHead),
                              ("side", d._sideHead), ("restore", d._restoreHead)):
@@ -218,7 +217,29 @@ def export_ptq_state(qt_model, modality: str = "m1") -> Dict[str, np.ndarray]:
                     out[p + tag + "_w"] = _np(lin.weight).astype(np.float32)
                     out[p + tag + "_b"] = _np(lin.bias).astype(np.float32)
         out["meta/codebook_levels"] = np.int64(len(cb._encoders))
+        out["meta/codebook_segs"] = np.int64(m)
+        ks = {out[f"codebook/{lvl}/codebook"].shape[0] // m for lvl in range(len(cb._encoders))}
+        if len(ks) != 1:
+            raise NotImplementedError(f"deployed codebook path: one dict_size for every level (got {sorted(ks)})")
+        k = ks.pop()
+        if k > 256 or (m > 1 and k % 64) or (m == 1 and k % 32) or m not in (1, 2, 4):
+            raise NotImplementedError(f"deployed codebook path: seg_num 1 | 2 | 4 and dict_size <= 256 (a multiple of 32; of 64 with seg_num > 1): "
+                                      f"got seg_num {m}, dict_size {k}")
     return check_finite(out)
+
+
+def extended_codebook(cb: np.ndarray) -> np.ndarray:
+    """``_multiCodebookQuantization._codebook`` f32 [m, k, d] (codebook.py:66-69) -> the EXTENDED form [m * k, m * d] the deployed path and
+    the oracle work on: row s * k + j holds C[s][j] in dims [s d, (s + 1) d) and zeros elsewhere.  With it the per-segment arithmetic of
+    codebook.py:115-131 / :192-201 is ordinary dense arithmetic, bit for bit: a row's dot product with q over all m * d dims is the
+    segment's own ascending fma chain (fmaf(q, 0, acc) = acc), the decode head applied to a row is the head applied to the zero-padded
+    codeword, and the wire's code plane (level l, segment s) indexes rows [s k, (s + 1) k) -- i.e. plane l * m + s of a table
+    [levels * m][k][width].  m = 1: the plain [k, d] codebook."""
+    m, k, d = cb.shape
+    ext = np.zeros((m * k, m * d), np.float32)
+    for s in range(m):
+        ext[s * k:(s + 1) * k, s * d:(s + 1) * d] = cb[s]
+    return ext
 
 
 def check_finite(state: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:

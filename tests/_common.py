@@ -94,7 +94,7 @@ def head_lsb(state, suffix=""):
     return max(float(state[k + suffix + "/a_delta"]) for k in ("cls_head", "reg_head", "dir_head"))
 
 
-def compare_frame(orc, eng, sc_np, state, every_layer=True, preds_exact_tol=None):
+def compare_frame(orc, eng, sc_np, state, every_layer=True, preds_exact_tol=None, flips_floor=0):
     """One frame through the CPU oracle and through the HIP engine (C ABI): every uint8 activation and every codebook
     index bit-exact, the fused fp32 map within FUSE_TOL, predictions equal up to rare +-1 LSB flips of the head
     quantizer (or within ``preds_exact_tol`` when the head output quantizer is disabled)."""
@@ -129,7 +129,8 @@ def compare_frame(orc, eng, sc_np, state, every_layer=True, preds_exact_tol=None
             assert d.max() <= preds_exact_tol, (key, d.max())
         else:
             lsb = head_lsb(state, "_single" if key.endswith("_single") else "")
-            assert d.max() <= lsb * 1.001 and (d > 1e-5).mean() < 1e-3, (key, d.max(), (d > 1e-5).mean())
+            # (``flips_floor``: the rate rule on a tensor of a few thousand elements allows two flips; a caller at tiny shape may grant a count)
+            assert d.max() <= lsb * 1.001 and ((d > 1e-5).mean() < 1e-3 or int((d > 1e-5).sum()) <= flips_floor), (key, d.max(), (d > 1e-5).mean())
     return otaps, gtaps, want, got
 
 

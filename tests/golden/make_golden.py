@@ -18,6 +18,7 @@ only expected outputs are stored):
                    conv / deconv / linear), ``fold_bn`` vectors, AdaRound hard rounding
   geometry.npz     ``normalize_pairwise_tfm`` + ``warp_affine_simple`` + ``AttFusion`` vectors
   codebook.npz     ``UMGMQuantizer.encode`` codes, top-2 distance gaps, ``decode`` output
+  codebook_seg.npz (``codebook_seg``) the same for seg_num / dict_size = (2, 256), (1, 256), (4, 64) + the (2, 256) model's hard-path predictions
 """
 import copy
 import os
@@ -449,6 +450,79 @@ def gen_codebook():
     print("codebook.npz", {k: v.shape for k, v in out.items()})
 
 
+SEG_CONFIGS = ((2, 256), (1, 256), (4, 64))      # (seg_num, dict_size): the reference's OPV2V / DAIR / Fcooper yamls use (2, 256)
+
+
+def gen_codebook_seg():
+    """codebook_seg.npz (round 5): ``UMGMQuantizer`` with seg_num m > 1 and dict_size up to 256 (codebook.py:115-131: ``x.reshape(n, m, d)``,
+    a distance and an argmin per segment; :192-201: per-segment gather, concat) -- the configuration of six of the reference's ten codebook
+    yamls (``seg_num: 2, dict_size: 256``).  Per (m, k): the reference model built by ``create_model`` from ``synth.make_hypes(dict_size=k,
+    seg_num=m)`` with the seeded weights; ``encode`` codes as planes [levels * m][rows] (plane l * m + s), top-2 distance gaps per plane,
+    ``decode`` output; for (2, 256) also the tiny model's hard-path predictions on the two-agent scene."""
+    out = {}
+    g = np.random.Generator(np.random.PCG64(13))
+    x = np.abs(g.normal(0, 0.6, (256, 256))).astype(np.float32)
+    x[g.uniform(size=x.shape) < 0.4] = 0
+    out['x'] = x
+    for m, k in SEG_CONFIGS:
+        model = build_ref(dict_size=k, seg_num=m)
+        cb = model.codebook
+        assert cb._m == m and tuple(cb._encoders[0]._quantizer._codebook.shape) == (m, k, 256 // m)
+        tag = f"m{m}k{k}/"
+        with torch.no_grad():
+            xt = torch.from_numpy(x)
+            codes = cb.encode(xt)                                         # levels x [n, m]
+            out[tag + 'codes'] = np.concatenate([np32(c).T for c in codes]).astype(np.uint8)      # [levels * m][n]
+            out[tag + 'decoded'] = np32(cb.decode(codes))
+            cur, gaps = xt, []
+            for enc in cb._encoders:
+                z = enc._latentStageEncoder(cur)
+                d = enc._quantizer._distance(enc._quantizationHead(z))   # [n, m, k]
+                top2 = torch.topk(d, 2, dim=-1, largest=False)[0]
+                gaps.append(np32(top2[..., 1] - top2[..., 0]).T)          # [m][n]
+                cur, _ = enc.encode(cur)
+            out[tag + 'gaps'] = np.concatenate(gaps)
+            if (m, k) == (2, 256):
+                taps = {}
+                out[tag + 'hard_preds_tensor'] = np32(hard_forward_seg(model, scene(2), taps))
+                out[tag + 'hard_codes'] = np32(taps['codes']).astype(np.uint8)
+    # the Pyramid model's 64-wide codebook with the setting of opv2v / dairv2x Codebook/Pyramid/pyramid_stage{2,3}_model.yaml:96-97:
+    # seg_num 2 (segments of 32 dims), dict_size 256 (heter_pyramid_collab_codebook_mc.py:19-27)
+    x64 = np.abs(g.normal(0, 0.6, (256, 64))).astype(np.float32)
+    x64[g.uniform(size=x64.shape) < 0.4] = 0
+    out['x64'] = x64
+    cb = build_ref_pyramid(dict_size=256, seg_num=2).codebook
+    assert cb._m == 2 and tuple(cb._encoders[0]._quantizer._codebook.shape) == (2, 256, 32)
+    with torch.no_grad():
+        xt = torch.from_numpy(x64)
+        codes = cb.encode(xt)
+        out['pyr_m2k256/codes'] = np.concatenate([np32(c).T for c in codes]).astype(np.uint8)
+        out['pyr_m2k256/decoded'] = np32(cb.decode(codes))
+        cur, gaps = xt, []
+        for enc in cb._encoders:
+            z = enc._latentStageEncoder(cur)
+            d = enc._quantizer._distance(enc._quantizationHead(z))
+            top2 = torch.topk(d, 2, dim=-1, largest=False)[0]
+            gaps.append(np32(top2[..., 1] - top2[..., 0]).T)
+            cur, _ = enc.encode(cur)
+        out['pyr_m2k256/gaps'] = np.concatenate(gaps)
+    np.savez_compressed(os.path.join(HERE, "codebook_seg.npz"), **out)
+    print("codebook_seg.npz", {k: v.shape for k, v in out.items()})
+
+
+def hard_forward_seg(model, dd, taps):
+    """``hard_forward`` for any seg_num: the code planes come as [levels * m, n, h, w]."""
+    affine = normalize_pairwise_tfm(dd['pairwise_t_matrix'].clone(), model.H, model.W, model.fake_voxel_size)
+    f = model.shrinker_m1(model.backbone_m1(model.encoder_m1(dd, 'm1')))
+    n, c, h, w = f.shape
+    rows = f.permute(0, 2, 3, 1).contiguous().view(-1, c)
+    codes = model.codebook.encode(rows)
+    dec = model.codebook.decode(codes)
+    taps['codes'] = torch.cat([cd.T for cd in codes]).view(-1, n, h, w)
+    fused = model.fusion_net(dec.view(n, h, w, c).permute(0, 3, 1, 2).contiguous(), dd['record_len'], affine)
+    return torch.cat([model.cls_head(fused), model.reg_head(fused), model.dir_head(fused)], dim=1)
+
+
 def gen_postprocess():
     """f2: VoxelPostprocessor.post_process (voxel_postprocessor.py:245-405) on random head maps.  shapely is absent here, so
     the reference's flow is run with ``nms_rotated`` replaced by "keep everything, in score order": every step but the
@@ -645,8 +719,8 @@ def gen_pyramid():
     print("pyramid_fuse.npz", {k: v.shape for k, v in out.items()})
 
 
-def build_ref_pyramid(shape="tiny"):
-    hy = synth.make_pyramid_hypes(shape)
+def build_ref_pyramid(shape="tiny", **kw):
+    hy = synth.make_pyramid_hypes(shape, **kw)
     model = ref_tu.create_model(copy.deepcopy(hy)).eval()
     synth.load_state_dict_numpy(model, synth.make_state_dict(model.state_dict(), seed=SEED_W))
     return model
@@ -924,6 +998,7 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["fp32", "w8a8", "uaq", "geometry", "codebook", "postprocess", "postprocess_mc", "recon", "pyramid", "pyramid_model", "maxfuse", "w4a8"]
     with torch.no_grad():
         pass
+    if "codebook_seg" in which: gen_codebook_seg()
     if "fp32" in which: gen_fp32()
     if "w8a8" in which: gen_w8a8()
     if "uaq" in which: gen_uaq_units()

@@ -46,7 +46,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(lib.PfnParams) == (640 + 64 + 4 + 6) * 4
     assert C.sizeof(lib.ConvDesc) == (7 + 3 * 4 + 3) * 4 + 8
     assert C.sizeof(lib.DeconvDesc) == 15 * 4
-    assert C.sizeof(lib.EncodeDesc) == 7 * 4
+    assert C.sizeof(lib.EncodeDesc) == 8 * 4
     assert C.sizeof(lib.FuseDesc) == 7 * 4 + 4 + 2 * 8 + 3 * 8 + 4 + 4    # 4 bytes of padding before the int64 fields, `fusion` + tail padding
     assert C.sizeof(lib.Conv1x1Desc) == 14 * 4 and C.sizeof(lib.GconvDesc) == 9 * 4 and C.sizeof(lib.OccDesc) == 10 * 4
 
