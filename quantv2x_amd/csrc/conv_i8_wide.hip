@@ -632,6 +632,7 @@ extern "C" int qv2x_conv3x3_i8_wide_ok(const qv2x_conv_desc* d) {
     const long long wgs = patches * (d->cout / wide_bn(d));
     // Stride 2 (measured, batch of 32 / 8): four tiles, barriers and window-sum passes per nine K steps instead of one -- 256 output
     // channels amortise them (34 vs 39 us, 13.8 vs 17.6 us), 128 do not (46 vs 44 us) and 64 lose (149 vs 129 us on the 192-pixel im2col tiles)
+    if (d->stride == 2 && qv2x::ws64_takes(d)) return 1;              // 64 input channels: the weights-stationary stride-2 form (conv_i8_ws.hip)
     if (d->stride == 2 && d->cout % 256) return 0;
     return chunks * (d->stride == 2 ? 4 : 1) <= qv2x::MAX_CHUNKS && patches * qv2x::TH * qv2x::TW >= 16384 && wgs >= (d->cout == 64 ? 1024 : 192);
 }

@@ -85,16 +85,21 @@ def _worker(rank, world, port, state, out_q, frames):
         eng = _OracleEngine(state)
         model = AgentShardedModel(eng, frames=frames)
         out = model.forward(inp, pose)
-        out_q.put((rank, out["preds_tensor"].numpy(), model.gathered.numpy().copy(), eng.calls, model.pairwise.numpy().copy()))
+        calls = list(eng.calls)
         ego_only = AgentShardedModel(eng, ego_only=True, frames=frames).forward(inp, pose)
         assert (ego_only is None) == (rank != 0)
+        assert len(eng.calls) == len(calls) + (1 if rank == 0 else 0)          # ego_only: rank 0 alone runs the post stage
+        out_q.put((rank, out["preds_tensor"].numpy(), model.gathered.numpy().copy(), calls, model.pairwise.numpy().copy(),
+                   None if ego_only is None else ego_only["preds_tensor"].numpy()))
     finally:
         dist.barrier()
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,frames", [(2, 1), (3, 1), (2, 2)])
+@pytest.mark.parametrize("world,frames", [(2, 1), (3, 1), (2, 2), (4, 1), (8, 1)])
 def test_sharded_agents_match_single_process(world, frames):
+    """worlds 2, 3, 4 (BASELINE configs[3]) and 8 (configs[4]): every rank the ego of its own view AND ``ego_only`` (rank 0 alone fuses: the
+    reference's single-ego output) against the single-process model at tiny shape"""
     from quantv2x_amd import synth
     from quantv2x_amd.dist import payload_layout
     from quantv2x_amd.ptq_state import export_ptq_state
@@ -121,7 +126,7 @@ def test_sharded_agents_match_single_process(world, frames):
     hw = codes[0].shape[-1]
     cbytes, pose_off, pbytes = payload_layout(3, frames, hw)
     poses = synth.agent_poses(world, "line")
-    for rank, preds, gathered, calls, pairwise in results:
+    for rank, preds, gathered, calls, pairwise, ego_preds in results:
         assert gathered.shape == (world, pbytes)
         for a in range(world):                                                   # agent-major wire layout: codes, then the pose
             planes = gathered[a, :cbytes].reshape(3, frames, hw)
@@ -137,8 +142,10 @@ def test_sharded_agents_match_single_process(world, frames):
         np.testing.assert_allclose(pairwise[0], scene_np(world)["pairwise_t_matrix"][0][:world, :world], rtol=0, atol=1e-12)
     want = np.concatenate(wants)
     np.testing.assert_allclose(results[0][1], want, rtol=1e-5, atol=1e-6)   # rank 0 = the reference's ego
+    np.testing.assert_array_equal(results[0][5], results[0][1])             # ego_only: the same output on rank 0 ...
+    assert all(r[5] is None for r in results[1:])                            # ... and none on the others
     # other ranks see the scene from their own pose: a different, finite prediction map of the same shape
-    for rank, preds, _, _, _ in results[1:]:
+    for rank, preds, _, _, _, _ in results[1:]:
         assert preds.shape == want.shape and np.isfinite(preds).all()
         assert not np.allclose(preds, want)
 
