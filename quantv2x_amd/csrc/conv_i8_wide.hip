@@ -20,6 +20,10 @@ namespace qv2x {
 
 // conv_i8_ws.hip: the weights-stationary form for layers with 64 input channels (same w_wide layout, same results)
 bool ws64_takes(const qv2x_conv_desc* d);
+// conv_i8_ws2.hip: the weights-stationary STRIDE-2 form for 64 input channels (cout 64 | 128)
+bool ws2_takes(const qv2x_conv_desc* d);
+int launch_ws2(const qv2x_conv_desc* d, const int8_t* in, const int8_t* w_wide, const float* scale, const int32_t* corr, const int32_t* aw,
+               const float* bias, int8_t* out, hipStream_t st);
 int launch_ws64(const qv2x_conv_desc* d, const int8_t* in, const int8_t* w_wide, const float* scale, const int32_t* corr, const int32_t* aw,
                 const float* bias, int8_t* out, hipStream_t st);
 
@@ -632,7 +636,7 @@ extern "C" int qv2x_conv3x3_i8_wide_ok(const qv2x_conv_desc* d) {
     const long long wgs = patches * (d->cout / wide_bn(d));
     // Stride 2 (measured, batch of 32 / 8): four tiles, barriers and window-sum passes per nine K steps instead of one -- 256 output
     // channels amortise them (34 vs 39 us, 13.8 vs 17.6 us), 128 do not (46 vs 44 us) and 64 lose (149 vs 129 us on the 192-pixel im2col tiles)
-    if (d->stride == 2 && qv2x::ws64_takes(d)) return 1;              // 64 input channels: the weights-stationary stride-2 form (conv_i8_ws.hip)
+    if (qv2x::ws2_takes(d)) return 1;                                  // stride 2, 64 input channels: the weights-stationary form (conv_i8_ws2.hip)
     if (d->stride == 2 && d->cout % 256) return 0;
     return chunks * (d->stride == 2 ? 4 : 1) <= qv2x::MAX_CHUNKS && patches * qv2x::TH * qv2x::TW >= 16384 && wgs >= (d->cout == 64 ? 1024 : 192);
 }
@@ -660,6 +664,7 @@ extern "C" int qv2x_conv3x3_i8_wide(const qv2x_conv_desc* d, const int8_t* in, c
     hipStream_t st = (hipStream_t)stream;
 #ifndef QV2X_NO_WS64
     if (ws64_takes(d)) return launch_ws64(d, in, w_wide, scale, corr, aw, bias, out, st);
+    if (ws2_takes(d)) return launch_ws2(d, in, w_wide, scale, corr, aw, bias, out, st);
 #endif
     const int patches8 = (a.n * a.tiles_x * a.tiles_y + 7) / 8 * 8;   // block ids come in groups of 8 (one per XCD)
     const int bn = wide_bn(d);

@@ -22,7 +22,7 @@ namespace qv2x {
 
 namespace {
 
-constexpr int TW = 32;
+constexpr int TW = 32, HWD = TW + 2;
 
 struct WsArgs {
     const int8_t* in; const int8_t* wt; const float* scale; const int* corr; const int* aw; const float* bias; int8_t* out;
@@ -30,7 +30,6 @@ struct WsArgs {
     int out_ctotal, out_c0, relu;
     float out_delta, out_zp;
     int items;
-    int tapstep[9];                    // weight step of tap t inside w_wide (stride 2: qv2x_conv3x3_i8_pack_wide stores the taps plane by plane)
 };
 
 template <int V> struct IC { static constexpr int value = V; };
@@ -46,23 +45,13 @@ __device__ long long g_ws_fine[4096 * 16];
 // <2, 2, 5>: four waves, a 10 x 32 patch, 60 KB of LDS -- TWO workgroups per CU, so the two waves of a SIMD belong to different workgroups:
 // the older wave of a SIMD gets most of its VALU issue slots and runs ahead of the younger one, which an eight-wave workgroup paid for at
 // both of its barriers per item (1.4k + 2.2k of 16.7k cycles, tools/ws_fine.py); here no barrier joins two waves of one SIMD.
-// Round 5: S2 = the ZeroPad2d + stride-2 first convolution of a backbone level with 64 input channels (base_bev_backbone.py:60-66: level 0's
-// 64 -> 64 over the pillar canvas, level 1's 64 -> 128) on the same form -- they ran on the im2col LDS-DMA ring of conv_i8.hip at 0.14 / 0.18
-// of the int8 peak (nine 64-byte gathers per output pixel, a barrier per K chunk).  Output pixel (y, x) reads input pixels (2 y + dy, 2 x + dx):
-// the halo tile is (2 TH + 1) x 65 input pixels, stored COLUMN-PARITY SPLIT -- a row holds its 33 even columns, then its 32 odd ones -- so that
-// the 32 pixels of a fragment (x = lane & 31, tap column dx) are 32 consecutive 16-byte slots again: slot (dx & 1) * 33 + (dx >> 1) + x, one base
-// register plus an immediate, conflict-free.  Only the DMA's per-lane source address knows about the stride.  The tile is 4x the bytes per
-// output of the stride-1 form: eight waves (NCB x RG = 2 x 4 or 4 x 2) share one workgroup per CU and its two 72 KB tiles.
-template <int NCB, int RG, int ROWS, bool S2 = false>
+template <int NCB, int RG, int ROWS>
 __global__ __launch_bounds__(NCB * RG * 64, NCB * RG == 4 ? 2 : 1) void conv3x3_i8_ws64_kernel(const WsArgs a) {
     constexpr int NW = NCB * RG;
     static_assert(NW == 4 || NW == 8, "four or eight waves");
-    constexpr int HWD = S2 ? 2 * TW + 1 : TW + 2;                      // halo pixels per tile row
-    constexpr int RSTEP = S2 ? 2 : 1;                                  // halo rows per output row
-    constexpr int TH = RG * ROWS, HPIX = (RSTEP * TH + 3 - RSTEP) * HWD, HPAD = (HPIX + 63) / 64 * 64, PLANE = HPAD * 16, HBUF = 4 * PLANE;
+    constexpr int TH = RG * ROWS, HPIX = (TH + 2) * HWD, HPAD = (HPIX + 63) / 64 * 64, PLANE = HPAD * 16, HBUF = 4 * PLANE;
     constexpr int HBLK = 4 * (HPAD / 64), LH = (HBLK + NW - 1) / NW;   // 1 KiB DMA pieces per halo tile; per wave
-    static_assert(2 * PLANE + (2 * HWD + TW + 2) * 16 + (ROWS - 1) * RSTEP * HWD * 16 < 65536, "fragment reads: base register + 16-bit immediate");
-    static_assert(2 * HBUF + 2 * HPAD * 4 <= 160 * 1024, "LDS");
+    static_assert(2 * PLANE + (2 * HWD + 2) * 16 + (ROWS - 1) * HWD * 16 < 65536, "fragment reads: base register + 16-bit immediate");
     __shared__ __attribute__((aligned(16))) int8_t lds[2 * HBUF + 2 * HPAD * 4];
     int8_t* hbuf = lds;
     int* psum = (int*)(lds + 2 * HBUF);                                // [set][halo pixel]: per-pixel channel sums of the item's tile
@@ -87,9 +76,8 @@ __global__ __launch_bounds__(NCB * RG * 64, NCB * RG == 4 ? 2 : 1) void conv3x3_
         const int blk = wave_u + NW * j;
         int hpx = (blk % (HPAD / 64)) * 64 + lane;
         hpx = hpx < HPIX ? hpx : HPIX - 1;
-        const int hy = hpx / HWD, r = hpx - hy * HWD;
-        // (stride 2: slot r of a row is input column 2 r for r <= 32, 2 (r - 33) + 1 beyond -- and its row is hy of the INPUT patch)
-        hyx[j] = (hy << 16) | (S2 ? (r > TW ? 2 * (r - TW - 1) + 1 : 2 * r) : r);
+        const int hy = hpx / HWD;
+        hyx[j] = (hy << 16) | (hpx - hy * HWD);
     }
     auto issue_halo = [&](const Where& w, int buf) __attribute__((always_inline)) {
         const unsigned ldsb = (unsigned)(uintptr_t)((__attribute__((address_space(3))) int8_t*)(hbuf + buf * HBUF));
@@ -98,7 +86,7 @@ __global__ __launch_bounds__(NCB * RG * 64, NCB * RG == 4 ? 2 : 1) void conv3x3_
         for (int j = 0; j < LH; ++j) {
             const int blk = wave_u + NW * j;
             if (HBLK % NW != 0 && blk >= HBLK) break;
-            const int yy = min(RSTEP * w.y0 + (hyx[j] >> 16), a.hp - 1), xx = min(RSTEP * w.x0 + (hyx[j] & 0xffff), a.wp - 1);
+            const int yy = min(w.y0 + (hyx[j] >> 16), a.hp - 1), xx = min(w.x0 + (hyx[j] & 0xffff), a.wp - 1);
             const unsigned src = (unsigned)(((rowb + yy) * a.wp + xx) * a.cin_total + a.cin_off + (blk / (HPAD / 64)) * 16);
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                          :: "s"(ldsb + blk * 1024), "v"(src), "s"(a.in) : "memory", "m0");
@@ -124,14 +112,14 @@ __global__ __launch_bounds__(NCB * RG * 64, NCB * RG == 4 ? 2 : 1) void conv3x3_
     };
 
     // ---- once per workgroup: this wave's 72 weight registers and its channels' constants ---------------------------------------------
-    // w_wide layout (qv2x_conv3x3_i8_pack_wide, one chunk): [step][cout / 32][K half][lane][16 B], step = a.tapstep[tap]
+    // w_wide layout (qv2x_conv3x3_i8_pack_wide, one chunk): [tap][cout / 32][K half][lane][16 B]
     v4i wreg[9][2];
     {
         const int8_t* wp = a.wt + (size_t)cb * 2048 + lane * 16;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) wreg[t][h] = *(const v4i*)(wp + (size_t)a.tapstep[t] * (a.cout / 32) * 2048 + h * 1024);
+            for (int h = 0; h < 2; ++h) wreg[t][h] = *(const v4i*)(wp + (size_t)t * (a.cout / 32) * 2048 + h * 1024);
     }
     // register r of the 32 x 32 accumulator holds channel 32 cb + 8 (r >> 2) + 4 half + (r & 3) of pixel lane & 31
     v16i corr0;
@@ -195,8 +183,7 @@ __global__ __launch_bounds__(NCB * RG * 64, NCB * RG == 4 ? 2 : 1) void conv3x3_
         v4i fr[4];
         auto rd_frag = [&](auto s_c) __attribute__((always_inline)) {
             constexpr int S = decltype(s_c)::value, TAP = S >> 1, KS = S & 1;
-            constexpr int DX = TAP % 3, COL = S2 ? (DX & 1) * (TW + 1) + (DX >> 1) : DX;
-            fr[S & 3] = *(const v4i*)(hb + KS * 2 * PLANE + (HWD * (TAP / 3) + COL) * 16);
+            fr[S & 3] = *(const v4i*)(hb + KS * 2 * PLANE + (HWD * (TAP / 3) + TAP % 3) * 16);
         };
         auto step = [&](auto s_c) __attribute__((always_inline)) {
             constexpr int S = decltype(s_c)::value, TAP = S >> 1, KS = S & 1;
@@ -245,29 +232,23 @@ __global__ __launch_bounds__(NCB * RG * 64, NCB * RG == 4 ? 2 : 1) void conv3x3_
 #endif
         int* nz = psum + (set ^ 1) * HPAD;                             // the other set: read for the last time before the barrier above
         for (int t = tid; t < HPAD; t += NW * 64) nz[t] = 0;
-        hb0 = hbuf + buf * HBUF + rlane + (rg * ROWS) * RSTEP * HWD * 16;
+        hb0 = hbuf + buf * HBUF + rlane + (rg * ROWS) * HWD * 16;
         WSFINE(3);
     };
     // row j of the current item has just been multiplied: it becomes the pending tile (window sum of its pixel, where it goes)
     auto after_row = [&]() __attribute__((always_inline)) {
-        const int* ps = psum + set * HPAD + (rg * ROWS) * RSTEP * HWD + (lane & 31);
-        // the three input columns under output column x: stride 1 slots x, x + 1, x + 2; stride 2 columns 2 x, 2 x + 1, 2 x + 2 = slots x, 33 + x, x + 1
-        auto rowsum = [&](int k) { return S2 ? ps[k * HWD] + ps[k * HWD + TW + 1] + ps[k * HWD + 1] : ps[k * HWD] + ps[k * HWD + 1] + ps[k * HWD + 2]; };
+        const int* ps = psum + set * HPAD + (rg * ROWS) * HWD + (lane & 31);
+        auto rowsum = [&](int k) { return ps[k * HWD] + ps[k * HWD + 1] + ps[k * HWD + 2]; };
         if (j == 0) {
             WSFINE(4);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                              // every wave's LDS atomics of this item are in
             WSFINE(5);
-            rs0 = rowsum(0); rs1 = S2 ? 0 : rowsum(1);
+            rs0 = rowsum(0); rs1 = rowsum(1);
         }
         if (j >= 1) WSFINE(5 + j);                                     // rows 1 .. ROWS - 1 done: stamps 6 ..
-        if (S2) {                                                      // input rows 2 j, 2 j + 1, 2 j + 2: the last is the next output row's first
-            const int mid = rowsum(2 * j + 1), rs2 = rowsum(2 * j + 2);
-            p_tot = rs0 + mid + rs2; rs0 = rs2;
-        } else {
-            const int rs2 = rowsum(j + 2);
-            p_tot = rs0 + rs1 + rs2; rs0 = rs1; rs1 = rs2;
-        }
+        const int rs2 = rowsum(j + 2);
+        p_tot = rs0 + rs1 + rs2; rs0 = rs1; rs1 = rs2;
         {
             const int row = cur.y0 + rg * ROWS + j, xo = cur.x0 + lane_x;
             const long long off = ((long long)(cur.img * (a.ho + 2) + row + 1) * (a.wo + 2) + xo + 1) * a.out_ctotal + ch_off;
@@ -282,11 +263,11 @@ __global__ __launch_bounds__(NCB * RG * 64, NCB * RG == 4 ? 2 : 1) void conv3x3_
     int last = 0;
     for (;;) {
         if (j == 0) item_start();
-        do_row(IC<0>{}, hb0 + j * RSTEP * HWD * 16);
+        do_row(IC<0>{}, hb0 + j * HWD * 16);
         after_row();
         if (done) { last = 0; break; }
         if (j == 0) item_start();
-        do_row(IC<1>{}, hb0 + j * RSTEP * HWD * 16);
+        do_row(IC<1>{}, hb0 + j * HWD * 16);
         after_row();
         if (done) { last = 1; break; }
     }
@@ -319,22 +300,11 @@ int launch_ws64(const qv2x_conv_desc* d, const int8_t* in, const int8_t* w_wide,
     WsArgs a{};
     a.in = in; a.wt = w_wide; a.scale = scale; a.corr = corr; a.aw = aw; a.bias = bias; a.out = out;
     a.n = d->n; a.hp = d->h + 2; a.wp = d->w + 2; a.cin_total = d->cin_total; a.cin_off = d->group_c0[0]; a.cout = d->cout;
-    const bool s2 = d->stride == 2;
-    a.ho = (d->h + 2 - 3) / d->stride + 1; a.wo = (d->w + 2 - 3) / d->stride + 1;       // (stride 1: h x w)
-    const int TH = s2 ? 8 : 10;
+    a.ho = d->h; a.wo = d->w;
+    constexpr int TH = 10;
     a.tiles_x = (a.wo + TW - 1) / TW; a.tiles_y = (a.ho + TH - 1) / TH;
     a.out_ctotal = d->out_ctotal; a.out_c0 = d->out_c0; a.relu = d->relu; a.out_delta = d->out_delta; a.out_zp = d->out_zp;
     a.items = a.n * a.tiles_x * a.tiles_y;
-    // stride 2: pack_wide stores the nine weight steps plane by plane -- taps 0 2 6 8 | 1 7 | 3 5 | 4 (conv_i8_wide.hip)
-    const int s2step[9] = {0, 4, 1, 6, 8, 7, 2, 5, 3};
-    for (int t = 0; t < 9; ++t) a.tapstep[t] = s2 ? s2step[t] : t;
-    if (s2) {
-        const int slots = 256;                                         // one eight-wave workgroup per CU (two 72 KB halo tiles)
-        const dim3 grid(a.items < slots ? a.items : slots);
-        if (d->cout == 64) conv3x3_i8_ws64_kernel<2, 4, 2, true><<<grid, 512, 0, st>>>(a);
-        else conv3x3_i8_ws64_kernel<4, 2, 4, true><<<grid, 512, 0, st>>>(a);
-        return hip_check(hipGetLastError(), "qv2x_conv3x3_i8_wide (weights-stationary stride-2 form) launch");
-    }
     const int slots = 2 * 256;                                         // two four-wave workgroups per CU
     const dim3 grid(a.items < slots ? a.items : slots);
     conv3x3_i8_ws64_kernel<2, 2, 5><<<grid, 256, 0, st>>>(a);
@@ -342,13 +312,7 @@ int launch_ws64(const qv2x_conv_desc* d, const int8_t* in, const int8_t* w_wide,
 }
 
 bool ws64_takes(const qv2x_conv_desc* d) {
-    if (d->ngroups != 1 || d->group_c[0] != 64) return false;
-    if (d->stride == 2) {
-        if (d->cout != 64 && d->cout != 128) return false;
-        const int ho = (d->h - 1) / 2 + 1, wo = (d->w - 1) / 2 + 1;
-        return (long long)d->n * ((ho + 7) / 8) * ((wo + TW - 1) / TW) >= 512;      // two items per workgroup at least
-    }
-    if (d->cout != 64) return false;
+    if (d->stride != 1 || d->ngroups != 1 || d->group_c[0] != 64 || d->cout != 64) return false;
     const long long patches = (long long)d->n * ((d->h + 9) / 10) * ((d->w + TW - 1) / TW);
     return patches >= 1024;                                            // two items per workgroup at least: the pipeline's fill is one row of 5
 }

@@ -117,9 +117,10 @@ def test_wide_matches_regular_and_oracle(n, h, w, groups, cout):
     (2, 50, 66, 128, 256),          # level 2's: two periods, eight plane chunks
     (40, 50, 64, 64, 64),           # 1000 patches on 768 slots: the next item's first tile requested from a one-step chunk
     (16, 50, 176, 128, 256),        # 480 patches: eight-wave workgroups, persistent items
-    (32, 100, 190, 64, 64),         # round 5: 672 items of 8 x 32 outputs -> the weights-stationary stride-2 form (conv_i8_ws.hip), ragged both ways
-    (32, 100, 190, 64, 128),        # the same form with four channel blocks (level 1's 64 -> 128)
-    (70, 34, 130, 64, 64),          # 630 items, 17 x 65 outputs: a last tile row of ONE output row, a last tile column of one pixel
+    (52, 100, 190, 64, 64),         # round 5: 1092 items of 8 x 32 outputs -> the weights-stationary stride-2 form (conv_i8_ws2.hip), ragged both ways
+    (52, 100, 190, 64, 128),        # the same form with four channel blocks (level 1's 64 -> 128)
+    (120, 34, 130, 64, 64),         # 1080 items, 17 x 65 outputs: a last tile row of ONE output row, a last tile column of one pixel
+    (40, 64, 254, 64, 128),         # 32 x 127 outputs: exact tile rows, the extra column (input column 64 of a tile) inside the map's last tile
 ])
 def test_wide_stride2_matches_regular_and_oracle(n, h, w, cin, cout):
     """The ZeroPad2d + stride-2 first convolution of a backbone level on the halo-patch kernel (parity-plane chunks): equal to the im2col
