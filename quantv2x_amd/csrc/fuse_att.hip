@@ -6,22 +6,24 @@
 //   affine_grid(theta, align_corners=False): x_j = (2j + 1)/W - 1, grid = theta . [x, y, 1]  (float64 theta ->
 //   float64 grid, cast to fp32 as the reference's `.to(src)` does), grid_sample bilinear / zeros.
 // Attention (fusion_in_one.py:41-45, 145-147): score_j = <f_0, f_j> / sqrt(C); softmax; out = sum_j p_j f_j.
+#include <cstdlib>
+
 #include "fuse_att.h"
 
 namespace qv2x {
 
-template <int NA>
+template <int NA, bool B3 = false>
 __global__ __launch_bounds__(256) void fuse_att_kernel(const FuseArgs a) {
     const int lane = threadIdx.x & 63;
     int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
     cell = __builtin_amdgcn_readfirstlane(cell);
     if (cell >= a.hw) return;
-    a.fused[(size_t)cell * 64 + lane] = fuse_cell_n<NA>(a, cell, lane);
+    a.fused[(size_t)cell * 64 + lane] = B3 ? fuse_cell_b3<NA>(a, cell, lane) : fuse_cell_n<NA>(a, cell, lane);
 }
 
 // several scenes in one launch: blockIdx.y = scene (SceneList: fuse_att.h)
 
-template <int NA>
+template <int NA, bool B3 = false>
 __global__ __launch_bounds__(256) void fuse_att_batch_kernel(FuseArgs a, const SceneList sl) {
     const int lane = threadIdx.x & 63;
     int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -32,7 +34,7 @@ __global__ __launch_bounds__(256) void fuse_att_batch_kernel(FuseArgs a, const S
     if (a.feats) a.feats = (const float4*)((const float*)a.feats + sl.off[sc]);
     else a.codes += sl.off[sc];
     a.pairwise += (size_t)sc * a.L * a.L * 16;
-    a.fused[((size_t)sc * a.hw + cell) * 64 + lane] = fuse_cell_n<NA>(a, cell, lane);
+    a.fused[((size_t)sc * a.hw + cell) * 64 + lane] = B3 ? fuse_cell_b3<NA>(a, cell, lane) : fuse_cell_n<NA>(a, cell, lane);
 }
 
 int fuse_args_from_desc(const qv2x_fuse_desc* d, const uint8_t* codes, const float* lut, const float* lut_bias, const float* feats,
@@ -65,6 +67,14 @@ extern "C" int qv2x_fuse_att_f32(const qv2x_fuse_desc* d, const uint8_t* codes, 
     a.fused = (float4*)fused;
     const dim3 grid((a.hw + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
+    if (!feats && a.levels == 3 && a.agents > 1) {                     // batched round trips (fuse_att.h:fuse_cell_b3), same bits
+        switch (fuse_bound(a.agents)) {
+            case 2: fuse_att_kernel<2, true><<<grid, 256, 0, st>>>(a); break;
+            case 4: fuse_att_kernel<4, true><<<grid, 256, 0, st>>>(a); break;
+            default: fuse_att_kernel<MAXA, true><<<grid, 256, 0, st>>>(a); break;
+        }
+        return hip_check(hipGetLastError(), "qv2x_fuse_att_f32 launch");
+    }
     switch (fuse_bound(a.agents)) {
         case 1: fuse_att_kernel<1><<<grid, 256, 0, st>>>(a); break;
         case 2: fuse_att_kernel<2><<<grid, 256, 0, st>>>(a); break;
@@ -93,8 +103,23 @@ extern "C" int qv2x_fuse_att_batch_f32(const qv2x_fuse_desc* d, int n_scenes, co
     FuseArgs a;
     if (int rc = fuse_args_from_desc(&d1, codes, lut, lut_bias, feats, pairwise, "qv2x_fuse_att_batch_f32", a)) return rc;
     a.fused = (float4*)fused;
-    const dim3 grid((a.hw + 3) / 4, n_scenes);
     hipStream_t st = (hipStream_t)stream;
+    // Scenes of two and more agents from ~four V2X-Real scenes on: persistent sixteen-wave workgroups with the table's first rows in LDS
+    // (profiles/r05_fuse_by_agents.log).  Below that the 128 KB table fill per workgroup is not paid back; single-agent scenes gather
+    // one tap per cell and are not bound by the table rows.
+    // Three code planes and scenes of 2+ agents: the form with batched round trips (fuse_cell_b3; 88 against 105 us per scene of eight
+    // V2X-Real agents, profiles/r05_fuse_by_agents.log).  QV2X_FUSE_MODE=0 (dev A/B switch, tools/bench_fuse.py): the round-4 walk.
+    static const int mode_env = [] { const char* e = getenv("QV2X_FUSE_MODE"); return e ? atoi(e) : -1; }();
+    const bool b3 = !feats && a.levels == 3 && most > 1 && mode_env != 0;   // (single-agent scenes: one tap per cell, nothing to batch)
+    const dim3 grid((a.hw + 3) / 4, n_scenes);
+    if (b3) {
+        switch (fuse_bound(most)) {
+            case 2: fuse_att_batch_kernel<2, true><<<grid, 256, 0, st>>>(a, sl); break;
+            case 4: fuse_att_batch_kernel<4, true><<<grid, 256, 0, st>>>(a, sl); break;
+            default: fuse_att_batch_kernel<MAXA, true><<<grid, 256, 0, st>>>(a, sl); break;
+        }
+        return hip_check(hipGetLastError(), "qv2x_fuse_att_batch_f32 launch");
+    }
     switch (fuse_bound(most)) {
         case 1: fuse_att_batch_kernel<1><<<grid, 256, 0, st>>>(a, sl); break;
         case 2: fuse_att_batch_kernel<2><<<grid, 256, 0, st>>>(a, sl); break;
