@@ -1094,6 +1094,9 @@ def deploy(qt_model=None, state: Optional[Dict[str, np.ndarray]] = None, path: O
         elif any(hasattr(m, "weight_quantizer") for m in qt_model.modules()):
             inner = qt_model.model if hasattr(qt_model, "model") else qt_model
             if len(getattr(inner, "modality_name_list", ["m1"])) > 1:        # heter_model_baseline.py:41-75: one stack per modality
+                if hasattr(inner, "pyramid_backbone"):                        # HEAL: one agent-side stack per modality in front of PyramidFusion
+                    from .engine_pyramid import deploy_heter_pyramid
+                    return deploy_heter_pyramid(qt_model, device=device)
                 return deploy_heter(qt_model, device=device, **kw)
             state = export_ptq_state(qt_model)
         elif hasattr(qt_model, "pyramid_backbone"):

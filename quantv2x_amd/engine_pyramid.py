@@ -650,3 +650,70 @@ class DeployedPyramidModel(nn.Module):
             return out
         replay.graph = graph
         return replay
+
+
+class DeployedHeterPyramidModel(nn.Module):
+    """HEAL's heterogeneous Pyramid scene (heter_pyramid_collab_codebook_mc.py:45-86, 164-249: one encoder / ResNet backbone / aligner per
+    modality, the agents' 64-channel maps assembled in ``agent_modality_list`` order, shared codebook / PyramidFusion / shrink_conv / heads).
+    One ``DeployedPyramidModel`` per modality (``export_ptq_state(qt, modality=m)``: its own agent-side weights and quantizers) runs
+    ``encode_features`` on that modality's agents; the code planes go into one buffer in agent order -- the wire format IS the interface --
+    and the ego modality's engine runs ``decode_features`` (round 5; the baseline model's twin is ``engine.DeployedHeterModel``)."""
+
+    def __init__(self, states: Dict[str, Dict[str, np.ndarray]], ego_modality: Optional[str] = None, device="cuda"):
+        super().__init__()
+        if not states:
+            raise ValueError("DeployedHeterPyramidModel: no modality")
+        self.engines = {m: DeployedPyramidModel(st, device=device) for m, st in states.items()}
+        self.main = self.engines[ego_modality if ego_modality in self.engines else next(iter(self.engines))]
+        for m, e in self.engines.items():
+            e._agent_ws(1)
+            if not e.has_codebook:
+                raise NotImplementedError("deployed heterogeneous Pyramid path: codebook models (the code planes are what the modalities share)")
+            if (e.fh, e.fw, e.levels, e.kc, e.D) != (self.main.fh, self.main.fw, self.main.levels, self.main.kc, self.main.D):
+                raise ValueError(f"modality {m}: feature map {e.fh} x {e.fw} / codebook {e.levels} x {e.kc} x {e.D} differs from the ego modality's")
+        self.dev = self.main.dev
+        self._slots: Dict[tuple, Dict[str, torch.Tensor]] = {}
+
+    @torch.no_grad()
+    def forward(self, data_dict: dict, taps: Optional[dict] = None) -> dict:
+        agents = [str(a) for a in data_dict["agent_modality_list"]]
+        n_total, hw, lv = len(agents), self.main.fh * self.main.fw, self.main.levels
+        unknown = sorted(set(agents) - set(self.engines))
+        if unknown:
+            raise NotImplementedError(f"deployed heterogeneous Pyramid path: no engine for modality {unknown}")
+        slots = self._slots.get(tuple(agents))
+        if slots is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise L.Qv2xError(f"DeployedHeterPyramidModel: agent layout {agents} is new and the stream is capturing; run one eager forward first")
+            slots = {m: torch.as_tensor([i for i, a in enumerate(agents) if a == m], dtype=torch.int64, device=self.dev) for m in self.engines}
+            self._slots[tuple(agents)] = slots
+        pairwise = data_dict["pairwise_t_matrix"]
+        if pairwise.dtype != torch.float64 or not pairwise.is_contiguous():
+            pairwise = pairwise.to(torch.float64).contiguous()
+        if pairwise.shape[0] == 1:
+            lens = [n_total]
+        else:
+            rl = data_dict["record_len"]
+            lens = [int(v) for v in (rl.tolist() if isinstance(rl, torch.Tensor) else rl)]
+        enc = torch.empty((lv, n_total * hw), dtype=torch.uint8, device=self.dev)
+        for m, eng in self.engines.items():
+            k = int(slots[m].numel())
+            if not k:
+                continue
+            mt = {} if taps is not None else None
+            codes = eng.encode_features(data_dict["inputs_" + m], k, mt).view(lv, k, hw)
+            enc.view(lv, n_total, hw).index_copy_(1, slots[m], codes)          # agent order (a copy, no arithmetic)
+            if taps is not None:
+                taps["modality/" + m] = mt
+        if taps is not None:
+            taps["codes"] = enc.view(lv, n_total, hw)
+        return self.main.decode_features(enc, hw, n_total * hw, lens, pairwise, 0, taps)
+
+    forward_with_encdec = forward
+
+
+def deploy_heter_pyramid(qt_model, device="cuda") -> DeployedHeterPyramidModel:
+    from .ptq_state import export_ptq_state
+    model = qt_model.model if hasattr(qt_model, "model") else qt_model
+    states = {m: export_ptq_state(qt_model, modality=m) for m in model.modality_name_list}
+    return DeployedHeterPyramidModel(states, ego_modality=getattr(model, "ego_modality", None), device=device)

@@ -70,10 +70,13 @@ def _check_structure(model) -> None:
             raise NotImplementedError("deployed Pyramid path: align_corners false")
         if not getattr(model, "shrink_flag", False):
             raise NotImplementedError("deployed Pyramid path: the post-fusion shrink_conv ('shrink_header') is part of the network")
-        if len(model.backbone_m1.deblocks) != 0 or model.backbone_m1.num_levels != 1:
-            raise NotImplementedError("deployed Pyramid path: a one-level per-agent ResNet backbone without deblocks")
-        if type(model.aligner_m1.channel_align).__name__ != "Identity":
-            raise NotImplementedError("deployed Pyramid path: aligner core_method identity")
+        for m in getattr(model, "modality_name_list", ["m1"]):
+            bb = getattr(model, "backbone_" + m)
+            if len(bb.deblocks) != 0 or bb.num_levels != 1:
+                raise NotImplementedError(f"deployed Pyramid path: a one-level per-agent ResNet backbone without deblocks (modality {m})")
+        for m in getattr(model, "modality_name_list", ["m1"]):
+            if type(getattr(model, "aligner_" + m).channel_align).__name__ != "Identity":
+                raise NotImplementedError(f"deployed Pyramid path: aligner core_method identity (modality {m})")
     else:
         fusion = getattr(model, "fusion_net", None)
         if type(fusion).__name__ not in ("AttFusion", "MaxFusion"):
@@ -116,8 +119,6 @@ def export_ptq_state(qt_model, modality: str = "m1") -> Dict[str, np.ndarray]:
     _check_structure(model)
     out: Dict[str, np.ndarray] = {}
     pyramid = _is_pyramid(model)
-    if modality != "m1" and pyramid:
-        raise NotImplementedError("deployed Pyramid path: one modality (m1)")
     if not hasattr(model, "encoder_" + modality):
         raise ValueError(f"the model has no modality {modality!r}")
     out["meta/fusion_method"] = np.array("pyramid" if pyramid else ("max" if type(getattr(model, "fusion_net", None)).__name__ == "MaxFusion" else "att"))
@@ -184,11 +185,17 @@ def export_ptq_state(qt_model, modality: str = "m1") -> Dict[str, np.ndarray]:
     out["meta/discrete_ratio"] = np.float64(model.fake_voxel_size)
 
     if pyramid:
-        for name, b in _residual_blocks(model):       # the quantizer after the fp32 add + ReLU (quant_block.py:92-96, :126-130)
+        block_names = []
+        for src_name, b in _residual_blocks(model):   # the quantizer after the fp32 add + ReLU (quant_block.py:92-96, :126-130)
+            pm = _PER_MODALITY.match(src_name)
+            if pm and pm.group(2) != modality:
+                continue                              # (another modality's agent-side stack: HEAL's per-modality backbones)
+            name = _PER_MODALITY.sub(lambda g: f"{g.group(1)}_m1{g.group(3)}", src_name) if pm else src_name
             out[name + "/a_delta"] = np.float32(_np(torch.as_tensor(b.act_quantizer.delta)).reshape(-1)[0])
             out[name + "/a_zp"] = np.float32(_np(torch.as_tensor(b.act_quantizer.zero_point)).reshape(-1)[0])
-        out["meta/block_names"] = np.array([n for n, _ in _residual_blocks(model)])
-        cfg_a, cfg_p = model.backbone_m1.model_cfg, model.pyramid_backbone.model_cfg
+            block_names.append(name)
+        out["meta/block_names"] = np.array(block_names)
+        cfg_a, cfg_p = getattr(model, "backbone_" + modality).model_cfg, model.pyramid_backbone.model_cfg
         out["meta/layer_nums"] = np.array(cfg_a["layer_nums"], dtype=np.int64)
         out["meta/layer_strides"] = np.array(cfg_a["layer_strides"], dtype=np.int64)
         out["meta/pyramid_layer_nums"] = np.array(cfg_p["layer_nums"], dtype=np.int64)

@@ -158,9 +158,12 @@ def make_hypes(shape: str = "v2xreal", multiclass: bool = True, codebook: bool =
 
 
 def make_pyramid_hypes(shape: str = "v2xreal", codebook: bool = True, dict_size: int = 128, seg_num: int = 1,
-                       encdec: bool = True) -> dict:
+                       encdec: bool = True, multiclass: bool = True, modalities: Sequence[str] = ("m1",)) -> dict:
     """The ``model`` section of ``hypes_yaml/v2x_real/Codebook/Pyramid/lidar_pyramid_stage3.yaml:110-157`` (HEAL Pyramid fusion,
-    ResNeXt levels, 64-channel codebook) at one of ``SHAPES``; ``hard_eval`` as in ``make_hypes``' codebook models."""
+    ResNeXt levels, 64-channel codebook) at one of ``SHAPES``; ``hard_eval`` as in ``make_hypes``' codebook models.
+    ``multiclass=False``: the single-class ``heter_pyramid_collab[_codebook]`` of the OPV2V / DAIR-V2X yamls (no ``num_class`` argument,
+    2 | 14 | 4 head channels).  ``modalities=("m1", "m2")``: HEAL's heterogeneous setting -- one encoder / ResNet backbone / aligner per
+    modality (heter_pyramid_collab_mc.py:45-86), here both LiDAR PointPillar with their own weights."""
     lidar_range, voxel_size, max_voxels, max_cav = SHAPES[shape]
     args = {
         "num_class": 3,
@@ -189,11 +192,18 @@ def make_pyramid_hypes(shape: str = "v2xreal", codebook: bool = True, dict_size:
         "anchor_number": 2,
         "dir_args": {"dir_offset": 0.7853, "num_bins": 2, "anchor_yaw": [0, 90]},
     }
-    core = "heter_pyramid_collab_mc"
+    m1 = args["m1"]
+    for m in modalities:
+        args[m] = copy.deepcopy(m1)
+    if "m1" not in modalities:
+        del args["m1"]
+    if not multiclass:
+        del args["num_class"]
+    core = "heter_pyramid_collab_mc" if multiclass else "heter_pyramid_collab"
     if codebook:
         args["codebook"] = {"seg_num": seg_num, "dict_size": dict_size, "hard_eval": True}
         args["use_codebook"] = True
-        core = "heter_pyramid_collab_codebook_mc" + ("_encdec" if encdec else "")
+        core = ("heter_pyramid_collab_codebook_mc" + ("_encdec" if encdec else "")) if multiclass else "heter_pyramid_collab_codebook"
     return {
         "name": f"synthetic_pyramid_{shape}",
         "model": {"core_method": core, "args": args},

@@ -726,6 +726,76 @@ def build_ref_pyramid(shape="tiny", **kw):
     return model
 
 
+def pyr_hard_forward(model, dd, taps):
+    """The reference's Pyramid forward (heter_pyramid_collab[_codebook][_mc].py) with the deterministic codebook pair, assembled from the
+    reference's own modules: per-modality encoder -> ResNet backbone -> aligner, features in ``agent_modality_list`` order,
+    ``codebook.encode`` -> ``decode``, ``pyramid_backbone``, ``shrink_conv``, heads.  taps['codes']: planes [levels * m, n, h, w]."""
+    agents = list(dd['agent_modality_list'])
+    affine = normalize_pairwise_tfm(dd['pairwise_t_matrix'].clone(), model.H, model.W, model.fake_voxel_size)
+    per = {}
+    for m in model.modality_name_list:
+        if m in agents:
+            per[m] = getattr(model, 'aligner_' + m)(getattr(model, 'backbone_' + m)(getattr(model, 'encoder_' + m)(dd, m)))
+    taken = {m: 0 for m in per}
+    rows = []
+    for m in agents:
+        rows.append(per[m][taken[m]]); taken[m] += 1
+    f = torch.stack(rows)
+    n, c, h, w = f.shape
+    codes = model.codebook.encode(f.permute(0, 2, 3, 1).contiguous().view(-1, c))
+    taps['codes'] = torch.cat([cd.T for cd in codes]).view(-1, n, h, w)
+    dec = model.codebook.decode(codes).view(n, h, w, c).permute(0, 3, 1, 2).contiguous()
+    fused, occ = model.pyramid_backbone(dec, dd['record_len'], affine, agents, model.cam_crop_info)
+    if model.shrink_flag:
+        fused = model.shrink_conv(fused)
+    taps['occ'] = occ
+    return torch.cat([model.cls_head(fused), model.reg_head(fused), model.dir_head(fused)], dim=1)
+
+
+def gen_pyramid_variants():
+    """pyramid_variants.npz (round 5): (sc) the SINGLE-class ``heter_pyramid_collab_codebook`` with the OPV2V / DAIR yamls' codebook setting
+    (seg_num 2, dict_size 256: opv2v/Codebook/Pyramid/pyramid_stage2_model.yaml:96-97) on the two-agent tiny scene; (het) the TWO-modality
+    ``heter_pyramid_collab_codebook_mc_encdec`` (m1, m2: LiDAR PointPillar stacks with their own weights) on the scene [m1, m2, m1].  Each in
+    fp32 and under the reference's QuantModel (W8A8 min-max, one EMA pass through the hard path, frozen): state-dict keys, every
+    (delta, zero_point), weight-code checksums, the hard path's code planes and predictions."""
+    out = {}
+    cases = (("sc", dict(multiclass=False, dict_size=256, seg_num=2), ["m1", "m1"]),
+             ("het", dict(modalities=("m1", "m2")), ["m1", "m2", "m1"]))
+    for tag, kw, agents in cases:
+        dd = synth.scene_to_torch(synth.make_scene("tiny", n_agents=len(agents), seed=SEED_SCENE, n_points=N_POINTS, modalities=agents))
+        model = build_ref_pyramid(**kw)
+        out[f'{tag}/state_dict_keys'] = np.array(list(model.state_dict().keys()))
+        with torch.no_grad():
+            taps = {}
+            out[f'{tag}/fp32/preds_tensor'] = np32(pyr_hard_forward(model, dd, taps))
+            out[f'{tag}/fp32/codes'] = np32(taps['codes']).astype(np.uint8)
+        qt = quant_wrap(build_ref_pyramid(**kw))
+        for a in act_quantizers(qt):
+            a.set_inited(False)
+        qt.set_quant_state(True, True)
+        with torch.no_grad():
+            pyr_hard_forward(qt.model, dd, {})
+        for a in act_quantizers(qt):
+            a.set_inited(True)
+        names = [n for n, m in qt.model.named_modules() if isinstance(m, QuantModule)]
+        out[f'{tag}/module_names'] = np.array(names)
+        mods = dict(qt.model.named_modules())
+        for name in names:
+            m, key = mods[name], f'{tag}/' + name.replace('.', '/')
+            wqz, aqz = m.weight_quantizer, m.act_quantizer
+            out[key + '/w_delta'] = np32(wqz.delta).reshape(-1)
+            out[key + '/w_zp'] = np32(wqz.zero_point).reshape(-1)
+            wcode = np32(torch.clamp(torch.round(m.weight / wqz.delta) + wqz.zero_point, 0, 255)).astype(np.uint8)
+            out[key + '/w_code_checksum'] = weight_checksums(wcode)
+            out[key + '/a_delta'], out[key + '/a_zp'] = np.float32(aqz.delta), np.float32(aqz.zero_point)
+        with torch.no_grad():
+            taps = {}
+            out[f'{tag}/w8a8/preds_tensor'] = np32(pyr_hard_forward(qt.model, dd, taps))
+            out[f'{tag}/w8a8/codes'] = np32(taps['codes']).astype(np.uint8)
+    np.savez_compressed(os.path.join(HERE, "pyramid_variants.npz"), **out)
+    print("pyramid_variants.npz", len(out), "arrays;", {k: v.shape for k, v in out.items() if k.endswith('preds_tensor') or k.endswith('codes')})
+
+
 def gen_pyramid_model():
     """pyramid_tiny.npz: the reference's HeterPyramidCollabCodebookMCEncDec (tiny shape, N = 2) in fp32 and under the reference's
     QuantModel (W8A8, min-max, one EMA pass, frozen): every (delta, zero_point), weight-code checksums, the output codes of every
@@ -999,6 +1069,7 @@ if __name__ == "__main__":
     with torch.no_grad():
         pass
     if "codebook_seg" in which: gen_codebook_seg()
+    if "pyramid_variants" in which: gen_pyramid_variants()
     if "fp32" in which: gen_fp32()
     if "w8a8" in which: gen_w8a8()
     if "uaq" in which: gen_uaq_units()
