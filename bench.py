@@ -374,9 +374,56 @@ def points_to_boxes_line(state, device):
                 lat.append((time.perf_counter() - t0) * 1e3)
             out[key]["latency_ms_p50"] = round(sorted(lat)[len(lat) // 2], 4)
         del graph
+    # ---- the two stages around the model as roofline entries: each alone inside a HIP graph, batch of 8 ----------------
+    frames = 8
+    sweeps = [torch.from_numpy(synth.make_points(lidar, N_POINTS, 3000 + f)).to(device) for f in range(frames)]
+    us_v = event_time_us(_graph_of(lambda: vz.fixed(sweeps, cap)), 30)
+    vbytes = frames * (N_POINTS * 16 + cap * (32 * 16 + 16 + 4))       # points read once; every handed-on pillar row written (zero-padded slots too)
+    out["stages"] = {"voxelize": {"bound": "hbm", "us_per_batch": round(us_v, 1), "frames": frames, "achieved": round(vbytes / us_v / 1e3, 1), "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": round(vbytes / us_v / 1e3 / HBM_PEAK_GBS, 4),
+                                  "work": f"{frames} sweeps x ({N_POINTS} points x 16 B read + {cap} pillar rows x 532 B written: the padded [rows][32][4] fp32 "
+                                          f"block the model's contract asks for); a 64-bit key sort over the points, segment heads, scatter"}}
+    pairwise = torch.eye(4, dtype=torch.float64).reshape(1, 1, 1, 4, 4).repeat(frames, 5, 5, 1, 1).to(device)
+    o = eng({"inputs_m1": vz.fixed(sweeps, cap), "agent_modality_list": ["m1"] * frames, "record_len": torch.ones(frames, dtype=torch.int64),
+             "pairwise_t_matrix": pairwise})
+    cls, reg = o["cls_preds"].clone(), o["reg_preds"].clone()
+
+    def post():
+        return [gpu_post_process(pp, cls[f:f + 1], reg[f:f + 1], None, anchors_dev, torch.eye(4), anchors_per_cell=per_cell,
+                                 num_classes=int(cls.shape[1] // per_cell), num_bins=0, dir_offset=0.0, rng=pp.gt_range, range_xy_only=True,
+                                 max_extent=100.0, z_lim=(-100.0, 100.0), max_boxes=1000, sync=False) for f in range(frames)]
+    res = post()
+    torch.cuda.synchronize()
+    us_p = event_time_us(_graph_of(post), 30)
+    hw = eng.fh * eng.fw
+    pbytes = frames * (int(cls.shape[1]) + int(reg.shape[1])) * hw * 4
+    out["stages"]["postprocess"] = {"bound": "latency (serial NMS sweep)", "us_per_batch": round(us_p, 1), "frames": frames,
+                                    "achieved": round(pbytes / us_p / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round(pbytes / us_p / 1e3 / HBM_PEAK_GBS, 4),
+                                    "nms_pairs_per_s": round(frames * 1000 * 999 / 2 / us_p * 1e6, 0),
+                                    "work": f"{frames} frames x ({int(cls.shape[1])} + {int(reg.shape[1])}) head maps x {hw} cells x 4 B read; sigmoid + box decode + "
+                                            f"score sort + rotated IoU of up to 1000 x 999 / 2 candidate pairs + the keep sweep; boxes kept: "
+                                            f"{[int(r[3].item()) for r in res][:2]}"}
     out["note"] = ("60k-point synthetic sweeps -> voxelize -> W8A8 model -> sigmoid / decode / rotated NMS (random-weight heads: ~450 boxes "
                    "out of 1000 candidates, the NMS works hard) as one hipGraph; the model body alone is `value` / `latency_ms_p50`")
     return out
+
+
+def _graph_of(fn):
+    """``fn`` captured into a HIP graph after two warm-up calls; returns its replay"""
+    import torch
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        keep = fn()
+    g.keep = keep
+    return g.replay
 
 
 def collapsed_encode_line(state, full, B, F, steps, device):

@@ -102,3 +102,56 @@ def test_fixed_capacity_form_inside_a_hip_graph_equals_the_eager_chain():
         torch.cuda.synchronize()
         want = model(vz([torch.from_numpy(c).cuda() for c in clouds[k]]))
         assert torch.equal(out["preds_tensor"], want["preds_tensor"]), k
+
+
+# ---- the 70 000-voxel budget and the 32-point cap at V2X-Real size (VERDICT r4 "missing 4"; sp_voxel_preprocessor.py:38-40, 54-85) -----------
+def _dense_v2xreal_cloud(n=400000, seed=11):
+    """a sweep that overflows BOTH limits of the V2X-Real yaml: ~130 000 occupied cells of the 704 x 200 grid (budget 70 000) and a
+    cluster of 30 000 points on ~120 cells (cap 32 points per voxel); 3 % of the points lie outside the range"""
+    rng, _, _, _ = synth.SHAPES["v2xreal"]
+    g = np.random.default_rng(seed)
+    lo, hi = np.asarray(rng[:3]), np.asarray(rng[3:])
+    pts = g.uniform(lo - 0.015 * (hi - lo), hi + 0.015 * (hi - lo), size=(n, 3))
+    pts[:30000, :2] = g.normal([20.0, -5.0], [2.0, 1.0], size=(30000, 2))
+    g.shuffle(pts)
+    return np.concatenate([pts, g.uniform(0, 1, (n, 1))], 1).astype(np.float32)
+
+
+def test_numpy_voxelizer_at_the_voxel_budget_follows_the_contract():
+    """the vectorised generator the suite uses (synth.voxelize) against the plain-Python contract on the overflowing full-size sweep"""
+    rng, vs, max_vox, _ = synth.SHAPES["v2xreal"]
+    assert max_vox == 70000
+    pts = _dense_v2xreal_cloud()
+    f, c, m = synth.voxelize(pts, rng, vs, 32, max_vox)
+    rf, rc, rm = ref_voxelize(pts, rng, vs, 32, max_vox)
+    assert rf.shape[0] == 70000 and rm.max() == 32 and (rm == 32).sum() > 50      # both limits bite
+    np.testing.assert_array_equal(c, rc); np.testing.assert_array_equal(m, rm); np.testing.assert_array_equal(f, rf)
+
+
+@pytest.mark.gpu
+def test_gpu_voxelizer_at_the_voxel_budget_and_point_cap_full_size():
+    """qv2x_voxelize_f32 on the same sweep: exactly the first 70 000 voxels in order of first appearance, later cells dropped with all their
+    points, 32 first-come points per voxel -- and the capturable fixed-capacity form hands the same rows on"""
+    import torch
+    from quantv2x_amd.voxelizer import GpuVoxelizer
+    rng, vs, max_vox, _ = synth.SHAPES["v2xreal"]
+    pts = _dense_v2xreal_cloud()
+    wf, wc, wm = synth.voxelize(pts, rng, vs, 32, max_vox)
+    assert wf.shape[0] == max_vox
+    vz = GpuVoxelizer(rng, vs, 32, max_vox)
+    dev_pts = torch.from_numpy(pts).cuda()
+    f, c, m = vz.one(dev_pts, agent=1)
+    assert f.shape[0] == max_vox
+    np.testing.assert_array_equal(m.cpu().numpy(), wm)
+    np.testing.assert_array_equal(c.cpu().numpy()[:, 1:], wc)
+    np.testing.assert_array_equal(f.cpu().numpy(), wf)
+    fixed = vz.fixed([dev_pts], max_vox)
+    torch.cuda.synchronize()
+    assert int(fixed["voxel_counts"][0]) == max_vox
+    np.testing.assert_array_equal(fixed["voxel_features"].cpu().numpy(), wf)
+    # a smaller hand-on capacity than the sweep's voxels: the first `capacity` voxels, nothing written past them
+    small = vz.fixed([dev_pts], 4096)
+    torch.cuda.synchronize()
+    assert int(small["voxel_counts"][0]) == 4096 and small["voxel_features"].shape[0] == 4096
+    np.testing.assert_array_equal(small["voxel_coords"].cpu().numpy()[:, 1:], wc[:4096])
+    np.testing.assert_array_equal(small["voxel_num_points"].cpu().numpy(), synth.voxelize(pts, rng, vs, 32, 4096)[2])
