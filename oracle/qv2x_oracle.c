@@ -37,6 +37,26 @@ static inline float q_code(float y, float delta, float zp) {
     return fminf(t, 255.0f);
 }
 
+/* The output quantizer of the CONVOLUTION epilogues (3x3 / 1x1 / grouped / transposed convolutions, the end of a residual block) in its
+ * deployed form (round 5):   code = clamp(rint(fma(y, fl(1 / delta), zp)), 0, 255)
+ * -- UniformAffineQuantizer.forward (quant_layer.py:132-133: round(x / delta) + zero_point, clamp) with the division replaced by ONE fused
+ * multiply-add with the fp32 reciprocal, which is what v_fma_f32 + v_cvt_pk_u8_f32 (round to nearest even, saturate) evaluate in two
+ * instructions per output; the division-exact form cost the HIP epilogues 5.25 (the 64- and 128-channel layers are bound by
+ * VALU issue).  The two forms give a different code only where x / delta lies within ~1.2e-7 |x / delta| of a rounding boundary -- the same
+ * order as the noise of the reference's own fp32 convolution sums, and bounded by the same golden-vector tests (<= 1 LSB on < 5e-4 of the
+ * elements per layer, tests/test_oracle_golden.py; measured flip rates in DESIGN.md 4).  Compile with -DORC_QDIV for the division form.
+ * The PFN's two quantizers and the heads keep q_code (pinned bit for bit on the reference's golden pillar codes). */
+static inline float q_code_mul(float y, float delta, float zp) {
+#ifdef ORC_QDIV
+    return q_code(y, delta, zp);
+#else
+    const float rd = 1.0f / delta;
+    float t = rintf(fmaf(y, rd, zp));
+    t = fmaxf(t, 0.0f);
+    return fminf(t, 255.0f);
+#endif
+}
+
 /* ---------------------------------------------------------------------------------------------
  * a1: pillar feature net under QuantModel.  vf [M][P][4], coords [M][4] = (b, z, y, x), npts [M].
  * w [64][10] = dequantized (fake-quant) folded weights, b [64] folded BN bias.
@@ -136,7 +156,7 @@ ORC_API void orc_conv3x3(const uint8_t* in, int N, int H, int W, int Cin, int st
                         y = y + (float)T * scale[(size_t)g * Cout + co];
                     }
                     if (relu) y = fmaxf(y, 0.0f);
-                    o[co] = (uint8_t)q_code(y, da, za);
+                    o[co] = (uint8_t)q_code_mul(y, da, za);
                 }
             }
             free(xw);
@@ -170,7 +190,7 @@ ORC_API void orc_deconv(const uint8_t* in, int N, int H, int W, int Cin, float d
                                 acc = fmaf(xf[c], wdeq[(((size_t)c * Cout + co) * s + i) * s + j], acc);
                             float yv = acc + bias[co];
                             if (relu) yv = fmaxf(yv, 0.0f);
-                            o[co] = (uint8_t)q_code(yv, da, za);
+                            o[co] = (uint8_t)q_code_mul(yv, da, za);
                         }
                     }
             }
@@ -442,7 +462,7 @@ ORC_API void orc_convg(const uint8_t* in, int N, int H, int W, int Cin, int zx, 
                     const size_t o = (((size_t)n * Ho + yo) * Wo + xo) * Cout + co;
                     if (mode == 1) { out_f32[o] = y; continue; }
                     if (relu) y = fmaxf(y, 0.0f);
-                    out_u8[o] = (uint8_t)q_code(y, da, za);
+                    out_u8[o] = (uint8_t)q_code_mul(y, da, za);
                 }
 }
 
@@ -464,7 +484,7 @@ ORC_API void orc_deconv_f32in(const float* xf, int N, int H, int W, int Cin, con
                             for (int c = 0; c < Cin; ++c) acc = fmaf(src[c], wdeq[(((size_t)c * Cout + co) * s + i) * s + j], acc);
                             float yv = acc + bias[co];
                             if (relu) yv = fmaxf(yv, 0.0f);
-                            o[co] = (uint8_t)q_code(yv, da, za);
+                            o[co] = (uint8_t)q_code_mul(yv, da, za);
                         }
                     }
             }
@@ -473,5 +493,5 @@ ORC_API void orc_deconv_f32in(const float* xf, int N, int H, int W, int Cin, con
 /* the end of a residual block: code = q_code(max(y + res, 0))   (out += residual; ReLU; act_quantizer) */
 ORC_API void orc_add_relu_quant(const float* y, const float* res, size_t n, float da, float za, uint8_t* out) {
 #pragma omp parallel for schedule(static)
-    for (size_t i = 0; i < n; ++i) out[i] = (uint8_t)q_code(fmaxf(y[i] + res[i], 0.0f), da, za);
+    for (size_t i = 0; i < n; ++i) out[i] = (uint8_t)q_code_mul(fmaxf(y[i] + res[i], 0.0f), da, za);
 }

@@ -31,6 +31,39 @@ __device__ __forceinline__ float q_code(float y, float delta, float zp) {
     return fminf(c, 255.0f);
 }
 
+// ---- the output quantizer of the CONVOLUTION epilogues, round 5: code = clamp(rint(fma(y, fl(1 / delta), zp)), 0, 255) -------------------
+// oracle/qv2x_oracle.c:q_code_mul states it and says why: UniformAffineQuantizer.forward (quant_layer.py:132-133) with the division replaced
+// by one fused multiply-add with the fp32 reciprocal.  v_fma_f32 + v_cvt_pk_u8_f32 (round to nearest even, saturate to 0..255, insert byte e:
+// tools/probes/cvt_pk_u8_probe.hip) evaluate exactly that in TWO instructions per output -- the division-exact sandwich of round 4 took 5.25
+// (below, q_pack4_div: kept for the sparse 3-D convolutions, whose CPU restatement is numpy), and the 64- / 128-channel layers are bound by
+// VALU issue (profiles/r05_ws64_ablations.log).  `rdelta` = 1.0f / delta, hoisted by the caller.
+// `low` = lowest code: 0 for the plain quantizer; zp folds a ReLU in front of the quantizer into a clamp -- q(max(y, 0)) =
+// max(rint(fma(y, rd, zp)), zp): fma(0, rd, zp) = zp exactly and fma, rint are monotone.  With zp = 0 (every post-ReLU quantizer the
+// reference's observers produce: the observed minimum is 0) the conversion's saturation IS that clamp.
+// NaN / Inf contract: the callers' y are finite by construction (ptq_state.check_finite); an infinite y saturates, a NaN y converts to 0.
+__device__ __forceinline__ void q_add(float y, int e, float rdelta, float zp, float low, unsigned& c) {
+    float t = __builtin_fmaf(y, rdelta, zp);
+    if (low > 0.0f) t = fmaxf(t, low);                  // (uniform; an integer bound: rint(max(t, low)) = max(rint(t), low))
+    c = __builtin_amdgcn_cvt_pk_u8_f32(t, e, c);
+}
+// four outputs -> one dword of (code - 128) bytes (byte e = element e).  `lowc`: lowest code + 2^23 (the callers' convention since round 3).
+__device__ __forceinline__ int q_pack4(float y0, float y1, float y2, float y3, float delta, float rdelta, float zp, float lowc = 8388608.0f) {
+    (void)delta;
+    const float low = lowc - 8388608.0f;
+    unsigned c = 0;
+    q_add(y0, 0, rdelta, zp, low, c);
+    q_add(y1, 1, rdelta, zp, low, c);
+    q_add(y2, 2, rdelta, zp, low, c);
+    q_add(y3, 3, rdelta, zp, low, c);
+    return (int)(c ^ 0x80808080u);
+}
+// one value, the same arithmetic (the 1x1 occupancy head of the Pyramid model): the code as a float
+__device__ __forceinline__ float q_code_mul(float y, float delta, float zp) {
+    const float rdelta = 1.0f / delta;                  // uniform: hoisted out of every loop
+    return fminf(fmaxf(rintf(__builtin_fmaf(y, rdelta, zp)), 0.0f), 255.0f);
+}
+
+// ---- the DIVISION-EXACT form of round 4 (clamp(rint(y / delta) + zp) bit for bit, without paying for the division on every element) ------
 // Four outputs -> one dword of (code - 128) bytes (byte e = element e), the same values q_code gives.  `rdelta` = 1.0f / delta,
 // hoisted by the caller.  The product p = y * rdelta is within 1.2e-7 |p| of y / delta and fl(y / delta) within 6e-8 more; a code only
 // depends on rint(.) for |p| < 256.5 (0 <= zp <= 255: beyond that both values clamp to 0 or 255 even when they differ by one), where the
@@ -66,7 +99,7 @@ __device__ __forceinline__ int q_sandwich_finish(unsigned ca, unsigned cb, float
     }
     return (int)(ca ^ 0x80808080u);
 }
-__device__ __forceinline__ int q_pack4(float y0, float y1, float y2, float y3, float delta, float rdelta, float zp, float lowc = 8388608.0f) {
+__device__ __forceinline__ int q_pack4_div(float y0, float y1, float y2, float y3, float delta, float rdelta, float zp, float lowc = 8388608.0f) {
     const float za = zp + 1.0e-4f, zb = zp - 1.0e-4f;
     unsigned ca = 0, cb = 0;
     q_sandwich_add(y0, 0, rdelta, za, zb, ca, cb);

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_i8_dma_kernel(const ConvArg
                 const int row = mfma32_row(r, lane);
                 float y = facc[i][j][r % NF];
                 if (a.relu) y = fmaxf(y, 0.0f);
-                stage[row * TN + j * 32 + (lane & 31)] = (int8_t)((int)q_code(y, a.out_delta, a.out_zp) - 128);
+                stage[row * TN + j * 32 + (lane & 31)] = (int8_t)((int)q_code_mul(y, a.out_delta, a.out_zp) - 128);
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);

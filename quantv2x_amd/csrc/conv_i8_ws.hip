@@ -148,8 +148,8 @@ __global__ __launch_bounds__(NCB * RG * 64, NCB * RG == 4 ? 2 : 1) void conv3x3_
     // fourth call closes a group of four (the sandwich of common.h), the sixteenth swaps half-waves and stores.  One output per MFMA gap:
     // the 18 MFMAs of a row are a dependent chain (~50 cycles from one to the next), and ten VALU instructions fit each gap; four outputs
     // behind every fourth MFMA left 14 gaps empty and made 4 too long (SQ counters: 28 % MFMA-busy, 42 % VALU-busy, 30 % issue stalls).
-    const float za = a.out_zp + 1.0e-4f, zb = a.out_zp - 1.0e-4f, qlow = lowc - 8388608.0f;
-    unsigned qa = 0, qb = 0;
+    const float qlow = lowc - 8388608.0f;
+    unsigned qa = 0;
     float yq[4];
     auto epi_one = [&](auto p_c, auto r_c) __attribute__((always_inline)) {
         constexpr int P = decltype(p_c)::value, R = decltype(r_c)::value, G = R >> 2, E = R & 3;
@@ -159,9 +159,9 @@ __global__ __launch_bounds__(NCB * RG * 64, NCB * RG == 4 ? 2 : 1) void conv3x3_
 #endif
         const int T = __mul24(awr[R], p_tot) + acc[P][R];              // (the channel's correction term went in as the first MFMA's C operand)
         yq[E] = bs[R] + (float)T * sc[R];
-        if (E == 0) { qa = 0; qb = 0; }
-        q_sandwich_add(yq[E], E, rd, za, zb, qa, qb);
-        if (E == 3) pk[G] = q_sandwich_finish(qa, qb, yq[0], yq[1], yq[2], yq[3], a.out_delta, a.out_zp, qlow);
+        if (E == 0) qa = 0;
+        q_add(yq[E], E, rd, a.out_zp, qlow, qa);                          // (common.h: fma + v_cvt_pk_u8_f32, two instructions per output)
+        if (E == 3) pk[G] = (int)(qa ^ 0x80808080u);
         if (R == 15) {                                                 // half-wave exchange -> 16 contiguous channels per lane, one 16-byte store
             const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
             const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);

@@ -170,17 +170,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_i8_ws2_kernel(const Ws2Args a)
     long long p_off = -1;                                              // byte offset of this lane's 16 output bytes; < 0: nothing to store
     int pk[4];
     const int ch_off = a.out_c0 + cb * 32 + half * 16;
-    const float za = a.out_zp + 1.0e-4f, zb = a.out_zp - 1.0e-4f, qlow = lowc - 8388608.0f;
-    unsigned qa = 0, qb = 0;
+    const float qlow = lowc - 8388608.0f;
+    unsigned qa = 0;
     float yq[4];
     // ONE output of the pending tile per call (conv_i8_ws.hip:epi_one): register R of its accumulator
     auto epi_one = [&](auto p_c, auto r_c) __attribute__((always_inline)) {
         constexpr int P = decltype(p_c)::value, R = decltype(r_c)::value, G = R >> 2, E = R & 3;
         const int T = __mul24(awr[R], p_tot) + acc[P][R];              // (the channel's correction term went in as the first MFMA's C operand)
         yq[E] = bs[R] + (float)T * sc[R];
-        if (E == 0) { qa = 0; qb = 0; }
-        q_sandwich_add(yq[E], E, rd, za, zb, qa, qb);
-        if (E == 3) pk[G] = q_sandwich_finish(qa, qb, yq[0], yq[1], yq[2], yq[3], a.out_delta, a.out_zp, qlow);
+        if (E == 0) qa = 0;
+        q_add(yq[E], E, rd, a.out_zp, qlow, qa);                          // (common.h: fma + v_cvt_pk_u8_f32, two instructions per output)
+        if (E == 3) pk[G] = (int)(qa ^ 0x80808080u);
         if (R == 15) {                                                 // half-wave exchange -> 16 contiguous channels per lane, one 16-byte store
             const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
             const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void occ_score_kernel(const OccArgs a) {
     }
     const int T = acc + a.aw * sum + a.corr;
     const float yv = a.bias + (float)T * a.scale;
-    const int code = (int)q_code(yv, a.out_delta, a.out_zp);
+    const int code = (int)q_code_mul(yv, a.out_delta, a.out_zp);
     a.score[m] = a.lut[code];
     if (a.code) a.code[m] = (uint8_t)code;
 }

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void sp_conv_f32in_kernel(const float* __restr
             v = v + hl[co];
             y[e] = fmaxf(v, 0.0f);
         }
-        pk[q] = q_pack4(y[0], y[1], y[2], y[3], delta, rd, zp);
+        pk[q] = q_pack4_div(y[0], y[1], y[2], y[3], delta, rd, zp);
     }
     if (valid) {
         const int fillw = (int)(((unsigned)((int)zp - 128) & 255u) * 0x01010101u);
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(512) void sp_conv_i8_kernel(const SpArgs a) {
                     v = v + xh[e];
                     y[e] = fmaxf(v, 0.0f);
                 }
-                const int pk = q_pack4(y[0], y[1], y[2], y[3], a.out_delta, rd, a.out_zp);
+                const int pk = q_pack4_div(y[0], y[1], y[2], y[3], a.out_delta, rd, a.out_zp);
                 if (valid) *(int*)(a.out + (size_t)m * CO + cl) = pk;
                 __builtin_amdgcn_sched_barrier(0);                  // keeps the constants of the next run of four from being hoisted (they spilled)
             }

@@ -239,7 +239,7 @@ def test_argument_errors_of_the_pyramid_entries_without_gpu():
     o.n, o.h, o.w, o.c, o.out_delta = 1, 4, 4, 60, 0.1
     assert l.qv2x_occ_score_i8(C.byref(o), p, p, p, p, None, None) == -1
     assert l.qv2x_codebook_decode_f32(p, 16, 16, 1, 16, 3, 128, 62, p, p, p, None) == -1            # width % 4
-    assert l.qv2x_codebook_decode_f32(p, 16, 16, 1, 16, 9, 128, 64, p, p, p, None) == -1            # levels
+    assert l.qv2x_codebook_decode_f32(p, 16, 16, 1, 16, 17, 128, 64, p, p, p, None) == -1           # planes (levels * seg_num <= 16)
     e = lib.EncodeDesc()
     e.n, e.h, e.w, e.levels, e.kc = 1, 4, 4, 3, 100
     ptrs = (C.c_void_p * 3)()
