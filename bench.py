@@ -274,6 +274,41 @@ def multi_agent_line(eng, device):
     return out
 
 
+def codebook_seg_line(full, B, device):
+    """The codebook setting of six of the reference's ten codebook yamls -- ``seg_num: 2, dict_size: 256`` (every OPV2V / DAIR-V2X codebook
+    config: hypes_yaml/opv2v/Codebook/Pyramid/pyramid_stage2_model.yaml:96-97, v2x_real/Codebook/Attfuse/lidar_attfuse_stage2.yaml:114-115)
+    -- on this run's V2X-Real workload: the same step (B frames per graph, one graph at a time) and the encode kernel alone.  Two segments
+    of 128 dims, 256 codes each: six code planes per agent-frame on the wire (211 200 B) and a distance GEMM of 512 columns per level
+    (the extended codebook, include/qv2x.h) where (1, 128) has 128 -- 32.3 GMAC per agent-frame instead of 21.9 as executed."""
+    import copy
+    import torch
+    from quantv2x_amd import synth
+    from quantv2x_amd.engine import deploy
+    from quantv2x_amd.plugin.tools import inference_quant, train_utils
+    from quantv2x_amd.ptq_state import export_ptq_state
+    model = train_utils.create_model(copy.deepcopy(synth.make_hypes(SHAPE, multiclass=True, dict_size=256, seg_num=2))).eval()
+    synth.load_state_dict_numpy(model, synth.make_state_dict(model.state_dict(), seed=1))
+    calib = synth.scene_to_torch(synth.make_scene(SHAPE, n_agents=1, seed=3, n_points=N_POINTS))
+    eng = deploy(state=export_ptq_state(inference_quant.calibrate_minmax(inference_quant.wrap(model), [calib])))
+    rep = eng.capture(full)
+    for _ in range(3):
+        rep()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        rep()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 10 * 1e3
+    us = event_time_us(lambda: eng.encode_codes(B), 5)
+    hw = eng.fh * eng.fw
+    macs = hw * 3 * (3 * 65536 + 2 * 256 * 256) - hw * 65536        # per agent-frame as executed: three 256 x 256 heads (two on the last level) + a 512 x 256 distance GEMM
+    return {"seg_num": eng.segs, "dict_size": eng.kc, "code_planes": eng.levels, "wire_bytes_per_agent_frame": eng.levels * hw,
+            "frames_per_s": round(B / ms * 1e3, 1), "ms_per_step": round(ms, 4), "frames_per_step": B, "batches_in_flight": 1,
+            "encode_us_per_batch": round(us, 1), "encode_tflops_as_executed": round(2.0 * macs * B / us / 1e6, 1),
+            "note": "the same V2X-Real single-agent batch with the (2, 256) codebook; ONE graph in flight (the headline runs two); the general "
+                    "a7-a11 path (six planes: the single-agent table shortcut holds four)"}
+
+
 def pyramid_model_line(device):
     """SURVEY.md §8(f) rank 3, reported beside the headline: the HEAL Pyramid-fusion model (2 agents per scene, V2X-Real grid) on its
     own engine -- one frame as a HIP graph, and batches of 4 scenes."""
@@ -999,6 +1034,10 @@ def main():
             line["second_encoder"] = second_encoder_line(device)
             line["collapsed_encode_opt_in"] = collapsed_encode_line(state, full, B, F, args.steps, device)
             line["points_to_boxes"] = points_to_boxes_line(state, device)
+            try:
+                line["codebook_seg2_dict256"] = codebook_seg_line(full, B, device)
+            except Exception as e:                                         # an extra must not cost the line
+                line["codebook_seg2_dict256"] = {"error": repr(e)[:300]}
             # what a rank of the N-GPU lines executes per step, inside the driver's clock: worlds 2 and 4 reuse this
             # run's engine (same V2X-Real mc model); world 8 is BASELINE configs[4]'s OPV2V grid -- its model is calibrated here
             reh = {}
