@@ -72,8 +72,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_i8_ws2_kernel(const Ws2Args a)
     auto issue_tile = [&](const Where& w) __attribute__((always_inline)) {
         // the lane's byte offset inside an input row for this wave's sub (clamped to the row: the last tile column of a ragged map)
         const int s = wave_u;
+#if defined(QV2X_WS2_ABL) && QV2X_WS2_ABL == 1      // dev ablation (timing only): every lane fetches the border pixel of its row -- the
+        const unsigned voff = (unsigned)(a.cin_off + qsw * 16);      // floor of an occupancy-redirected fetch (profiles/r05_ws2_ablations.log)
+#else
         const unsigned voff = (unsigned)(min(2 * w.x0 + 32 * (s & 1) + (s >> 1) + 2 * (lane >> 2), a.wp - 1) * a.cin_total + a.cin_off + qsw * 16);
+#endif
         const int rowb = w.img * a.hp;
+#if defined(QV2X_WS2_ABL) && QV2X_WS2_ABL == 2      // dev ablation: no halo DMA after the first tile
+        if (w.img + w.y0 + w.x0 != 0) return;
+#endif
 #pragma unroll
         for (int k = 0; k < IR; ++k) {                                  // piece (row k, sub s) -> LDS k * ROWB + s * 1024
             const int yy = min(2 * w.y0 + k, a.hp - 1);

@@ -51,6 +51,11 @@ if what in ("conv", "all"):
         tot_us += us; tot_ops += 2 * macs if kind != "deconv" else 0
         print(f"{kind:6s} {layer.name:42s} h={h:4d} w={w:4d} macs={macs/1e9:7.3f}G  {us:8.1f} us  {2*macs/us/1e6:8.1f} {unit}")
     print(f"total {tot_us:.1f} us; conv {tot_ops/1e9:.1f} GOP")
+if what in ("deconv", "conv", "all"):                                 # the three deblocks as the engine launches them: one batch
+    items = [(layer, x, h, w, out, c0) for (kind, layer, x, h, w, out, c0, macs) in eng.conv_plan(n) if kind == "deconv"]
+    flops = sum(2 * macs for (kind, *_r, macs) in eng.conv_plan(n) if kind == "deconv")
+    us = timeit(lambda: eng._deconv_batch(items, n))
+    print(f"deconv batch of {len(items)}: {us:.1f} us  ({flops/us/1e6:.1f} TFLOPS fp32 = {flops/us/1e6/157.3:.3f})")
 if what in ("encode", "all"):
     us = timeit(lambda: eng.encode_codes(n), 10)
     print(f"encode {us:.1f} us  ({2*21.92*n/us*1e3:.1f} TFLOPS fp32)")
