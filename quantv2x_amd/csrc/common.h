@@ -43,7 +43,8 @@ __device__ __forceinline__ float q_code(float y, float delta, float zp) {
 // NaN / Inf contract: the callers' y are finite by construction (ptq_state.check_finite); an infinite y saturates, a NaN y converts to 0.
 __device__ __forceinline__ void q_add(float y, int e, float rdelta, float zp, float low, unsigned& c) {
     float t = __builtin_fmaf(y, rdelta, zp);
-    if (low > 0.0f) t = fmaxf(t, low);                  // (uniform; an integer bound: rint(max(t, low)) = max(rint(t), low))
+    t = fmaxf(t, low);                                  // (an integer bound: rint(max(t, low)) = max(rint(t), low); with low = 0 a no-op in front of
+                                                        //  the saturating conversion -- but ONE v_max: `if (low > 0)` compiled to v_max + v_cndmask)
     c = __builtin_amdgcn_cvt_pk_u8_f32(t, e, c);
 }
 // four outputs -> one dword of (code - 128) bytes (byte e = element e).  `lowc`: lowest code + 2^23 (the callers' convention since round 3).

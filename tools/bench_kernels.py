@@ -59,6 +59,19 @@ if what in ("deconv", "conv", "all"):                                 # the thre
 if what in ("encode", "all"):
     us = timeit(lambda: eng.encode_codes(n), 10)
     print(f"encode {us:.1f} us  ({2*21.92*n/us*1e3:.1f} TFLOPS fp32)")
+if what == "pfn":
+    inp = dd["inputs_m1"]
+    def run():
+        eng.pillars_to_canvas(inp, n, resident=True); eng.clear_pillars(inp, n)
+    run()
+    print(f"pfn scatter + clear, {n} frames: {timeit(run):.1f} us")
+    def run1():
+        eng._workspace(n)["canvas_clean"] = True; eng.pillars_to_canvas(inp, n, resident=True)   # (dev: scatter only, onto a canvas it believes clean)
+    try:
+        run1(); print(f"pfn scatter alone: {timeit(run1):.1f} us")
+    except Exception as e:
+        print("scatter-alone timing skipped:", e)
+    eng.clear_pillars(inp, n)
 if what in ("rest", "all"):
     print("pfn", timeit(lambda: eng.pillars_to_canvas(dd["inputs_m1"], n)))
     hw = eng.fh * eng.fw
