@@ -301,7 +301,9 @@ def codebook_seg_line(full, B, device):
     ms = (time.perf_counter() - t0) / 10 * 1e3
     us = event_time_us(lambda: eng.encode_codes(B), 5)
     hw = eng.fh * eng.fw
-    macs = hw * 3 * (3 * 65536 + 2 * 256 * 256) - hw * 65536        # per agent-frame as executed: three 256 x 256 heads (two on the last level) + a 512 x 256 distance GEMM
+    # per agent-frame as executed: three 256 x 256 heads per level (two on the last) + the distances to a segment's codes over the segment's
+    # dims only (round 5: the wave form walks the extended codebook's diagonal blocks -- seg_num x [dict_size x 256 / seg_num])
+    macs = hw * 3 * (3 * 65536 + eng.segs * eng.kc * (256 // eng.segs)) - hw * 65536
     return {"seg_num": eng.segs, "dict_size": eng.kc, "code_planes": eng.levels, "wire_bytes_per_agent_frame": eng.levels * hw,
             "frames_per_s": round(B / ms * 1e3, 1), "ms_per_step": round(ms, 4), "frames_per_step": B, "batches_in_flight": 1,
             "encode_us_per_batch": round(us, 1), "encode_tflops_as_executed": round(2.0 * macs * B / us / 1e6, 1),

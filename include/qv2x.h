@@ -175,7 +175,10 @@ int qv2x_deconv_i8_batch(const qv2x_deconv_desc* descs /* host */, int n, const 
  *     then the same four matrices once more in MFMA A-operand order for the wave-per-32-cells form that launches of many frames take,
  *       stage [4][32][2][64][4] | qhead [4][32][2][64][4] | cb [ceil(Kc/64)][32][2][64][4] | lhead [4][32][2][64][4] | 4096 floats of padding
  *     ([pair][group][tile][lane = 32 h + c][s] = W[64 pair + 32 tile + c][8 group + 2 s + h], rows past Kc zero: one linear stream of
- *     1 KiB groups)
+ *     1 KiB groups).  seg_num m > 1: the cb part holds the DIAGONAL blocks of the extended codebook only -- a code of segment sg is zero
+ *     outside dims [256 sg / m, 256 (sg + 1) / m), and the wave form walks just those: [m / 2 segment pairs][dict_size / 32][32 / m groups]
+ *     [2 segments of the pair][lane][s] = cb[sg * dict_size + 32 tile + c][256 sg / m + 8 group + 2 s + h]; lhead follows it directly and
+ *     the section is zero-filled to the size above (quantv2x_amd/engine.py:_pack_wave_seg is the reference packing)
  *   codes: u8 [levels * m][N*H*W] -- THE WIRE FORMAT: plane l * m + s holds segment s's index (0 .. kc - 1) of level l; the decode side
  *   (qv2x_fuse_att_f32, qv2x_decode_lut_f32, ...) takes `levels` = levels * m planes and a table [levels * m][kc][256], which is the
  *   per-level table over the extended codebook's rows [levels][m * kc][256] read plane by plane. */

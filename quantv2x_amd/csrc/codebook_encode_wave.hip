@@ -72,7 +72,13 @@ __device__ long long g_encw_fine[4096][32];
 
 }  // namespace
 
-template <bool F32IN>
+template <int V> struct IC { static constexpr int value = V; };
+
+// SEGS = seg_num (m).  SEGS > 1 (round 5): the distances walk only the codebook's DIAGONAL blocks -- a code of segment s is zero outside the
+// 256 / m dims of its segment, and fma(x, 0, acc) = acc, so the sums are the dense walk's bit for bit with 1 / m of its MFMAs.  A tile pair
+// then is one 32-code tile of each of TWO segments (tile 0 against operand registers [OFF0, ...), tile 1 against [OFF1, ...)), 32 / m groups
+// long; the blob's codebook stream is packed in that order (engine.py:_pack_wave_seg, include/qv2x.h).
+template <bool F32IN, int SEGS>
 __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(1, 1))) void codebook_encode_wave_kernel(const EncArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[32 * RS];
     const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
@@ -144,6 +150,11 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
 #pragma unroll
                 for (int i = 0; i < 4; ++i) bn[1][i] = v4f{INFINITY, INFINITY, INFINITY, INFINITY};
         };
+        // SEGS > 1: |C|^2 of code tile P of segments s0 (tile 0) and s1 (tile 1): rows s * kc + 32 P ... of the extended codebook
+        auto next_c2s = [&](int s0, int s1, int P) __attribute__((always_inline)) {
+            tile_vec(c2 + s0 * a.kc, h, P, bn[0]);
+            tile_vec(c2 + s1 * a.kc, h, P, bn[1]);
+        };
         next_vec(stage_b, 0);
         __builtin_amdgcn_sched_barrier(0);
         v4f ring[2 * NPF];
@@ -158,7 +169,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
 #ifdef QV2X_ENCW_FINE
         bool fine2 = false;
 #endif
-        auto tile2 = [&](const float (&m)[128], const bool biased, auto&& hook) __attribute__((always_inline)) {
+        auto tile2g = [&](const float (&m)[128], const bool biased, auto&& hook, auto ng_c, auto off0_c, auto off1_c) __attribute__((always_inline)) {
+            constexpr int NG = decltype(ng_c)::value, OFF0 = decltype(off0_c)::value, OFF1 = decltype(off1_c)::value;
             WFINE2(0);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -166,24 +178,24 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
                 for (int r = 0; r < 16; ++r) acc[t][r] = biased ? bn[t][r >> 2][r & 3] : 0.0f;
             WFINE2(1);
 #pragma unroll
-            for (int g = 0; g < 32; ++g) {
+            for (int g = 0; g < NG; ++g) {
                 const v4f A0 = ring[(2 * g) % (2 * NPF)], A1 = ring[(2 * g + 1) % (2 * NPF)];
                 // (sched_barrier after every step: hipcc otherwise groups the four MFMAs of ONE accumulator -- a dependent chain again)
-                acc[0] = mfma(A0.x, m[4 * g], acc[0]);
-                acc[1] = mfma(A1.x, m[4 * g], acc[1]);
+                acc[0] = mfma(A0.x, m[OFF0 + 4 * g], acc[0]);
+                acc[1] = mfma(A1.x, m[OFF1 + 4 * g], acc[1]);
                 __builtin_amdgcn_sched_barrier(0);
-                acc[0] = mfma(A0.y, m[4 * g + 1], acc[0]);
-                acc[1] = mfma(A1.y, m[4 * g + 1], acc[1]);
+                acc[0] = mfma(A0.y, m[OFF0 + 4 * g + 1], acc[0]);
+                acc[1] = mfma(A1.y, m[OFF1 + 4 * g + 1], acc[1]);
                 __builtin_amdgcn_sched_barrier(0);
-                acc[0] = mfma(A0.z, m[4 * g + 2], acc[0]);
-                acc[1] = mfma(A1.z, m[4 * g + 2], acc[1]);
+                acc[0] = mfma(A0.z, m[OFF0 + 4 * g + 2], acc[0]);
+                acc[1] = mfma(A1.z, m[OFF1 + 4 * g + 2], acc[1]);
                 __builtin_amdgcn_sched_barrier(0);
-                acc[0] = mfma(A0.w, m[4 * g + 3], acc[0]);
-                acc[1] = mfma(A1.w, m[4 * g + 3], acc[1]);
-                if (g == 32 - NPF - 1) hook();
-                if (g == 7) WFINE2(2);
-                if (g == 15) WFINE2(3);
-                if (g == 23) WFINE2(4);
+                acc[0] = mfma(A0.w, m[OFF0 + 4 * g + 3], acc[0]);
+                acc[1] = mfma(A1.w, m[OFF1 + 4 * g + 3], acc[1]);
+                if (g == NG - NPF - 1) hook();
+                if (NG == 32 && g == 7) WFINE2(2);
+                if (NG == 32 && g == 15) WFINE2(3);
+                if (NG == 32 && g == 23) WFINE2(4);
 #ifndef QV2X_ENCW_ABL_NOLOAD                                              // (dev ablation: the ring is never refilled)
                 ring[(2 * g) % (2 * NPF)] = wload(2 * (g + NPF));
                 ring[(2 * g + 1) % (2 * NPF)] = wload(2 * (g + NPF) + 1);
@@ -191,9 +203,12 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
                 __builtin_amdgcn_sched_barrier(0);                      // (hipcc otherwise sinks every load to its first use)
             }
 #ifndef QV2X_ENCW_ABL_SAMEW                                               // (dev ablation: every pair streams the same 64 KiB -- L1 / L2 latency out of the picture)
-            wo += 64 * 1024;
+            wo += NG * 2048;
 #endif
             WFINE2(5);
+        };
+        auto tile2 = [&](const float (&m)[128], const bool biased, auto&& hook) __attribute__((always_inline)) {
+            tile2g(m, biased, hook, IC<32>{}, IC<0>{}, IC<0>{});
         };
 
         WFINE(0);
@@ -213,7 +228,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
         // ---- q = qhead(z) -------------------------------------------------------------------------------------------------
 #pragma unroll 1
         for (int P = 0; P < 4; ++P) {
-            tile2(z, true, [&]() __attribute__((always_inline)) { if (P < 3) next_vec(qhead_b, P + 1); else next_c2(0); });
+            tile2(z, true, [&]() __attribute__((always_inline)) { if (P < 3) next_vec(qhead_b, P + 1); else if (SEGS == 1) next_c2(0); else next_c2s(0, 1, 0); });
             tile_to_lds(row, h, 2 * P, acc[0]);
             tile_to_lds(row, h, 2 * P + 1, acc[1]);
         }
@@ -251,9 +266,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
         WFINE(4);
         // ---- distances to the codes, 64 per pair, and the running first-argmin inside the lane; a pair lies inside ONE segment
         //      (kc % 64 == 0 when segs > 1), a segment's argmin closes with its last pair ------------------------------------------------
+        unsigned bcs = 0;                                               // the segments' codes, one byte each
+        if constexpr (SEGS == 1) {
         float best = INFINITY;
         int bc = 0;
-        unsigned bcs = 0;                                               // the segments' codes, one byte each
         const int ppseg = npair / a.segs;                               // pairs per segment
 #pragma unroll 1
         for (int P = 0; P < npair; ++P) {
@@ -285,6 +301,52 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
                 best = INFINITY; bc = 0;
             }
         }
+        } else {
+            // ---- SEGS > 1: a pair = code tile P of segments (sa, sb), 32 / SEGS groups; each segment its own running first-argmin ----------
+            const int ntile = a.kc >> 5;                                // 32-code tiles per segment
+            auto seg_pairs = [&](auto sa_c, auto sb_c, const bool more_after) __attribute__((always_inline)) {
+                constexpr int SA = decltype(sa_c)::value, SB = decltype(sb_c)::value, NG = 32 / SEGS;
+                float best[2] = {INFINITY, INFINITY};
+                int bc[2] = {0, 0};
+#pragma unroll 1
+                for (int P = 0; P < ntile; ++P) {
+                    v4f c2t[2][4];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) c2t[t][i] = bn[t][i];
+                    tile2g(xq, false, [&]() __attribute__((always_inline)) {
+                        if (P + 1 < ntile) next_c2s(SA, SB, P + 1);
+                        else if (more_after) next_c2s(SA + 2, SB + 2, 0);
+                        else if (!last) next_vec(lhead_b, 0);
+                    }, IC<NG>{}, IC<4 * NG * SA>{}, IC<4 * NG * SB>{});
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const float x2 = x2s[t ? SB : SA];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {                     // codes ascend with r inside a lane: a strict < keeps the first
+                            const float sv = x2 + c2t[t][r >> 2][r & 3];
+                            const float d = sv - 2.0f * acc[t][r];
+                            const int code = 32 * P + 8 * (r >> 2) + 4 * h + (r & 3);
+                            const bool lt = d < best[t];
+                            best[t] = lt ? d : best[t];
+                            bc[t] = lt ? code : bc[t];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {                           // the two half-waves' minima, ties to the lower code
+                    const int seg = t ? SB : SA;
+                    const float od = __shfl_xor(best[t], 32);
+                    const int oc = __shfl_xor(bc[t], 32);
+                    if (od < best[t] || (od == best[t] && oc < bc[t])) bc[t] = oc;
+                    if (h == 0 && m0 + j < a.m_hi) a.codes[((size_t)l * SEGS + seg) * a.M + m0 + j] = (uint8_t)bc[t];
+                    bcs |= (unsigned)bc[t] << (8 * seg);
+                }
+            };
+            if constexpr (SEGS == 2) seg_pairs(IC<0>{}, IC<1>{}, false);
+            else { seg_pairs(IC<0>{}, IC<1>{}, true); seg_pairs(IC<2>{}, IC<3>{}, false); }
+        }
         WFINE(5);
         if (last) break;
         // ---- x <- lhead(z) - C[code] ------------------------------------------------------------------------------------------
@@ -313,8 +375,14 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
 
 int encode_wave_launch(const EncArgs& a, hipStream_t st) {
     const unsigned grid = (unsigned)((a.m_hi - a.m_lo + 31) / 32);
-    if (a.in_f32) codebook_encode_wave_kernel<true><<<grid, 64, 0, st>>>(a);
-    else codebook_encode_wave_kernel<false><<<grid, 64, 0, st>>>(a);
+    if (a.segs == 2) {
+        if (a.in_f32) codebook_encode_wave_kernel<true, 2><<<grid, 64, 0, st>>>(a);
+        else codebook_encode_wave_kernel<false, 2><<<grid, 64, 0, st>>>(a);
+    } else if (a.segs == 4) {
+        if (a.in_f32) codebook_encode_wave_kernel<true, 4><<<grid, 64, 0, st>>>(a);
+        else codebook_encode_wave_kernel<false, 4><<<grid, 64, 0, st>>>(a);
+    } else if (a.in_f32) codebook_encode_wave_kernel<true, 1><<<grid, 64, 0, st>>>(a);
+    else codebook_encode_wave_kernel<false, 1><<<grid, 64, 0, st>>>(a);
     return hip_check(hipGetLastError(), "qv2x_codebook_encode_f32 (wave form) launch");
 }
 

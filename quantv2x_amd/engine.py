@@ -117,10 +117,26 @@ def _pack_wave(w: np.ndarray) -> np.ndarray:
 ENC_WAVE_PAD = 16 * 256          # floats behind a level blob's wave section (codebook_encode.h)
 
 
-def wave_section(stage_w, qhead_w, lhead_w, cb) -> np.ndarray:
-    """The second half of a level blob (include/qv2x.h): stage | qhead | codebook | lhead in A-operand order -- one linear stream."""
-    return np.concatenate([_pack_wave(stage_w).reshape(-1), _pack_wave(qhead_w).reshape(-1), _pack_wave(cb).reshape(-1),
-                           _pack_wave(lhead_w).reshape(-1), np.zeros(ENC_WAVE_PAD, np.float32)])
+def _pack_wave_seg(cb: np.ndarray, segs: int) -> np.ndarray:
+    """The codebook stream of the wave form for seg_num = 2 | 4 (codebook_encode_wave.hip, SEGS > 1): only the DIAGONAL blocks of the extended
+    codebook [segs * kc][256] -- a tile pair is code tile ``P`` (32 codes) of two segments, ``32 / segs`` groups of eight dims long:
+    [segment pair][kc / 32 tiles][32 / segs groups][2 segments][64 lanes][4], lane ``32 h + c`` of group ``g`` of segment ``seg`` of tile ``P`` holding
+    ``cb[seg * kc + 32 P + c, (256 / segs) * seg + 8 g + 2 s + h]`` for the four MFMA steps s."""
+    ke, k = cb.shape
+    kc, d = ke // segs, 256 // segs
+    assert k == 256 and segs in (2, 4) and kc % 32 == 0
+    blocks = np.stack([cb[sg * kc:(sg + 1) * kc, sg * d:(sg + 1) * d] for sg in range(segs)])          # [seg][kc][d]
+    b = blocks.reshape(segs // 2, 2, kc // 32, 32, d // 8, 4, 2)                                        # [pair][t][P][c][g][s][h]
+    return np.ascontiguousarray(b.transpose(0, 2, 4, 1, 6, 3, 5), dtype=np.float32)                     # [pair][P][g][t][h][c][s]
+
+
+def wave_section(stage_w, qhead_w, lhead_w, cb, segs: int = 1) -> np.ndarray:
+    """The second half of a level blob (include/qv2x.h): stage | qhead | codebook | lhead in A-operand order -- one linear stream.  With
+    ``segs`` > 1 the codebook part holds the diagonal blocks only (1 / segs of the dense stream); the section keeps its stated size."""
+    cbs = _pack_wave(cb) if segs == 1 else _pack_wave_seg(cb, segs)
+    sec = np.concatenate([_pack_wave(stage_w).reshape(-1), _pack_wave(qhead_w).reshape(-1), cbs.reshape(-1), _pack_wave(lhead_w).reshape(-1)])
+    full = 3 * 65536 + (cb.shape[0] + 63) // 64 * 64 * 256
+    return np.concatenate([sec, np.zeros(full - sec.size + ENC_WAVE_PAD, np.float32)])
 
 
 class _ConvLayer:
@@ -395,7 +411,7 @@ class DeployedModel(nn.Module):
                  _pack_k4p(cb), cb, np.zeros(kc, np.float32)]
         flat = np.concatenate([p.reshape(-1) for p in parts])
         wg = flat.size                                                 # the workgroup form's section ends with c2
-        flat = np.concatenate([flat, wave_section(g("stage_w"), g("qhead_w"), np.zeros((256, 256), np.float32) if last else g("lhead_w"), cb)])
+        flat = np.concatenate([flat, wave_section(g("stage_w"), g("qhead_w"), np.zeros((256, 256), np.float32) if last else g("lhead_w"), cb, self.segs)])
         assert flat.size == self.lib.qv2x_codebook_level_floats(kc)
         blob = _dev(flat, self.dev)
         cb_off = wg - kc - kc * 256

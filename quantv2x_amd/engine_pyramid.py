@@ -256,7 +256,7 @@ class DeployedPyramidModel(nn.Module):
 
             def full(w):
                 out = np.zeros((W, W), np.float32); out[:D, :D] = w; return out
-            flat = np.concatenate([flat, wave_section(full(g("stage_w")), full(g("qhead_w")), np.zeros((W, W), np.float32) if last else full(g("lhead_w")), cb)])
+            flat = np.concatenate([flat, wave_section(full(g("stage_w")), full(g("qhead_w")), np.zeros((W, W), np.float32) if last else full(g("lhead_w")), cb, self.segs)])
         floats, c2fn = ((self.lib.qv2x_codebook64_level_floats, self.lib.qv2x_codebook64_c2_f32) if self.native64
                         else (self.lib.qv2x_codebook_level_floats, self.lib.qv2x_codebook_c2_f32))
         assert flat.size == floats(kc)

@@ -149,7 +149,7 @@ def test_hip_encode_forms_agree_on_random_heads(m, k, levels):
         parts = [_pack_k4p(w[0]), b[0], _pack_k4p(w[1]), b[1], _pack_k4p(w[2]), b[2], _pack_k4p(cb), cb, np.zeros(ke, np.float32)]
         flat = np.concatenate([p.reshape(-1) for p in parts])
         wg = flat.size
-        flat = np.concatenate([flat, wave_section(w[0], w[1], w[2], cb)])
+        flat = np.concatenate([flat, wave_section(w[0], w[1], w[2], cb, m)])
         assert flat.size == lib.qv2x_codebook_level_floats(ke)
         t = torch.from_numpy(flat).to(dev)
         L.check(lib.qv2x_codebook_c2_f32(C.c_void_p(t.data_ptr() + 4 * (wg - ke - ke * 256)), ke, C.c_void_p(t.data_ptr() + 4 * (wg - ke)), L.current_stream()), "c2")

@@ -3,7 +3,7 @@ the order its kernel form reads -- the workgroup form's [K/4][cols][k0, k2, k1, 
 [pair][group][tile][lane = 32 h + c][step] = W[64 pair + 32 tile + c][8 group + 2 step + h] (codebook_encode_wave.hip)."""
 import numpy as np
 
-from quantv2x_amd.engine import ENC_WAVE_PAD, _pack_k4p, _pack_wave, wave_section
+from quantv2x_amd.engine import ENC_WAVE_PAD, _pack_k4p, _pack_wave, _pack_wave_seg, wave_section
 
 
 def test_wave_order_is_the_mfma_a_operand_order():
@@ -48,3 +48,29 @@ def test_both_sections_hold_the_same_matrices_and_the_size_the_library_states():
             assert a == b == mats[0][col, k]
         lh = sec[2 * 65536 + (kc + 63) // 64 * 64 * 256:][:65536].reshape(4, 32, 2, 2, 32, 4)
         assert lh[1, 2, 1, 0, 3, 1] == mats[2][64 + 32 + 3, 8 * 2 + 2 * 1 + 0]
+
+
+def test_segmented_codebooks_stream_their_diagonal_blocks_only():
+    """seg_num m > 1 (codebook_encode_wave.hip, SEGS > 1): the wave form's codebook stream = the m diagonal [kc x 256 / m] blocks of the extended
+    codebook, a tile pair = code tile P of two segments; the section keeps the size the library states, lhead follows the shorter stream"""
+    from quantv2x_amd import lib as L
+    from quantv2x_amd.ptq_state import extended_codebook
+    lib = L.load()
+    rng = np.random.default_rng(3)
+    for segs, kc in ((2, 256), (4, 64), (2, 64), (4, 128)):
+        d = 256 // segs
+        cb = extended_codebook(rng.standard_normal((segs, kc, d)).astype(np.float32))
+        assert cb.shape == (segs * kc, 256)
+        p = _pack_wave_seg(cb, segs)
+        assert p.shape == (segs // 2, kc // 32, 32 // segs, 2, 2, 32, 4)           # [segment pair][tile][group][segment of the pair][h][c][step]
+        for (pr, P, g, t, h, c, st) in [(0, 0, 0, 0, 0, 0, 0), (segs // 2 - 1, kc // 32 - 1, 32 // segs - 1, 1, 1, 31, 3), (0, 1, 3, 1, 0, 5, 2)]:
+            seg = 2 * pr + t
+            assert p[pr, P, g, t, h, c, st] == cb[seg * kc + 32 * P + c, d * seg + 8 * g + 2 * st + h]
+        assert p.size * segs == cb.size                                           # 1 / m of the dense stream: the zero blocks are never read
+        mats = [rng.standard_normal((256, 256)).astype(np.float32) for _ in range(3)]
+        sec = wave_section(mats[0], mats[1], mats[2], cb, segs)
+        wg = sum(_pack_k4p(m).size + 256 for m in mats) + _pack_k4p(cb).size + cb.size + segs * kc
+        assert wg + sec.size == lib.qv2x_codebook_level_floats(segs * kc)
+        lh = sec[2 * 65536 + p.size:][:65536].reshape(4, 32, 2, 2, 32, 4)
+        assert lh[1, 2, 1, 0, 3, 1] == mats[2][64 + 32 + 3, 8 * 2 + 2 * 1 + 0]
+        assert not sec[3 * 65536 + p.size:].any()
