@@ -59,6 +59,12 @@ if what in ("deconv", "conv", "all"):                                 # the thre
 if what in ("encode", "all"):
     us = timeit(lambda: eng.encode_codes(n), 10)
     print(f"encode {us:.1f} us  ({2*21.92*n/us*1e3:.1f} TFLOPS fp32)")
+if what == "heads":                                                  # a11 on a fused map in memory (the general path's qv2x_heads_f32)
+    hw = eng.fh * eng.fw
+    rows = torch.randn((n, hw, 256), dtype=torch.float32, device="cuda")
+    us = timeit(lambda: eng._run_heads(eng.heads, rows, n, hw))
+    fl = 2.0 * n * hw * 256 * eng.heads.cout
+    print(f"heads on {n} fused maps: {us:.1f} us  ({fl/us/1e6:.1f} TFLOPS on the {eng.heads.cout} real channels = {fl/us/1e6/157.3:.3f}; on the {eng.heads.cout_pad} padded ones {fl/us/1e6/157.3*eng.heads.cout_pad/eng.heads.cout:.3f})")
 if what == "pfn":
     inp = dd["inputs_m1"]
     def run():
