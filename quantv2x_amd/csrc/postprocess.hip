@@ -26,6 +26,13 @@ namespace {
 constexpr int TOPK_MAX = 1024;                       // bit-matrix row = 16 x u64
 
 constexpr int MAX_CAVS = 8;
+// Step 4, round 5: the sweep only ever reads the first `topk` entries of the order, so the stable descending sort of ALL `na` slots (hipCUB
+// fell back to a merge sort of 22 launches, 140 us per frame for 70 400 slots) became a radix SELECT of the top-k + one workgroup's bitonic sort:
+// two 12-bit histogram passes over the score bits find the 24-bit prefix below which nothing can make the top-k; everything at or above it
+// (top-k + what shares the last prefix: a handful) is compacted as 64-bit keys (score bits, ~slot) -- distinct, so their descending order IS
+// the stable sort's -- and sorted in LDS.  More than SEL_CAP survivors (thousands of EQUAL scores) take a slow exact path in the same kernel.
+constexpr int SEL_BINS = 4096, SEL_CAP = 2048, SEL_WORDS = 16;
+enum { SEL_B1 = 0, SEL_ABOVE1, SEL_THR24, SEL_COUNT };
 
 struct PPArgs {
     const float* cls[MAX_CAVS]; const float* reg[MAX_CAVS]; const float* dir[MAX_CAVS]; const float* anchors[MAX_CAVS];
@@ -35,6 +42,7 @@ struct PPArgs {
     // workspace
     float* prob; int* flag; int* pos; float* cand_corners; float* cand_score; unsigned* key_in; unsigned* key_out;
     int* idx_in; int* idx_out; unsigned long long* mask;
+    int* sel; unsigned long long* cand;                              // top-k selection: 2 x 4096 histogram bins + SEL_WORDS ints; the candidates' composite keys
     int* label; int* cand_label;
     float* out_corners; float* out_scores; int* out_labels; int* out_count;
 };
@@ -120,6 +128,142 @@ __global__ void pp_decode_kernel(const PPArgs p) {
     p.key_in[c] = keep ? __builtin_bit_cast(unsigned, s) : 0u;     // positive floats order like their bit patterns
 }
 
+__global__ void pp_sel_clear_kernel(const PPArgs p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * SEL_BINS + SEL_WORDS) p.sel[i] = 0;
+}
+
+// histogram of the 12 score bits of pass PASS (0: bits 31..20 of every non-empty slot; 1: bits 19..8 of the slots whose bits 31..20 = b1)
+template <int PASS>
+__global__ __launch_bounds__(256) void pp_sel_hist_kernel(const PPArgs p) {
+    __shared__ int h[SEL_BINS];
+    for (int t = threadIdx.x; t < SEL_BINS; t += 256) h[t] = 0;
+    __syncthreads();
+    const int b1 = PASS ? p.sel[2 * SEL_BINS + SEL_B1] : 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < p.na; i += gridDim.x * 256) {
+        const unsigned k = p.key_in[i];
+        if (k == 0u) continue;
+        if (PASS == 0) atomicAdd(&h[k >> 20], 1);
+        else if ((int)(k >> 20) == b1) atomicAdd(&h[(k >> 8) & 0xfffu], 1);
+    }
+    __syncthreads();
+    int* g = p.sel + PASS * SEL_BINS;
+    for (int t = threadIdx.x; t < SEL_BINS; t += 256)
+        if (h[t]) atomicAdd(&g[t], h[t]);
+}
+
+// the bin in which the running count FROM THE TOP reaches `want` (the last non-empty bin when the slots hold fewer): one workgroup of 1024
+template <int PASS>
+__global__ __launch_bounds__(1024) void pp_sel_pick_kernel(const PPArgs p) {
+    __shared__ int part[1024];
+    __shared__ int found[2];
+    const int* g = p.sel + PASS * SEL_BINS;
+    int* sel = p.sel + 2 * SEL_BINS;
+    const int want = PASS ? p.topk - sel[SEL_ABOVE1] : p.topk;
+    const int t = threadIdx.x;                                     // thread t owns bins 4 t .. 4 t + 3; suffix sums from the top
+    const int c0 = g[4 * t], c1 = g[4 * t + 1], c2 = g[4 * t + 2], c3 = g[4 * t + 3];
+    part[t] = c0 + c1 + c2 + c3;
+    if (t < 2) found[t] = t ? 0 : -1;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {                     // inclusive suffix scan: part[t] = sum of the bins >= 4 t
+        const int v = t + off < 1024 ? part[t + off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    const int above_me = part[t] - (c0 + c1 + c2 + c3);           // count in the bins above this thread's four
+    int above = above_me;
+    const int cs[4] = {c3, c2, c1, c0};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {                                  // bins 4 t + 3 down to 4 t
+        if (above < want && above + cs[e] >= want) { found[0] = 4 * t + 3 - e; found[1] = above; }
+        above += cs[e];
+    }
+    __syncthreads();
+    if (t == 0) {
+        int b = found[0], ab = found[1];
+        if (b < 0) { b = 0; ab = 0; }                              // fewer than `want` in all: everything non-empty survives
+        if (PASS == 0) { sel[SEL_B1] = b; sel[SEL_ABOVE1] = ab; }
+        else sel[SEL_THR24] = (sel[SEL_B1] << 12) | b;
+    }
+}
+
+__global__ __launch_bounds__(256) void pp_sel_compact_kernel(const PPArgs p) {
+    __shared__ int n_here, base;
+    int* sel = p.sel + 2 * SEL_BINS;
+    const unsigned thr24 = (unsigned)sel[SEL_THR24];
+    if (threadIdx.x == 0) n_here = 0;
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const unsigned k = i < p.na ? p.key_in[i] : 0u;
+    const bool take = k != 0u && (k >> 8) >= thr24;
+    int at = 0;
+    if (take) at = atomicAdd(&n_here, 1);                          // (the order inside the list is free: the keys are distinct)
+    __syncthreads();
+    if (threadIdx.x == 0 && n_here) base = atomicAdd(&sel[SEL_COUNT], n_here);   // one device-scope atomic per workgroup that holds a survivor
+    __syncthreads();
+    if (take && base + at < SEL_CAP) p.cand[base + at] = ((unsigned long long)k << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
+}
+
+// the survivors in descending (score, -slot) order = the first entries of the stable descending sort; entries past them: empty
+__global__ __launch_bounds__(1024) void pp_sel_sort_kernel(const PPArgs p) {
+    __shared__ unsigned long long v[SEL_CAP];
+    __shared__ unsigned long long red[16];
+    const int t = threadIdx.x;
+    const int count = p.sel[2 * SEL_BINS + SEL_COUNT];
+    if (count <= SEL_CAP) {
+        int N = 64;
+        while (N < count) N <<= 1;                                 // (top-k + the few that share its last 24-bit prefix: 1024 or 2048)
+        for (int e = t; e < SEL_CAP; e += 1024) v[e] = e < count ? p.cand[e] : 0ull;
+        __syncthreads();
+        for (int k = 2; k <= N; k <<= 1)                           // bitonic sort, descending
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int e = t; e < N; e += 1024) {
+                    const int o = e ^ j;
+                    if (o > e) {
+                        const unsigned long long a = v[e], b = v[o];
+                        const bool desc = (e & k) == 0;
+                        if (desc ? a < b : a > b) { v[e] = b; v[o] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        for (int e = t; e < p.topk; e += 1024) {
+            const unsigned long long c = v[e];
+            p.key_out[e] = (unsigned)(c >> 32);
+            p.idx_out[e] = c ? (int)(0xffffffffu - (unsigned)c) : 0;
+        }
+        return;
+    }
+    // more survivors than the LDS sort holds (thousands of equal scores): top-k by repeated maximum over all the slots -- exact, slow, rare
+    unsigned long long last = ~0ull;
+    for (int r = 0; r < p.topk; ++r) {
+        unsigned long long best = 0ull;
+        for (int i = t; i < p.na; i += 1024) {
+            const unsigned k = p.key_in[i];
+            const unsigned long long c = k ? ((unsigned long long)k << 32) | (unsigned long long)(0xffffffffu - (unsigned)i) : 0ull;
+            if (c < last && c > best) best = c;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(best, off);
+            best = o > best ? o : best;
+        }
+        if ((t & 63) == 0) red[t >> 6] = best;
+        __syncthreads();
+        best = red[0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) best = red[w] > best ? red[w] : best;
+        __syncthreads();
+        if (t == 0) { p.key_out[r] = (unsigned)(best >> 32); p.idx_out[r] = best ? (int)(0xffffffffu - (unsigned)best) : 0; }
+        if (best == 0ull) {                                         // nothing left: the rest is empty
+            for (int e = r + 1 + t; e < p.topk; e += 1024) { p.key_out[e] = 0u; p.idx_out[e] = 0; }
+            return;
+        }
+        last = best;
+    }
+}
+
 // area of the intersection of two convex quadrilaterals, Sutherland-Hodgman in fp64 (oracle/postprocess.py)
 __device__ double quad_inter_area(const double (&p)[4][2], const double (&q)[4][2]) {
     double qa = 0.0;
@@ -194,60 +338,153 @@ __global__ __launch_bounds__(256) void pp_iou_kernel(const PPArgs p) {
     }
 }
 
-// greedy sweep in score order + range mask + compaction.  One workgroup; the bit matrix (<= 128 KB) sits in LDS.
-__global__ __launch_bounds__(256) void pp_sweep_kernel(const PPArgs p) {
-    __shared__ unsigned long long m[TOPK_MAX * (TOPK_MAX / 64)];
-    __shared__ int picked[TOPK_MAX];
-    __shared__ int npick;
+// OR over the wave of a 64-bit value (every lane gets it): quad, half-row and row steps by DPP, the four rows by readlane
+__device__ __forceinline__ unsigned wave_or32(unsigned x) {
+    x |= (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]
+    x |= (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xf, 0xf, true);      // quad_perm [2,3,0,1]
+    x |= (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0x141, 0xf, 0xf, true);     // row_half_mirror
+    x |= (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0x140, 0xf, 0xf, true);     // row_mirror
+    return (unsigned)__builtin_amdgcn_readlane((int)x, 0) | (unsigned)__builtin_amdgcn_readlane((int)x, 16) |
+           (unsigned)__builtin_amdgcn_readlane((int)x, 32) | (unsigned)__builtin_amdgcn_readlane((int)x, 48);
+}
+__device__ __forceinline__ unsigned long long wave_or64(unsigned long long x) {
+    return ((unsigned long long)wave_or32((unsigned)(x >> 32)) << 32) | wave_or32((unsigned)x);
+}
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long x, int l) {
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), l) << 32) |
+           (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, l);
+}
+
+#ifdef QV2X_PP_FINE                            // dev build (tools/bench_post.py <tag>): s_memtime stamps of the sweep kernel's phases
+__device__ long long g_pp_fine[8];
+#define PFINE(k) do { if (threadIdx.x == 0) g_pp_fine[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PFINE(k) do { } while (0)
+#endif
+// greedy sweep in score order + range mask + compaction.  One workgroup; the bit matrix (<= 136 KB, row pitch 17 words) sits in LDS.
+// Round 5: the sweep walked the candidates one by one (two readlanes, a branch and an LDS read per candidate behind the previous one's
+// result: 177 us per frame of 1000 candidates).  Now 64 candidates at a time: lane i holds candidate 64 c + i; inside the chunk only the
+// kept ones cost a step (scalar bit scan over "not yet removed", the kept one's own-chunk word by readlane); what the chunk's kept rows
+// remove further down is one wave-wide OR per later word.  Same greedy order, same result.
+__global__ __launch_bounds__(1024) void pp_sweep_kernel(const PPArgs p) {
+    constexpr int W = TOPK_MAX / 64, WP = W + 1;
+    __shared__ unsigned long long m[(TOPK_MAX + 1) * WP];
+    __shared__ unsigned long long pickw[W], insidew[W];
+    __shared__ int base[W + 1];
     const int n = p.topk, words = (n + 63) >> 6;
-    for (int t = threadIdx.x; t < n * (TOPK_MAX / 64); t += blockDim.x) m[t] = (t % (TOPK_MAX / 64)) < words ? p.mask[t] : 0ull;
-    __syncthreads();
-    if (threadIdx.x < 64) {                                        // one wave; lane w < 16 keeps word w of the removed set
-        unsigned long long mine = 0ull;
-        int np = 0;
-        for (int i = 0; i < n; ++i) {
-            if (p.key_out[i] == 0u) break;                          // sorted: nothing valid after the first empty slot
-            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mine, i >> 6);
-            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mine >> 32), i >> 6);
-            const unsigned long long r = ((unsigned long long)hi << 32) | lo;
-            if (!((r >> (i & 63)) & 1ull)) {
-                if (threadIdx.x == 0) picked[np] = i;
-                ++np;
-                if (threadIdx.x < TOPK_MAX / 64) mine |= m[i * (TOPK_MAX / 64) + threadIdx.x];
-            }
+    PFINE(0);
+    {   // the matrix into LDS: every thread's loads requested together (sixteen 8-byte words per thread at 1024 threads and 1024 rows)
+        unsigned long long tmp[W];
+#pragma unroll
+        for (int q = 0; q < W; ++q) {
+            const int t = threadIdx.x + q * 1024;
+            tmp[q] = (t < n * W && (t & (W - 1)) < words) ? p.mask[t] : 0ull;
         }
-        if (threadIdx.x == 0) npick = np;
+#pragma unroll
+        for (int q = 0; q < W; ++q) {
+            const int t = threadIdx.x + q * 1024;
+            if (t < n * W) m[(t / W) * WP + (t & (W - 1))] = tmp[q];
+        }
     }
+    if (threadIdx.x < W) { pickw[threadIdx.x] = 0ull; insidew[threadIdx.x] = 0ull; }
+    if (threadIdx.x < WP) m[TOPK_MAX * WP + threadIdx.x] = 0ull;
     __syncthreads();
-    // range mask on all eight corners, then compaction in pick order (serial prefix: <= 1000 entries)
-    __shared__ int inside[TOPK_MAX];
-    for (int t = threadIdx.x; t < npick; t += blockDim.x) {
-        const float* c = p.cand_corners + (size_t)p.idx_out[picked[t]] * 24;
-        bool in = true;
-        for (int k = 0; k < 8; ++k)
-            in = in && c[k * 3] >= p.range[0] && c[k * 3 + 1] >= p.range[1] && c[k * 3] <= p.range[3] && c[k * 3 + 1] <= p.range[4] &&
-                 (p.xy_only || (c[k * 3 + 2] >= p.range[2] && c[k * 3 + 2] <= p.range[5]));
-        inside[t] = in ? 1 : 0;
+    PFINE(1);
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        unsigned long long mine = 0ull;                            // lane w: word w of the removed set
+        // how many slots hold a candidate (sorted: the first `nvalid`): all the keys requested at once -- one global round trip, not one per chunk
+        int nvalid = 0;
+        {
+            unsigned kk[W];
+#pragma unroll
+            for (int q = 0; q < W; ++q) kk[q] = 64 * q + lane < n ? p.key_out[64 * q + lane] : 0u;
+#pragma unroll
+            for (int q = 0; q < W; ++q) nvalid += __builtin_popcountll(__builtin_amdgcn_ballot_w64(kk[q] != 0u));
+        }
+        for (int c = 0; c < words; ++c) {
+            const int i = 64 * c + lane;
+            if (64 * c >= nvalid) break;                           // sorted: nothing valid after the first empty slot
+            const unsigned long long vmask = nvalid - 64 * c >= 64 ? ~0ull : (1ull << (nvalid - 64 * c)) - 1ull;
+            const unsigned long long own = i < n ? m[i * WP + c] : 0ull;          // bit j: IoU(i, 64 c + j) > threshold, j > lane only
+            unsigned long long r = readlane64(mine, c);
+            unsigned long long picked = 0ull;
+            unsigned long long cand = vmask & ~r;
+            while (cand) {                                          // (wave-uniform)
+                const int b = __builtin_ctzll(cand);
+                picked |= 1ull << b;
+                r |= readlane64(own, b);
+                cand = vmask & ~r & ~((2ull << b) - 1ull);         // (b = 63: 2 << 63 = 0, the mask is all ones: nothing left)
+            }
+            if (lane == 0) pickw[c] = picked;
+            // what the chunk's kept rows remove further down: lane w ORs word w of every kept row (four rows requested at a time; row
+            // TOPK_MAX is zeros)
+            unsigned long long acc = 0ull, pp = picked;
+            const int col = lane < W ? lane : 0;
+            while (pp) {                                            // (wave-uniform)
+                int rows[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    rows[q] = pp ? 64 * c + __builtin_ctzll(pp) : TOPK_MAX;
+                    pp &= pp - 1ull;                                // (0 stays 0)
+                }
+                unsigned long long x[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x[q] = m[rows[q] * WP + col];
+                acc |= (x[0] | x[1]) | (x[2] | x[3]);
+            }
+            if (lane > c && lane < words) mine |= acc;
+        }
+    }
+    PFINE(2);
+    __syncthreads();
+    PFINE(3);
+    // range mask on all eight corners of the kept boxes, then compaction in score order (prefix of popcounts)
+    for (int i = threadIdx.x; i < words * 64; i += blockDim.x) {
+        bool in = false;
+        if ((pickw[i >> 6] >> (i & 63)) & 1ull) {
+            const v4f* cp = (const v4f*)(p.cand_corners + (size_t)p.idx_out[i] * 24);     // (96-byte records: six aligned float4, requested together)
+            float c[24];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { const v4f v = cp[q]; c[4 * q] = v[0]; c[4 * q + 1] = v[1]; c[4 * q + 2] = v[2]; c[4 * q + 3] = v[3]; }
+            in = true;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                in = in & (c[k * 3] >= p.range[0]) & (c[k * 3 + 1] >= p.range[1]) & (c[k * 3] <= p.range[3]) & (c[k * 3 + 1] <= p.range[4]) &
+                     (p.xy_only || (c[k * 3 + 2] >= p.range[2] && c[k * 3 + 2] <= p.range[5]));
+        }
+        const unsigned long long bits = __builtin_amdgcn_ballot_w64(in);          // (a wave = one word)
+        if ((threadIdx.x & 63) == 0) insidew[i >> 6] = bits;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         int o = 0;
-        for (int t = 0; t < npick; ++t) { const int f = inside[t]; inside[t] = f ? o : -1; o += f; }
+        for (int w = 0; w < words; ++w) { base[w] = o; o += __builtin_popcountll(insidew[w]); }
         *p.out_count = o;
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < npick; t += blockDim.x) {
-        const int o = inside[t];
-        if (o < 0) continue;
-        const int cand = p.idx_out[picked[t]];
-        for (int k = 0; k < 24; ++k) p.out_corners[(size_t)o * 24 + k] = p.cand_corners[(size_t)cand * 24 + k];
+    PFINE(4);
+    for (int i = threadIdx.x; i < words * 64; i += blockDim.x) {
+        const unsigned long long wbits = insidew[i >> 6];
+        if (!((wbits >> (i & 63)) & 1ull)) continue;
+        const int o = base[i >> 6] + __builtin_popcountll(wbits & ((1ull << (i & 63)) - 1ull));
+        const int cand = p.idx_out[i];
+        const v4f* cp = (const v4f*)(p.cand_corners + (size_t)cand * 24);
+        v4f cv[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) cv[q] = cp[q];
+#pragma unroll
+        for (int q = 0; q < 6; ++q)                                 // (the caller's array: no alignment promised -- dword stores)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) p.out_corners[(size_t)o * 24 + 4 * q + e] = cv[q][e];
         p.out_scores[o] = p.cand_score[cand];
         if (p.out_labels) p.out_labels[o] = p.cand_label[cand];
     }
+    PFINE(5);
 }
 
 struct Layout {
-    size_t prob, flag, pos, corners, score, key_in, key_out, idx_in, idx_out, mask, label, cand_label, cub, cub_bytes, total;
+    size_t prob, flag, pos, corners, score, key_in, key_out, idx_in, idx_out, mask, label, cand_label, sel, cand, cub, cub_bytes, total;
 };
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -261,10 +498,10 @@ Layout layout(int na) {
     l.key_in = take((size_t)na * 4); l.key_out = take((size_t)na * 4); l.idx_in = take((size_t)na * 4); l.idx_out = take((size_t)na * 4);
     l.mask = take((size_t)TOPK_MAX * (TOPK_MAX / 64) * 8);
     l.label = take((size_t)na * 4); l.cand_label = take((size_t)na * 4);
-    size_t a = 0, b = 0;
+    l.sel = take((size_t)(2 * SEL_BINS + SEL_WORDS) * 4); l.cand = take((size_t)SEL_CAP * 8);
+    size_t a = 0;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, a, (int*)nullptr, (int*)nullptr, na);
-    (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, b, (unsigned*)nullptr, (unsigned*)nullptr, (int*)nullptr, (int*)nullptr, na, 0, 32);
-    l.cub_bytes = a > b ? a : b;
+    l.cub_bytes = a;
     l.cub = take(l.cub_bytes);
     l.total = o;
     return l;
@@ -314,19 +551,26 @@ static int postprocess_run(const qv2x_postprocess_desc* d, int ncav, const float
     p.key_in = (unsigned*)(ws + l.key_in); p.key_out = (unsigned*)(ws + l.key_out);
     p.idx_in = (int*)(ws + l.idx_in); p.idx_out = (int*)(ws + l.idx_out); p.mask = (unsigned long long*)(ws + l.mask);
     p.label = (int*)(ws + l.label); p.cand_label = (int*)(ws + l.cand_label);
+    p.sel = (int*)(ws + l.sel); p.cand = (unsigned long long*)(ws + l.cand);
     p.out_corners = out_corners; p.out_scores = out_scores; p.out_labels = out_labels; p.out_count = out_count;
     hipStream_t st = (hipStream_t)stream;
     const int blocks = (na + 255) / 256;
     int rc;
     pp_score_kernel<<<blocks, 256, 0, st>>>(p);
+    pp_sel_clear_kernel<<<(2 * SEL_BINS + SEL_WORDS + 255) / 256, 256, 0, st>>>(p);
     size_t tb = l.cub_bytes;
     if ((rc = hip_check(hipcub::DeviceScan::ExclusiveSum(ws + l.cub, tb, p.flag, p.pos, na, st), "postprocess scan"))) return rc;
     pp_decode_kernel<<<blocks, 256, 0, st>>>(p);
-    tb = l.cub_bytes;
-    if ((rc = hip_check(hipcub::DeviceRadixSort::SortPairsDescending(ws + l.cub, tb, p.key_in, p.key_out, p.idx_in, p.idx_out, na, 0, 32, st),
-                        "postprocess sort"))) return rc;
+    // the first `topk` entries of the stable descending order (see SEL_* above)
+    const int hblocks = blocks < 64 ? blocks : 64;                 // (4096 LDS bins to clear and flush per workgroup)
+    pp_sel_hist_kernel<0><<<hblocks, 256, 0, st>>>(p);
+    pp_sel_pick_kernel<0><<<1, 1024, 0, st>>>(p);
+    pp_sel_hist_kernel<1><<<hblocks, 256, 0, st>>>(p);
+    pp_sel_pick_kernel<1><<<1, 1024, 0, st>>>(p);
+    pp_sel_compact_kernel<<<blocks, 256, 0, st>>>(p);
+    pp_sel_sort_kernel<<<1, 1024, 0, st>>>(p);
     pp_iou_kernel<<<p.topk, 256, 0, st>>>(p);
-    pp_sweep_kernel<<<1, 256, 0, st>>>(p);
+    pp_sweep_kernel<<<1, 1024, 0, st>>>(p);
     return hip_check(hipGetLastError(), who);
 }
 
@@ -357,3 +601,9 @@ extern "C" int qv2x_postprocess_late_f32(const qv2x_postprocess_desc* d, int nca
     return postprocess_run(d, ncav, cls, reg, dir, anchors, transforms, workspace, workspace_bytes, out_corners, out_scores, out_labels,
                            out_count, stream, "qv2x_postprocess_late_f32");
 }
+
+#ifdef QV2X_PP_FINE
+extern "C" __attribute__((visibility("default"))) int qv2x_debug_pp_fine(long long* host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(qv2x::g_pp_fine), sizeof(long long) * 8) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -104,6 +104,25 @@ def test_edge_cases():
     np.testing.assert_allclose(got_b, want_b, **TOL)
 
 
+def test_v2xreal_size_thousands_of_equal_scores():
+    """more equal top scores than the top-k selection's LDS sort holds (postprocess.hip: SEL_CAP = 2048): the exact slow path -- the stable
+    (h, w, anchor) order decides which 1000 of them enter the NMS, as on the oracle's side"""
+    rng = np.random.default_rng(11)
+    lidar = [-140.8, -40.0, -3.0, 140.8, 40.0, 1.0]
+    h, w = 100, 352
+    anchors = P.generate_anchor_box(lidar, 704, 200, 0.4, 0.4)
+    t = np.eye(4, dtype=np.float32)
+    reg = rng.normal(0.0, 0.05, size=(1, 14, h, w)).astype(np.float32)
+    cls = rng.normal(-1.0, 0.1, size=(1, 2, h, w)).astype(np.float32)              # above the threshold of 0.2, below the ties
+    ties = rng.choice(h * w, size=3000, replace=False)
+    cls.reshape(2, h * w)[0, ties] = 2.5                                            # 3000 equal scores at scattered cells: 1000 of them make the cut
+    want_b, want_s = P.post_process(cls, reg, None, anchors, t, lidar)
+    got_b, got_s = _run_gpu(_params(lidar, 704, 200), cls, reg, None, anchors, t)
+    assert len(want_s) > 100 and got_b.shape == want_b.shape
+    np.testing.assert_allclose(got_s, want_s, **TOL)
+    np.testing.assert_allclose(got_b, want_b, **TOL)
+
+
 def test_errors():
     import ctypes as C
     from quantv2x_amd import lib as L
