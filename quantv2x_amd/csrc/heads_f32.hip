@@ -140,11 +140,36 @@ __device__ __forceinline__ void rows_heads_tile(const HeadArgs& h, const FuseArg
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = b;
     }
-    if (active) loadB(wa, 0);
+    // Round 5: a last column tile of at most 16 real channels (72 = 2 x 32 + 8: the multi-class heads) runs on v_mfma_f32_16x16x4_f32 -- two
+    // 16-row tiles against 16 columns, HALF the 32 x 32 tile's MFMA time; the instruction sums its four k in ascending order onto the
+    // accumulator (profiles/r01_mfma_probe.log: bit-exact against the fmaf chain), so the outputs are the 32-wide form's bit for bit.
+    const bool tail16 = active && ct == nct - 1 && h.cout - 32 * ct <= 16;
+    v4f c16[2];
+    if (active && !tail16) loadB(wa, 0);
     __syncthreads();                                // rows (DMA or ds_write) of every wave have landed
     HTRACE(1);
 
-    if (active) {
+    if (tail16) {
+        const int j = lane & 15, kk = lane >> 4;
+        const float* wt = h.w + (size_t)(ct * 32 + j) * 4 + (kk == 1 ? 2 : (kk == 2 ? 1 : kk));     // (a quad is stored k0, k2, k1, k3)
+        const float bia = h.bias[ct * 32 + j];
+        c16[0] = v4f{bia, bia, bia, bia}; c16[1] = c16[0];
+        const float* a0p = rows + j * 256 + kk;
+        const float* a1p = rows + (16 + j) * 256 + kk;
+#pragma unroll 1
+        for (int q0 = 0; q0 < 64; q0 += 16) {
+            float bw[16], x0[16], x1[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) bw[t] = wt[(size_t)(q0 + t) * h.cout_pad * 4];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { x0[t] = a0p[((q0 + t) ^ j) << 2]; x1[t] = a1p[((q0 + t) ^ (16 + j)) << 2]; }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                c16[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[t], bw[t], c16[0], 0, 0, 0);
+                c16[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[t], bw[t], c16[1], 0, 0, 0);
+            }
+        }
+    } else if (active) {
         const int r = lane & 31;
         const float* ar = rows + r * 256;
         auto block = [&](const float2 (&bv)[8], int q0) __attribute__((always_inline)) {
@@ -176,13 +201,26 @@ __device__ __forceinline__ void rows_heads_tile(const HeadArgs& h, const FuseArg
     HTRACE(3);
     if (active) {
         float (*tr)[33] = (float (*)[33])(smem + ct * 32 * 33);
-        const int co = ct * 32 + (lane & 31);
-        const float d = h.da[co], z = h.za[co];
+        if (tail16) {                               // D of the 16 x 16 form: lane = column lane & 15, register r = row 4 (lane >> 4) + r
+            const int co = ct * 32 + (lane & 15);
+            const float d = h.da[co], z = h.za[co];
 #pragma unroll
-        for (int r2 = 0; r2 < 16; ++r2) {
-            float y = acc[r2];
-            if (d > 0.0f) y = (q_code(y, d, z) - z) * d;
-            tr[mfma32_row(r2, lane)][lane & 31] = y;
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int r2 = 0; r2 < 4; ++r2) {
+                    float y = c16[hf][r2];
+                    if (d > 0.0f) y = (q_code(y, d, z) - z) * d;
+                    tr[16 * hf + 4 * (lane >> 4) + r2][lane & 15] = y;
+                }
+        } else {
+            const int co = ct * 32 + (lane & 31);
+            const float d = h.da[co], z = h.za[co];
+#pragma unroll
+            for (int r2 = 0; r2 < 16; ++r2) {
+                float y = acc[r2];
+                if (d > 0.0f) y = (q_code(y, d, z) - z) * d;
+                tr[mfma32_row(r2, lane)][lane & 31] = y;
+            }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): this wave's LDS writes have landed
         __builtin_amdgcn_wave_barrier();
