@@ -68,7 +68,9 @@ __device__ __forceinline__ void rows_heads_tile(const HeadArgs& h, const FuseArg
                 if (a.feats) a.feats = (const float4*)((const float*)a.feats + sl->off[sc]);
                 else a.codes += sl->off[sc];
                 a.pairwise += (size_t)sc * a.L * a.L * 16;
-                v = fuse_cell_n<NA>(a, cell, lane);
+                // (round 5: the batched-round-trip form where fuse_att.hip takes it -- three code planes, more than one agent; same bits)
+                if (NA > 1 && !a.feats && a.levels == 3 && a.agents > 1) v = fuse_cell_b3<NA>(a, cell, lane);
+                else v = fuse_cell_n<NA>(a, cell, lane);
                 if (fa.fused) fa.fused[(size_t)m * 64 + lane] = v;
             }
             *(float4*)(rows + r * 256 + ((lane ^ r) << 2)) = v;

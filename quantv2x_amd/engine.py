@@ -260,10 +260,12 @@ class DeployedModel(nn.Module):
     """The hot path as HIP kernels.  Same call contract as the reference's model."""
     # a7-a11 as ONE launch (qv2x_fuse_heads_batch_f32: the fused map stays in LDS) from this many 32-cell tiles on -- four rounds of the
     # chip's 1280 resident workgroups; below it (one frame: a single round) the two launches are faster.  Measured at a batch of 32
-    # V2X-Real frames (profiles/r04_fuse_heads_times.log): single-agent scenes 1160 against 1224 us; scenes of four agents 780 against
-    # 632 us (eight serial cells per wave, each a chain of dependent gathers per agent) -- so only scenes of ONE agent take it.
+    # V2X-Real frames: round 4 (the agent-by-agent walk inside the tile kernel, profiles/r04_fuse_heads_times.log): single-agent scenes 1160
+    # against 1224 us, scenes of four agents 780 against 632 us -- only scenes of ONE agent took it.  Round 5 (the batched round trips of
+    # fuse_att.h:fuse_cell_b3 inside it, tools/bench_fuse.py 32 ring): scenes of two agents 1421 against 877 + 635 us, of four 2010 against
+    # 1428 + 629; of five / eight (the eight-agent instantiation: 140 registers) 2889 against 2450 / 3790 against 3156 -- up to FOUR agents.
     fuse_heads_min_tiles = 4 * 1280
-    fuse_heads_max_agents = 1
+    fuse_heads_max_agents = 4           # (with three code planes: the batched form needs them; otherwise scenes of one agent -- _one_launch_agents)
     # scenes of ONE agent: every head by table look-up on the agent's own codes (qv2x_table_heads_f32; see __init__)
     single_agent_tables = True
     table_heads = None                                                   # (engines that build their own heads -- the fp32 ones -- keep the general path)
@@ -715,7 +717,7 @@ class DeployedModel(nn.Module):
             # a world of one agent: the own code planes ARE the scene (pairwise here comes from qv2x_pairwise_from_poses_*: T[0][0] of a
             # world of one is the identity by construction, so the shortcut's contract holds without a read-back)
             return self._table_heads_out(own_codes, frames)
-        if frames * hw // 32 >= self.fuse_heads_min_tiles and n_agents <= self.fuse_heads_max_agents:    # one launch, no fused map in HBM (see finish)
+        if frames * hw // 32 >= self.fuse_heads_min_tiles and n_agents <= self._one_launch_agents():    # one launch, no fused map in HBM (see finish)
             preds = self.fuse_heads_scenes(L.ptr(gathered), agent_stride, level_stride, None, pairwise, [f * frame_stride for f in range(frames)],
                                            [n_agents] * frames, ego)
             if self.heads_single is not None and own_codes is not None:
@@ -813,6 +815,11 @@ class DeployedModel(nn.Module):
         if key is not None:
             self._ident_key, self._ident_val = key, ok
         return ok
+
+    def _one_launch_agents(self) -> int:
+        """most agents per scene for which a7-a11 run as one launch (see ``fuse_heads_max_agents``)"""
+        batched = self.has_codebook and self.levels == 3
+        return self.fuse_heads_max_agents if batched else min(self.fuse_heads_max_agents, 1)
 
     def _table_heads_out(self, codes, n: int) -> dict:
         """The model's output dict for ``n`` single-agent scenes from their code planes u8 [levels, n * H*W] (qv2x_table_heads_f32).
@@ -960,7 +967,7 @@ class DeployedModel(nn.Module):
             if torch.cuda.is_current_stream_capturing():
                 raise ValueError("pairwise_t_matrix on the host cannot be uploaded during HIP-graph capture: pass a device tensor")
             pairwise = pairwise.to(self.dev)
-        one_launch = taps is None and nb * hw // 32 >= self.fuse_heads_min_tiles and max(lens) <= self.fuse_heads_max_agents
+        one_launch = taps is None and nb * hw // 32 >= self.fuse_heads_min_tiles and max(lens) <= self._one_launch_agents()
         fused = None if one_launch else torch.empty((nb, hw, 256), dtype=torch.float32, device=self.dev)
         if one_launch:                                                   # decode + warp + fusion + heads, tile by tile: no fused map in HBM
             if self.has_codebook:

@@ -44,4 +44,6 @@ for n in (1, 2, 4, 5, 8):
     offs, cnts = [s * n * hw for s in range(S)], [n] * S
     us_f = timeit(lambda: eng.fuse_scenes(L.ptr(codes), hw, S * n * hw, None, pw, offs, cnts, fused))
     us_h = timeit(lambda: eng._run_heads(eng.heads, fused, S, hw))
-    print(f"agents {n} scenes {S} layout {layout}: fuse {us_f:8.1f} us ({us_f / S:6.1f} per scene, {us_f / S / n:5.1f} per agent)   heads {us_h:8.1f} us", flush=True)
+    us_fh = timeit(lambda: eng.fuse_heads_scenes(L.ptr(codes), hw, S * n * hw, None, pw, offs, cnts))
+    print(f"agents {n} scenes {S} layout {layout}: fuse {us_f:8.1f} us ({us_f / S:6.1f} per scene, {us_f / S / n:5.1f} per agent)   heads {us_h:8.1f} us   "
+          f"both in one launch {us_fh:8.1f} us ({us_fh - us_f - us_h:+.1f})", flush=True)
