@@ -72,6 +72,7 @@ def _run(layers, n, relu=1, use_batch=True):
     (2, [(256, 64, 2, 33, 47)]),                                                      # one layer through the batch entry, 64-column chunks
     (2, [(128, 64, 1, 31, 33), (64, 192, 1, 31, 33)]),                                # 64 / 192 columns: one pair, and three (items of ONE pair each)
     (2, [(32, 64, 2, 15, 17), (64, 64, 2, 15, 17)]),                                  # Cin 32: not a pixel-stationary shape -> the wave-tile form
+    (8, [(32, 64, 2, 64, 64), (96, 64, 2, 64, 64)]),                                  # ... and its 64 x 64-tile variant (>= 16384 wave tiles)
 ])
 def test_batch_equals_oracle_and_single(n, layers):
     got, want = _run(layers, n)
