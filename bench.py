@@ -307,8 +307,9 @@ def codebook_seg_line(full, B, device):
     return {"seg_num": eng.segs, "dict_size": eng.kc, "code_planes": eng.levels, "wire_bytes_per_agent_frame": eng.levels * hw,
             "frames_per_s": round(B / ms * 1e3, 1), "ms_per_step": round(ms, 4), "frames_per_step": B, "batches_in_flight": 1,
             "encode_us_per_batch": round(us, 1), "encode_tflops_as_executed": round(2.0 * macs * B / us / 1e6, 1),
-            "note": "the same V2X-Real single-agent batch with the (2, 256) codebook; ONE graph in flight (the headline runs two); the general "
-                    "a7-a11 path (six planes: the single-agent table shortcut holds four)"}
+            "heads_by_tables": eng.table_heads is not None,
+            "note": "the same V2X-Real single-agent batch with the (2, 256) codebook; ONE graph in flight (the headline runs two); six code planes: "
+                    "the single-agent table look-up reads its 565 KB of tables from global memory (round 5; the LDS form holds four planes)"}
 
 
 def pyramid_model_line(device):

@@ -274,7 +274,9 @@ int qv2x_fuse_heads_batch_f32(const qv2x_fuse_desc* desc /* host */, int n_scene
  *     y[co] = bias[co] + sum_l tables[l][code_l][co],    out = (clamp(rint(y / da[co]) + za[co], 0, 255) - za[co]) * da[co]   (da <= 0: no quantizer)
  * for co < c0 + c1: the first c0 channels go to out0 f32 NCHW [R / hw][c0][hw], the next c1 to out1 [R / hw][c1][hw] (either set may be empty:
  * c = 0 and a null pointer).  codes u8 [levels][R], rows agent-major; tables f32 [levels][kc][c0 + c1] = decode table x head weights, made by
- * the caller in float64 (engine.py); levels * kc * (c0 + c1) floats must fit the 160 KB of LDS.  A different fp32 association than
+ * the caller in float64 (engine.py); `levels` = code planes (1..16).  Tables of up to four planes that fit the 160 KB of LDS are copied there;
+ * larger ones (seg_num 2 x dict_size 256: six planes) are read row by row from global memory: c0 + c1 a multiple of 4, <= 128, the arrays
+ * 16-byte aligned.  A different fp32 association than
  * decode-then-GEMM: equal to ~1e-6 relative before the output quantizer (bounded in the tests like every head). */
 int qv2x_table_heads_f32(const uint8_t* codes, int R, int hw, int levels, int kc, int c0, int c1, const float* tables,
                          const float* bias, const float* da, const float* za, float* out0, float* out1, void* stream);

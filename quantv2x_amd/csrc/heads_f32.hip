@@ -487,18 +487,93 @@ extern "C" int qv2x_single_heads_lut_f32(const uint8_t* codes, int R, int hw, in
     return hip_check(hipGetLastError(), "qv2x_single_heads_lut_f32 launch");
 }
 
+namespace qv2x {
+// Round 5: the same look-up for tables that do NOT fit the LDS (seg_num 2 x dict_size 256: six planes of 256 rows x 92 channels = 565 KB;
+// three planes of 256 rows: 283 KB) -- the rows stay in global memory (they live in L2) and are fetched WHOLE: lanes = channels (a float4
+// per lane, two cells per instruction -- one per half-wave), so a row is one contiguous 368-byte request instead of 64 lanes picking 16
+// bytes out of 64 different rows.  A wave takes 32 cells: their code bytes up front (lane = cell), the sums in plane order with the
+// channel's quantizer in registers, the results through a [channel][cell] tile of its own LDS into NCHW stores of 128 contiguous bytes.
+// The same fp32 operations in the same order as table_heads_kernel.  CT % 4 == 0, planes <= 16.
+constexpr int TG_CELLS = 32, TG_PITCH = 33;
+__global__ __launch_bounds__(256) void table_heads_global_kernel(const uint8_t* __restrict__ codes, int R, int hw, int planes, int kc, int CT, int c0, int c1,
+                                                                 const float* __restrict__ tables, const float* __restrict__ bias, const float* __restrict__ da,
+                                                                 const float* __restrict__ za, float* __restrict__ out0, float* __restrict__ out1) {
+    extern __shared__ __attribute__((aligned(16))) float tg[];       // [4 waves][CT][TG_PITCH]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
+    float* tr = tg + (size_t)wave * CT * TG_PITCH;
+    const int run = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave));
+    const int m0 = run * TG_CELLS;
+    if (m0 >= R) return;
+    // this lane's cell (lanes 0-31; the upper half-wave mirrors it) and its code bytes
+    const int mc = m0 + l31 < R ? m0 + l31 : R - 1;
+    int code[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) code[p] = p < planes ? (int)codes[(size_t)p * R + mc] : 0;
+    const int ch = 4 * l31;                                           // this lane's four channels
+    const bool chan = ch < CT;
+    v4f b4 = {0.f, 0.f, 0.f, 0.f}, d4 = {-1.f, -1.f, -1.f, -1.f}, z4 = {0.f, 0.f, 0.f, 0.f};
+    if (chan) { b4 = *(const v4f*)(bias + ch); d4 = *(const v4f*)(da + ch); z4 = *(const v4f*)(za + ch); }
+    const float* tcol = tables + (chan ? ch : 0);
+#pragma unroll 2
+    for (int it = 0; it < TG_CELLS / 2; ++it) {                      // cells 2 it (lower half-wave) and 2 it + 1 (upper)
+        const int cell = 2 * it + half;
+        v4f t[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            if (p < planes) {                                         // (uniform)
+                const int lo = __builtin_amdgcn_readlane(code[p], 2 * it), hi = __builtin_amdgcn_readlane(code[p], 2 * it + 1);
+                t[p] = *(const v4f*)(tcol + (size_t)(p * kc + (half ? hi : lo)) * CT);
+            }
+        }
+        v4f y = b4;
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+            if (p < planes) y += t[p];
+        if (chan) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = y[e];
+                if (d4[e] > 0.0f) v = (q_code(v, d4[e], z4[e]) - z4[e]) * d4[e];
+                tr[(ch + e) * TG_PITCH + cell] = v;
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    // lane -> cell lane & 31; half-wave h stores the channels h, h + 2, ...
+    const int mm = m0 + l31;
+    if (mm < R) {
+        const int agent = mm / hw, cl = mm - agent * hw;
+        float* o0 = out0 ? out0 + (size_t)agent * c0 * hw + cl : nullptr;
+        float* o1 = out1 ? out1 + (size_t)agent * c1 * hw + cl : nullptr;
+        for (int c = half; c < CT; c += 2) {
+            const float v = tr[c * TG_PITCH + l31];
+            if (c < c0) o0[(size_t)c * hw] = v; else o1[(size_t)(c - c0) * hw] = v;
+        }
+    }
+}
+}  // namespace qv2x
+
 extern "C" int qv2x_table_heads_f32(const uint8_t* codes, int R, int hw, int levels, int kc, int c0, int c1, const float* tables,
                                     const float* bias, const float* da, const float* za, float* out0, float* out1, void* stream) {
     using namespace qv2x;
     const char* who = "qv2x_table_heads_f32";
     if (!codes || !tables || !bias || !da || !za || (!out0 && !out1)) return fail(QV2X_EINVAL, "%s: null pointer", who);
     const int CT = c0 + c1;
-    if (R <= 0 || hw <= 0 || R % hw || levels < 1 || levels > 4 || kc < 1 || kc > 256 || c0 < 0 || c1 < 0 || CT < 1 || (c0 > 0) != (out0 != nullptr) || (c1 > 0) != (out1 != nullptr))
-        return fail(QV2X_EINVAL, "%s: R=%d hw=%d levels=%d kc=%d c0=%d c1=%d (an output per non-empty channel set)", who, R, hw, levels, kc, c0, c1);
+    if (R <= 0 || hw <= 0 || R % hw || levels < 1 || levels > 16 || kc < 1 || kc > 256 || c0 < 0 || c1 < 0 || CT < 1 || (c0 > 0) != (out0 != nullptr) || (c1 > 0) != (out1 != nullptr))
+        return fail(QV2X_EINVAL, "%s: R=%d hw=%d levels=%d kc=%d c0=%d c1=%d (1..16 planes; an output per non-empty channel set)", who, R, hw, levels, kc, c0, c1);
     const int CT4 = (CT + 3) & ~3;
     const int ST = (CT4 / 4) % 2 ? CT4 : CT4 + 4;                     // row stride in floats, ST / 4 odd: 64 different rows start in 16 different bank quads
     const size_t lds = ((size_t)levels * kc * ST + 3 * CT4) * sizeof(float);
-    if (lds > 160 * 1024) return fail(QV2X_EINVAL, "%s: tables of %zu bytes do not fit the 160 KB of LDS", who, lds);
+    if (levels > 4 || lds > 160 * 1024) {                             // the tables stay in global memory (round 5)
+        if (CT % 4 || CT > 128 || ((uintptr_t)tables & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)da & 15) || ((uintptr_t)za & 15))
+            return fail(QV2X_EINVAL, "%s: tables past the 160 KB of LDS need c0 + c1 %% 4 == 0, <= 128, and 16-byte aligned arrays", who);
+        const size_t tl = (size_t)4 * CT * TG_PITCH * sizeof(float);
+        if (int rc = hip_check(hipFuncSetAttribute((const void*)table_heads_global_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl), who)) return rc;
+        const int runs = (R + TG_CELLS - 1) / TG_CELLS;
+        table_heads_global_kernel<<<(runs + 3) / 4, 256, tl, (hipStream_t)stream>>>(codes, R, hw, levels, kc, CT, c0, c1, tables, bias, da, za, out0, out1);
+        return hip_check(hipGetLastError(), "qv2x_table_heads_f32 launch");
+    }
     if (int rc = hip_check(hipFuncSetAttribute((const void*)table_heads_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), who)) return rc;
     int dev = 0, cus = 256, v = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;

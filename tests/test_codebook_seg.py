@@ -124,6 +124,19 @@ def test_hip_indices_exact_at_v2xreal_size(m, k):
     orc = Oracle(state)
     sc = synth.make_scene("v2xreal", n_agents=1, seed=3, n_points=60000)
     compare_frame(orc, eng, sc, state, every_layer=False)
+    # the single-agent look-up with tables past the LDS (six planes x 256 rows: qv2x_table_heads_f32 reads them from global memory, round 5)
+    # against the general path on the same frame: the head rule (+-1 LSB on < 1e-3 of the elements)
+    from _common import head_lsb
+    assert eng.table_heads is not None
+    dd = synth.scene_to_torch(sc, "cuda")
+    got = {k: v.clone() for k, v in eng(dd).items()}
+    eng.single_agent_tables = False
+    want = eng(dd)
+    torch.cuda.synchronize()
+    for k in want:
+        lsb = head_lsb(state, "_single" if k.endswith("_single") else "")
+        d = (got[k] - want[k]).abs()
+        assert float(d.max()) <= lsb * 1.001 and float((d > 1e-5).float().mean()) < 1e-3, (k, float(d.max()))
 
 
 @pytest.mark.gpu

@@ -1,0 +1,16 @@
+import os, sys, time
+sys.path.insert(0, "/root/repo")
+import torch, numpy as np, ctypes as C
+import bench
+from quantv2x_amd import lib as L
+lib = L.load()
+dev = torch.device("cuda", 0)
+hw, n = 35200, 32
+for (planes, kc, c0, c1) in ((6, 256, 72, 20), (3, 256, 72, 20), (3, 128, 72, 20)):
+    R = n * hw; CT = c0 + c1
+    codes = torch.randint(0, kc, (planes, R), dtype=torch.uint8, device=dev)
+    tab = torch.randn((planes, kc, CT), device=dev); b = torch.randn(CT, device=dev); da = torch.full((CT,), 0.05, device=dev); za = torch.full((CT,), 128.0, device=dev)
+    o0 = torch.empty((n, c0, hw), device=dev); o1 = torch.empty((n, c1, hw), device=dev)
+    f = lambda: L.check(lib.qv2x_table_heads_f32(L.ptr(codes), R, hw, planes, kc, c0, c1, L.ptr(tab), L.ptr(b), L.ptr(da), L.ptr(za), L.ptr(o0), L.ptr(o1), L.current_stream()), "t")
+    f(); torch.cuda.synchronize()
+    print(planes, kc, f"{bench.event_time_us(bench._graph_of(f), 10):.1f} us per 32 frames")
