@@ -377,7 +377,10 @@ class DeployedModel(nn.Module):
         # the *_single heads see one agent's own decoded feature: with the codebook that is three table rows per cell -- no GEMM
         self.single_by_tables = (self.heads_single is not None and self.has_codebook and self.levels <= 4
                                  and self.levels * self.kc * self.heads_single.cout * 4 <= 60 * 1024)
-        if self.single_by_tables:
+        # (round 5: tables past that kernel's LDS -- six planes x 256 rows -- through qv2x_table_heads_f32's global-memory form)
+        self.single_by_global_tables = (not self.single_by_tables and self.heads_single is not None and self.has_codebook and self.levels <= 16
+                                        and self.heads_single.cout % 4 == 0)
+        if self.single_by_tables or self.single_by_global_tables:
             self.heads_single.collapse_over_decode(lut, lut_bias, dev)
         # single-agent scenes (round 4): AttFusion over one agent is the identity, so EVERY head is a table look-up on the agent's own codes
         # (qv2x_table_heads_f32): cls | reg | dir [+ the *_single heads] stacked, tables = decode table x head weights in float64
@@ -878,6 +881,11 @@ class DeployedModel(nn.Module):
             L.check(self.lib.qv2x_single_heads_lut_f32(L.ptr(codes), n_agents * hw, hw, self.levels, self.kc, hd.cout, L.ptr(tab), L.ptr(tb),
                                                        L.ptr(hd.da), L.ptr(hd.za), L.ptr(sp), L.current_stream()), "qv2x_single_heads_lut_f32")
             return sp
+        if getattr(self, "single_by_global_tables", False):
+            tab, tb = hd.lut_tables
+            L.check(self.lib.qv2x_table_heads_f32(L.ptr(codes), n_agents * hw, hw, self.levels, self.kc, hd.cout, 0, L.ptr(tab), L.ptr(tb),
+                                                  L.ptr(hd.da), L.ptr(hd.za), L.ptr(sp), None, L.current_stream()), "qv2x_table_heads_f32")
+            return sp
         L.check(self.lib.qv2x_decode_heads_f32(L.ptr(codes), n_agents * hw, hw, self.levels, self.kc, L.ptr(self.lut), L.ptr(self.lut_bias),
                                                hd.cout, hd.cout_pad, L.ptr(hd.w), L.ptr(hd.bias), L.ptr(hd.da), L.ptr(hd.za),
                                                L.ptr(sp), L.current_stream()), "qv2x_decode_heads_f32")
@@ -887,7 +895,7 @@ class DeployedModel(nn.Module):
         """heads on the fused rows [nb*hw, 256] + *_single heads on the agents' own codes [levels, n_agents*hw]"""
         hw = self.fh * self.fw
         hd, hs = self.heads, self.heads_single
-        if getattr(self, "single_by_tables", False):                   # the single heads are a table look-up: their own small launch
+        if getattr(self, "single_by_tables", False) or getattr(self, "single_by_global_tables", False):   # the single heads are a table look-up: their own launch
             return self._run_heads(hd, fused, nb, hw), self._decode_heads_single(codes, n_agents)
         preds = torch.empty((nb, hd.cout, self.fh, self.fw), dtype=torch.float32, device=self.dev)
         sp = torch.empty((n_agents, hs.cout, self.fh, self.fw), dtype=torch.float32, device=self.dev)
