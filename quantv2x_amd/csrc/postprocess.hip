@@ -30,9 +30,11 @@ constexpr int MAX_CAVS = 8;
 // fell back to a merge sort of 22 launches, 140 us per frame for 70 400 slots) became a radix SELECT of the top-k + one workgroup's bitonic sort:
 // two 12-bit histogram passes over the score bits find the 24-bit prefix below which nothing can make the top-k; everything at or above it
 // (top-k + what shares the last prefix: a handful) is compacted as 64-bit keys (score bits, ~slot) -- distinct, so their descending order IS
-// the stable sort's -- and sorted in LDS.  More than SEL_CAP survivors (thousands of EQUAL scores) take a slow exact path in the same kernel.
+// the stable sort's -- and sorted in LDS.  More than SEL_CAP survivors means hundreds of (near-)EQUAL scores at the cut -- a quantized head
+// has at most 256 different logits per class -- and the sort kernel finishes the selection itself: the low byte of the score, then the slot
+// index (ties enter in slot order) by three more histogram passes of its one workgroup, exact.
 constexpr int SEL_BINS = 4096, SEL_CAP = 2048, SEL_WORDS = 16;
-enum { SEL_B1 = 0, SEL_ABOVE1, SEL_THR24, SEL_COUNT };
+enum { SEL_B1 = 0, SEL_ABOVE1, SEL_THR24, SEL_COUNT, SEL_ABOVE2 };
 
 struct PPArgs {
     const float* cls[MAX_CAVS]; const float* reg[MAX_CAVS]; const float* dir[MAX_CAVS]; const float* anchors[MAX_CAVS];
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(1024) void pp_sel_pick_kernel(const PPArgs p) {
         int b = found[0], ab = found[1];
         if (b < 0) { b = 0; ab = 0; }                              // fewer than `want` in all: everything non-empty survives
         if (PASS == 0) { sel[SEL_B1] = b; sel[SEL_ABOVE1] = ab; }
-        else sel[SEL_THR24] = (sel[SEL_B1] << 12) | b;
+        else { sel[SEL_THR24] = (sel[SEL_B1] << 12) | b; sel[SEL_ABOVE2] = ab; }
     }
 }
 
@@ -208,7 +210,6 @@ __global__ __launch_bounds__(256) void pp_sel_compact_kernel(const PPArgs p) {
 // the survivors in descending (score, -slot) order = the first entries of the stable descending sort; entries past them: empty
 __global__ __launch_bounds__(1024) void pp_sel_sort_kernel(const PPArgs p) {
     __shared__ unsigned long long v[SEL_CAP];
-    __shared__ unsigned long long red[16];
     const int t = threadIdx.x;
     const int count = p.sel[2 * SEL_BINS + SEL_COUNT];
     if (count <= SEL_CAP) {
@@ -235,32 +236,82 @@ __global__ __launch_bounds__(1024) void pp_sel_sort_kernel(const PPArgs p) {
         }
         return;
     }
-    // more survivors than the LDS sort holds (thousands of equal scores): top-k by repeated maximum over all the slots -- exact, slow, rare
-    unsigned long long last = ~0ull;
-    for (int r = 0; r < p.topk; ++r) {
-        unsigned long long best = 0ull;
-        for (int i = t; i < p.na; i += 1024) {
-            const unsigned k = p.key_in[i];
-            const unsigned long long c = k ? ((unsigned long long)k << 32) | (unsigned long long)(0xffffffffu - (unsigned)i) : 0ull;
-            if (c < last && c > best) best = c;
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long o = __shfl_xor(best, off);
-            best = o > best ? o : best;
-        }
-        if ((t & 63) == 0) red[t >> 6] = best;
+    // More survivors than the LDS sort holds: finish the radix select here.  Entries above the boundary prefix all make the cut (fewer than
+    // top-k of them); of the prefix's own entries the best r do -- by the score's low byte, ties by ascending slot.  A thread's slots are
+    // t, t + 1024, ...: slot >> 10 = its trip count, slot & 1023 = t.
+    __shared__ int hb[1024];
+    __shared__ int pick[4];
+    const unsigned thr24 = (unsigned)p.sel[2 * SEL_BINS + SEL_THR24];
+    const int r = p.topk - p.sel[2 * SEL_BINS + SEL_ABOVE1] - p.sel[2 * SEL_BINS + SEL_ABOVE2];     // >= 1
+    auto pass = [&](auto&& bin_of, const int want, const bool from_top) __attribute__((always_inline)) {
+        // histogram of bin_of(slot, key) (-1: not a member) into hb[0..1023]; pick[0] = the bin where the running count reaches `want`
+        // (from the top bin down, or from bin 0 up), pick[1] = the count before it
+        hb[t] = 0;
         __syncthreads();
-        best = red[0];
+        for (int i0 = t; i0 < p.na; i0 += 8 * 1024) {                // (eight keys per thread requested together: the pass is latency-bound)
+            unsigned kk[8];
 #pragma unroll
-        for (int w = 1; w < 16; ++w) best = red[w] > best ? red[w] : best;
-        __syncthreads();
-        if (t == 0) { p.key_out[r] = (unsigned)(best >> 32); p.idx_out[r] = best ? (int)(0xffffffffu - (unsigned)best) : 0; }
-        if (best == 0ull) {                                         // nothing left: the rest is empty
-            for (int e = r + 1 + t; e < p.topk; e += 1024) { p.key_out[e] = 0u; p.idx_out[e] = 0; }
-            return;
+            for (int q = 0; q < 8; ++q) kk[q] = i0 + q * 1024 < p.na ? p.key_in[i0 + q * 1024] : 0u;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int bn = i0 + q * 1024 < p.na ? bin_of(i0 + q * 1024, kk[q]) : -1;
+                if (bn >= 0) atomicAdd(&hb[bn], 1);
+            }
         }
-        last = best;
+        __syncthreads();
+        if (t == 0) {
+            int acc = 0, b = from_top ? 1023 : 0;
+            for (int s2 = 0; s2 < 1024; ++s2) {
+                b = from_top ? 1023 - s2 : s2;
+                if (acc + hb[b] >= want) break;
+                acc += hb[b];
+            }
+            pick[0] = b; pick[1] = acc;
+        }
+        __syncthreads();
+    };
+    pass([&](int, unsigned k) { return (k != 0u && (k >> 8) == thr24) ? (int)(k & 0xffu) : -1; }, r, true);
+    const unsigned T = (thr24 << 8) | (unsigned)pick[0];           // the exact score at the cut
+    const int ties = r - pick[1];                                   // how many slots with that score enter, lowest slots first
+    __syncthreads();
+    pass([&](int i, unsigned k) { return k == T ? (i >> 10) : -1; }, ties, false);
+    const int g = pick[0], ties2 = ties - pick[1];
+    __syncthreads();
+    pass([&](int i, unsigned k) { return (k == T && (i >> 10) == g) ? (i & 1023) : -1; }, ties2, false);
+    const int last_slot = (g << 10) | pick[0];                      // ties with slot <= last_slot enter: exactly `ties` of them
+    __syncthreads();
+    if (t == 0) pick[2] = 0;
+    for (int e = t; e < SEL_CAP; e += 1024) v[e] = 0ull;
+    __syncthreads();
+    for (int i0 = t; i0 < p.na; i0 += 8 * 1024) {
+        unsigned kk[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) kk[q] = i0 + q * 1024 < p.na ? p.key_in[i0 + q * 1024] : 0u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = i0 + q * 1024;
+            const unsigned k = kk[q];
+            if (i < p.na && (k > T || (k == T && i <= last_slot))) {
+                const int at = atomicAdd(&pick[2], 1);              // (exactly top-k entries, or all there are)
+                if (at < SEL_CAP) v[at] = ((unsigned long long)k << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = 2; k <= 1024; k <<= 1)                             // bitonic sort of 1024, descending
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int e = t, o = e ^ j;
+            if (o > e) {
+                const unsigned long long a = v[e], b = v[o];
+                const bool desc = (e & k) == 0;
+                if (desc ? a < b : a > b) { v[e] = b; v[o] = a; }
+            }
+            __syncthreads();
+        }
+    for (int e = t; e < p.topk; e += 1024) {
+        const unsigned long long c = v[e];
+        p.key_out[e] = (unsigned)(c >> 32);
+        p.idx_out[e] = c ? (int)(0xffffffffu - (unsigned)c) : 0;
     }
 }
 
@@ -530,6 +581,7 @@ static int postprocess_run(const qv2x_postprocess_desc* d, int ncav, const float
     if (ncav < 1 || ncav > MAX_CAVS) return fail(QV2X_EINVAL, "%s: 1..%d CAVs", who, MAX_CAVS);
     if (!cls || !reg || !anchors || !transforms || !workspace || !out_corners || !out_scores || !out_count) return fail(QV2X_EINVAL, "%s: null pointer", who);
     const int na1 = d->h * d->w * d->anchors_per_cell, na = na1 * ncav;
+    if ((long long)na1 * ncav > (1ll << 20)) return fail(QV2X_EINVAL, "%s: %lld anchors in all; the top-k selection indexes 2^20", who, (long long)na1 * ncav);
     const Layout l = layout(na);
     if (workspace_bytes < (int64_t)l.total) return fail(QV2X_EINVAL, "%s: workspace of %lld bytes, need %lld", who, (long long)workspace_bytes, (long long)l.total);
     if ((uintptr_t)workspace & 255) return fail(QV2X_EALIGN, "%s: workspace must be 256-byte aligned", who);

@@ -121,6 +121,21 @@ def test_v2xreal_size_thousands_of_equal_scores():
     assert len(want_s) > 100 and got_b.shape == want_b.shape
     np.testing.assert_allclose(got_s, want_s, **TOL)
     np.testing.assert_allclose(got_b, want_b, **TOL)
+    # a quantized head: eight different logits over all 70 400 anchors -- thousands of ties at every level, the cut inside one of them
+    levels = np.array([-0.5, 0.0, 0.4, 0.9, 1.3, 1.8, 2.2, 3.0], np.float32)
+    cls = levels[rng.integers(0, 8, size=(1, 2, h, w))]
+    far = dict(rtol=0, atol=2e-5)                                      # (boxes out to |x| = 140 m: an fp32 ulp there is 1.5e-5)
+    want_b, want_s = P.post_process(cls, reg, None, anchors, t, lidar)
+    got_b, got_s = _run_gpu(_params(lidar, 704, 200), cls, reg, None, anchors, t)
+    assert len(want_s) > 100 and got_b.shape == want_b.shape
+    np.testing.assert_allclose(got_s, want_s, **TOL)
+    np.testing.assert_allclose(got_b, want_b, **far)
+    # every anchor the same score: the first 1000 slots enter
+    cls[:] = 1.0
+    want_b, want_s = P.post_process(cls, reg, None, anchors, t, lidar)
+    got_b, got_s = _run_gpu(_params(lidar, 704, 200), cls, reg, None, anchors, t)
+    assert got_b.shape == want_b.shape
+    np.testing.assert_allclose(got_b, want_b, **far)
 
 
 def test_errors():
