@@ -199,6 +199,67 @@ def test_hip_encode_forms_agree_on_random_heads(m, k, levels):
     np.testing.assert_array_equal(got["wave"], want)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,k,levels", [(1, 128, 3), (2, 256, 3), (4, 64, 2), (1, 96, 3), (2, 64, 1)])
+@pytest.mark.parametrize("fp32_rows", [False, True])
+def test_hip_encode64_forms_equal_the_oracle(m, k, levels, fp32_rows):
+    """the Pyramid model's 64-wide encode kernel on random heads in its blob layout: the workgroup form (launches below 2048 cells) and the
+    wave-per-32-cells form (round 5: from 2048 cells on), int8 and fp32 rows, ragged sizes -- every plane equal to oracle/qv2x_oracle.c"""
+    import ctypes as C
+    from oracle.spec import _f32, _p, lib as olib
+    from quantv2x_amd import lib as L
+    from quantv2x_amd.engine import _pack_k4p
+    lib = L.load()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(77 * m + k + levels)
+    ke, d = m * k, 64 // m
+    blobs, heads = [], []
+    for l in range(levels):
+        last = l + 1 == levels
+        w = [rng.standard_normal((64, 64)).astype(np.float32) / 8 for _ in range(3)]
+        b = [rng.standard_normal(64).astype(np.float32) * 0.1 for _ in range(3)]
+        if last:
+            w[2][:] = 0; b[2][:] = 0
+        cb = np.zeros((ke, 64), np.float32)
+        for sg in range(m):
+            cb[sg * k:(sg + 1) * k, sg * d:(sg + 1) * d] = rng.standard_normal((k, d)).astype(np.float32)
+        parts = [_pack_k4p(w[0]), b[0], _pack_k4p(w[1]), b[1], _pack_k4p(w[2]), b[2], _pack_k4p(cb), cb, np.zeros(ke, np.float32)]
+        flat = np.concatenate([p.reshape(-1) for p in parts])
+        assert flat.size == lib.qv2x_codebook64_level_floats(ke)
+        t = torch.from_numpy(flat).to(dev)
+        L.check(lib.qv2x_codebook64_c2_f32(C.c_void_p(t.data_ptr() + 4 * (flat.size - ke - ke * 64)), ke, C.c_void_p(t.data_ptr() + 4 * (flat.size - ke)),
+                                           L.current_stream()), "c2")
+        blobs.append(t); heads.append((w, b, cb))
+    ptrs = (C.c_void_p * levels)(*[b.data_ptr() for b in blobs])
+    for (n, h, w_) in ((1, 9, 37), (2, 35, 41)):                       # 333 cells: the workgroup form; 2870: the wave form (ragged last wave)
+        M = n * h * w_
+        dsc = L.EncodeDesc()
+        dsc.n, dsc.h, dsc.w, dsc.levels, dsc.kc, dsc.in_zx, dsc.in_delta, dsc.segs = n, h, w_, levels, k, 117, 0.0173, m
+        codes = torch.full((levels * m, M), 255, dtype=torch.uint8, device=dev)
+        if fp32_rows:
+            xf = rng.standard_normal((n, h + 2, w_ + 2, 64)).astype(np.float32)
+            xd = torch.from_numpy(xf).to(dev)
+            L.check(lib.qv2x_codebook_encode64_f32in(C.byref(dsc), 64, L.ptr(xd), ptrs, L.ptr(codes), L.current_stream()), "f32in")
+            rows = xf[:, 1:-1, 1:-1].reshape(M, 64)
+        else:
+            x = rng.integers(-128, 128, size=(n, h + 2, w_ + 2, 64), dtype=np.int8)
+            xd = torch.from_numpy(x).to(dev)
+            L.check(lib.qv2x_codebook_encode64_f32(C.byref(dsc), 64, L.ptr(xd), ptrs, L.ptr(codes), L.current_stream()), "i8")
+            rows = ((x[:, 1:-1, 1:-1].astype(np.float32) + np.float32(128 - 117)) * np.float32(0.0173)).reshape(M, 64)
+        keep = []
+
+        def arr(fn):
+            p = (C.c_void_p * levels)()
+            for l in range(levels):
+                a = _f32(fn(heads[l])); keep.append(a); p[l] = a.ctypes.data
+            return p
+        want = np.zeros((levels * m, M), np.uint8)
+        olib().orc_codebook_encode_seg(_p(_f32(np.ascontiguousarray(rows))), M, levels, k, 64, m,
+                                       arr(lambda t: t[0][0]), arr(lambda t: t[1][0]), arr(lambda t: t[0][1]), arr(lambda t: t[1][1]),
+                                       arr(lambda t: t[0][2]), arr(lambda t: t[1][2]), arr(lambda t: t[2]), _p(want), None)
+        np.testing.assert_array_equal(codes.cpu().numpy(), want, err_msg=f"{M} cells")
+
+
 # ---- the Pyramid model's 64-wide codebook with seg_num 2 / dict_size 256 (opv2v / dairv2x Codebook/Pyramid yamls) ---------------------
 def _pyramid_state():
     from _common import calibrated_pyramid_plugin
