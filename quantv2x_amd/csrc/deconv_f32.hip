@@ -170,7 +170,7 @@ __device__ long long g_dps_fine[3][1024][12];
 #define DFINE(k) do { } while (0)
 #endif
 
-template <int K, int MT>
+template <int K, int MT, bool F32IN = false>
 __device__ __forceinline__ void deconv_ps_item(const DeconvArgs& a, const int item) {
     const int NP = a.np;
     const int lane = threadIdx.x & 63, par = lane >> 5, l31 = lane & 31, half = par;
@@ -194,7 +194,32 @@ __device__ __forceinline__ void deconv_ps_item(const DeconvArgs& a, const int it
     // this lane's MT pixels (one per 32-pixel tile), their parity's K / 2 channels as fp32: m[i][j] = channel 2 j + par
     float m[MT][K / 2];
     int pixbase[MT];            // padded output pixel index at sub-position (0, 0); -1 past the end
-    {
+    if constexpr (F32IN) {
+        // the input is an fp32 map [M][K] (a fused pyramid level, the decoded feature): the lane's row, eight float4 at a time; half-wave
+        // `par` keeps k = 2 j + par
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m_raw = (tm * MT + i) * 32 + l31;
+            const int mm = m_raw < a.M ? m_raw : a.M - 1;
+            const int img = mm / (a.h * a.wd), rem = mm - img * (a.h * a.wd);
+            const int y = rem / a.wd, x = rem - y * a.wd;
+            pixbase[i] = m_raw < a.M ? (img * (a.h * a.s + 2) + y * a.s + 1) * (a.wd * a.s + 2) + x * a.s + 1 : -1;
+            const v4f* src = (const v4f*)((const float*)a.in + (size_t)mm * K);
+#pragma unroll
+            for (int c0 = 0; c0 < K / 4; c0 += 4) {
+                v4f rawf[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) rawf[c] = src[c0 + c];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float e0 = rawf[c][0], e1 = rawf[c][1], e2 = rawf[c][2], e3 = rawf[c][3];
+                    m[i][2 * (c0 + c)] = par ? e1 : e0;
+                    m[i][2 * (c0 + c) + 1] = par ? e3 : e2;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else {
         v4i raw[MT][K / 16];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -350,15 +375,16 @@ __global__ __launch_bounds__(256) void deconv_f32_batch_kernel(const DeconvBatch
 // falling Cin, so the long items run first and the launch's tail is made of short ones.  Cin 64: two pixel tiles per item (64 operand
 // registers; a weight load feeds four MFMAs), all 128 columns of a 64 -> 128 s = 1 deblock; Cin 128 | 256: 512 columns per item.
 constexpr int ps_mt(int k) { return k == 64 ? 2 : 1; }
+template <bool F32IN>
 __global__ __launch_bounds__(256, 2) void deconv_ps_batch_kernel(const DeconvBatch b) {
     const int item = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (item >= b.tile_end[b.n - 1]) return;
     int l = 0, begin = 0;
     while (l < b.n - 1 && item >= b.tile_end[l]) { begin = b.tile_end[l]; ++l; }
     const DeconvArgs& a = b.a[l];                                      // (wave-uniform index into the kernel argument: scalar loads)
-    if (a.cin == 256) deconv_ps_item<256, ps_mt(256)>(a, item - begin);
-    else if (a.cin == 128) deconv_ps_item<128, ps_mt(128)>(a, item - begin);
-    else deconv_ps_item<64, ps_mt(64)>(a, item - begin);
+    if (!F32IN && a.cin == 256) deconv_ps_item<256, ps_mt(256), false>(a, item - begin);      // (fp32 rows of 256 channels keep the wave-tile kernel: registers)
+    else if (a.cin == 128) deconv_ps_item<128, ps_mt(128), F32IN>(a, item - begin);
+    else deconv_ps_item<64, ps_mt(64), F32IN>(a, item - begin);
 }
 
 // does the pixel-stationary form take this layer?  Cin of 64 | 128 | 256 (the operand registers are sized at compile time)
@@ -451,7 +477,7 @@ extern "C" int qv2x_deconv_i8_batch(const qv2x_deconv_desc* descs, int n, const 
 #endif
         while (cap > 1 && total < 2560) total = ps_plan(b, n, cap >>= 1);
         b.n = n;
-        deconv_ps_batch_kernel<<<dim3((total + 3) / 4), 256, 0, (hipStream_t)stream>>>(b);
+        deconv_ps_batch_kernel<false><<<dim3((total + 3) / 4), 256, 0, (hipStream_t)stream>>>(b);
         return hip_check(hipGetLastError(), "qv2x_deconv_i8_batch launch");
     }
     int total = 0;
@@ -468,8 +494,16 @@ extern "C" int qv2x_deconv_i8_batch(const qv2x_deconv_desc* descs, int n, const 
 
 extern "C" int qv2x_deconv_f32in(const qv2x_deconv_desc* d, const float* in, const float* w, const float* bias, int8_t* out, void* stream) {
     using namespace qv2x;
-    DeconvArgs a;
+    DeconvBatch b{};
+    DeconvArgs& a = b.a[0];
     if (int rc = deconv_args(d, (const int8_t*)in, w, bias, out, "qv2x_deconv_f32in", a)) return rc;
+    if (ps_takes(a) && a.cin <= 128) {      // round 5: the pixel-stationary items (a lane's row of the fp32 map straight into operand registers)
+        int cap = 8, total = ps_plan(b, 1, cap);
+        while (cap > 1 && total < 2560) total = ps_plan(b, 1, cap >>= 1);
+        b.n = 1;
+        deconv_ps_batch_kernel<true><<<dim3((total + 3) / 4), 256, 0, (hipStream_t)stream>>>(b);
+        return hip_check(hipGetLastError(), "qv2x_deconv_f32in launch");
+    }
     const int tiles = ((a.M + 31) / 32) * (a.ncols / 32);
     deconv_f32_kernel<1, true><<<(tiles + 3) / 4, 256, 0, (hipStream_t)stream>>>(a);
     return hip_check(hipGetLastError(), "qv2x_deconv_f32in launch");

@@ -86,3 +86,29 @@ def test_many_items_take_eight_pairs_per_item():
     """enough pixels for the rule's longest items (finding 14): 12 frames of 50 x 88 -> 8 column pairs per item at Cin 128 | 256"""
     got, want = _run([(64, 128, 1, 100, 88), (128, 128, 2, 50, 44), (256, 128, 4, 25, 22)], 12, relu=0)
     np.testing.assert_array_equal(got[..., 16:], want[..., 16:])
+
+
+@pytest.mark.parametrize("cin,cout,s,n,h,w", [(64, 128, 1, 2, 37, 45), (128, 128, 2, 2, 19, 23), (256, 128, 4, 1, 9, 11), (64, 64, 1, 1, 5, 7), (32, 64, 2, 1, 9, 9)])
+def test_f32in_equals_oracle(cin, cout, s, n, h, w):
+    """qv2x_deconv_f32in (the Pyramid model's deblocks and first 1x1 on fp32 maps): the pixel-stationary items for 64 / 128 input channels
+    (round 5), the wave-tile kernel for the rest -- against orc_deconv_f32in, bit for bit"""
+    from oracle.spec import _cf, _f32, _p, lib as olib
+    from quantv2x_amd import lib as L
+    lib = L.load()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(cin + cout + s + n)
+    wdeq, bias, packed = _layer(rng, cin, cout, s)
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    H, W, ctot, c0, da, za = h * s, w * s, cout + 16, 16, 0.043, 1.0
+    want = np.zeros((n, H, W, ctot), np.uint8)
+    olib().orc_deconv_f32in(_p(x), n, h, w, cin, _p(wdeq), _p(_f32(bias)), cout, s, 1, _cf(da), _cf(za), _p(want), ctot, c0)
+    out = torch.full((n, H + 2, W + 2, ctot), -128, dtype=torch.int8, device=dev)
+    d = L.DeconvDesc()
+    d.n, d.h, d.w, d.cin, d.cout, d.s, d.in_zx, d.in_delta = n, h, w, cin, cout, s, 0, 1.0
+    d.out_ctotal, d.out_c0, d.relu, d.out_delta, d.out_zp, d.out_h, d.out_w = ctot, c0, 1, da, za, H, W
+    xt, wt, bt = torch.from_numpy(x).to(dev), torch.from_numpy(packed).to(dev), torch.from_numpy(bias).to(dev)
+    L.check(lib.qv2x_deconv_f32in(C.byref(d), L.ptr(xt), L.ptr(wt), L.ptr(bt), L.ptr(out), L.current_stream()), "f32in")
+    torch.cuda.synchronize()
+    got = (out[:, 1:-1, 1:-1].cpu().numpy().astype(np.int16) + 128).astype(np.uint8)
+    np.testing.assert_array_equal(got[..., 16:], want[..., 16:])
+    assert (got[..., :16] == 0).all()
