@@ -39,7 +39,7 @@ for B in [int(a) for a in sys.argv[1:]] or [8, 16, 32]:
         out[f"frames_per_s_inflight{F}"] = round(B * steps / dt, 1)
         del reps, engines
     _, stages = bench.rooflines(eng, full, B, iters=10)
-    out["stages"] = {k: {"us_per_frame": round(v["us_per_batch"] / B, 2), "frac": v["frac"]} for k, v in stages.items()}
+    out["stages"] = {k: {"us_per_frame": round(v["us_per_batch"] / B, 2), "frac": v["frac"]} for k, v in stages.items() if "us_per_batch" in v}
     print(json.dumps(out), flush=True)
     del eng
     torch.cuda.empty_cache()
