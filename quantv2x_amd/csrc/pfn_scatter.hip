@@ -10,13 +10,13 @@ namespace qv2x {
 // Round 4: FOUR pillars per wave, their headers and first point slots requested together (a pillar of a 60k-point sweep holds 2.2
 // points on average): one wave per pillar was a chain of three dependent round trips (header -> points -> points again) per 64 bytes of
 // output -- 268 us per batch of 32 sweeps, 0.27 of HBM.  Slots past the prefetched ones take the per-slot loop as before.
-// Round 5: TWO prefetched slots and eight workgroups per CU (209 -> 190 us; four slots at that occupancy 231, eight pillars per wave 216).
+// Round 5: TWO prefetched slots and six workgroups per CU (209 -> 190-202 us; eight: the same time with 16 bytes of scratch; four slots 231, eight pillars per wave 216).
 // What did NOT move it (profiles/r05_pfn_variants.log): the pillar mean by a table reciprocal + one exact correction step instead of three
 // IEEE divisions, and the two quantizers as common.h's sandwich -- a third fewer VALU instructions, the same 197-199 us: the kernel waits
 // for its scalar loads (34 s_load_dwordx4 per wave, lgkmcnt(0) each time -- scalar loads return out of order), not for the VALU.
 constexpr int PFN_PB = 4, PFN_PQ = 2;
 
-__global__ __launch_bounds__(256, 8) void pfn_scatter_kernel(const float4* __restrict__ vf, const int4* __restrict__ coords,
+__global__ __launch_bounds__(256, 6) void pfn_scatter_kernel(const float4* __restrict__ vf, const int4* __restrict__ coords,
                                                           const int* __restrict__ npts, int M, int P,
                                                           const qv2x_pfn_params prm, int8_t* __restrict__ canvas,
                                                           int N, int ny, int nx) {
