@@ -379,7 +379,7 @@ static int conv3x3_entry(const qv2x_conv_desc* d, const int8_t* in, const int8_t
     if (res_mode) {
         if (multi || a.cout != 64 || a.gc[0] != 64 || !res || ((uintptr_t)res & 15) || (res_mode != 2 && res_mode != 3))
             return fail(QV2X_EINVAL, "qv2x_conv3x3_i8_res: one input group of 64 channels, cout 64, res_mode 2 | 3, aligned shortcut");
-        return res_mode == 2 ? launch_dma<64, 64, 2, 2, 64, false, 3, 6, 2>(a, st) : launch_dma<64, 64, 2, 2, 64, false, 3, 6, 3>(a, st);
+        return res_mode == 2 ? launch_dma<64, 64, 2, 2, 64, false, 3, 4, 2>(a, st) : launch_dma<64, 64, 2, 2, 64, false, 3, 4, 3>(a, st);   // (four workgroups per CU: the shortcut epilogue spilled 104 bytes at six, 28 at five)
     }
 #ifndef QV2X_CONV_FORCE
 #define QV2X_CONV_FORCE 0     // dev builds: 1 never the 128 x 128 variant, 2 also BK = 128 instead of 256, 3 only BK = 128 instead of 256
