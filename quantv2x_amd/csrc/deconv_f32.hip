@@ -195,7 +195,7 @@ __device__ __forceinline__ void deconv_ps_item(const DeconvArgs& a, const int it
     float m[MT][K / 2];
     int pixbase[MT];            // padded output pixel index at sub-position (0, 0); -1 past the end
     if constexpr (F32IN) {
-        // the input is an fp32 map [M][K] (a fused pyramid level, the decoded feature): the lane's row, eight float4 at a time; half-wave
+        // the input is an fp32 map [M][K] (a fused pyramid level, the decoded feature): the lane's row, sixteen float4 at a time; half-wave
         // `par` keeps k = 2 j + par
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -206,12 +206,12 @@ __device__ __forceinline__ void deconv_ps_item(const DeconvArgs& a, const int it
             pixbase[i] = m_raw < a.M ? (img * (a.h * a.s + 2) + y * a.s + 1) * (a.wd * a.s + 2) + x * a.s + 1 : -1;
             const v4f* src = (const v4f*)((const float*)a.in + (size_t)mm * K);
 #pragma unroll
-            for (int c0 = 0; c0 < K / 4; c0 += 4) {
-                v4f rawf[4];
+            for (int c0 = 0; c0 < K / 4; c0 += 16) {
+                v4f rawf[16];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) rawf[c] = src[c0 + c];
+                for (int c = 0; c < 16; ++c) rawf[c] = src[c0 + c];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
+                for (int c = 0; c < 16; ++c) {
                     const float e0 = rawf[c][0], e1 = rawf[c][1], e2 = rawf[c][2], e3 = rawf[c][3];
                     m[i][2 * (c0 + c)] = par ? e1 : e0;
                     m[i][2 * (c0 + c) + 1] = par ? e3 : e2;
