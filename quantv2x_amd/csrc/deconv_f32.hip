@@ -164,7 +164,7 @@ __device__ __forceinline__ void deconv_tile(const DeconvArgs& a, const int tile,
 constexpr int PS_NPF = 4;                     // weight quads in flight per tile
 
 #ifdef QV2X_DPS_FINE                          // dev build (tools/dps_fine.py): s_memtime stamps of every 36th item of every Cin
-__device__ long long g_dps_fine[3][1024][12];
+__device__ long long g_dps_fine[3][1024][20];                  // (up to eight pairs per item: 2 + 2 x 8 stamps)
 #define DFINE(k) do { if (lane == 0 && item % 36 == 0 && item < 36 * 1024) g_dps_fine[K == 256 ? 0 : K == 128 ? 1 : 2][item / 36][(k)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define DFINE(k) do { } while (0)
@@ -511,6 +511,6 @@ extern "C" int qv2x_deconv_f32in(const qv2x_deconv_desc* d, const float* in, con
 
 #ifdef QV2X_DPS_FINE
 extern "C" __attribute__((visibility("default"))) int qv2x_debug_dps_fine(long long* host) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(qv2x::g_dps_fine), sizeof(long long) * 3 * 1024 * 12) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(qv2x::g_dps_fine), sizeof(long long) * 3 * 1024 * 20) == hipSuccess ? 0 : -1;
 }
 #endif

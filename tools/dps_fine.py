@@ -17,10 +17,10 @@ for _ in range(3):
     e0.record(); eng._deconv_batch(items, n); e1.record()
 torch.cuda.synchronize()
 raw = C.CDLL(L.LIB_PATH)
-buf = np.zeros((3, 1024, 12), np.int64)
+buf = np.zeros((3, 1024, 20), np.int64)
 assert raw.qv2x_debug_dps_fine(buf.ctypes.data_as(C.c_void_p)) == 0
 print(f"{n}-frame launch: {e0.elapsed_time(e1) * 1e3:.0f} us")
-for li, (K, NP) in enumerate([(256, 4), (128, 4), (64, 2)]):
+for li, (K, NP) in enumerate([(256, 8), (128, 8), (64, 2)]):                     # (pairs per item at a batch of 32 frames)
     b = buf[li]
     b = b[b[:, 0] > 0]
     d = np.diff(b[:, :2 + 2 * NP], axis=1)
