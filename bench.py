@@ -684,8 +684,8 @@ def dry_run_ranks(rank, world, args):
     return 0 if ok else 1
 
 
-def rehearse_line(W, B, steps, warmup, device, engine=None):
-    """Rank 0's step of the W-GPU line on one GPU (``AgentShardedModel(emulate_world=W)``): the own agent's B frames encoded, the own payload
+def rehearse_line(W, B, steps, warmup, device, engine=None, rank=0):
+    """Rank ``rank``'s step of the W-GPU line on one GPU (``AgentShardedModel(emulate_world=W)``): the own agent's B frames encoded, the own payload
     copied into every agent slot with the agents' poses beside it (a device copy where the all-gather would be), then the pairwise matrices, the
     fusion of W agents and the heads -- its two stages timed with HIP events.  ``engine``: a deployed model of the workload's shape to reuse
     (the N = 1 line's own engine serves W = 2..4: same V2X-Real model); None builds (calibrates) the workload's model."""
@@ -700,19 +700,19 @@ def rehearse_line(W, B, steps, warmup, device, engine=None):
         eng = engine
         if eng is None:
             _, eng, _, _ = build_engine(max(1, min(32, os.cpu_count() or 8)), multiclass=wl["multiclass"])
-        _, _, mine, poses = frame_batch(W, 0, B, device, layout=wl["layout"], max_cav=wl["max_cav"], own_only=True)
+        _, _, mine, poses = frame_batch(W, rank, B, device, layout=wl["layout"], max_cav=wl["max_cav"], own_only=True)
         n_points = N_POINTS
     finally:
         SHAPE, N_POINTS = keep
     pose_t = torch.from_numpy(np.stack(poses)).to(device)
     tables = eng.single_agent_tables
-    sh = AgentShardedModel(eng, frames=B, max_cav=wl["max_cav"], emulate_world=W, emulate_poses=pose_t)
-    out = sh.forward(mine, pose_t[0])
+    sh = AgentShardedModel(eng, frames=B, max_cav=wl["max_cav"], emulate_world=W, emulate_poses=pose_t, emulate_rank=rank)
+    out = sh.forward(mine, pose_t[rank])
     torch.cuda.synchronize()
     pre, post = sh.stage_graphs()
 
     def step():
-        sh.forward(mine, pose_t[0])
+        sh.forward(mine, pose_t[rank])
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -726,25 +726,28 @@ def rehearse_line(W, B, steps, warmup, device, engine=None):
     eng.single_agent_tables = tables
     hw = eng.fh * eng.fw
     return {"metric": "frames/sec of ONE rank's step (rehearsal of an N-GPU run on one GPU; NOT a multi-GPU measurement)",
-            "value": round(B * steps / dt, 2), "unit": "frames/s", "n_gpus": 1, "rehearsal_of_n_gpus": W, "steps": steps,
+            "value": round(B * steps / dt, 2), "unit": "frames/s", "n_gpus": 1, "rehearsal_of_n_gpus": W, "rehearsed_rank": rank, "ego": rank, "steps": steps,
             "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "dtype": "i8", "data": "synthetic",
             "config": {"workload": wl["workload"], "baseline_config_index": wl["index"], "grid": wl["grid"], "agents_per_frame": W,
                        "max_cav": wl["max_cav"], "layout": wl["layout"], "points_per_agent": n_points, "batch_per_rank": B,
                        "heads": "multi-class (mc, 72 channels)" if wl["multiclass"] else "single-class (20 channels)",
-                       "pillars_per_step_rank0": int(mine["voxel_features"].shape[0]), "wire_bytes_per_agent_frame": eng.levels * hw,
+                       "pillars_per_step": int(mine["voxel_features"].shape[0]), "wire_bytes_per_agent_frame": eng.levels * hw,
                        "launch": "hipGraph (a1-a6 on the own agent's frames) -> the own payload copied into every agent slot, the agents' poses "
                                  "written beside it (stands in for the all-gather) -> hipGraph (pairwise matrices, a7-a11 over W agents)"},
             "stage_us": {"pre_a1_to_a6": round(pre_us, 1), "post_a7_to_a11": round(post_us, 1)},
             "note": f"what every rank of `bench.py --gpus {W}` executes per step, with the collective replaced by a device copy; with a free "
                     f"link the {W}-GPU line would read {W} x value (every rank the ego of its own view)",
-            "output_shapes": {k: list(v.shape) for k, v in out.items() if hasattr(v, "shape")}}
+            "output_shapes": {k: list(v.shape) for k, v in out.items() if hasattr(v, "shape")},
+            "_engine": eng}                                  # (for a second rank of the same world: popped by the callers, never printed)
 
 
 def rehearse(args, device):
     """--rehearse-world W (see its help)"""
     import torch
     torch.cuda.set_device(device)
-    print(json.dumps(rehearse_line(args.rehearse_world, max(1, args.batch), args.steps, args.warmup, device)), flush=True)
+    line = rehearse_line(args.rehearse_world, max(1, args.batch), args.steps, args.warmup, device, rank=args.rehearse_rank)
+    line.pop("_engine")
+    print(json.dumps(line), flush=True)
     return 0
 
 
@@ -824,6 +827,9 @@ def main():
                          "encoded, every other agent slot of the gathered payload filled with the own code planes + that agent's pose, the "
                          "fusion of W agents and the heads -- the per-rank step of the W-GPU line with its true shapes, WITHOUT the link. "
                          "Prints its own line (n_gpus 1, rehearsal_of_n_gpus W): not a multi-GPU measurement")
+    ap.add_argument("--rehearse-rank", type=int, default=0, metavar="R",
+                    help="with --rehearse-world W: the rank played (its own sweeps, its pose, ego = R: what ranks 1 .. W-1 of the default "
+                         "every-rank-is-its-own-ego mode execute); default 0")
     ap.add_argument("--dry-run-ranks", action="store_true",
                     help="launcher check (CPU, gloo): every rank joins the group, rank 0 prints a line with n_gpus = world size; no GPU work")
     args = ap.parse_args()
@@ -848,6 +854,8 @@ def main():
     if args.rehearse_world:
         if world != 1 or args.rehearse_world < 2 or args.rehearse_world > 8:
             raise SystemExit("--rehearse-world W: one process, 2 <= W <= 8")
+        if not 0 <= args.rehearse_rank < args.rehearse_world:
+            raise SystemExit("--rehearse-rank R: 0 <= R < W")
         raise SystemExit(rehearse(args, torch.device("cuda", local)))
     wl = workload_for(world)
     SHAPE, N_POINTS = wl["shape"], wl["n_points"]
@@ -1048,8 +1056,13 @@ def main():
                 try:
                     r = rehearse_line(W, B, 10, 2, device, engine=eng if W <= 4 else None)
                     reh[f"world{W}"] = {"ms_per_step": r["ms_per_step"], "frames_per_s_of_one_rank": r["value"], "stage_us": r["stage_us"],
-                                        "workload": r["config"]["workload"], "pillars_per_step": r["config"]["pillars_per_step_rank0"],
+                                        "workload": r["config"]["workload"], "pillars_per_step": r["config"]["pillars_per_step"],
                                         "frames_per_step": B}
+                    # the LAST rank's step (its own sweeps, ego = W - 1: the every-rank-is-its-own-ego mode of the N-GPU line)
+                    rl = rehearse_line(W, B, 10, 2, device, engine=r.pop("_engine"), rank=W - 1)
+                    reh[f"world{W}"]["last_rank"] = {"rank": W - 1, "ego": W - 1, "ms_per_step": rl["ms_per_step"], "stage_us": rl["stage_us"],
+                                                     "pillars_per_step": rl["config"]["pillars_per_step"],
+                                                     "ms_per_step_over_rank0": round(rl["ms_per_step"] / r["ms_per_step"], 4)}
                 except Exception as e:                                     # an extra must not cost the line
                     reh[f"world{W}"] = {"error": repr(e)[:300]}
             reh["note"] = ("rank 0's step of `bench.py --gpus W` rehearsed on ONE GPU (AgentShardedModel(emulate_world=W)): a1-a6 on the own agent's "

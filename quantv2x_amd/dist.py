@@ -60,7 +60,7 @@ class AgentShardedModel:
 
     def __init__(self, engine, group=None, ego_only: bool = False, frames: int = 1, link: str = "torch", graphs: Optional[bool] = None,
                  max_cav: Optional[int] = None, graph_link: bool = False, emulate_world: Optional[int] = None,
-                 emulate_poses: Optional[torch.Tensor] = None):
+                 emulate_poses: Optional[torch.Tensor] = None, emulate_rank: int = 0):
         if not getattr(engine, "has_codebook", True):
             raise NotImplementedError("AgentShardedModel exchanges the codebook's uint8 code planes: the codebook-less model "
                                       "has no compressed wire format (run it single-process through DeployedModel.forward)")
@@ -69,14 +69,19 @@ class AgentShardedModel:
         self.engine, self.group, self.ego_only, self.frames, self.link = engine, group, ego_only, int(frames), link
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        # REHEARSAL (bench.py --rehearse-world W): one process plays rank 0 of a world of W -- its own payload fills every agent slot, the
-        # other agents' poses come from ``emulate_poses`` [W, 4, 4] -- so that the per-rank kernels of a W-GPU step run with their true
-        # shapes on one GPU.  Not a multi-GPU run: no collective, and the "other agents" are copies of the own code planes.
+        # REHEARSAL (bench.py --rehearse-world W [--rehearse-rank r]): one process plays rank ``emulate_rank`` of a world of W -- its own payload
+        # fills every agent slot, the other agents' poses come from ``emulate_poses`` [W, 4, 4] -- so that the per-rank kernels of a W-GPU step
+        # run with their true shapes, and with that rank's ego index (``ego = rank`` unless ``ego_only``), on one GPU.  Not a multi-GPU run:
+        # no collective, and the "other agents" are copies of the own code planes.
         self.emulate = None
         if emulate_world is not None:
             if self.world != 1 or link != "torch" or emulate_poses is None or tuple(emulate_poses.shape) != (emulate_world, 4, 4):
                 raise ValueError("emulate_world: one process, link='torch', emulate_poses [W, 4, 4]")
-            self.world, self.emulate = int(emulate_world), emulate_poses.to(torch.float64)
+            if not 0 <= int(emulate_rank) < int(emulate_world):
+                raise ValueError("emulate_rank: 0 <= r < emulate_world")
+            self.world, self.emulate, self.rank = int(emulate_world), emulate_poses.to(torch.float64), int(emulate_rank)
+        elif emulate_rank:
+            raise ValueError("emulate_rank needs emulate_world")
         self.max_cav = max(self.world, max_cav or 0)
         self.levels, self.hw = engine.wire_shape()
         self.codes_bytes, self.pose_off, self.payload_bytes = payload_layout(self.levels, self.frames, self.hw)

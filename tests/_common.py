@@ -228,3 +228,20 @@ def calibrated_mixed_plugin(shape="tiny", n_points=N_POINTS, **kw):
     from quantv2x_amd.plugin.tools.inference_quant import calibrate_minmax
     model = build_plugin(shape, modalities=("m1", "m3"), encoders=MIXED_ENCODERS, **kw)
     return calibrate_minmax(quant_wrap(model), [synth.scene_to_torch(mixed_scene_np(shape=shape, n_points=n_points))])
+
+
+# ---- a scene seen from agent r (the every-rank-is-its-own-ego mode of the N-GPU path, dist.py) ----------------------------------------
+def ego_first(n_agents, ego):
+    """The reference has no ``ego`` argument: the ego is agent 0 of the scene and only its row is kept (fusion_in_one.py:141-147,
+    ``i = 0 # ego``).  The scene as agent ``ego`` sees it is therefore the same agents presented ego-first."""
+    return [ego] + [a for a in range(n_agents) if a != ego]
+
+
+def ego_view(feats, pairwise_b, n_agents, ego):
+    """(feats [n, ...] re-ordered ego-first, pairwise [1, L, L, 4, 4] with rows and columns permuted the same way: T'[i][j] =
+    T[order[i]][order[j]], the matrix get_pairwise_transformation builds for that agent order, transformation_utils.py:21-66)."""
+    order = ego_first(n_agents, ego)
+    t = np.array(pairwise_b, dtype=np.float64, copy=True)
+    sub = t[:n_agents, :n_agents][order][:, order]
+    t[:n_agents, :n_agents] = sub
+    return feats[order], t[None]

@@ -12,7 +12,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from _common import calibrated_plugin, scene_np
+from _common import calibrated_plugin, ego_view, scene_np
 
 
 def _free_port():
@@ -144,10 +144,20 @@ def test_sharded_agents_match_single_process(world, frames):
     np.testing.assert_allclose(results[0][1], want, rtol=1e-5, atol=1e-6)   # rank 0 = the reference's ego
     np.testing.assert_array_equal(results[0][5], results[0][1])             # ego_only: the same output on rank 0 ...
     assert all(r[5] is None for r in results[1:])                            # ... and none on the others
-    # other ranks see the scene from their own pose: a different, finite prediction map of the same shape
+    # Every other rank is the ego of its own view (ego = rank): the single-process oracle on the scene presented ego-first -- agents
+    # [r] + others, the DATASET's pairwise matrix (np.linalg.solve on the agents' poses in that order, transformation_utils.py:21-66)
+    # permuted the same way; the reference keeps agent 0's row of that scene (fusion_in_one.py:131-151).  What is under test is the driver:
+    # the ego index it hands on, its pairwise matrices from the gathered poses, the wire layout.
+    h, w = orc.ny // 2, orc.nx // 2
     for rank, preds, _, _, _, _ in results[1:]:
-        assert preds.shape == want.shape and np.isfinite(preds).all()
-        assert not np.allclose(preds, want)
+        assert preds.shape == want.shape
+        for f in range(frames):
+            sc = scene_np(world, seed=3 + f)
+            feats = orc.decode(np.ascontiguousarray(codes[f]).reshape(3, -1)).reshape(world, h, w, 256)
+            f2, t2 = ego_view(feats, sc["pairwise_t_matrix"][0], world, rank)
+            view = np.concatenate(orc.heads(orc.fuse(f2, t2, [world])), axis=1)
+            np.testing.assert_allclose(preds[f:f + 1], view, rtol=1e-5, atol=1e-6, err_msg=f"rank {rank} as the ego, frame {f}")
+            assert not np.allclose(view, wants[f])                                # (and that view is not rank 0's)
 
 
 def test_exchange_world_one_is_a_copy():
@@ -192,6 +202,21 @@ def test_rehearsal_of_a_world_of_three_on_one_process():
     assert np.isfinite(out["preds_tensor"].numpy()).all()
     with pytest.raises(ValueError):
         AgentShardedModel(eng, emulate_world=W, emulate_poses=poses[:2])
+    # --rehearse-rank r: the same world played as rank r -- ego = r in the post stage (the every-rank-is-its-own-ego mode); with
+    # ``ego_only`` a rank r > 0 runs no post stage at all
+    for r in (1, 2):
+        shr = AgentShardedModel(eng, frames=1, max_cav=5, emulate_world=W, emulate_poses=poses, emulate_rank=r)
+        out_r = shr.forward(mine, poses[r])
+        assert eng.calls[-1][4:] == (W, r) and shr.rank == r
+        np.testing.assert_array_equal(shr.pairwise[0].numpy(), sh.pairwise[0].numpy())
+        assert out_r["preds_tensor"].shape == out["preds_tensor"].shape
+    n_calls = len(eng.calls)
+    assert AgentShardedModel(eng, frames=1, max_cav=5, emulate_world=W, emulate_poses=poses, emulate_rank=2, ego_only=True).forward(mine, poses[2]) is None
+    assert len(eng.calls) == n_calls
+    with pytest.raises(ValueError):
+        AgentShardedModel(eng, emulate_world=W, emulate_poses=poses, emulate_rank=W)
+    with pytest.raises(ValueError):
+        AgentShardedModel(eng, emulate_rank=1)
 
 
 def test_bench_starts_its_own_ranks():

@@ -75,6 +75,18 @@ def test_opv2v_eight_agents_exact(opv2v):
     assert gt["codes"].shape == (3, 8, 65536)
 
 
+def test_v2xreal_every_agent_as_ego(v2xreal):
+    """configs[3] (4 agents, ring layout) seen from EVERY agent: the N-GPU path's default mode (``ego = rank``) against the oracle on the
+    scene presented ego-first (fusion_in_one.py:131-151 has no ego argument: agent 0 is the ego) -- every a7-a11 entry point, the
+    gathered wire layout with device-built pairwise matrices included (tests/test_hip_ego.py)."""
+    from quantv2x_amd import synth
+    from test_hip_ego import every_entry_point_as_ego
+    state, eng, orc = v2xreal
+    sc = synth.make_scene("v2xreal", n_agents=4, seed=5, n_points=60000, layout="ring")
+    worst = every_entry_point_as_ego(state, eng, orc, sc, 4, range(4), layout="ring")
+    assert worst < 2e-4
+
+
 def test_v2xreal_properties_four_agents(v2xreal):
     """configs[3] shape (4 agents, ring layout): agent permutation-equivariance of the encode, determinism, identity-pose
     fusion of identical agents returns the agent itself, and the N = 1 slice of a batch equals the single-agent run."""

@@ -22,6 +22,34 @@ def tiny():
     return st, OraclePyramid(st), deploy(state=st)
 
 
+def check_after_fuse(orc, st, gtaps, got, otaps):
+    """Everything after ``weighted_fuse`` on the ENGINE's own fused maps (the oracle stage fed the GPU's input): the deblocks and
+    shrink_conv bit-exact, the heads within one LSB of their quantizer; the deblock codes also against the ones of the oracle's own
+    fused maps in ``otaps`` (rare +-1 flips)."""
+    cat_q, c0 = [], 0
+    for lvl in range(3):
+        name = f"pyramid_backbone.deblocks.{lvl}.0"
+        gf = gtaps[f"fused{lvl}"].cpu().numpy().reshape(otaps[f"fused{lvl}"].shape)
+        ref, oq = orc.dense_f32in(name, gf, orc.ups[lvl])
+        np.testing.assert_array_equal(interior_u8(gtaps["cat"])[..., c0:c0 + 128], ref, err_msg=name)
+        cat_q.append((c0, 128, oq[0], oq[1]))
+        c0 += 128
+        flips = (ref != otaps[name]).mean()
+        assert flips < 5e-3, (name, flips)                              # vs the oracle's own fused map: rare +-1 flips
+    gcat = interior_u8(gtaps["cat"])
+    taps2 = {}
+    shr, shr_q = orc.shrink(gcat, cat_q, taps2)
+    for nme in ("shrink_conv.layers.0.double_conv.0", "shrink_conv.layers.0.double_conv.1"):
+        np.testing.assert_array_equal(interior_u8(gtaps[nme]), taps2[nme], err_msg=nme)
+    cls, reg, dr = orc.heads(orc.dequant(shr, shr_q))
+    ref_preds = np.concatenate([cls, reg, dr], axis=1)
+    lsb = max(float(st[h + "/a_delta"]) for h in ("cls_head", "reg_head", "dir_head"))
+    d = np.abs(got["preds_tensor"].cpu().numpy() - ref_preds)
+    assert d.max() <= lsb * 1.001 and (d > 1e-5).mean() < 1e-3, (d.max(), (d > 1e-5).mean())
+    for k, sl in (("cls_preds", slice(0, 18)), ("reg_preds", slice(18, 60)), ("dir_preds", slice(60, 72))):
+        assert torch.equal(got[k], got["preds_tensor"][:, sl])
+
+
 def compare_pyramid_frame(orc, eng, sc, st):
     from quantv2x_amd import synth
     from oracle import geometry
@@ -43,35 +71,14 @@ def compare_pyramid_frame(orc, eng, sc, st):
     H, W = (float(v) for v in st["meta/HW_metres"])
     affine = geometry.normalize_pairwise_tfm(np.asarray(sc["pairwise_t_matrix"]), H, W, float(st["meta/discrete_ratio"]))
     lens = [int(v) for v in sc["record_len"]]
-    cat_q, c0 = [], 0
     for lvl in range(3):
         oc, sco, fu = otaps[f"occ_code{lvl}"], otaps[f"score{lvl}"], otaps[f"fused{lvl}"]
-        h, w = oc.shape[1:3]
         np.testing.assert_array_equal(gtaps[f"occ_code{lvl}"].cpu().numpy().reshape(oc.shape), oc, err_msg=f"occupancy codes {lvl}")
         np.testing.assert_array_equal(gtaps[f"score{lvl}"].cpu().numpy().reshape(sco.shape), sco, err_msg=f"score {lvl}")
         gf = gtaps[f"fused{lvl}"].cpu().numpy().reshape(fu.shape)
         np.testing.assert_allclose(gf, fu, **FUSE_TOL)
         np.testing.assert_allclose(got["occ_single_list"][lvl].cpu().numpy(), want["occ_single_list"][lvl], rtol=0, atol=0)
-        # the deblock on the ENGINE's fused map: bit-exact
-        name = f"pyramid_backbone.deblocks.{lvl}.0"
-        ref, oq = orc.dense_f32in(name, gf, orc.ups[lvl])
-        np.testing.assert_array_equal(interior_u8(gtaps["cat"])[..., c0:c0 + 128], ref, err_msg=name)
-        cat_q.append((c0, 128, oq[0], oq[1]))
-        c0 += 128
-        flips = (ref != otaps[name]).mean()
-        assert flips < 5e-3, (name, flips)                          # vs the oracle's own fused map: rare +-1 flips
-    gcat = interior_u8(gtaps["cat"])
-    taps2 = {}
-    shr, shr_q = orc.shrink(gcat, cat_q, taps2)
-    for nme in ("shrink_conv.layers.0.double_conv.0", "shrink_conv.layers.0.double_conv.1"):
-        np.testing.assert_array_equal(interior_u8(gtaps[nme]), taps2[nme], err_msg=nme)
-    cls, reg, dr = orc.heads(orc.dequant(shr, shr_q))
-    ref_preds = np.concatenate([cls, reg, dr], axis=1)
-    lsb = max(float(st[h + "/a_delta"]) for h in ("cls_head", "reg_head", "dir_head"))
-    d = np.abs(got["preds_tensor"].cpu().numpy() - ref_preds)
-    assert d.max() <= lsb * 1.001 and (d > 1e-5).mean() < 1e-3, (d.max(), (d > 1e-5).mean())
-    for k, sl in (("cls_preds", slice(0, 18)), ("reg_preds", slice(18, 60)), ("dir_preds", slice(60, 72))):
-        assert torch.equal(got[k], got["preds_tensor"][:, sl])
+    check_after_fuse(orc, st, gtaps, got, otaps)
     return want, got
 
 
