@@ -58,15 +58,10 @@ def decode_tables(state: Dict[str, np.ndarray], levels: int, width: int = 256):
     return np.ascontiguousarray(np.stack(tables), dtype=np.float32), np.ascontiguousarray(const, dtype=np.float32)
 
 
-def collapse_encoder(state: Dict[str, np.ndarray], levels: int, in_delta: float, in_zx: int):
-    """UMGMQuantizer.encode (codebook.py:330-337 -> :231-239 -> :106-131) with its affine heads multiplied out in float64 -- the operands
-    of the OPT-IN ``qv2x_codebook_encode_collapsed_f32`` (not the parity path: the argmin may differ where the two best distances are
-    within fp32 rounding error of each other).  With z = stage(x), q = qhead(z), x' = lhead(z) - C[code]:
-
-        dist_l[k] - |q_l|^2 = |C_l[k]|^2 - 2 C_l[k] . q_l = G_l[k] . x_1 + g_l[k] + sum_{j<l} T_lj[code_j][k]
-
-    Returns (g_packed f32 [L*kc/32][128][64], bias f32 [L*kc], tables f32 [L(L-1)/2][kc][kc]); the input dequantization
-    x_1 = in_delta * (code - in_zx) is folded in: the kernel multiplies by the uint8 code itself."""
+def collapse_encoder_f64(state: Dict[str, np.ndarray], levels: int):
+    """The float64 algebra of ``collapse_encoder``: (G [levels*kc, 256], g [levels*kc], {(l, j): T_lj [kc_j][kc_l]}) with
+    ``dist_l[k] - |q_l|^2 = G_l[k] . x_1 + g_l[k] + sum_{j<l} T_lj[code_j][k]`` on the shared feature x_1 (also the candidate stage of the
+    two-stage exact encode, encode_two_stage.py)."""
     g = lambda l, n: state[f"codebook/{l}/{n}"].astype(np.float64)
     kc = int(state["codebook/0/codebook"].shape[0])
     front, shift = np.eye(256), np.zeros(256)          # x_l = front @ x_1 + shift - sum_j back[j] @ C_j[code_j]
@@ -85,7 +80,20 @@ def collapse_encoder(state: Dict[str, np.ndarray], levels: int, in_delta: float,
             d = g(l, "lhead_w") @ bs + g(l, "lhead_b")
             front, shift = A @ front, A @ shift + d
             back = [A @ Bj for Bj in back] + [np.eye(256)]
-    Gall, gall = np.concatenate(G), np.concatenate(gb)                  # [L*kc, 256], [L*kc]
+    return np.concatenate(G), np.concatenate(gb), tables                # [L*kc, 256], [L*kc]
+
+
+def collapse_encoder(state: Dict[str, np.ndarray], levels: int, in_delta: float, in_zx: int):
+    """UMGMQuantizer.encode (codebook.py:330-337 -> :231-239 -> :106-131) with its affine heads multiplied out in float64 -- the operands
+    of the OPT-IN ``qv2x_codebook_encode_collapsed_f32`` (not the parity path: the argmin may differ where the two best distances are
+    within fp32 rounding error of each other).  With z = stage(x), q = qhead(z), x' = lhead(z) - C[code]:
+
+        dist_l[k] - |q_l|^2 = |C_l[k]|^2 - 2 C_l[k] . q_l = G_l[k] . x_1 + g_l[k] + sum_{j<l} T_lj[code_j][k]
+
+    Returns (g_packed f32 [L*kc/32][128][64], bias f32 [L*kc], tables f32 [L(L-1)/2][kc][kc]); the input dequantization
+    x_1 = in_delta * (code - in_zx) is folded in: the kernel multiplies by the uint8 code itself."""
+    Gall, gall, tables = collapse_encoder_f64(state, levels)
+    kc = Gall.shape[0] // levels
     bias = gall + in_delta * (0.0 - in_zx) * Gall.sum(1)
     Gs = in_delta * Gall
     nct = levels * kc // 32
