@@ -213,6 +213,31 @@ int qv2x_codebook_encode_wave_f32(const qv2x_encode_desc* desc /* host */, const
 int qv2x_codebook_encode_collapsed_f32(const qv2x_encode_desc* desc /* host */, const int8_t* in, const float* g_packed, const float* bias,
                                        const float* tables, uint8_t* codes, void* stream);
 
+/* The two-stage EXACT encode (round 6; quantv2x_amd/encode_two_stage.py has the derivation and builds the operands): the same indices as
+ * qv2x_codebook_encode_f32 -- UMGMQuantizer.encode, codebook.py:330-337 -> :231-239 -> :106-131, first-argmin ties included -- for a
+ * fraction of its work.
+ *
+ * Stage 1, qv2x_codebook_encode_candidates_i8: the collapsed scores s_l[k] = dist_l[k] - |q_l|^2 of every cell in EXACT integer arithmetic
+ * (G on a fixed-point grid h as three balanced int8 limbs, v_mfma_i32_32x32x32_i8; limbs, bias and table rows combined on integers below
+ * 2^53) -> codes [levels][n*h*w] for every cell, and the cells whose gap between the two best scores at ANY level does not exceed
+ *     tau_l / h = tau[l][0] + tau[l][1] N0 + tau[l][2] N0^2 + sum |code - zx|,    N0 = in_delta * sqrt(sum (code - zx)^2)
+ * appended (in no particular order) to `list`, their number in counters[0].  tau bounds twice the largest difference the fp32 chain's
+ * rounding can make to a score plus this stage's own grid error: a cell NOT listed has the fp32 chain's strict minimum at every level.
+ *   g_limbs  i8  [levels][kc/32][3][8][64][16]: A fragments, lane = 32 * half + score % 32, bytes = input channel 32 * step + 16 * half + 0..15
+ *   bias_packed f64 [levels*kc] = 128 * (rint(g / h) + (128 - zx) * rowsum(G_int)) + k      (the kernel multiplies by the stored byte code - 128)
+ *   tables   i32 [levels(levels-1)/2][kc][kc] = rint(T_lj / h), table (l, j) at l (l - 1) / 2 + j (>= one table's worth allocated)
+ *   tau      f32 [levels][3], HOST (copied into the launch)
+ *   list u32 [n*h*w]; counters u32 [4]: [0] listed cells, [1 + l] cells first listed at level l -- DEVICE, zeroed by this call (a kernel
+ *   node under stream capture)
+ * Stage 2, qv2x_codebook_encode_listed_f32: qv2x_codebook_encode_f32's kernel (one wave per 32 cells, the reference's op order, bit-exact)
+ * on the listed cells only; `list_count` points at the DEVICE count (counters + 0), the launch is a fixed number of persistent waves: both
+ * stages are capturable in a HIP graph.  seg_num 1, dict_size 32 | 64 | 96 | 128, up to three levels. */
+int qv2x_codebook_encode_candidates_i8(const qv2x_encode_desc* desc /* host */, const int8_t* in, const int8_t* g_limbs, const double* bias_packed,
+                                       const int32_t* tables, const float* tau /* host */, uint8_t* codes, uint32_t* list, uint32_t* counters,
+                                       void* stream);
+int qv2x_codebook_encode_listed_f32(const qv2x_encode_desc* desc /* host */, const int8_t* in, const float* const* level_weights /* host array */,
+                                    const uint32_t* list, const uint32_t* list_count, uint8_t* codes, void* stream);
+
 /* a7 + a8 + a9 + a10.  UMGMQuantizer.decode as three table look-ups (codebook.py:339-343; all heads affine),
  * warp_affine_simple (torch_transformation_utils.py:323-332: affine_grid + bilinear grid_sample, zeros,
  * align_corners=False) of every agent into the ego frame and AttFusion's per-cell scaled-dot-product

@@ -14,6 +14,7 @@ struct EncArgs {
     int segs, ke;                       // seg_num (m) = 1 | 2 | 4 segments of 256 / segs dims; ke = segs * kc rows of the extended codebook
     float dx;
     int m_lo, m_hi;             // the rows [m_lo, m_hi) of the M = n h w cells this launch encodes (a launch may be split between the two forms)
+    const unsigned* list = nullptr; const unsigned* list_count = nullptr;      // LIST form of the wave kernel: the cells to encode and their DEVICE-side count
 };
 
 // A level blob (include/qv2x.h): the workgroup form's section, then the wave form's.  `kc` here = rows of the (extended) codebook.
@@ -22,5 +23,6 @@ __device__ __host__ __forceinline__ int64_t level_floats(int kc) { return level_
 
 // codebook_encode_wave.hip
 int encode_wave_launch(const EncArgs& a, hipStream_t st);      // rows [a.m_lo, a.m_hi): one wave per 32
+int encode_wave_list_launch(const EncArgs& a, int waves, hipStream_t st);   // the cells a.list[0 .. *a.list_count): persistent waves
 
 }  // namespace qv2x

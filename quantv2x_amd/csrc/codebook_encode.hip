@@ -446,6 +446,32 @@ extern "C" int qv2x_codebook_encode_f32in(const qv2x_encode_desc* d, const float
     return encode_launch(d, (const int8_t*)in, in, level_weights, codes, stream);
 }
 
+// Stage 2 of the two-stage exact encode (encode_two_stage.py, codebook_encode_cand.hip): qv2x_codebook_encode_f32's arithmetic on the cells
+// `list[0 .. *list_count)` only -- the count lives on the DEVICE (the candidate stage wrote it), the launch is a fixed number of persistent
+// waves, so the pair of launches is capturable in a HIP graph.
+extern "C" int qv2x_codebook_encode_listed_f32(const qv2x_encode_desc* d, const int8_t* in, const float* const* level_weights,
+                                               const uint32_t* list, const uint32_t* list_count, uint8_t* codes, void* stream) {
+    using namespace qv2x;
+    if (!d || !in || !level_weights || !codes || !list || !list_count) return fail(QV2X_EINVAL, "qv2x_codebook_encode_listed_f32: null pointer");
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->levels < 1 || d->levels > 4) return fail(QV2X_EINVAL, "qv2x_codebook_encode_listed_f32: bad shape");
+    if (d->segs > 1) return fail(QV2X_EINVAL, "qv2x_codebook_encode_listed_f32: seg_num 1 only");
+    if (d->kc < 32 || d->kc > 256 || d->kc % 32) return fail(QV2X_EINVAL, "qv2x_codebook_encode_listed_f32: dict_size must be a multiple of 32 up to 256 (got %d)", d->kc);
+    if ((uintptr_t)in & 15) return fail(QV2X_EALIGN, "qv2x_codebook_encode_listed_f32: in must be 16-byte aligned");
+    EncArgs a;
+    a.in = in; a.in_f32 = nullptr; a.codes = codes; a.n = d->n; a.h = d->h; a.w = d->w; a.levels = d->levels; a.kc = d->kc;
+    a.segs = 1; a.ke = d->kc;
+    a.ax = 128 - d->in_zx; a.dx = d->in_delta; a.M = d->n * d->h * d->w; a.m_lo = 0; a.m_hi = a.M;
+    a.list = list; a.list_count = list_count;
+    for (int l = 0; l < 4; ++l) {
+        a.lvl[l] = l < d->levels ? level_weights[l] : nullptr;
+        if (l < d->levels && (!a.lvl[l] || ((uintptr_t)a.lvl[l] & 15))) return fail(QV2X_EALIGN, "qv2x_codebook_encode_listed_f32: level %d weights null or unaligned", l);
+    }
+    int cus = 256, dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    const int waves = (a.M + 31) / 32;
+    return encode_wave_list_launch(a, waves < 4 * cus ? waves : 4 * cus, (hipStream_t)stream);
+}
+
 static int encode_launch(const qv2x_encode_desc* d, const int8_t* in, const float* in_f32, const float* const* level_weights, uint8_t* codes, void* stream,
                          int form) {
     using namespace qv2x;

@@ -78,16 +78,31 @@ template <int V> struct IC { static constexpr int value = V; };
 // 256 / m dims of its segment, and fma(x, 0, acc) = acc, so the sums are the dense walk's bit for bit with 1 / m of its MFMAs.  A tile pair
 // then is one 32-code tile of each of TWO segments (tile 0 against operand registers [OFF0, ...), tile 1 against [OFF1, ...)), 32 / m groups
 // long; the blob's codebook stream is packed in that order (engine.py:_pack_wave_seg, include/qv2x.h).
-template <bool F32IN, int SEGS>
+// LIST (round 6, stage 2 of the two-stage exact encode -- encode_two_stage.py): the wave's cells are `a.list[32 tile + j]`, tile = blockIdx.x,
+// blockIdx.x + gridDim.x, ... below ceil(*a.list_count / 32) -- a persistent launch of fixed size whose work is a DEVICE-side count (the cells
+// the candidate stage could not decide), so the whole encode stays capturable in a HIP graph.  The arithmetic is untouched.
+template <bool F32IN, int SEGS, bool LIST = false>
 __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(1, 1))) void codebook_encode_wave_kernel(const EncArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[32 * RS];
     const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
-    const int m0 = a.m_lo + (int)blockIdx.x * 32;
     float* const row = smem + j * RS;
+    const int n_listed = LIST ? (int)*a.list_count : 0;
+#pragma unroll 1
+    for (int tile = (int)blockIdx.x; LIST ? tile * 32 < n_listed : tile == (int)blockIdx.x; tile += (int)gridDim.x) {
+    int mrow;                                                        // this lane's cell, and whether its codes are stored
+    bool owned;
+    if (LIST) {
+        const int i = tile * 32 + j;
+        owned = i < n_listed;
+        mrow = (int)a.list[owned ? i : n_listed - 1];
+    } else {
+        mrow = a.m_lo + tile * 32 + j;
+        owned = mrow < a.m_hi;
+    }
 
     float xq[128], z[128];              // B operands: x, then q, then the next x | z (read by qhead and by lhead)
     {   // ---- the wave's 32 rows of the BEV map, dequantized, straight into B-operand order -------------------------------
-        int m = m0 + j;
+        int m = mrow;
         m = m < a.M ? m : a.M - 1;
         const int img = m / (a.h * a.w), rem = m - img * (a.h * a.w);
         const int y = rem / a.w, x = rem - y * a.w;
@@ -296,7 +311,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
                 const float od = __shfl_xor(best, 32);
                 const int oc = __shfl_xor(bc, 32);
                 if (od < best || (od == best && oc < bc)) bc = oc;
-                if (h == 0 && m0 + j < a.m_hi) a.codes[((size_t)l * a.segs + seg) * a.M + m0 + j] = (uint8_t)bc;
+                if (h == 0 && owned) a.codes[((size_t)l * a.segs + seg) * a.M + mrow] = (uint8_t)bc;
                 bcs |= (unsigned)bc << (8 * seg);
                 best = INFINITY; bc = 0;
             }
@@ -340,7 +355,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
                     const float od = __shfl_xor(best[t], 32);
                     const int oc = __shfl_xor(bc[t], 32);
                     if (od < best[t] || (od == best[t] && oc < bc[t])) bc[t] = oc;
-                    if (h == 0 && m0 + j < a.m_hi) a.codes[((size_t)l * SEGS + seg) * a.M + m0 + j] = (uint8_t)bc[t];
+                    if (h == 0 && owned) a.codes[((size_t)l * SEGS + seg) * a.M + mrow] = (uint8_t)bc[t];
                     bcs |= (unsigned)bc[t] << (8 * seg);
                 }
             };
@@ -371,6 +386,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
         lds_to_operand(row, h, xq);
         WFINE(7);
     }
+    }                                                                   // (the persistent loop of the LIST form)
 }
 
 int encode_wave_launch(const EncArgs& a, hipStream_t st) {
@@ -384,6 +400,14 @@ int encode_wave_launch(const EncArgs& a, hipStream_t st) {
     } else if (a.in_f32) codebook_encode_wave_kernel<true, 1><<<grid, 64, 0, st>>>(a);
     else codebook_encode_wave_kernel<false, 1><<<grid, 64, 0, st>>>(a);
     return hip_check(hipGetLastError(), "qv2x_codebook_encode_f32 (wave form) launch");
+}
+
+
+// stage 2 of the two-stage encode: the listed cells, `waves` persistent single-wave workgroups (four per CU fill the chip)
+int encode_wave_list_launch(const EncArgs& a, int waves, hipStream_t st) {
+    if (a.segs != 1 || a.in_f32) return fail(QV2X_EINVAL, "qv2x_codebook_encode_listed_f32: seg_num 1, i8 rows");
+    codebook_encode_wave_kernel<false, 1, true><<<(unsigned)waves, 64, 0, st>>>(a);
+    return hip_check(hipGetLastError(), "qv2x_codebook_encode_listed_f32 launch");
 }
 
 }  // namespace qv2x

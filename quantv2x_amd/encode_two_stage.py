@@ -189,7 +189,9 @@ def candidate_emulate(codes_u8: np.ndarray, tabs: Dict[str, np.ndarray], in_delt
         order = np.argsort(sc, axis=1, kind="stable")
         best, second = np.take_along_axis(sc, order[:, :1], 1)[:, 0], np.take_along_axis(sc, order[:, 1:2], 1)[:, 0]
         out[l] = order[:, 0]
-        t = (tau[l, 0] + tau[l, 1] * n0 + tau[l, 2] * n0 * n0).astype(np.float32).astype(np.float64) + n1
+        t = (((tau[l, 0] + tau[l, 1] * n0) + (tau[l, 2] * n0) * n0) + n1.astype(np.float32)).astype(np.float32)     # the kernel's fp32 statement
+        assert t.dtype == np.float32 and n0.dtype == np.float32
+        t = t.astype(np.float64)
         # the kernel compares packed values 128 S + k: accepted iff second - best > 128 T + 127  (implies S_second - S_best > T)
         k2 = np.take_along_axis(order, np.ones((len(sc), 1), np.int64), 1)[:, 0]
         flags[l] = (128.0 * second + k2) - (128.0 * best + out[l]) <= 128.0 * np.ceil(t) + 127.0

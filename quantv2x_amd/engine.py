@@ -411,7 +411,7 @@ class DeployedModel(nn.Module):
         self.use_wide_conv, self.batch_deconvs, self.use_chains = True, True, True
         self.chain_max_agents = 1
         # "exact": the reference's eleven chained GEMMs, bit-identical indices (the parity configuration).  "collapsed": opt-in, see collapse_encoder
-        self.encode_mode, self._collapsed = "exact", None
+        self.encode_mode, self._collapsed, self._two_stage = "exact", None, None
         self.encode_form = "auto"                                      # "wave": force the wave-per-32-cells encode kernel (same codes)
 
     # ------------------------------------------------------------------------------------------------------
@@ -681,8 +681,11 @@ class DeployedModel(nn.Module):
             L.check(self.lib.qv2x_codebook_encode_collapsed_f32(C.byref(d), L.ptr(b["s1"]), L.ptr(gp), L.ptr(bias), L.ptr(tab), L.ptr(codes),
                                                                 L.current_stream()), "qv2x_codebook_encode_collapsed_f32")
             return codes
+        if self.encode_mode == "two_stage":                           # exact by construction: candidates on the integer grid + the chain on the undecided
+            return self._encode_two_stage(d, b, codes, n_agents)
         if self.encode_mode != "exact":
-            raise ValueError(f"encode_mode {self.encode_mode!r}: 'exact' (the reference's op order, the default) or 'collapsed'")
+            raise ValueError(f"encode_mode {self.encode_mode!r}: 'exact' (every cell through the reference's op order), 'two_stage' (the same "
+                             "indices: exact integer candidates, the chain only where the bound cannot decide) or 'collapsed' (opt-in, approximate)")
         if self.encode_form == "wave":                                # tests: the many-frames form at any size (the library picks by launch size)
             L.check(self.lib.qv2x_codebook_encode_wave_f32(C.byref(d), L.ptr(b["s1"]), None, self.level_ptrs, L.ptr(codes),
                                                            L.current_stream()), "qv2x_codebook_encode_wave_f32")
@@ -690,6 +693,41 @@ class DeployedModel(nn.Module):
         L.check(self.lib.qv2x_codebook_encode_f32(C.byref(d), L.ptr(b["s1"]), self.level_ptrs, L.ptr(codes),
                                                   L.current_stream()), "qv2x_codebook_encode_f32")
         return codes
+
+    def two_stage_supported(self) -> bool:
+        """seg_num 1, dict_size 32 | 64 | 96 | 128, up to three levels, i8 rows (qv2x_codebook_encode_candidates_i8's contract)"""
+        return bool(self.has_codebook and self.segs == 1 and self.kc <= 128 and self.kc % 32 == 0 and self.enc_levels <= 3
+                    and getattr(self, "encode_rows_i8", True))
+
+    def _encode_two_stage(self, d, b, codes, n_agents: int):
+        """a6 as two launches (encode_two_stage.py): qv2x_codebook_encode_candidates_i8 decides every cell it can PROVE, the listed rest
+        goes through the reference-order kernel (qv2x_codebook_encode_listed_f32) -- identical indices, ~a tenth of the fp32 work."""
+        if not self.two_stage_supported():
+            raise NotImplementedError("encode_mode 'two_stage': seg_num 1, dict_size <= 128, up to three levels (encode_mode 'exact' takes the rest)")
+        if self._two_stage is None:
+            from .encode_two_stage import candidate_tables
+            t = candidate_tables(self.state, self.enc_levels, d.in_delta, d.in_zx)
+            k = np.arange(t["bias"].shape[0], dtype=np.int64) % self.kc
+            packed = (128 * t["bias"] + k).astype(np.float64)
+            assert np.array_equal(packed.astype(np.int64), 128 * t["bias"] + k)          # below 2^53: exact
+            self._two_stage = (_dev(t["gpack"], self.dev), _dev(packed, self.dev), _dev(t["tables"], self.dev),
+                               (C.c_float * (3 * self.enc_levels))(*[float(v) for v in t["tau"].reshape(-1)]), t)
+        gp, bias, tab, tau, _ = self._two_stage
+        if "enc_list" not in b:
+            b["enc_list"] = torch.zeros(n_agents * self.fh * self.fw, dtype=torch.int32, device=self.dev)
+            b["enc_counters"] = torch.zeros(4, dtype=torch.int32, device=self.dev)
+        L.check(self.lib.qv2x_codebook_encode_candidates_i8(C.byref(d), L.ptr(b["s1"]), L.ptr(gp), L.ptr(bias), L.ptr(tab), tau, L.ptr(codes),
+                                                            L.ptr(b["enc_list"]), L.ptr(b["enc_counters"]), L.current_stream()),
+                "qv2x_codebook_encode_candidates_i8")
+        L.check(self.lib.qv2x_codebook_encode_listed_f32(C.byref(d), L.ptr(b["s1"]), self.level_ptrs, L.ptr(b["enc_list"]), L.ptr(b["enc_counters"]),
+                                                         L.ptr(codes), L.current_stream()), "qv2x_codebook_encode_listed_f32")
+        return codes
+
+    def encode_refine_stats(self, n_agents: int) -> dict:
+        """after a two-stage encode of ``n_agents`` frames: how many cells stage 2 recomputed (counters the candidate stage left on the device)"""
+        c = self._workspace(n_agents)["enc_counters"].cpu().numpy().astype(np.int64)
+        cells = n_agents * self.fh * self.fw
+        return {"cells": cells, "refined": int(c[0]), "refined_fraction": float(c[0]) / cells, "first_flagged_at_level": [int(v) for v in c[1:1 + self.enc_levels]]}
 
     # ---- stage interface of the multi-GPU driver (quantv2x_amd/dist.py) -----------------------------------------------------
     def wire_shape(self):

@@ -24,7 +24,7 @@ SYMBOLS = [
     "qv2x_codebook64_level_floats", "qv2x_codebook64_c2_f32", "qv2x_codebook_encode64_f32", "qv2x_codebook_encode64_f32in",
     "qv2x_add_relu_f32", "qv2x_occ_sigmoid_f32", "qv2x_pyramid_weighted_fuse_f32p", "qv2x_bottleneck_i8",
     "qv2x_comm_unique_id", "qv2x_comm_init", "qv2x_comm_destroy", "qv2x_allgather_codes", "qv2x_pairwise_from_poses_f64", "qv2x_pairwise_from_poses_batch_f64",
-    "qv2x_codebook_encode_collapsed_f32", "qv2x_mean_vfe_f32", "qv2x_sp_index_scatter", "qv2x_sp_out_sites_workspace_bytes", "qv2x_sp_out_sites", "qv2x_sp_rulebook", "qv2x_sp_conv_f32in", "qv2x_sp_conv_i8", "qv2x_sp_to_bev_i8",
+    "qv2x_codebook_encode_collapsed_f32", "qv2x_codebook_encode_candidates_i8", "qv2x_codebook_encode_listed_f32", "qv2x_mean_vfe_f32", "qv2x_sp_index_scatter", "qv2x_sp_out_sites_workspace_bytes", "qv2x_sp_out_sites", "qv2x_sp_rulebook", "qv2x_sp_conv_f32in", "qv2x_sp_conv_i8", "qv2x_sp_to_bev_i8",
 ]
 COMM_ID_BYTES = 128
 
@@ -159,6 +159,8 @@ def load() -> C.CDLL:
                                         vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.qv2x_dequant_i8_f32.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]
     lib.qv2x_codebook_encode_collapsed_f32.argtypes = [C.POINTER(EncodeDesc), vp, vp, vp, vp, vp, vp]
+    lib.qv2x_codebook_encode_candidates_i8.argtypes = [C.POINTER(EncodeDesc), vp, vp, vp, vp, C.POINTER(C.c_float), vp, vp, vp, vp]
+    lib.qv2x_codebook_encode_listed_f32.argtypes = [C.POINTER(EncodeDesc), vp, C.POINTER(vp), vp, vp, vp, vp]
     lib.qv2x_mean_vfe_f32.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp]
     lib.qv2x_sp_index_scatter.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]
     lib.qv2x_sp_out_sites_workspace_bytes.argtypes = [C.POINTER(SpconvDesc)]
