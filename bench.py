@@ -175,8 +175,60 @@ def rooflines(eng, full, frames, iters):
     stage("shrinker_convs_i8", lambda: eng.run_plan(n, only=lambda k, l: k == "conv" and l.name.startswith("shrinker")), "mfma-i8",
           sum(2.0 * p[7] for p in sh), "TOP/s", INT8_MFMA_PEAK_TOPS, len(sh), f"{sum(2.0 * p[7] for p in sh) / 1e9:.1f} GOP: 3x3 384->256 + 3x3 256->256")
     enc_gflop = round(2.0 * ENCODE_GMAC_PER_CELL * hw / 1e9, 2)          # 43.84 at V2X-Real (35 200 cells), 81.61 at OPV2V (65 536)
+    two_stage = eng.encode_mode == "two_stage" and eng.encode_form == "auto"
+    if two_stage:
+        # a6 as the engine runs it (round 6): exact integer candidates for every cell, the reference-order chain for the cells a proven bound
+        # cannot decide -- the SAME indices (encode_two_stage.py).  Three entries: the pair of launches, and each stage by itself on the work it
+        # EXECUTES (so that no fraction exceeds 1); the reference-order flops of the whole batch are stated beside them.
+        import ctypes as C
+        from quantv2x_amd import lib as L
+        eng.encode_codes(n)
+        torch.cuda.synchronize()
+        ref = eng.encode_refine_stats(n)
+        b = eng._workspace(n)
+        gp, bias, tab, tau, _ = eng._two_stage
+        d = L.EncodeDesc()
+        d.n, d.h, d.w, d.levels, d.kc, d.segs = n, eng.fh, eng.fw, eng.enc_levels, eng.kc, 1
+        d.in_zx, d.in_delta = int(eng.shrink1.out_q[1]), float(eng.shrink1.out_q[0])
+
+        def stage1():
+            L.check(eng.lib.qv2x_codebook_encode_candidates_i8(C.byref(d), L.ptr(b["s1"]), L.ptr(gp), L.ptr(bias), L.ptr(tab), tau, L.ptr(b["codes"]),
+                                                               L.ptr(b["enc_list"]), L.ptr(b["enc_counters"]), L.current_stream()), "candidates")
+
+        def stage2():                                    # (the list of the last stage 1 stays on the device: the same cells every time)
+            L.check(eng.lib.qv2x_codebook_encode_listed_f32(C.byref(d), L.ptr(b["s1"]), eng.level_ptrs, L.ptr(b["enc_list"]), L.ptr(b["enc_counters"]),
+                                                            L.ptr(b["codes"]), L.current_stream()), "listed")
+        cand_ops = 2.0 * 3 * 256 * eng.enc_levels * eng.kc * n * hw
+        stage("codebook_encode_candidates_i8", stage1, "mfma-i8", cand_ops, "TOP/s", INT8_MFMA_PEAK_TOPS, 1,
+              f"stage 1: {n * hw} cells x (256 -> {eng.enc_levels * eng.kc} scores x 3 int8 limbs) = {cand_ops / 1e9:.1f} GOP on v_mfma_i32_32x32x32_i8, fp64 packed "
+              f"argmin chain; lists the cells whose top-2 gap does not exceed the proven bound")
+        stage1()
+        listed_flop = 2.0 * ENCODE_GMAC_PER_CELL * ref["refined"]
+        stage("codebook_encode_listed_f32", stage2, "mfma-f32", listed_flop, "TFLOP/s", F32_MFMA_PEAK_TFLOPS, 1,
+              f"stage 2: the {ref['refined']} listed cells ({ref['refined_fraction']:.4f} of {n * hw}) through the reference-order chain "
+              f"(codebook_encode_wave_kernel, list form: persistent waves): {listed_flop / 1e9:.1f} GFLOP executed")
+        stage("codebook_encode_two_stage", lambda: eng.encode_codes(n), "mfma-f32", enc_gflop * 1e9 * n, "TFLOP/s", F32_MFMA_PEAK_TFLOPS, 3,
+              f"both stages + the counter reset, as the step runs them: {n} x {enc_gflop} GFLOP in the REFERENCE's op order are replaced by "
+              f"{cand_ops / 1e9:.1f} GOP int8 + {listed_flop / 1e9:.1f} GFLOP fp32 -- `achieved` here is reference-equivalent TFLOP/s, NOT a roofline "
+              f"fraction (the stages above carry those)")
+        stages["codebook_encode_two_stage"].update({"frac": None, "refined_cells": ref["refined"], "refined_fraction": round(ref["refined_fraction"], 5),
+                                                    "first_flagged_at_level": ref["first_flagged_at_level"],
+                                                    "reference_order_gflop": round(enc_gflop * n, 2), "executed_gop_int8": round(cand_ops / 1e9, 2),
+                                                    "executed_gflop_fp32": round(listed_flop / 1e9, 2)})
+        eng.encode_mode = "exact"
     stage("codebook_encode_f32", lambda: eng.encode_codes(n), "mfma-f32", enc_gflop * 1e9 * n, "TFLOP/s",
-          F32_MFMA_PEAK_TFLOPS, 1, f"{n} x {enc_gflop} GFLOP (11 chained 256-wide GEMMs per cell, reference op order)")
+          F32_MFMA_PEAK_TFLOPS, 1, f"{n} x {enc_gflop} GFLOP (11 chained 256-wide GEMMs per cell, reference op order)"
+          + (" -- EVERY cell through the chain (encode_mode 'exact'): not what the step runs, timed beside it" if two_stage else ""))
+    if two_stage:
+        eng.encode_mode = "two_stage"
+        stages["codebook_encode_f32_every_cell"] = stages.pop("codebook_encode_f32")
+        eng.encode_codes(n)                              # (leave the workspace as the step does)
+    # every launch of the shrinker and the deblocks by itself: candidates for the dominant kernel
+    per_layer = {}
+    for p_ in sh:
+        nm = p_[1].name
+        us = event_time_us(lambda: eng.run_plan(n, only=lambda k, l, nm=nm: k == "conv" and l.name == nm), iters)
+        per_layer[nm] = (us, 2.0 * p_[7])
     codes = eng._workspace(n)["codes"]
     pw = full["pairwise_t_matrix"].contiguous()
     import ctypes as C
@@ -210,36 +262,56 @@ def rooflines(eng, full, frames, iters):
     if by_tables:
         general["note"] = ("the GENERAL path of a7-a11 (scenes of 2+ agents; every rank of an N-GPU run), timed here on the same single-agent batch for "
                            "reference -- not part of this line's step")
-    enc = stages["codebook_encode_f32"]
-    traffic, note = None, "no PMC profile committed for this round yet"
+    # ---- `roofline`: the DOMINANT kernel by time of one launch, live --------------------------------------------------------------------
+    cands = []                                       # (us per launch, kernel, bound, work per launch, unit, peak, algorithmic bytes, pmc key)
+    if two_stage:
+        s2 = stages["codebook_encode_listed_f32"]
+        rc = stages["codebook_encode_two_stage"]["refined_cells"]
+        cands.append((s2["us_per_batch"], "codebook_encode_wave_kernel<.., LIST> (f32 MFMA v_mfma_f32_32x32x2_f32; a wave per 32 listed cells, persistent)",
+                      "mfma", 2.0 * ENCODE_GMAC_PER_CELL * rc, "TFLOP/s", F32_MFMA_PEAK_TFLOPS,
+                      rc * 256 + rc * eng.levels + rc * 4 + sum(int(bl.numel()) * 4 for bl in eng.level_blobs), "encode_listed"))
+        s1 = stages["codebook_encode_candidates_i8"]
+        cands.append((s1["us_per_batch"], "encode_candidates_kernel (int8 MFMA v_mfma_i32_32x32x32_i8; a wave per 128 cells)", "mfma",
+                      2.0 * 3 * 256 * eng.enc_levels * eng.kc * n * hw, "TOP/s", INT8_MFMA_PEAK_TOPS,
+                      n * hw * 256 + n * hw * eng.levels + eng.enc_levels * eng.kc * 256 * 3, "encode_candidates"))
+    else:
+        e_ = stages["codebook_encode_f32"]
+        cands.append((e_["us_per_batch"], "codebook_encode_wave_kernel (f32 MFMA v_mfma_f32_32x32x2_f32; a wave per 32 cells)", "mfma",
+                      enc_gflop * 1e9 * n, "TFLOP/s", F32_MFMA_PEAK_TFLOPS,
+                      n * hw * 256 + n * hw * eng.levels + sum(int(bl.numel()) * 4 for bl in eng.level_blobs), "encode"))
+    for p_ in sh:
+        us, ops = per_layer[p_[1].name]
+        cin = p_[1].w.shape[1] // 9
+        cands.append((us, f"conv3x3_i8_wide_kernel ({p_[1].name}: 3x3 {cin}->{p_[1].cout}, int8 MFMA v_mfma_i32_32x32x32_i8, halo patch)", "mfma", ops, "TOP/s",
+                      INT8_MFMA_PEAK_TOPS, n * hw * (cin + p_[1].cout) + int(p_[1].w.numel()), "conv_" + p_[1].name))
+    de_s = stages["backbone_deconvs_f32"]
+    cands.append((de_s["us_per_batch"], "deconv_ps_batch_kernel (f32 MFMA: the three deblocks of the batch in one launch)", "mfma",
+                  sum(2.0 * p_[7] for p_ in de), "TFLOP/s", F32_MFMA_PEAK_TFLOPS, None, "deconv"))
+    cands.sort(key=lambda c: -c[0])
+    us, kname, bound, work, unit, peak, alg, key = cands[0]
+    ach = work / (us * 1e-6) / 1e12
+    traffic, note = None, "no PMC profile committed for this kernel in this round yet"
     import glob
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_encode.json")))     # the latest round's PMC passes
-    pmc = found[-1] if found else ""
-    if pmc:
-        with open(pmc) as f:
-            j = json.load(f)
-        af = float(j.get("agent_frames_per_launch") or 0)
-        if af > 0:
-            # The counters were taken over the launches of one batch size; per agent-frame the kernel's traffic does not depend on it (every
-            # wave streams the same 3.4 MB of level blobs through its XCD's L2 and reads its own 32 rows once), so the stored figure is kept
-            # PER AGENT-FRAME and scaled to this run's launch -- VERDICT r4: the field was null whenever the two sizes differed by a remainder.
-            traffic = int(round(float(j.get("traffic_bytes_per_launch")) / af * n))
-            note = (f"profiles/{os.path.basename(pmc)}: {j.get('traffic_bytes_per_launch')} B per launch of {af} agent-frames = "
-                    f"{float(j.get('traffic_bytes_per_launch')) / af / 1e6:.3f} MB per agent-frame, x {n} agent-frames of this run's launch; " + j.get("note", ""))
-    roof = {"bound": "mfma", "achieved": enc["achieved"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": enc["frac"],
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_dominant.json")))     # the latest round's PMC passes, per kernel key
+    if found:
+        with open(found[-1]) as f:
+            j = json.load(f).get(key)
+        if j and float(j.get("units_per_launch") or 0) > 0:
+            # stored per unit of the kernel's work (agent-frames for the dense kernels, listed cells for stage 2) and scaled to this run's launch
+            units = float(stages["codebook_encode_two_stage"]["refined_cells"]) if key == "encode_listed" else float(n)
+            traffic = int(round(float(j["traffic_bytes_per_launch"]) / float(j["units_per_launch"]) * units))
+            note = f"profiles/{os.path.basename(found[-1])}[{key}]: {j['traffic_bytes_per_launch']} B per launch of {j['units_per_launch']} {j.get('unit', 'units')}, scaled to this launch; " + j.get("note", "")
+    roof = {"bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
             "traffic": traffic, "traffic_note": "STORED figure, not measured by this run: " + note,
-            "algorithmic_bytes_per_launch": None, "traffic_over_algorithmic": None,
-            "kernel": "codebook_encode_wave_kernel (f32 MFMA v_mfma_f32_32x32x2_f32; the dominant kernel by time; a wave per 32 cells)", "launches_per_batch": 1,
-            "avg_launch_us": enc["us_per_batch"], "agent_frames_per_launch": n,
-            "algorithmic_gflop_per_launch": round(enc_gflop * n, 2),
-            "share_of_batch_time": None}
-    # algorithmic bytes of the launch: every cell's 256 input codes read once, its code planes written, the level blobs read once
-    alg = n * hw * 256 + n * hw * eng.levels + sum(int(b.numel()) * 4 for b in eng.level_blobs)
-    roof["algorithmic_bytes_per_launch"] = alg
-    if traffic:
-        roof["traffic_over_algorithmic"] = round(traffic / alg, 3)
-    total = sum(s["us_per_batch"] for s in stages.values() if "us_per_batch" in s)
-    roof["share_of_batch_time"] = round(enc["us_per_batch"] / total, 3)
+            "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": round(traffic / alg, 3) if (traffic and alg) else None,
+            "kernel": kname + " -- the dominant kernel by time of one launch", "launches_per_batch": 1,
+            "avg_launch_us": round(us, 2), "agent_frames_per_launch": n,
+            "algorithmic_gop_per_launch": round(work / 1e9, 2),
+            "share_of_batch_time": None,
+            "runners_up": [{"kernel": c[1].split(" (")[0], "us": round(c[0], 1), "frac": round(c[3] / (c[0] * 1e-6) / 1e12 / c[5], 4)} for c in cands[1:4]]}
+    step_stages = [k for k in stages if k not in ("codebook_encode_f32_every_cell", "codebook_encode_candidates_i8", "codebook_encode_listed_f32")]
+    total = sum(stages[k]["us_per_batch"] for k in step_stages if "us_per_batch" in stages[k])
+    roof["share_of_batch_time"] = round(us / total, 3)
     if general:
         stages["general_path_multi_agent"] = general
     int8_us = stages["backbone_convs_i8"]["us_per_batch"] + stages["shrinker_convs_i8"]["us_per_batch"]
@@ -464,40 +536,46 @@ def _graph_of(fn):
     return g.replay
 
 
-def collapsed_encode_line(state, full, B, F, steps, device):
-    """NOT the headline: the same step (B frames per graph, F graphs in flight) with the OPT-IN collapsed codebook encode
-    (engine.encode_mode = "collapsed": the encoder's affine heads multiplied out on the host, one GEMM + an argmin chain per cell).  Its
-    indices differ from the exact path's in ~1 cell of 10 000, all of them cells whose two best distances tie to within fp32 rounding
-    (tools/bench_collapsed_encode.py, profiles/r02_collapsed_encode.json); the exact kernel stays the default and the parity configuration."""
+def encode_modes_line(state, full, B, F, steps, device):
+    """NOT the headline: the same step (B frames per graph, F graphs in flight) with the codebook encode in its other modes -- ``exact``:
+    EVERY cell through the reference-order chain (the configuration of rounds 1-5; identical indices, checked here on the whole batch);
+    ``collapsed``: the opt-in approximate form (one fp32 GEMM + an argmin chain; differs at near-ties, tools/bench_collapsed_encode.py)."""
     import torch
     from quantv2x_amd.engine import deploy
     engines = [deploy(state=state) for _ in range(F)]
     streams = [torch.cuda.Stream() for _ in range(F)]
-    reps = []
-    for e, st in zip(engines, streams):
-        e.encode_mode = "collapsed"
-        with torch.cuda.stream(st):
-            reps.append(e.capture(full))
-    torch.cuda.synchronize()
-    for i in range(2 * F):
-        with torch.cuda.stream(streams[i % F]):
-            reps[i % F]()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        with torch.cuda.stream(streams[i % F]):
-            reps[i % F]()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    exact = engines[0]
-    exact.encode_mode = "exact"
-    a = exact.encode_agents(full["inputs_m1"], B).clone()
-    exact.encode_mode = "collapsed"
-    b = exact.encode_agents(full["inputs_m1"], B)
-    torch.cuda.synchronize()
-    return {"frames_per_s": round(B * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4),
-            "index_mismatch_rate_vs_exact": float((a != b).float().mean().item()),
-            "note": "opt-in, not the parity configuration and not `value`: same graphs with engine.encode_mode = 'collapsed'"}
+    out = {}
+    ref = engines[0]
+    default_mode = ref.encode_mode
+    want = ref.encode_agents(full["inputs_m1"], B).clone()               # the default mode's indices
+    for mode in ("exact", "collapsed"):
+        reps = []
+        for e, st in zip(engines, streams):
+            e.encode_mode = mode
+            with torch.cuda.stream(st):
+                reps.append(e.capture(full))
+        torch.cuda.synchronize()
+        for i in range(2 * F):
+            with torch.cuda.stream(streams[i % F]):
+                reps[i % F]()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            with torch.cuda.stream(streams[i % F]):
+                reps[i % F]()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        got = ref.encode_agents(full["inputs_m1"], B)
+        torch.cuda.synchronize()
+        out[mode] = {"frames_per_s": round(B * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4),
+                     "index_mismatches_vs_default_mode": int((got != want).sum().item()), "indices_compared": int(want.numel())}
+        del reps
+    for e in engines:
+        e.encode_mode = default_mode
+    out["default_mode"] = default_mode
+    out["note"] = ("`value` runs the default mode (two_stage where its contract holds: exact by construction).  'exact' = every cell through the eleven "
+                   "chained GEMMs (what rounds 1-5 timed); 'collapsed' = opt-in, approximate, not a parity configuration")
+    return out
 
 
 def second_encoder_line(device):
@@ -1043,7 +1121,7 @@ def main():
             line["multi_agent_one_gpu"] = multi_agent_line(eng, device)
             line["pyramid_model"] = pyramid_model_line(device)
             line["second_encoder"] = second_encoder_line(device)
-            line["collapsed_encode_opt_in"] = collapsed_encode_line(state, full, B, F, args.steps, device)
+            line["encode_modes"] = encode_modes_line(state, full, B, F, args.steps, device)
             line["points_to_boxes"] = points_to_boxes_line(state, device)
             try:
                 line["codebook_seg2_dict256"] = codebook_seg_line(full, B, device)

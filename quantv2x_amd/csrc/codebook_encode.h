@@ -14,6 +14,7 @@ struct EncArgs {
     int segs, ke;                       // seg_num (m) = 1 | 2 | 4 segments of 256 / segs dims; ke = segs * kc rows of the extended codebook
     float dx;
     int m_lo, m_hi;             // the rows [m_lo, m_hi) of the M = n h w cells this launch encodes (a launch may be split between the two forms)
+    int list_slots = 1, list_tail_max = 0;                 // the split of the listed cells between the two forms (codebook_encode.hip:list_full_tiles)
     const unsigned* list = nullptr; const unsigned* list_count = nullptr;      // LIST form of the wave kernel: the cells to encode and their DEVICE-side count
 };
 

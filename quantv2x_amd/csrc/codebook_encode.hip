@@ -148,9 +148,11 @@ template <int ER> constexpr int enc_smem_floats() { return 2 * ER * LDF + 4 * ER
 // EXT = false: one segment and one round of code tiles (ke <= 32 * 8 / ERT: every (m, kc) = (1, <= 128) model) -- the loop over tile rounds
 // and the per-segment bookkeeping cost the 32-row form 15 registers and 8 bytes of scratch under its 128-register bound, so they are
 // compiled out of the form every V2X-Real / OPV2V attfuse model takes; EXT = true: seg_num > 1 or an extended codebook of several rounds.
-template <int ER, bool EXT>
+// LIST (round 6): the rows are the listed cells a.list[m0 .. m0 + ER) (stage 2 of the two-stage encode), not the cells m0 .. m0 + ER.
+template <int ER, bool EXT, bool LIST = false>
 __device__ __forceinline__ void encode_rows(const EncArgs& a, const int m0, float* __restrict__ smem) {
     constexpr int ERT = ER / 32;
+    const int n_listed = LIST ? (int)*a.list_count : 0;
     const int segs = EXT ? a.segs : 1;
     float* bufA = smem;                       // x, then q, then next x
     float* bufB = smem + ER * LDF;            // z
@@ -171,6 +173,7 @@ __device__ __forceinline__ void encode_rows(const EncArgs& a, const int m0, floa
         constexpr int CPT = D / TPR;                  // channels per thread (16 for ER = 32)
         const int row = tid / TPR, part = tid % TPR;
         int m = m0 + row;
+        if (LIST) m = (int)a.list[m < n_listed ? m : n_listed - 1];
         m = m < a.M ? m : a.M - 1;
         const int img = m / (a.h * a.w), rem = m - img * (a.h * a.w);
         const int y = rem / a.w, x = rem - y * a.w;
@@ -351,7 +354,9 @@ __device__ __forceinline__ void encode_rows(const EncArgs& a, const int m0, floa
                 }
                 const int bi = (int)(unsigned)bk;                      // row of the extended codebook: sg * kc + code
                 code_s[sg * ER + tid] = bi;
-                if (m0 + tid < a.m_hi) a.codes[((size_t)l * segs + sg) * a.M + m0 + tid] = (uint8_t)(bi - sg * a.kc);
+                if (LIST) {
+                    if (m0 + tid < n_listed) a.codes[((size_t)l * segs + sg) * a.M + a.list[m0 + tid]] = (uint8_t)(bi - sg * a.kc);
+                } else if (m0 + tid < a.m_hi) a.codes[((size_t)l * segs + sg) * a.M + m0 + tid] = (uint8_t)(bi - sg * a.kc);
             }
         }
         lds_barrier();
@@ -390,6 +395,25 @@ template <int ER, bool EXT = false>
 __global__ __launch_bounds__(512, ER == 32 ? 4 : 2) void codebook_encode_kernel(const EncArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[enc_smem_floats<ER>()];
     encode_rows<ER, EXT>(a, a.m_lo + blockIdx.x * ER, smem);
+}
+
+// Stage 2 of the two-stage encode, the REMAINDER of the list: the wave form (codebook_encode_wave.hip, LIST) takes whole rounds of its
+// `a.list_slots` persistent waves; what is left -- up to `a.list_tail_max` tiles of 32 cells, e.g. ALL of one frame's ~100 tiles -- runs here
+// as 8-wave workgroups, a third of a wave's latency (the same split qv2x_codebook_encode_f32 makes on the host; here both kernels derive it
+// from the DEVICE-side count).
+__device__ __forceinline__ int list_full_tiles(const EncArgs& a, int n_listed) {
+    const int ntiles = (n_listed + 31) >> 5;
+    const int full = ntiles / a.list_slots * a.list_slots;
+    return ntiles - full > a.list_tail_max ? ntiles : full;
+}
+
+__global__ __launch_bounds__(512, 4) void codebook_encode_list_tail_kernel(const EncArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[enc_smem_floats<32>()];
+    const int n_listed = (int)*a.list_count, ntiles = (n_listed + 31) >> 5;
+    for (int t = list_full_tiles(a, n_listed) + (int)blockIdx.x; t < ntiles; t += (int)gridDim.x) {
+        encode_rows<32, false, true>(a, t * 32, smem);
+        __syncthreads();
+    }
 }
 
 // Launches of one or two frames: whole rounds of 64-row workgroups (one per CU: n64 of them, a multiple of the CU count), then the rows
@@ -466,10 +490,17 @@ extern "C" int qv2x_codebook_encode_listed_f32(const qv2x_encode_desc* d, const 
         a.lvl[l] = l < d->levels ? level_weights[l] : nullptr;
         if (l < d->levels && (!a.lvl[l] || ((uintptr_t)a.lvl[l] & 15))) return fail(QV2X_EALIGN, "qv2x_codebook_encode_listed_f32: level %d weights null or unaligned", l);
     }
+    if (d->kc > 128) return fail(QV2X_EINVAL, "qv2x_codebook_encode_listed_f32: dict_size <= 128 (the candidate stage's contract)");
     int cus = 256, dev = 0, v = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    const int waves = (a.M + 31) / 32;
-    return encode_wave_list_launch(a, waves < 4 * cus ? waves : 4 * cus, (hipStream_t)stream);
+    const int tiles = (a.M + 31) / 32;
+    a.list_slots = 4 * cus; a.list_tail_max = 2 * cus;
+    // whole rounds of the chip's wave slots as persistent waves, the remainder as workgroups: both launches have a fixed size, the split is
+    // made on the device from the count (list_full_tiles)
+    if (tiles >= a.list_slots)
+        if (int rc = encode_wave_list_launch(a, a.list_slots, (hipStream_t)stream)) return rc;
+    codebook_encode_list_tail_kernel<<<tiles < a.list_tail_max ? tiles : a.list_tail_max, 512, 0, (hipStream_t)stream>>>(a);
+    return hip_check(hipGetLastError(), "qv2x_codebook_encode_listed_f32 launch");
 }
 
 static int encode_launch(const qv2x_encode_desc* d, const int8_t* in, const float* in_f32, const float* const* level_weights, uint8_t* codes, void* stream,

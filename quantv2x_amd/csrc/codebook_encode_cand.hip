@@ -92,6 +92,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         double best[CT], second[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) best[ct] = second[ct] = 1.0e300;
+        // a group's bias and table rows are requested one group AHEAD of their use (the first group's under the tile's last MFMAs): a wave is
+        // alone on its SIMD, so a load issued where it is used costs its whole L2 round trip (first version: 878 us per 32 frames)
+        v4i qb[2][2], qt0[2][CT], qt1[2][CT];
+        auto issue = [&](int T, int g, int slot) __attribute__((always_inline)) {
+            const int kofs = l * a.kc + 32 * T + 8 * g;                 // + 4 hf + e
+            qb[slot][0] = (v4i)__builtin_amdgcn_raw_buffer_load_b128(brs, 32 * hf, kofs * 8, 0);
+            qb[slot][1] = (v4i)__builtin_amdgcn_raw_buffer_load_b128(brs, 32 * hf + 16, kofs * 8, 0);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                if (l >= 1) qt0[slot][ct] = (v4i)__builtin_amdgcn_raw_buffer_load_b128(trs, o0[ct], ((l * (l - 1) / 2) * a.kc * a.kc + 32 * T + 8 * g) * 4, 0);
+                if (l >= 2) qt1[slot][ct] = (v4i)__builtin_amdgcn_raw_buffer_load_b128(trs, o1[ct], ((l * (l - 1) / 2 + 1) * a.kc * a.kc + 32 * T + 8 * g) * 4, 0);
+            }
+        };
 #pragma unroll 1
         for (int T = 0; T < ntile; ++T) {
             v16i acc[LIMBS][CT];
@@ -107,39 +120,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) acc[f >> 3][ct] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, xb[ct][f & 7], acc[f >> 3][ct], 0, 0, 0);
                 ring[f % NPF] = gload(f + NPF);
+                if (f == LIMBS * 8 - 6) issue(T, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);                      // (hipcc otherwise sinks every load to its first use)
             }
             wo += LIMBS * 8 * 1024;
             // ---- the tile's 32 scores of each cell: lane (j, hf) holds scores 32 T + 8 g + 4 hf + e, g = r >> 2, e = r & 3 -----------------
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                __builtin_amdgcn_sched_barrier(0);                      // (one group's loads and doubles at a time)
-                const int kofs = l * a.kc + 32 * T + 8 * g;             // + 4 hf + e
-                const v4i blo = (v4i)__builtin_amdgcn_raw_buffer_load_b128(brs, 32 * hf, kofs * 8, 0);
-                const v4i bhi = (v4i)__builtin_amdgcn_raw_buffer_load_b128(brs, 32 * hf + 16, kofs * 8, 0);
+                if (g < 3) issue(T, g + 1, (g + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const int sl = g & 1;
                 double b[4];                                            // 128 * bias + k: the packed form
-                b[0] = __builtin_bit_cast(double, ((unsigned long long)(unsigned)blo[1] << 32) | (unsigned)blo[0]);
-                b[1] = __builtin_bit_cast(double, ((unsigned long long)(unsigned)blo[3] << 32) | (unsigned)blo[2]);
-                b[2] = __builtin_bit_cast(double, ((unsigned long long)(unsigned)bhi[1] << 32) | (unsigned)bhi[0]);
-                b[3] = __builtin_bit_cast(double, ((unsigned long long)(unsigned)bhi[3] << 32) | (unsigned)bhi[2]);
+                b[0] = __builtin_bit_cast(double, ((unsigned long long)(unsigned)qb[sl][0][1] << 32) | (unsigned)qb[sl][0][0]);
+                b[1] = __builtin_bit_cast(double, ((unsigned long long)(unsigned)qb[sl][0][3] << 32) | (unsigned)qb[sl][0][2]);
+                b[2] = __builtin_bit_cast(double, ((unsigned long long)(unsigned)qb[sl][1][1] << 32) | (unsigned)qb[sl][1][0]);
+                b[3] = __builtin_bit_cast(double, ((unsigned long long)(unsigned)qb[sl][1][3] << 32) | (unsigned)qb[sl][1][2]);
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
-                    v4i t0 = {0, 0, 0, 0}, t1 = {0, 0, 0, 0};
-                    if (l >= 1) t0 = (v4i)__builtin_amdgcn_raw_buffer_load_b128(trs, o0[ct], ((l * (l - 1) / 2) * a.kc * a.kc + 32 * T + 8 * g) * 4, 0);
-                    if (l >= 2) t1 = (v4i)__builtin_amdgcn_raw_buffer_load_b128(trs, o1[ct], ((l * (l - 1) / 2 + 1) * a.kc * a.kc + 32 * T + 8 * g) * 4, 0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int r = 4 * g + e;
-                        // 128 S + k = 128 (65536 a2 + 256 a1 + a0 + bias + tables) + k: integers below 2^53, every operation exact
-                        double c = __builtin_fma((double)acc[0][ct][r], 128.0, b[e]);
-                        c = __builtin_fma((double)acc[1][ct][r], 32768.0, c);
+                        // 128 S + k = 128 (65536 a2 + [256 a1 + a0 + tables] + bias) + k: the bracket in i32 (|a1| <= 2^22, |a0| <= 2^22, table
+                        // entries below 2^28: encode_two_stage.py refuses larger ones), the rest on integers below 2^53 in fp64 -- all exact
+                        int lo = (acc[1][ct][r] << 8) + acc[0][ct][r];
+                        if (l >= 1) lo += qt0[sl][ct][e];
+                        if (l >= 2) lo += qt1[sl][ct][e];
+                        double c = __builtin_fma((double)lo, 128.0, b[e]);
                         c = __builtin_fma((double)acc[2][ct][r], 8388608.0, c);
-                        if (l >= 1) c = __builtin_fma((double)t0[e], 128.0, c);
-                        if (l >= 2) c = __builtin_fma((double)t1[e], 128.0, c);
                         second[ct] = fmin(second[ct], fmax(best[ct], c));
                         best[ct] = fmin(best[ct], c);
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // ---- close the level: the two half-waves' (best, second), the index out of the packed value, the gap against the bound ---------------

@@ -87,8 +87,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
     const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
     float* const row = smem + j * RS;
     const int n_listed = LIST ? (int)*a.list_count : 0;
+    int list_tiles = 0;                                              // LIST: whole rounds of the launch's waves; the remainder is the workgroup form's
+    if (LIST) {                                                      // (codebook_encode.hip: list_full_tiles, codebook_encode_list_tail_kernel)
+        const int ntiles = (n_listed + 31) >> 5, full = ntiles / a.list_slots * a.list_slots;
+        list_tiles = ntiles - full > a.list_tail_max ? ntiles : full;
+    }
 #pragma unroll 1
-    for (int tile = (int)blockIdx.x; LIST ? tile * 32 < n_listed : tile == (int)blockIdx.x; tile += (int)gridDim.x) {
+    for (int tile = (int)blockIdx.x; LIST ? tile < list_tiles : tile == (int)blockIdx.x; tile += (int)gridDim.x) {
     int mrow;                                                        // this lane's cell, and whether its codes are stored
     bool owned;
     if (LIST) {

@@ -410,9 +410,12 @@ class DeployedModel(nn.Module):
         # launch-plan switches for the ablation tools (tools/bench_*_abl.py); the defaults are the shipped configuration
         self.use_wide_conv, self.batch_deconvs, self.use_chains = True, True, True
         self.chain_max_agents = 1
-        # "exact": the reference's eleven chained GEMMs, bit-identical indices (the parity configuration).  "collapsed": opt-in, see collapse_encoder
-        self.encode_mode, self._collapsed, self._two_stage = "exact", None, None
-        self.encode_form = "auto"                                      # "wave": force the wave-per-32-cells encode kernel (same codes)
+        # "exact": every cell through the reference's eleven chained GEMMs.  "two_stage" (round 6, the default wherever its contract holds):
+        # the SAME indices by construction -- exact integer candidates, the chain only for the cells a proven bound cannot decide
+        # (encode_two_stage.py).  "collapsed": opt-in and approximate, see collapse_encoder.
+        self._collapsed, self._two_stage = None, None
+        self.encode_form = "auto"                                      # "wave": force the wave-per-32-cells encode kernel on every cell (same codes)
+        self.encode_mode = "two_stage" if self.two_stage_supported() else "exact"
 
     # ------------------------------------------------------------------------------------------------------
     def _level_blob(self, l: int) -> torch.Tensor:
@@ -681,9 +684,9 @@ class DeployedModel(nn.Module):
             L.check(self.lib.qv2x_codebook_encode_collapsed_f32(C.byref(d), L.ptr(b["s1"]), L.ptr(gp), L.ptr(bias), L.ptr(tab), L.ptr(codes),
                                                                 L.current_stream()), "qv2x_codebook_encode_collapsed_f32")
             return codes
-        if self.encode_mode == "two_stage":                           # exact by construction: candidates on the integer grid + the chain on the undecided
+        if self.encode_mode == "two_stage" and self.encode_form == "auto":   # exact by construction: candidates on the integer grid + the chain on the undecided
             return self._encode_two_stage(d, b, codes, n_agents)
-        if self.encode_mode != "exact":
+        if self.encode_mode not in ("exact", "two_stage"):
             raise ValueError(f"encode_mode {self.encode_mode!r}: 'exact' (every cell through the reference's op order), 'two_stage' (the same "
                              "indices: exact integer candidates, the chain only where the bound cannot decide) or 'collapsed' (opt-in, approximate)")
         if self.encode_form == "wave":                                # tests: the many-frames form at any size (the library picks by launch size)
@@ -851,20 +854,23 @@ class DeployedModel(nn.Module):
         ``get_pairwise_transformation`` produces, transformation_utils.py:21-66).  The reference warps with whatever it is handed
         (AttFusion -> warp_affine_simple, fusion_in_one.py:142-143), so a non-identity self-transform (pose-noise experiments, a caller's
         bug) must take the general path.  Checked on the host whenever the matrix can be read: a CPU tensor always; a device tensor unless
-        the stream is capturing (the verdict is cached per tensor version, so a replayed input costs one read-back).  During capture of a
+        the stream is capturing (the verdict is remembered per tensor OBJECT and version, so a replayed input costs one read-back).  During capture of a
         device tensor the contract cannot be verified and is assumed -- ``capture()`` runs an eager forward first, which does check."""
         if pairwise.is_cuda:
             if torch.cuda.is_current_stream_capturing():
                 return True
-            key = (pairwise.data_ptr(), pairwise._version, tuple(pairwise.shape))
-            if getattr(self, "_ident_key", None) == key:
-                return self._ident_val
+            # The verdict is remembered for the tensor OBJECT (a weak reference) at its version -- never for an address: a fresh tensor that
+            # reuses a freed block has the same data_ptr and version 0 but other contents (ADVICE r5; GPU suite of round 6 hit exactly that).
+            ref = getattr(self, "_ident_ref", None)
+            if ref is not None and ref[0]() is pairwise and ref[1] == pairwise._version:
+                return ref[2]
             t00 = pairwise[:, 0, 0].cpu()
         else:
-            key, t00 = None, pairwise[:, 0, 0]
+            t00 = pairwise[:, 0, 0]
         ok = bool((t00 == torch.eye(4, dtype=t00.dtype)).all())
-        if key is not None:
-            self._ident_key, self._ident_val = key, ok
+        if pairwise.is_cuda:
+            import weakref
+            self._ident_ref = (weakref.ref(pairwise), pairwise._version, ok)
         return ok
 
     def _one_launch_agents(self) -> int:
@@ -1017,7 +1023,7 @@ class DeployedModel(nn.Module):
         feats = None if self.has_codebook else self._shared_features(enc, n_total)
         starts = [sum(lens[:bi]) for bi in range(nb)]
         if (taps is None and self.table_heads is not None and self.single_agent_tables and all(n == 1 for n in lens)
-                and self._self_transforms_are_identity(pairwise)):
+                and self._self_transforms_are_identity(data_dict["pairwise_t_matrix"])):      # (the caller's own tensor object: see there)
             return self._table_heads_out(enc, nb)                         # every scene is one agent: all heads straight from its code planes
         if not pairwise.is_cuda:                                         # a host tensor (the reference's collate output before to_device): copied here
             if torch.cuda.is_current_stream_capturing():

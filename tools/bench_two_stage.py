@@ -27,5 +27,19 @@ def main():
         if mode == "two_stage":
             print("equal to exact:", bool(torch.equal(out, exact)), eng.encode_refine_stats(frames))
     print(f"frames {frames}: exact {res['exact']:.3f} ms, two-stage {res['two_stage']:.3f} ms")
+    # the two stages by themselves (the list of the last run stays on the device: stage 2 alone repeats the same work)
+    import ctypes as C
+    b = eng._workspace(frames)
+    gp, bias, tab, tau, _ = eng._two_stage
+    d = L.EncodeDesc()
+    d.n, d.h, d.w, d.levels, d.kc, d.segs = frames, eng.fh, eng.fw, eng.enc_levels, eng.kc, 1
+    d.in_zx, d.in_delta = int(eng.shrink1.out_q[1]), float(eng.shrink1.out_q[0])
+    codes = b["codes"]
+    s1 = lambda: L.check(eng.lib.qv2x_codebook_encode_candidates_i8(C.byref(d), L.ptr(b["s1"]), L.ptr(gp), L.ptr(bias), L.ptr(tab), tau, L.ptr(codes),
+                                                                    L.ptr(b["enc_list"]), L.ptr(b["enc_counters"]), L.current_stream()), "s1")
+    s2 = lambda: L.check(eng.lib.qv2x_codebook_encode_listed_f32(C.byref(d), L.ptr(b["s1"]), eng.level_ptrs, L.ptr(b["enc_list"]), L.ptr(b["enc_counters"]),
+                                                                 L.ptr(codes), L.current_stream()), "s2")
+    s1(); torch.cuda.synchronize()
+    print(f"stage 1 {bench.event_time_us(s1, 20):.1f} us, stage 2 {bench.event_time_us(s2, 20):.1f} us")
 
 main()
