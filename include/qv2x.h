@@ -36,7 +36,11 @@ extern "C" {
 #define QV2X_MAX_GROUPS 4
 
 const char* qv2x_last_error(void);
-int qv2x_version(void);
+/* The ABI of this header.  A caller built against another value must not pass its structs: 5 = qv2x_encode_desc grew the trailing `segs`
+ * field (round 5; a caller built before it passes garbage there unless its struct was zero-initialised -- ADVICE r5); 6 = round 6:
+ * qv2x_codebook_encode_candidates_i8 / qv2x_codebook_encode_listed_f32 added, no struct changed. */
+#define QV2X_ABI_VERSION 6
+int qv2x_version(void);            /* == QV2X_ABI_VERSION of the library's own build */
 
 /* Fill a padded i8 BEV tensor (border AND interior) with one byte value: the per-frame canvas clear and the
  * one-time border initialisation.  Replaces torch.zeros(...) in PointPillarScatter.forward

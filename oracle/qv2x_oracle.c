@@ -25,6 +25,7 @@
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: the compiler must not fuse mul+add).
  */
 #include <math.h>
+#include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -42,9 +43,12 @@ static inline float q_code(float y, float delta, float zp) {
  * -- UniformAffineQuantizer.forward (quant_layer.py:132-133: round(x / delta) + zero_point, clamp) with the division replaced by ONE fused
  * multiply-add with the fp32 reciprocal, which is what v_fma_f32 + v_cvt_pk_u8_f32 (round to nearest even, saturate) evaluate in two
  * instructions per output; the division-exact form cost the HIP epilogues 5.25 (the 64- and 128-channel layers are bound by
- * VALU issue).  The two forms give a different code only where x / delta lies within ~1.2e-7 |x / delta| of a rounding boundary -- the same
- * order as the noise of the reference's own fp32 convolution sums, and bounded by the same golden-vector tests (<= 1 LSB on < 5e-4 of the
- * elements per layer, tests/test_oracle_golden.py; measured flip rates in DESIGN.md 4).  Compile with -DORC_QDIV for the division form.
+ * VALU issue).  The two forms give a different code only where p = x / delta lies close to a rounding boundary: within ~1.2e-7 |p| when
+ * zp = 0 (every post-ReLU quantizer), and within ~ulp(p + zp) / 2 <= 3e-5 when zp != 0 -- there the division form rounds p to an integer
+ * BEFORE zp is added, this form rounds p + zp once.  Measured on a 3x3 layer's 393 216 outputs
+ * (tests/test_sanitizers_cpu.py::test_reciprocal_multiply_quantizer_against_the_division_form): 0 codes differ at zp = 0, 2 (5e-6) at
+ * zp = 131, never by more than one LSB -- below the noise of the reference's own fp32 convolution sums and inside the golden-vector bound
+ * (<= 1 LSB on < 5e-4 of the elements per layer, tests/test_oracle_golden.py).  Compile with -DORC_QDIV (make qdiv) for the division form.
  * The PFN's two quantizers and the heads keep q_code (pinned bit for bit on the reference's golden pillar codes). */
 static inline float q_code_mul(float y, float delta, float zp) {
 #ifdef ORC_QDIV
@@ -265,7 +269,11 @@ ORC_API void orc_codebook_encode_seg(const float* x_in, int R, int L, int Kc, in
                                      const float* const* lhead_w, const float* const* lhead_b,
                                      const float* const* codebook, uint8_t* codes /* [L * S][R] */,
                                      float* gap_out /* [L * S][R] top-2 gap or NULL */) {
-    if ((D != 256 && D != 64) || S < 1 || D % S || Kc < 1 || Kc > 256) return;
+    if ((D != 256 && D != 64) || S < 1 || D % S || Kc < 1 || Kc > 256) {
+        /* (never a silent return: zero codes would look like an answer -- ADVICE r5) */
+        fprintf(stderr, "orc_codebook_encode_seg: unsupported shape D %d, seg_num %d, dict_size %d\n", D, S, Kc);
+        abort();
+    }
     const int d = D / S, KE = S * Kc;
     float* x = (float*)malloc((size_t)R * D * sizeof(float));
     float* z = (float*)malloc((size_t)R * D * sizeof(float));

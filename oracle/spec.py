@@ -29,7 +29,8 @@ _f32p = ctypes.POINTER(ctypes.c_float)
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "_build", "libqv2x_oracle.so")
+        # QV2X_ORACLE_LIB: another build of the same checker (tests: the sanitizer build `make -C oracle asan`, the division-form build)
+        path = os.environ.get("QV2X_ORACLE_LIB") or os.path.join(_HERE, "_build", "libqv2x_oracle.so")
         if not os.path.exists(path):
             subprocess.check_call(["make", "-C", _HERE, "-s"])
         _LIB = ctypes.CDLL(path)

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void fill16_kernel(v4i* __restrict__ p, long l
 
 extern "C" {
 const char* qv2x_last_error(void) { return qv2x::g_err; }
-int qv2x_version(void) { return 1; }
+int qv2x_version(void) { return QV2X_ABI_VERSION; }
 
 int qv2x_fill_i8(int8_t* buf, int64_t bytes, int value, void* stream) {
     if (!buf || bytes < 0) return qv2x::fail(QV2X_EINVAL, "qv2x_fill_i8: null buffer or negative size");

@@ -373,6 +373,9 @@ class DeployedModel(nn.Module):
             self.levels = self.enc_levels * self.segs
             self.ke = int(s["codebook/0/codebook"].shape[0])
             self.kc = self.ke // self.segs
+            if self.ke > 512 or self.kc > 256:
+                raise NotImplementedError(f"deployed codebook path: seg_num * dict_size <= 512, dict_size <= 256 (got {self.segs} x {self.kc}): "
+                                          "the encode kernels' tile budget (qv2x_codebook_encode_f32)")
             lut, lut_bias = decode_tables(s, self.enc_levels)
             lut = lut.reshape(self.levels, self.kc, lut.shape[-1])
             self.lut = _dev(lut, dev)
@@ -386,8 +389,10 @@ class DeployedModel(nn.Module):
         self.single_by_tables = (self.heads_single is not None and self.has_codebook and self.levels <= 4
                                  and self.levels * self.kc * self.heads_single.cout * 4 <= 60 * 1024)
         # (round 5: tables past that kernel's LDS -- six planes x 256 rows -- through qv2x_table_heads_f32's global-memory form)
+        # (the C entry's global-memory form: c0 + c1 a multiple of 4 and <= 128, 16-byte aligned arrays -- torch allocations are 256-byte
+        #  aligned; a wider single head keeps qv2x_decode_heads_f32, which handles it: ADVICE r5)
         self.single_by_global_tables = (not self.single_by_tables and self.heads_single is not None and self.has_codebook and self.levels <= 16
-                                        and self.heads_single.cout % 4 == 0)
+                                        and self.heads_single.cout % 4 == 0 and self.heads_single.cout <= 128)
         if self.single_by_tables or self.single_by_global_tables:
             self.heads_single.collapse_over_decode(lut, lut_bias, dev)
         # single-agent scenes (round 4): AttFusion over one agent is the identity, so EVERY head is a table look-up on the agent's own codes

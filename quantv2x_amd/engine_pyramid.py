@@ -664,6 +664,7 @@ class DeployedHeterPyramidModel(nn.Module):
         if not states:
             raise ValueError("DeployedHeterPyramidModel: no modality")
         self.engines = {m: DeployedPyramidModel(st, device=device) for m, st in states.items()}
+        self.modality_names = list(states)                               # the model's modality_name_list order (deploy passes it that way)
         self.main = self.engines[ego_modality if ego_modality in self.engines else next(iter(self.engines))]
         for m, e in self.engines.items():
             e._agent_ws(1)
@@ -676,7 +677,11 @@ class DeployedHeterPyramidModel(nn.Module):
 
     @torch.no_grad()
     def forward(self, data_dict: dict, taps: Optional[dict] = None) -> dict:
-        agents = [str(a) for a in data_dict["agent_modality_list"]]
+        # the reference's heter_pyramid_collab takes a TENSOR of 1-based modality codes and maps it onto modality_name_list
+        # (heter_pyramid_collab.py:143-150; the plugin mirror's _named_modalities does the same); names pass through
+        aml = data_dict["agent_modality_list"]
+        aml = aml.tolist() if isinstance(aml, torch.Tensor) else list(aml)
+        agents = [self.modality_names[int(a) - 1] if isinstance(a, (int, np.integer)) or (isinstance(a, float) and a == int(a)) else str(a) for a in aml]
         n_total, hw, lv = len(agents), self.main.fh * self.main.fw, self.main.levels
         unknown = sorted(set(agents) - set(self.engines))
         if unknown:

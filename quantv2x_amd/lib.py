@@ -11,6 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libqv2x.so")
 MAX_GROUPS = 4
+ABI_VERSION = 6             # include/qv2x.h: QV2X_ABI_VERSION (the structs below mirror that header)
 
 SYMBOLS = [
     "qv2x_last_error", "qv2x_version", "qv2x_fill_i8", "qv2x_pfn_scatter_i8", "qv2x_pfn_unscatter_i8", "qv2x_conv3x3_i8",
@@ -131,6 +132,8 @@ def load() -> C.CDLL:
     vp = C.c_void_p
     lib.qv2x_last_error.restype = C.c_char_p
     lib.qv2x_version.restype = C.c_int
+    if lib.qv2x_version() != ABI_VERSION:
+        raise Qv2xError(f"libqv2x.so has ABI {lib.qv2x_version()}, this binding mirrors ABI {ABI_VERSION} (include/qv2x.h): rebuild the library")
     lib.qv2x_fill_i8.argtypes = [vp, C.c_int64, C.c_int, vp]
     lib.qv2x_pfn_scatter_i8.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(PfnParams), vp, C.c_int, C.c_int, C.c_int, vp]
     lib.qv2x_pfn_unscatter_i8.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]

@@ -229,9 +229,11 @@ def export_ptq_state(qt_model, modality: str = "m1") -> Dict[str, np.ndarray]:
         if len(ks) != 1:
             raise NotImplementedError(f"deployed codebook path: one dict_size for every level (got {sorted(ks)})")
         k = ks.pop()
-        if k > 256 or (m > 1 and k % 64) or (m == 1 and k % 32) or m not in (1, 2, 4):
-            raise NotImplementedError(f"deployed codebook path: seg_num 1 | 2 | 4 and dict_size <= 256 (a multiple of 32; of 64 with seg_num > 1): "
-                                      f"got seg_num {m}, dict_size {k}")
+        if k > 256 or (m > 1 and k % 64) or (m == 1 and k % 32) or m not in (1, 2, 4) or m * k > 512:
+            # (m k <= 512: the encode kernels' tile budget, qv2x_codebook_encode_f32 -- ADVICE r5: (4, 256) used to export and then fail
+            #  with EINVAL on its first encode)
+            raise NotImplementedError(f"deployed codebook path: seg_num 1 | 2 | 4 and dict_size <= 256 (a multiple of 32; of 64 with seg_num > 1; "
+                                      f"seg_num * dict_size <= 512): got seg_num {m}, dict_size {k}")
     return check_finite(out)
 
 

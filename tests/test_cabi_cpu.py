@@ -24,7 +24,8 @@ def test_library_exports_every_declared_symbol():
     l = _lib()
     for s in declared:
         assert hasattr(l, s), s
-    assert l.qv2x_version() == 1
+    abi = int(re.search(r"#define QV2X_ABI_VERSION (\d+)", header).group(1))
+    assert l.qv2x_version() == abi == lib.ABI_VERSION
 
 
 def test_dynamic_symbol_table_is_the_header_only():
