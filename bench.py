@@ -322,6 +322,42 @@ def rooflines(eng, full, frames, iters):
     return roof, stages
 
 
+def same_scene_scenes(world, batch=32):
+    """scenes per HIP graph of the one-GPU same-scene denominator: the bench's batch for the V2X-Real workloads (N <= 4), 32 agent-frames'
+    worth of scenes on the OPV2V grid (N = 8: 4 scenes x 8 agents -- 256 agent-frames of the 512 x 512 grid would be 30 GB of maps)"""
+    return batch if world <= 4 else max(1, 32 // world)
+
+
+def same_scene_one_gpu(eng, world, device, scenes, iters=10):
+    """The workload of the N-GPU line (``workload_for(world)``: the same grid, layout and sweeps -- ``frame_batch`` seeds them by agent) WHOLLY on
+    one GPU: ``scenes`` scenes of ``world`` agents per HIP graph -- a1-a6 for every agent, a7-a11 once per scene with agent 0 as the ego
+    (the reference's single-ego output).  Its fused frames/s is the DENOMINATOR of the scaling figure north_star asks for
+    ("matched detection output"): ``bench.py --gpus N --ego-only`` produces the same ego-0 frames on N GPUs.  The engine must be the
+    workload's (V2X-Real mc model for N <= 4, the OPV2V single-class model above)."""
+    global SHAPE, N_POINTS
+    import torch
+    wl = workload_for(world)
+    keep = (SHAPE, N_POINTS)
+    SHAPE, N_POINTS = wl["shape"], wl["n_points"]
+    try:
+        _, full, _, _ = frame_batch(world, 0, scenes, device, layout=wl["layout"], max_cav=wl["max_cav"])
+    finally:
+        SHAPE, N_POINTS = keep
+    rep = eng.capture(full)
+    for _ in range(3):
+        rep()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        rep()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    del rep
+    return {"agents_per_scene": world, "scenes_per_graph": scenes, "agent_frames_per_graph": scenes * world, "ms_per_graph": round(ms, 3),
+            "fused_frames_per_s": round(scenes / ms * 1e3, 1), "agent_frames_per_s": round(scenes * world / ms * 1e3, 1),
+            "workload": wl["workload"], "baseline_config_index": wl["index"]}
+
+
 def multi_agent_line(eng, device):
     """BASELINE configs[2] / [3] on ONE GPU (every agent of a scene on this device): scenes of 2 and of 4 agents, 8 agent-frames per
     HIP graph, one graph at a time.  A fused frame = one ego-view detection output of one scene."""
@@ -343,6 +379,18 @@ def multi_agent_line(eng, device):
         del rep
     out["note"] = ("V2X-Real grid, synthetic sweeps, line (2) / ring (4) layout; a1-a6 per agent, decode + warp + attention over the scene's agents, "
                    "heads on the fused map + *_single heads; not the headline metric (that is the single-agent configuration)")
+    # the N-GPU lines' workloads wholly on ONE GPU at the bench's batch: the denominators of `scaling_vs_one_gpu_same_scene`
+    same = {}
+    for agents in (2, 4):
+        try:
+            same[f"{agents}_agents"] = same_scene_one_gpu(eng, agents, device, same_scene_scenes(agents))
+        except Exception as e:                                             # an extra must not cost the line
+            same[f"{agents}_agents"] = {"error": repr(e)[:300]}
+    same["note"] = ("BASELINE configs[2] / [3] (and configs[4] under `8_agents_opv2v`, filled by the world-8 rehearsal's engine) with EVERY agent of a scene "
+                    "on this GPU, 32 scenes per HIP graph (OPV2V: 4 scenes = 32 agent-frames), ego = agent 0: fused frames/s.  "
+                    "`bench.py --gpus N` divides its ego-only figure (the same ego-0 frames, agents sharded one per GPU) by a run of this on rank 0: "
+                    "`scaling_vs_one_gpu_same_scene`")
+    out["same_scene_b32"] = same
     return out
 
 
@@ -1092,6 +1140,9 @@ def main():
                                             else "one ego-view fused detection frame; with N GPUs every rank is the ego of its own view"),
                        "ego_only": bool(args.ego_only),
                        "launch": launch, "quantization": "W8A8 min-max PTQ (reference QuantModel recipe), random He-init weights",
+                       "codebook_encode": (f"{eng.encode_mode}: exact integer candidates for every cell (int8 MFMA) + the reference-order fp32 chain on the cells a proven "
+                                           "bound cannot decide -- the indices of the every-cell chain, by construction (quantv2x_amd/encode_two_stage.py)"
+                                           if eng.encode_mode == "two_stage" else f"{eng.encode_mode}: every cell through the reference-order fp32 chain"),
                        "wire_bytes_per_agent_frame": 3 * hw,
                        "rccl_world_size": dist.get_world_size() if dist.is_initialized() else 1},
             "latency_ms_p50": round(lat[len(lat) // 2], 4), "latency_ms_p95": round(lat[int(len(lat) * 0.95) - 1], 4),
@@ -1100,6 +1151,18 @@ def main():
         }
         if ego_line is not None:
             line["ego_only"] = ego_line
+        if sharded_mode and not args.no_extras:
+            # north_star: ">= 6x 1 -> 8 at matched detection output".  The matched output is the ego-0 frame of every scene: this job's ego-only
+            # figure over the SAME scenes (all `world` agents) on one GPU, measured here on rank 0 while the other ranks wait at the barrier below
+            try:
+                one = same_scene_one_gpu(eng, world, device, same_scene_scenes(world, B), iters=5)
+                eo = (ego_line or {}).get("value") if not args.ego_only else line["value"]
+                line["scaling_vs_one_gpu_same_scene"] = {"one_gpu": one, "n_gpu_ego_only_frames_per_s": eo,
+                                                         "ratio": round(eo / one["fused_frames_per_s"], 3) if eo else None,
+                                                         "note": "N-GPU ego-only fused frames/s (rank 0 fuses the all-gathered codes of the scene's agents) / the same scenes "
+                                                                 "wholly on one GPU (every agent encoded here, ego = agent 0); both produce the reference's single-ego output"}
+            except Exception as e:
+                line["scaling_vs_one_gpu_same_scene"] = {"error": repr(e)[:300]}
         roof, stages = rooflines(eng, full if not sharded_mode else frame_batch(1, 0, B, device)[1], B, iters=max(10, args.steps // 5))
         line["roofline"], line["roofline_stages"] = roof, stages
         if world == 1 and not sharded_mode and not args.no_extras:
@@ -1137,7 +1200,15 @@ def main():
                                         "workload": r["config"]["workload"], "pillars_per_step": r["config"]["pillars_per_step"],
                                         "frames_per_step": B}
                     # the LAST rank's step (its own sweeps, ego = W - 1: the every-rank-is-its-own-ego mode of the N-GPU line)
-                    rl = rehearse_line(W, B, 10, 2, device, engine=r.pop("_engine"), rank=W - 1)
+                    eng_w = r.pop("_engine")
+                    rl = rehearse_line(W, B, 10, 2, device, engine=eng_w, rank=W - 1)
+                    rl.pop("_engine")
+                    if W == 8 and isinstance(line.get("multi_agent_one_gpu", {}).get("same_scene_b32"), dict):
+                        try:                                                 # configs[4] wholly on one GPU: 4 scenes x 8 agents of the OPV2V grid per graph
+                            line["multi_agent_one_gpu"]["same_scene_b32"]["8_agents_opv2v"] = same_scene_one_gpu(eng_w, 8, device, same_scene_scenes(8), iters=5)
+                        except Exception as e:
+                            line["multi_agent_one_gpu"]["same_scene_b32"]["8_agents_opv2v"] = {"error": repr(e)[:300]}
+                    del eng_w
                     reh[f"world{W}"]["last_rank"] = {"rank": W - 1, "ego": W - 1, "ms_per_step": rl["ms_per_step"], "stage_us": rl["stage_us"],
                                                      "pillars_per_step": rl["config"]["pillars_per_step"],
                                                      "ms_per_step_over_rank0": round(rl["ms_per_step"] / r["ms_per_step"], 4)}

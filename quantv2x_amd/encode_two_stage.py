@@ -149,7 +149,11 @@ def candidate_tables(state: Dict[str, np.ndarray], levels: int, in_delta: float,
     if kc % 32 or kc > 128 or levels > 3:
         raise ValueError("two-stage encode: dict_size 32 | 64 | 96 | 128, up to three levels, seg_num 1")
     gs = float(in_delta) * G
-    h = float(np.abs(gs).max()) / G_MAX_INT
+    # the grid: 24 bits for the largest entry of G -- coarser when a table or bias entry would leave the kernel's integer ranges (two table
+    # entries are added to 256 a1 + a0 in i32: below 2^28 each; the packed scores stay below 2^53: bias below 2^44).  A coarser grid only
+    # costs bound (e2 = 0.5 h sum |code - zx|), never exactness.
+    tmax = max([float(np.abs(t).max()) for t in tabs.values()] + [0.0])
+    h = max(float(np.abs(gs).max()) / G_MAX_INT, tmax / (2.0 ** 28 - 2.0), float(np.abs(gb).max()) / (2.0 ** 44 - 2.0 ** 32))
     gi = np.rint(gs / h).astype(np.int64)
     limbs, rest = [], gi.copy()
     for _ in range(LIMBS):

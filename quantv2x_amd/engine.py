@@ -714,7 +714,11 @@ class DeployedModel(nn.Module):
             raise NotImplementedError("encode_mode 'two_stage': seg_num 1, dict_size <= 128, up to three levels (encode_mode 'exact' takes the rest)")
         if self._two_stage is None:
             from .encode_two_stage import candidate_tables
-            t = candidate_tables(self.state, self.enc_levels, d.in_delta, d.in_zx)
+            try:
+                t = candidate_tables(self.state, self.enc_levels, d.in_delta, d.in_zx)
+            except ValueError as e:                                    # a codebook outside the candidate stage's fixed-point contract:
+                self.encode_mode, self.two_stage_refused = "exact", str(e)   # every cell through the chain (same indices), and say why
+                return self.encode_codes(n_agents, out=codes)
             k = np.arange(t["bias"].shape[0], dtype=np.int64) % self.kc
             packed = (128 * t["bias"] + k).astype(np.float64)
             assert np.array_equal(packed.astype(np.int64), 128 * t["bias"] + k)          # below 2^53: exact

@@ -259,6 +259,8 @@ def test_bench_workload_follows_baseline_configs_per_world_size():
     for n, (idx, shape, mc, cav, layout) in want.items():
         wl = bench.workload_for(n)
         assert (wl["index"], wl["shape"], wl["multiclass"], wl["max_cav"], wl["layout"]) == (idx, shape, mc, cav, layout), (n, wl)
+    # the one-GPU same-scene denominators of the scaling figure: 32 scenes per graph on V2X-Real, 4 x 8 agents on OPV2V
+    assert [bench.same_scene_scenes(n) for n in (2, 3, 4, 8)] == [32, 32, 32, 4] and callable(bench.same_scene_one_gpu)
     w8 = bench.workload_for(8)
     assert "8-agent OPV2V-H" in w8["workload"] and "8xMI355X" in w8["workload"]
     sc = synth.make_scene(w8["shape"], n_agents=1, seed=3, n_points=w8["n_points"], max_cav=w8["max_cav"])
