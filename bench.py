@@ -286,7 +286,9 @@ def rooflines(eng, full, frames, iters):
                       INT8_MFMA_PEAK_TOPS, n * hw * (cin + p_[1].cout) + int(p_[1].w.numel()), "conv_" + p_[1].name))
     de_s = stages["backbone_deconvs_f32"]
     cands.append((de_s["us_per_batch"], "deconv_ps_batch_kernel (f32 MFMA: the three deblocks of the batch in one launch)", "mfma",
-                  sum(2.0 * p_[7] for p_ in de), "TFLOP/s", F32_MFMA_PEAK_TFLOPS, None, "deconv"))
+                  sum(2.0 * p_[7] for p_ in de), "TFLOP/s", F32_MFMA_PEAK_TFLOPS,
+                  # every deblock's input map read once, its slice of the concat written once, the fp32 weights once
+                  sum(n * p_[3] * p_[4] * p_[1].cin + n * p_[3] * p_[4] * p_[1].s * p_[1].s * p_[1].cout + int(p_[1].w.numel()) * 4 for p_ in de), "deconv"))
     cands.sort(key=lambda c: -c[0])
     us, kname, bound, work, unit, peak, alg, key = cands[0]
     ach = work / (us * 1e-6) / 1e12
@@ -463,6 +465,58 @@ def pyramid_model_line(device):
         us = event_time_us(rep, 30)
         out["ms_per_frame" if frames == 1 else f"ms_per_frame_batch{frames}"] = round(us / frames / 1e3, 4)
     out["frames_per_s_batch4"] = round(1e3 / out["ms_per_frame_batch4"], 1)
+    # ---- roofline entries of the Pyramid model: one 2-agent frame, the two halves as HIP graphs and the launches counted ------
+    try:
+        dd = batch(1)
+        inv = eng.work_inventory(2, 1)
+        hw = eng.fh * eng.fw
+        codes = eng.encode_features(dd["inputs_m1"], 2).clone()
+        pw = dd["pairwise_t_matrix"].to(torch.float64).contiguous()
+        enc_us = event_time_us(_graph_of(lambda: eng.encode_features(dd["inputs_m1"], 2)), 30)
+        dec_us = event_time_us(_graph_of(lambda: eng.decode_features(codes, hw, 2 * hw, [2], pw)), 30)
+        counted = {"n": 0}
+
+        class _Count:                                                       # every qv2x_* call of one eager forward = one kernel launch (or a short fixed group)
+            def __init__(self, lib):
+                self._lib = lib
+
+            def __getattr__(self, name):
+                f = getattr(self._lib, name)
+                if not name.startswith("qv2x_") or name.endswith("_floats") or name.endswith("_bytes"):
+                    return f
+
+                def g(*a, **k):
+                    counted["n"] += 1
+                    return f(*a, **k)
+                return g
+        real = eng.lib
+        eng.lib = _Count(real)
+        try:
+            eng(dd)
+            torch.cuda.synchronize()
+        finally:
+            eng.lib = real
+        i8_ego = sum(l["int8_macs"] for l in inv["levels"]) + inv["shrink_int8_macs"]
+        f32_ego = sum(l["deblock_f32_macs"] for l in inv["levels"]) + inv["heads_f32_macs"]
+        agent_ops = 2.0 * inv["agent_int8_macs"]
+        out["roofline_stages"] = {
+            "agent_side_encode_features": {"us": round(enc_us, 1), "int8_gop": round(agent_ops / 1e9, 2), "f32_encode_gflop": round(2.0 * inv["encode_f32_macs"] / 1e9, 2),
+                                           "achieved_int8_TOPs": round(agent_ops / (enc_us * 1e-6) / 1e12, 1), "peak": INT8_MFMA_PEAK_TOPS,
+                                           "frac_int8": round(agent_ops / (enc_us * 1e-6) / 1e12 / INT8_MFMA_PEAK_TOPS, 4),
+                                           "work": "PFN + scatter, the agent's 3 ResNet blocks (int8 MFMA), the 64-wide codebook encode (f32 MFMA) for 2 agents"},
+            "ego_side_decode_features": {"us": round(dec_us, 1), "int8_gop": round(2.0 * i8_ego / 1e9, 2), "f32_gflop": round(2.0 * f32_ego / 1e9, 2),
+                                         "hbm_mb": round((inv["decode_bytes"] + sum(l["fuse_bytes"] for l in inv["levels"])) / 1e6, 2),
+                                         "achieved_int8_TOPs": round(2.0 * i8_ego / (dec_us * 1e-6) / 1e12, 1), "peak": INT8_MFMA_PEAK_TOPS,
+                                         "frac_int8": round(2.0 * i8_ego / (dec_us * 1e-6) / 1e12 / INT8_MFMA_PEAK_TOPS, 4),
+                                         "work": "decode, 16 ResNeXt bottlenecks per agent over three levels, occupancy heads + weighted fusion, deblocks (f32), shrink_conv, heads"},
+            "levels": [{"level": i, "blocks": l["blocks"], "map": [l["h"], l["w"]], "planes": l["planes"], "int8_gop": round(2.0 * l["int8_macs"] / 1e9, 3),
+                        "us_at_int8_peak": round(2.0 * l["int8_macs"] / (INT8_MFMA_PEAK_TOPS * 1e12) * 1e6, 2)} for i, l in enumerate(inv["levels"])],
+            "launches_per_frame": counted["n"],
+            "note": "a 2-agent frame is ~%d launches on maps of 100 x 352 .. 25 x 88 cells: %.2f GOP of int8 work would take %.1f us at the MFMA peak -- the frame is bound by "
+                    "launch latency and small grids, not by a pipe (DESIGN.md 3)" % (counted["n"], (agent_ops + 2.0 * i8_ego) / 1e9,
+                                                                                      (agent_ops + 2.0 * i8_ego) / (INT8_MFMA_PEAK_TOPS * 1e12) * 1e6)}
+    except Exception as e:                                                 # an extra must not cost the line
+        out["roofline_stages"] = {"error": repr(e)[:300]}
     out["note"] = ("heter_pyramid_collab_codebook_mc_encdec under W8A8, 2 agents per scene: agent side (3 ResNet blocks, 64-wide codebook "
                    "encode) + ego side (decode, 16 ResNeXt bottlenecks per agent, occupancy-weighted fusion, deblocks, shrink, heads)")
     return out

@@ -341,6 +341,42 @@ class DeployedPyramidModel(nn.Module):
         self._bufs[key] = b
         return b
 
+    def work_inventory(self, n_agents: int, n_scenes: int) -> dict:
+        """Algorithmic work of one forward of ``n_scenes`` scenes with ``n_agents`` agents in all, stage by stage (bench.py's roofline entries of the
+        Pyramid model): multiply-accumulates of every layer = output pixels x the weight tensor's elements (a grouped 3x3: c x cg x 9 per
+        pixel), and the bytes the memory-bound stages move."""
+        s = self.state
+        wsize = lambda name: int(np.prod(s[name + "/w_code"].shape))
+        self._agent_ws(1)
+        fh, fw = self.fh, self.fw
+        agent = 0
+        for blk in self.agent_blocks:                                   # conv1 (strided on the first block) and conv2 at the agent map's resolution
+            agent += n_agents * fh * fw * (wsize(blk.name + ".conv1") + wsize(blk.name + ".conv2"))
+            if blk.down is not None:
+                agent += n_agents * fh * fw * wsize(blk.name + ".downsample")
+        levels, h, w = [], fh, fw
+        for lvl, blocks in enumerate(self.pyr_blocks):
+            st = self.p_strides[lvl]
+            ho, wo = (h - 1) // st + 1, (w - 1) // st + 1
+            macs = 0
+            for i, blk in enumerate(blocks):
+                hi, wi = (h, w) if i == 0 else (ho, wo)
+                macs += n_agents * hi * wi * wsize(blk.name + ".conv1") + n_agents * ho * wo * (wsize(blk.name + ".conv2") + wsize(blk.name + ".conv3"))
+                if blk.down is not None:
+                    macs += n_agents * ho * wo * wsize(blk.name + ".downsample")
+            planes = blocks[-1].cout
+            levels.append({"int8_macs": macs, "blocks": len(blocks), "h": ho, "w": wo, "planes": planes,
+                           # occupancy head + weighted_fuse: every agent's level map read (codes), the fused fp32 map written
+                           "fuse_bytes": n_agents * ho * wo * planes + n_scenes * ho * wo * planes * 4,
+                           "deblock_f32_macs": n_scenes * ho * wo * wsize(f"pyramid_backbone.deblocks.{lvl}.0")})
+            h, w = ho, wo
+        oh, ow = levels[0]["h"] * self.ups[0], levels[0]["w"] * self.ups[0]
+        return {"agent_int8_macs": agent, "levels": levels,
+                "encode_f32_macs": (n_agents * fh * fw * self.enc_levels * (3 * self.D * self.D + self.D * self.ke)) if self.has_codebook else 0,
+                "decode_bytes": (n_agents * fh * fw * (self.levels + self.D * 4)) if self.has_codebook else 0,
+                "shrink_int8_macs": n_scenes * oh * ow * (wsize(self.shrink0.name) + wsize(self.shrink1.name)),
+                "heads_f32_macs": n_scenes * oh * ow * 256 * self.heads.cout}
+
     # ---- launch helpers ------------------------------------------------------------------------------------------------------------
     def _conv3x3(self, layer: _ConvLayer, x, n, h, w, out, out_q, res_mode=0, res=None, res_q=(0.0, 128)):
         d = L.ConvDesc()

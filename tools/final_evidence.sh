@@ -30,7 +30,8 @@ if [ $what = pmc ]; then
     rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $out/pmc_$c.err
   done
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma -o p -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $out/pmc_mfma.err
-  python tools/pmc_encode_traffic.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE $out/pmc_encode.json > $out/pmc_encode.log 2>&1; cat $out/pmc_encode.log
+  python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras > $out/bench_n1_pmc_command.json 2> /dev/null      # (the same command un-profiled: its refined-cell count)
+  python tools/pmc_dominant.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE $out/bench_n1_pmc_command.json $out/pmc_dominant.json > $out/pmc_dominant.log 2>&1; cat $out/pmc_dominant.log
   python tools/pmc_by_grid.py /tmp/pmc_mfma > $out/pmc_mfma_busy.csv 2>&1
   python tools/pmc_by_grid.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE > $out/pmc_fetch_write_summary.csv 2>&1
   head -20 $out/pmc_mfma_busy.csv
