@@ -188,7 +188,16 @@ def test_hip_engines_equal_the_oracle(case):
     lsb = max(float(st0[k + "/a_delta"]) for k in ("cls_head", "reg_head", "dir_head"))
     d = np.abs(got["preds_tensor"].cpu().numpy() - want["preds_tensor"])
     assert d.max() <= 2 * lsb * 1.001 and (d > 1e-5).mean() < 5e-3, (d.max(), (d > 1e-5).mean())
-    if tag == "het":                                                 # the per-modality agent-side blocks too
+    if tag == "het":
+        # the reference's heter_pyramid_collab hands the model a TENSOR of 1-based modality codes (heter_pyramid_collab.py:143-150): the
+        # deployed heterogeneous engine maps them onto modality_name_list like the mirror does -- the same output as with names
+        dd = synth.scene_to_torch(sc, "cuda")
+        names = list(dd["agent_modality_list"])
+        order = list(states)                                        # modality_name_list order
+        coded = eng(dict(dd, agent_modality_list=torch.tensor([order.index(a) + 1 for a in names])))
+        torch.cuda.synchronize()
+        assert torch.equal(coded["preds_tensor"], got["preds_tensor"])
+        # the per-modality agent-side blocks too
         for m in ("m1", "m2"):
             for name, arr in otaps["modality/" + m].items():
                 if ".resnet.layer" in name and name in gtaps["modality/" + m]:
