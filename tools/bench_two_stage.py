@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import numpy as np, torch
 import bench
 from quantv2x_amd import lib as L
+if os.environ.get("QV2X_LIB_TAG"):
+    L.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cache", "abl", f"libqv2x_{os.environ['QV2X_LIB_TAG']}.so")
 
 def main():
     frames = int(sys.argv[1]) if len(sys.argv) > 1 else 32
@@ -42,4 +44,27 @@ def main():
     s1(); torch.cuda.synchronize()
     print(f"stage 1 {bench.event_time_us(s1, 20):.1f} us, stage 2 {bench.event_time_us(s2, 20):.1f} us")
 
-main()
+if not (len(sys.argv) > 2 and sys.argv[2] == "levels"):
+    main()
+
+
+def by_levels():
+    """stage 1 alone with 1, 2, 3 levels (same operands: the kernel walks fewer tiles)"""
+    import ctypes as C
+    frames = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    state, eng, _, _ = bench.build_engine(min(32, os.cpu_count() or 8))
+    _, full, _, _ = bench.frame_batch(1, 0, frames, torch.device("cuda"))
+    eng(full)
+    b = eng._workspace(frames)
+    gp, bias, tab, tau, t = eng._two_stage
+    for lv in (1, 2, 3):
+        d = L.EncodeDesc()
+        d.n, d.h, d.w, d.levels, d.kc, d.segs = frames, eng.fh, eng.fw, lv, eng.kc, 1
+        d.in_zx, d.in_delta = int(eng.shrink1.out_q[1]), float(eng.shrink1.out_q[0])
+        s1 = lambda: L.check(eng.lib.qv2x_codebook_encode_candidates_i8(C.byref(d), L.ptr(b["s1"]), L.ptr(gp), L.ptr(bias), L.ptr(tab), tau,
+                                                                        L.ptr(b["codes"]), L.ptr(b["enc_list"]), L.ptr(b["enc_counters"]), L.current_stream()), "s1")
+        print(f"levels {lv}: stage 1 {bench.event_time_us(s1, 20):.1f} us", flush=True)
+
+
+if len(sys.argv) > 2 and sys.argv[2] == "levels":
+    by_levels()
