@@ -231,11 +231,13 @@ int qv2x_codebook_encode_collapsed_f32(const qv2x_encode_desc* desc /* host */, 
  *   bias_packed f64 [levels*kc] = 128 * (rint(g / h) + (128 - zx) * rowsum(G_int)) + k      (the kernel multiplies by the stored byte code - 128)
  *   tables   i32 [levels(levels-1)/2][kc][kc] = rint(T_lj / h), table (l, j) at l (l - 1) / 2 + j (>= one table's worth allocated)
  *   tau      f32 [levels][3], HOST (copied into the launch)
- *   list u32 [n*h*w]; counters u32 [4]: [0] listed cells, [1 + l] cells first listed at level l -- DEVICE, zeroed by this call (a kernel
- *   node under stream capture)
+ *   list u32 [3][n*h*w]: list c = the cells first undecided at level c (their codes BELOW level c are proven); counters u32 [4]: [0] all
+ *   listed cells, [1 + c] the length of list c -- DEVICE, zeroed by this call (a kernel node under stream capture)
  * Stage 2, qv2x_codebook_encode_listed_f32: qv2x_codebook_encode_f32's kernel (one wave per 32 cells, the reference's op order, bit-exact)
- * on the listed cells only; `list_count` points at the DEVICE count (counters + 0), the launch is a fixed number of persistent waves: both
- * stages are capturable in a HIP graph.  seg_num 1, dict_size 32 | 64 | 96 | 128, up to three levels. */
+ * on the listed cells only -- for a cell of list c the quantization head, |q|^2 and the distances of the levels below c are skipped and the
+ * code stage 1 stored is used (the latent chain stage -> lhead -> residual runs as always: the same x at level c); `list` and `list_count`
+ * are stage 1's `list` and `counters` (DEVICE), the launch is a fixed number of persistent waves + a fixed number of workgroups for the
+ * remainder: both stages are capturable in a HIP graph.  seg_num 1, dict_size 32 | 64 | 96 | 128, up to three levels. */
 int qv2x_codebook_encode_candidates_i8(const qv2x_encode_desc* desc /* host */, const int8_t* in, const int8_t* g_limbs, const double* bias_packed,
                                        const int32_t* tables, const float* tau /* host */, uint8_t* codes, uint32_t* list, uint32_t* counters,
                                        void* stream);

@@ -150,9 +150,9 @@ template <int ER> constexpr int enc_smem_floats() { return 2 * ER * LDF + 4 * ER
 // compiled out of the form every V2X-Real / OPV2V attfuse model takes; EXT = true: seg_num > 1 or an extended codebook of several rounds.
 // LIST (round 6): the rows are the listed cells a.list[m0 .. m0 + ER) (stage 2 of the two-stage encode), not the cells m0 .. m0 + ER.
 template <int ER, bool EXT, bool LIST = false>
-__device__ __forceinline__ void encode_rows(const EncArgs& a, const int m0, float* __restrict__ smem) {
+__device__ __forceinline__ void encode_rows(const EncArgs& a, const int m0, float* __restrict__ smem, const unsigned* __restrict__ lst = nullptr,
+                                            const int n_listed = 0) {
     constexpr int ERT = ER / 32;
-    const int n_listed = LIST ? (int)*a.list_count : 0;
     const int segs = EXT ? a.segs : 1;
     float* bufA = smem;                       // x, then q, then next x
     float* bufB = smem + ER * LDF;            // z
@@ -173,7 +173,7 @@ __device__ __forceinline__ void encode_rows(const EncArgs& a, const int m0, floa
         constexpr int CPT = D / TPR;                  // channels per thread (16 for ER = 32)
         const int row = tid / TPR, part = tid % TPR;
         int m = m0 + row;
-        if (LIST) m = (int)a.list[m < n_listed ? m : n_listed - 1];
+        if (LIST) m = (int)lst[m < n_listed ? m : n_listed - 1];
         m = m < a.M ? m : a.M - 1;
         const int img = m / (a.h * a.w), rem = m - img * (a.h * a.w);
         const int y = rem / a.w, x = rem - y * a.w;
@@ -355,7 +355,7 @@ __device__ __forceinline__ void encode_rows(const EncArgs& a, const int m0, floa
                 const int bi = (int)(unsigned)bk;                      // row of the extended codebook: sg * kc + code
                 code_s[sg * ER + tid] = bi;
                 if (LIST) {
-                    if (m0 + tid < n_listed) a.codes[((size_t)l * segs + sg) * a.M + a.list[m0 + tid]] = (uint8_t)(bi - sg * a.kc);
+                    if (m0 + tid < n_listed) a.codes[((size_t)l * segs + sg) * a.M + lst[m0 + tid]] = (uint8_t)(bi - sg * a.kc);
                 } else if (m0 + tid < a.m_hi) a.codes[((size_t)l * segs + sg) * a.M + m0 + tid] = (uint8_t)(bi - sg * a.kc);
             }
         }
@@ -400,18 +400,14 @@ __global__ __launch_bounds__(512, ER == 32 ? 4 : 2) void codebook_encode_kernel(
 // Stage 2 of the two-stage encode, the REMAINDER of the list: the wave form (codebook_encode_wave.hip, LIST) takes whole rounds of its
 // `a.list_slots` persistent waves; what is left -- up to `a.list_tail_max` tiles of 32 cells, e.g. ALL of one frame's ~100 tiles -- runs here
 // as 8-wave workgroups, a third of a wave's latency (the same split qv2x_codebook_encode_f32 makes on the host; here both kernels derive it
-// from the DEVICE-side count).
-__device__ __forceinline__ int list_full_tiles(const EncArgs& a, int n_listed) {
-    const int ntiles = (n_listed + 31) >> 5;
-    const int full = ntiles / a.list_slots * a.list_slots;
-    return ntiles - full > a.list_tail_max ? ntiles : full;
-}
-
+// from the DEVICE-side counts: codebook_encode.h:list_plan).
 __global__ __launch_bounds__(512, 4) void codebook_encode_list_tail_kernel(const EncArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[enc_smem_floats<32>()];
-    const int n_listed = (int)*a.list_count, ntiles = (n_listed + 31) >> 5;
-    for (int t = list_full_tiles(a, n_listed) + (int)blockIdx.x; t < ntiles; t += (int)gridDim.x) {
-        encode_rows<32, false, true>(a, t * 32, smem);
+    const ListPlan plan = list_plan(a);
+    for (int t = plan.full + (int)blockIdx.x; t < plan.total; t += (int)gridDim.x) {
+        int cls, i0;
+        list_tile(plan, t, cls, i0);                                    // (every level of the chain for these cells, whatever their list: the same codes)
+        encode_rows<32, false, true>(a, i0, smem, a.list + (size_t)cls * a.M, plan.n[cls]);
         __syncthreads();
     }
 }

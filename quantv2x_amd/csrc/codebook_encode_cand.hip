@@ -41,7 +41,7 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int m) {
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void encode_candidates_kernel(const CandArgs a) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 31, hf = lane >> 5;
     const int m0 = ((int)blockIdx.x * 4 + wave) * (32 * CT);
-    if (m0 >= a.M) return;
+    // (a wave past the last cell walks on with clamped cells and stores nothing: the workgroup meets at a barrier at the end)
 
     // ---- the wave's 64 cells: B fragments straight from the padded map, and the two sums the bound needs ---------------------------------
     v4i xb[CT][8];
@@ -85,7 +85,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.levels * a.kc * 8, 0x00020000);
     const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)a.tables, 0, a.tbytes, 0x00020000);
     int o0[CT] = {}, o1[CT] = {};                                    // byte offsets of the cells' table rows: (code_0 | code_1) * kc + 4 hf
-    bool flag[CT] = {};
+    int first[CT];                                                   // the level a cell is first undecided at (3: never)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) first[ct] = 3;
     const int ntile = a.kc >> 5;
     auto level = [&](auto lc) __attribute__((always_inline)) {
         constexpr int l = decltype(lc)::value;
@@ -155,7 +157,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         }
         // ---- close the level: the two half-waves' (best, second), the index out of the packed value, the gap against the bound ---------------
-        unsigned cnt = 0;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const double ob = shfl_xor_f64(best[ct], 32), os = shfl_xor_f64(second[ct], 32);
@@ -165,25 +166,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (l == 1) o1[ct] = (c * a.kc + 4 * hf) * 4;
             const float t = ((a.tau[l][0] + a.tau[l][1] * n0[ct]) + (a.tau[l][2] * n0[ct]) * n0[ct]) + n1[ct];
             const bool weak = !(ns - nb > 128.0 * (double)ceilf(t) + 127.0);      // (not accepted: the gap in S is <= ceil(t))
-            cnt += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(weak && hf == 0 && m[ct] < a.M && !flag[ct]));
-            flag[ct] = flag[ct] || weak;
+            if (weak && first[ct] == 3) first[ct] = l;
             if (hf == 0 && m[ct] < a.M) a.codes[(size_t)l * a.M + m[ct]] = (uint8_t)c;
         }
-        if (lane == 0 && cnt) atomicAdd(a.counters + 1 + l, cnt);       // statistics: cells FIRST flagged at level l
     };
     level(IC<0>{});
     if (a.levels > 1) level(IC<1>{});
     if (a.levels > 2) level(IC<2>{});
-    // ---- the cells stage 2 recomputes, in no particular order ------------------------------------------------------------------------------
+    // ---- the cells stage 2 recomputes, in THREE lists by the level they are first undecided at (list c at a.list + c M, its length in
+    //      counters[1 + c], counters[0] = all of them): a cell of list c has PROVEN codes below level c, so stage 2 skips the quantization
+    //      head and the distances of those levels for it (codebook_encode_wave.hip).  No particular order inside a list. ------------------
+    // (ONE returning atomic per list and wave, the three issued together: a returning atomic is a whole L2 round trip for a lone wave, and a
+    //  first version with one per list and cell tile -- twelve, each behind a branch -- cost the kernel 15 %)
+    unsigned long long mask[3][CT];
+    unsigned cnt[3] = {0, 0, 0};
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-        const bool mine = flag[ct] && hf == 0 && m[ct] < a.M;
-        const unsigned long long mask = __builtin_amdgcn_ballot_w64(mine);
-        if (mask) {
-            unsigned base = 0;
-            if (lane == 0) base = atomicAdd(a.counters, (unsigned)__builtin_popcountll(mask));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (mine) a.list[base + (unsigned)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (unsigned)m[ct];
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            mask[c][ct] = __builtin_amdgcn_ballot_w64(first[ct] == c && hf == 0 && m[ct] < a.M);
+            cnt[c] += (unsigned)__builtin_popcountll(mask[c][ct]);
+        }
+    // ... and one per list and WORKGROUP: the waves' counts meet in LDS, wave 0 reserves the workgroup's ranges
+    __shared__ unsigned wcnt[4][3], wbase[3];
+    if (lane == 0) { wcnt[wave][0] = cnt[0]; wcnt[wave][1] = cnt[1]; wcnt[wave][2] = cnt[2]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const unsigned tot = wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
+        wbase[threadIdx.x] = tot ? atomicAdd(a.counters + 1 + threadIdx.x, tot) : 0u;
+        if (tot) atomicAdd(a.counters, tot);
+    }
+    __syncthreads();
+    unsigned base[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        base[c] = wbase[c];
+        for (int w2 = 0; w2 < wave; ++w2) base[c] += wcnt[w2][c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        unsigned at = __builtin_amdgcn_readfirstlane(base[c]);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            if (first[ct] == c && hf == 0 && m[ct] < a.M)
+                a.list[(size_t)c * a.M + at + (unsigned)__builtin_popcountll(mask[c][ct] & ((1ull << lane) - 1ull))] = (unsigned)m[ct];
+            at += (unsigned)__builtin_popcountll(mask[c][ct]);
         }
     }
 }

@@ -86,20 +86,19 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
     __shared__ __attribute__((aligned(16))) float smem[32 * RS];
     const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
     float* const row = smem + j * RS;
-    const int n_listed = LIST ? (int)*a.list_count : 0;
-    int list_tiles = 0;                                              // LIST: whole rounds of the launch's waves; the remainder is the workgroup form's
-    if (LIST) {                                                      // (codebook_encode.hip: list_full_tiles, codebook_encode_list_tail_kernel)
-        const int ntiles = (n_listed + 31) >> 5, full = ntiles / a.list_slots * a.list_slots;
-        list_tiles = ntiles - full > a.list_tail_max ? ntiles : full;
-    }
+    ListPlan plan{};
+    if (LIST) plan = list_plan(a);
 #pragma unroll 1
-    for (int tile = (int)blockIdx.x; LIST ? tile < list_tiles : tile == (int)blockIdx.x; tile += (int)gridDim.x) {
+    for (int tile = (int)blockIdx.x; LIST ? tile < plan.full : tile == (int)blockIdx.x; tile += (int)gridDim.x) {
     int mrow;                                                        // this lane's cell, and whether its codes are stored
     bool owned;
-    if (LIST) {
-        const int i = tile * 32 + j;
-        owned = i < n_listed;
-        mrow = (int)a.list[owned ? i : n_listed - 1];
+    int start = 0;                                                   // LIST: the cells' codes below this level are PROVEN (the candidate stage accepted them):
+    if (LIST) {                                                      // their quantization head, |q|^2 and distances are skipped, the stored code is used
+        int cls, i0;
+        list_tile(plan, tile, cls, i0);
+        owned = i0 + j < plan.n[cls];
+        mrow = (int)a.list[(size_t)cls * a.M + (owned ? i0 + j : plan.n[cls] - 1)];
+        start = cls;
     } else {
         mrow = a.m_lo + tile * 32 + j;
         owned = mrow < a.m_hi;
@@ -245,6 +244,16 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
         WFINE(1);
         lds_to_operand(row, h, z);
         WFINE(2);
+        unsigned bcs = 0;                                               // the segments' codes, one byte each
+        if (LIST && l < start) {
+            // a level whose code the candidate stage PROVED: no quantization head, no |q|^2, no distances -- the weight stream jumps to the
+            // latent head (stage | qhead | codebook | lhead, 64 KiB per tile pair), the ring is primed again, the stored code is the code
+            wo = (8 + npair) * 65536;
+            next_vec(lhead_b, 0);
+#pragma unroll
+            for (int i = 0; i < 2 * NPF; ++i) ring[i] = wload(i);
+            bcs = a.codes[(size_t)l * a.M + mrow];
+        } else {
         // ---- q = qhead(z) -------------------------------------------------------------------------------------------------
 #pragma unroll 1
         for (int P = 0; P < 4; ++P) {
@@ -286,7 +295,6 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
         WFINE(4);
         // ---- distances to the codes, 64 per pair, and the running first-argmin inside the lane; a pair lies inside ONE segment
         //      (kc % 64 == 0 when segs > 1), a segment's argmin closes with its last pair ------------------------------------------------
-        unsigned bcs = 0;                                               // the segments' codes, one byte each
         if constexpr (SEGS == 1) {
         float best = INFINITY;
         int bc = 0;
@@ -367,6 +375,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
             if constexpr (SEGS == 2) seg_pairs(IC<0>{}, IC<1>{}, false);
             else { seg_pairs(IC<0>{}, IC<1>{}, true); seg_pairs(IC<2>{}, IC<3>{}, false); }
         }
+        }                                                               // (the level's code was computed, not taken over)
         WFINE(5);
         if (last) break;
         // ---- x <- lhead(z) - C[code] ------------------------------------------------------------------------------------------

@@ -726,7 +726,7 @@ class DeployedModel(nn.Module):
                                (C.c_float * (3 * self.enc_levels))(*[float(v) for v in t["tau"].reshape(-1)]), t)
         gp, bias, tab, tau, _ = self._two_stage
         if "enc_list" not in b:
-            b["enc_list"] = torch.zeros(n_agents * self.fh * self.fw, dtype=torch.int32, device=self.dev)
+            b["enc_list"] = torch.zeros(3 * n_agents * self.fh * self.fw, dtype=torch.int32, device=self.dev)     # three lists (by first undecided level)
             b["enc_counters"] = torch.zeros(4, dtype=torch.int32, device=self.dev)
         L.check(self.lib.qv2x_codebook_encode_candidates_i8(C.byref(d), L.ptr(b["s1"]), L.ptr(gp), L.ptr(bias), L.ptr(tab), tau, L.ptr(codes),
                                                             L.ptr(b["enc_list"]), L.ptr(b["enc_counters"]), L.current_stream()),

@@ -65,7 +65,10 @@ def stage1_alone(eng, n):
                                                        L.ptr(b["enc_list"]), L.ptr(b["enc_counters"]), L.current_stream()), "candidates")
     torch.cuda.synchronize()
     cnt = b["enc_counters"].cpu().numpy().astype(np.int64)
-    return codes.cpu().numpy(), np.sort(b["enc_list"][:cnt[0]].cpu().numpy().astype(np.int64)), cnt
+    m_cells = n * eng.fh * eng.fw
+    lists = [b["enc_list"][c * m_cells:c * m_cells + cnt[1 + c]].cpu().numpy().astype(np.int64) for c in range(3)]     # by first undecided level
+    assert cnt[0] == sum(len(v) for v in lists)
+    return codes.cpu().numpy(), np.sort(np.concatenate(lists)), cnt, lists
 
 
 @pytest.mark.parametrize("adversarial", [False, True])
@@ -85,7 +88,7 @@ def test_golden_rows_two_stage_equals_exact_oracle_and_reference(golden, adversa
     if not adversarial:
         assert np.array_equal(got["two_stage"], g["codes"]) or int((got["two_stage"] != g["codes"]).sum()) == int((want != g["codes"]).sum())
     # stage 1 alone = the CPU emulation, bit for bit: every candidate index, and exactly the same cells listed
-    cand, listed, cnt = stage1_alone(eng, 1)
+    cand, listed, cnt, lists = stage1_alone(eng, 1)
     t = eng._two_stage[4]
     e_cand, e_flag, e_flags, _ = candidate_emulate(codes_u8, t, float(g["in_delta"]), int(g["in_zp"]))
     assert np.array_equal(listed, np.flatnonzero(e_flag)), (len(listed), int(e_flag.sum()))
@@ -93,8 +96,10 @@ def test_golden_rows_two_stage_equals_exact_oracle_and_reference(golden, adversa
     assert np.array_equal(cand[:, ok], e_cand[:, ok])
     # (a listed cell's later levels follow a candidate the kernel and the emulation both computed: equal as well)
     assert np.array_equal(cand, e_cand)
-    first = [int((e_flags[l] & ~e_flags[:l].any(0)).sum()) for l in range(3)]
-    assert cnt[0] == e_flag.sum() and list(cnt[1:4]) == first
+    first = [e_flags[l] & ~e_flags[:l].any(0) for l in range(3)]
+    assert cnt[0] == e_flag.sum() and list(cnt[1:4]) == [int(f.sum()) for f in first]
+    for c in range(3):                                               # list c = exactly the cells first undecided at level c
+        assert np.array_equal(np.sort(lists[c]), np.flatnonzero(first[c])), c
     stats = eng.encode_refine_stats(1)
     print("two-stage encode on the golden rows:", stats, "adversarial" if adversarial else "")
     assert 0.01 < stats["refined_fraction"] < 0.5
