@@ -488,6 +488,74 @@ extern "C" int qv2x_single_heads_lut_f32(const uint8_t* codes, int R, int hw, in
 }
 
 namespace qv2x {
+// Round 6: FOUR consecutive cells per lane (hw % 4 == 0: the four share their agent, and an NCHW store is 16 bytes per lane, 1 KB per wave
+// and channel instead of 256 B; the code bytes of a plane come as one dword; the channel constants are read once per four cells).  The
+// same fp32 operations per output in the same order as table_heads_kernel.
+__global__ __launch_bounds__(1024, 1) void table_heads4_kernel(const uint8_t* __restrict__ codes, int R, int hw, int levels, int kc, int CT, int ST, int c0, int c1,
+                                                              const float* __restrict__ tables, const float* __restrict__ bias, const float* __restrict__ da,
+                                                              const float* __restrict__ za, float* __restrict__ out0, float* __restrict__ out1) {
+    extern __shared__ __attribute__((aligned(16))) float tab[];       // [levels * kc][ST], then bias [CT4], da [CT4], za [CT4]
+    const int CT4 = (CT + 3) & ~3, rows = levels * kc;
+    float* cst = tab + (size_t)rows * ST;
+    for (int i = threadIdx.x; i < rows * (ST / 4); i += blockDim.x) {
+        const int row = i / (ST / 4), q = i - row * (ST / 4);
+        v4f v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * q + e < CT) v[e] = tables[(size_t)row * CT + 4 * q + e];
+        *(v4f*)(tab + (size_t)row * ST + 4 * q) = v;
+    }
+    for (int i = threadIdx.x; i < CT4; i += blockDim.x) {
+        cst[i] = i < CT ? bias[i] : 0.f; cst[CT4 + i] = i < CT ? da[i] : -1.f; cst[2 * CT4 + i] = i < CT ? za[i] : 0.f;
+        cst[3 * CT4 + i] = i < CT && da[i] > 0.0f ? 1.0f / da[i] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int runs = (R + 255) / 256;
+    for (int run = blockIdx.x * nw + wave; run < runs; run += gridDim.x * nw) {
+        const int m = run * 256 + 4 * lane;                           // R % 4 == 0: the four cells are all inside or all outside
+        const int mc = m < R ? m : R - 4;
+        const int agent = mc / hw, cell = mc - agent * hw;
+        const float* rp[4][4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const unsigned cw = l < levels ? *(const unsigned*)(codes + (size_t)l * R + mc) : 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rp[l][j] = tab + (size_t)(l < levels ? l * kc + ((cw >> (8 * j)) & 0xff) : 0) * ST;
+        }
+        float* o0 = out0 ? out0 + (size_t)agent * c0 * hw + cell : nullptr;
+        float* o1 = out1 ? out1 + (size_t)agent * c1 * hw + cell : nullptr;
+        for (int g = 0; g < CT4 / 4; ++g) {
+            const v4f b4 = *(const v4f*)(cst + 4 * g), d4 = *(const v4f*)(cst + CT4 + 4 * g), z4 = *(const v4f*)(cst + 2 * CT4 + 4 * g);
+            const v4f r4 = *(const v4f*)(cst + 3 * CT4 + 4 * g);
+            v4f y[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                y[j] = b4;
+#pragma unroll
+                for (int l = 0; l < 4; ++l)
+                    if (l < levels) { const v4f t = *(const v4f*)(rp[l][j] + 4 * g); y[j][0] += t[0]; y[j][1] += t[1]; y[j][2] += t[2]; y[j][3] += t[3]; }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 4 * g + e;
+                v4f v = {y[0][e], y[1][e], y[2][e], y[3][e]};
+                if (d4[e] > 0.0f) {                                   // (uniform) clamp(rint(v / d) + z, 0, 255) bit for bit: common.h's division-exact sandwich
+                    const unsigned cw = (unsigned)q_pack4_div(v[0], v[1], v[2], v[3], d4[e], r4[e], z4[e]) ^ 0x80808080u;
+                    v[0] = ((float)(cw & 0xff) - z4[e]) * d4[e];
+                    v[1] = ((float)((cw >> 8) & 0xff) - z4[e]) * d4[e];
+                    v[2] = ((float)((cw >> 16) & 0xff) - z4[e]) * d4[e];
+                    v[3] = ((float)(cw >> 24) - z4[e]) * d4[e];
+                }
+                if (m < R && c < CT) {
+                    if (c < c0) { if (o0) *(v4f*)(o0 + (size_t)c * hw) = v; }
+                    else if (o1) *(v4f*)(o1 + (size_t)(c - c0) * hw) = v;
+                }
+            }
+        }
+    }
+}
+
 // Round 5: the same look-up for tables that do NOT fit the LDS (seg_num 2 x dict_size 256: six planes of 256 rows x 92 channels = 565 KB;
 // three planes of 256 rows: 283 KB) -- the rows stay in global memory (they live in L2) and are fetched WHOLE: lanes = channels (a float4
 // per lane, two cells per instruction -- one per half-wave), so a row is one contiguous 368-byte request instead of 64 lanes picking 16
@@ -564,7 +632,7 @@ extern "C" int qv2x_table_heads_f32(const uint8_t* codes, int R, int hw, int lev
         return fail(QV2X_EINVAL, "%s: R=%d hw=%d levels=%d kc=%d c0=%d c1=%d (1..16 planes; an output per non-empty channel set)", who, R, hw, levels, kc, c0, c1);
     const int CT4 = (CT + 3) & ~3;
     const int ST = (CT4 / 4) % 2 ? CT4 : CT4 + 4;                     // row stride in floats, ST / 4 odd: 64 different rows start in 16 different bank quads
-    const size_t lds = ((size_t)levels * kc * ST + 3 * CT4) * sizeof(float);
+    const size_t lds = ((size_t)levels * kc * ST + 4 * CT4) * sizeof(float);
     if (levels > 4 || lds > 160 * 1024) {                             // the tables stay in global memory (round 5)
         if (CT % 4 || CT > 128 || ((uintptr_t)tables & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)da & 15) || ((uintptr_t)za & 15))
             return fail(QV2X_EINVAL, "%s: tables past the 160 KB of LDS need c0 + c1 %% 4 == 0, <= 128, and 16-byte aligned arrays", who);
@@ -579,6 +647,12 @@ extern "C" int qv2x_table_heads_f32(const uint8_t* codes, int R, int hw, int lev
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     // sixteen waves per workgroup (four per SIMD: the kernel is bound by instruction issue -- 153 against 206 us per batch of 32 frames with
     // eight) once every wave has a run of 64 cells to take; below that (one frame: 550 runs) eight, whose table copy-in is over sooner
+    static const int cells_per_lane = getenv("QV2X_TABLE_HEADS_CELLS") ? atoi(getenv("QV2X_TABLE_HEADS_CELLS")) : 4;          // development switch
+    if (cells_per_lane == 4 && hw % 4 == 0 && (R + 255) / 256 >= 16 * cus && !((uintptr_t)codes & 3) && !((uintptr_t)out0 & 15) && !((uintptr_t)out1 & 15)) {
+        if (int rc = hip_check(hipFuncSetAttribute((const void*)table_heads4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), who)) return rc;
+        table_heads4_kernel<<<cus, 1024, lds, (hipStream_t)stream>>>(codes, R, hw, levels, kc, CT, ST, c0, c1, tables, bias, da, za, out0, out1);
+        return hip_check(hipGetLastError(), "qv2x_table_heads_f32 launch");
+    }
     const int runs = (R + 63) / 64;
     const int nwav = runs >= 16 * cus ? 16 : 8, want = (runs + nwav - 1) / nwav;
     table_heads_kernel<<<want < cus ? want : cus, nwav * 64, lds, (hipStream_t)stream>>>(codes, R, hw, levels, kc, CT, ST, c0, c1, tables, bias, da, za, out0, out1);

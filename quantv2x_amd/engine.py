@@ -403,7 +403,7 @@ class DeployedModel(nn.Module):
             ct = sum(h.cout for h in sets)
             ct4 = (ct + 3) // 4 * 4
             st = ct4 if (ct4 // 4) % 2 else ct4 + 4
-            in_lds = self.levels <= 4 and (self.levels * self.kc * st + 3 * ct4) * 4 <= 160 * 1024
+            in_lds = self.levels <= 4 and (self.levels * self.kc * st + 4 * ct4) * 4 <= 160 * 1024
             # (round 5: tables past the LDS -- seg_num 2 x dict_size 256: six planes, 565 KB -- stay in global memory, qv2x.h)
             if in_lds or (self.levels <= 16 and ct % 4 == 0 and ct <= 128):
                 t = np.concatenate([np.einsum("lkd,cd->lkc", lut.astype(np.float64), h._w_np) for h in sets], axis=2)
