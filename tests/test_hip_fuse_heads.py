@@ -140,3 +140,38 @@ def test_single_agent_shortcut_honours_a_non_identity_self_transform():
         assert d.max() <= lsb * 1.001 and (d > 1e-5).mean() < 1e-3, (on_cpu, d.max())
     # and the identity still takes the shortcut
     assert eng._self_transforms_are_identity(_batch([ident])["pairwise_t_matrix"])
+
+
+@pytest.mark.parametrize("c0,c1,kc", [(72, 20, 128), (70, 21, 96), (0, 8, 32)])
+def test_table_heads_at_batch_size_four_cells_per_lane(c0, c1, kc):
+    """qv2x_table_heads_f32 at the bench's batch (32 V2X-Real frames: the launch takes table_heads4_kernel -- four cells per lane, 16-byte NCHW
+    stores, the output quantizer as the division-exact sandwich) against the statement of the same fp32 operations in torch: bias + the
+    planes' rows in plane order, then (clamp(rint(y / d) + z, 0, 255) - z) * d on the channels that carry a quantizer.  Bit for bit."""
+    import ctypes as C
+    from quantv2x_amd import lib as L
+    lib = L.load()
+    g = torch.Generator(device="cuda").manual_seed(7)
+    hw, n, planes = 35200, 32, 3
+    R, CT = n * hw, c0 + c1
+    codes = torch.randint(0, kc, (planes, R), dtype=torch.uint8, device="cuda", generator=g)
+    tab = torch.randn((planes, kc, CT), device="cuda", generator=g)
+    b = torch.randn(CT, device="cuda", generator=g)
+    da = torch.rand(CT, device="cuda", generator=g) * 0.05 + 0.01
+    da[::5] = -1.0                                                     # channels without an output quantizer
+    za = torch.randint(0, 256, (CT,), device="cuda", generator=g).float()
+    o0 = torch.empty((n, c0, hw), device="cuda") if c0 else None
+    o1 = torch.empty((n, c1, hw), device="cuda")
+    L.check(lib.qv2x_table_heads_f32(L.ptr(codes), R, hw, planes, kc, c0, c1, L.ptr(tab), L.ptr(b), L.ptr(da), L.ptr(za),
+                                     L.ptr(o0) if c0 else None, L.ptr(o1), L.current_stream()), "table heads")
+    torch.cuda.synchronize()
+    for lo in range(0, CT, 8):                                         # eight channels at a time: 144 MB per temporary
+        hi = min(CT, lo + 8)
+        y = b[lo:hi].expand(R, hi - lo).clone()
+        for p in range(planes):
+            y += tab[p, :, lo:hi][codes[p].long()]
+        d, z = da[lo:hi], za[lo:hi]
+        q = (torch.clamp(torch.round(y / d) + z, 0, 255) - z) * d
+        want = torch.where(d > 0, q, y).reshape(n, hw, hi - lo).permute(0, 2, 1)
+        for c in range(lo, hi):
+            got = o0[:, c] if c < c0 else o1[:, c - c0]
+            assert torch.equal(got, want[:, c - lo]), c
