@@ -19,6 +19,7 @@ if [ $what = trace ]; then
   python tools/rocpd_stats.py $db > $out/bench_n1_kernel_stats_inflight1.txt 2>&1
   python tools/prof_summary.py $db 60 > $out/bench_n1_kernel_stats_by_grid_inflight1.txt 2>&1
   head -30 $out/bench_n1_kernel_stats_by_grid_inflight1.txt
+  python tools/step_timeline.py $db 2 > $out/bench_n1_step_timeline_inflight1.txt 2>&1; tail -3 $out/bench_n1_step_timeline_inflight1.txt
   rm -rf /tmp/prof1
   rocprofv3 --kernel-trace --stats -d /tmp/prof -o bench -- python3 bench.py --no-cpu-baseline --no-extras --steps 30 --warmup 5 > $out/bench_n1_under_rocprof.json 2> $out/prof.err
   db=$(find /tmp/prof -name "*results.db" | head -1)
