@@ -30,7 +30,6 @@ struct CandArgs {
 constexpr int NPF = 8;                                               // A fragments (1 KiB each) in flight ahead of the MFMAs
 constexpr int LIMBS = 3;
 template <int V> struct IC { static constexpr int value = V; };
-constexpr int CT = 4;                                                // 32-cell B tiles per wave: every A fragment feeds CT MFMAs
 
 __device__ __forceinline__ double shfl_xor_f64(double v, int m) {
     const long long b = __builtin_bit_cast(long long, v);
@@ -38,6 +37,10 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int m) {
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
 }
 
+// CT = 32-cell B tiles per wave: every A fragment feeds CT MFMAs.  4 at the batch (the 288 KB of limbs a wave streams are shared by 128 cells);
+// 2 where that launch would not reach every SIMD (one V2X-Real frame, 275 waves of 128 cells on 1024 SIMDs: 51.9 us; of 64 cells 33.2; of 32
+// cells 40.9 -- the limbs are streamed per wave; four frames: 106.6 / 96.2 / 100.7).
+template <int CT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void encode_candidates_kernel(const CandArgs a) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 31, hf = lane >> 5;
     const int m0 = ((int)blockIdx.x * 4 + wave) * (32 * CT);
@@ -242,6 +245,11 @@ extern "C" int qv2x_codebook_encode_candidates_i8(const qv2x_encode_desc* d, con
     a.tbytes = (d->levels > 1 ? d->levels * (d->levels - 1) / 2 : 1) * d->kc * d->kc * 4;
     a.delta = d->in_delta;
     zero_counters_kernel<<<1, 64, 0, (hipStream_t)stream>>>(counters);
-    encode_candidates_kernel<<<(a.M + 128 * CT - 1) / (128 * CT), 256, 0, (hipStream_t)stream>>>(a);
+    static const int force_ct = getenv("QV2X_CAND_CT") ? atoi(getenv("QV2X_CAND_CT")) : 0;          // development switch
+    int dev = 0, cus = 256, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    const int ct = force_ct ? force_ct : (a.M >= 4 * cus * 128 * 2 ? 4 : 2);      // two rounds of waves of 128 cells, or the smaller tile
+    if (ct == 4) encode_candidates_kernel<4><<<(a.M + 128 * 4 - 1) / (128 * 4), 256, 0, (hipStream_t)stream>>>(a);
+    else encode_candidates_kernel<2><<<(a.M + 128 * 2 - 1) / (128 * 2), 256, 0, (hipStream_t)stream>>>(a);
     return hip_check(hipGetLastError(), "qv2x_codebook_encode_candidates_i8 launch");
 }

@@ -114,7 +114,7 @@ constexpr int PFN_R = 8;
 __global__ __launch_bounds__(256, 4) void pfn_scatter16_kernel(const float4* __restrict__ vf, const int4* __restrict__ coords,
                                                             const int* __restrict__ npts, int M, int P,
                                                             const qv2x_pfn_params prm, int8_t* __restrict__ canvas,
-                                                            int N, int ny, int nx) {
+                                                            int N, int ny, int nx, int rounds) {
     __shared__ float wl[640 + 64];
     __shared__ uint8_t lut[256];
     for (int i = threadIdx.x; i < 640; i += 256) wl[i] = prm.w[i];
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, 4) void pfn_scatter16_kernel(const float4* __r
         for (int k = 0; k < 10; ++k) w[c][k] = wl[(sub * 4 + c) * 10 + k];
         b[c] = wl[640 + sub * 4 + c];
     }
-    const int mbase = blockIdx.x * (16 * PFN_R) + slot;
+    const int mbase = blockIdx.x * (16 * rounds) + slot;
 
     auto header = [&](int m, int4& c, int& np, float4 (&q)[PFN_NQ]) __attribute__((always_inline)) {
         const int mm = m < M ? m : M - 1;
@@ -150,9 +150,9 @@ __global__ __launch_bounds__(256, 4) void pfn_scatter16_kernel(const float4* __r
     float4 q[PFN_NQ], qn[PFN_NQ];
     header(mbase, c, np, q);
 #pragma unroll 1
-    for (int r = 0; r < PFN_R; ++r) {
+    for (int r = 0; r < rounds; ++r) {
         const int m = mbase + r * 16;
-        if (r + 1 < PFN_R) header(m + 16, cn, npn, qn);
+        if (r + 1 < rounds) header(m + 16, cn, npn, qn);
         if (m < M) {
             const float4* pts = vf + (size_t)m * P;
             const int real = np < P ? np : P;
@@ -245,8 +245,15 @@ extern "C" int qv2x_pfn_scatter_i8(const float* voxel_features, const int32_t* v
     if (form == 64)
         pfn_scatter_kernel<<<(M + 4 * PFN_PB - 1) / (4 * PFN_PB), 256, 0, (hipStream_t)stream>>>((const float4*)voxel_features, (const int4*)voxel_coords,
                                                                          voxel_num_points, M, max_points, *params, canvas, N, ny, nx);
-    else
-        pfn_scatter16_kernel<<<(M + 16 * PFN_R - 1) / (16 * PFN_R), 256, 0, (hipStream_t)stream>>>((const float4*)voxel_features, (const int4*)voxel_coords,
-                                                                          voxel_num_points, M, max_points, *params, canvas, N, ny, nx);
+    else {
+        // rounds of 16 pillars per workgroup: PFN_R at the batch (the weights' trip through LDS amortised), fewer for one sweep (27 k pillars:
+        // eight rounds would leave 213 workgroups on 256 CUs -- 44 us against 14)
+        int dev = 0, cus = 256, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        int rounds = M / (16 * 8 * cus);
+        rounds = rounds < 1 ? 1 : (rounds > PFN_R ? PFN_R : rounds);
+        pfn_scatter16_kernel<<<(M + 16 * rounds - 1) / (16 * rounds), 256, 0, (hipStream_t)stream>>>((const float4*)voxel_features, (const int4*)voxel_coords,
+                                                                          voxel_num_points, M, max_points, *params, canvas, N, ny, nx, rounds);
+    }
     return hip_check(hipGetLastError(), "qv2x_pfn_scatter_i8 launch");
 }
