@@ -490,12 +490,19 @@ extern "C" int qv2x_codebook_encode_listed_f32(const qv2x_encode_desc* d, const 
     int cus = 256, dev = 0, v = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     const int tiles = (a.M + 31) / 32;
-    a.list_slots = 4 * cus; a.list_tail_max = 2 * cus;
+    static const int tail_knob = getenv("QV2X_LIST_TAIL") ? atoi(getenv("QV2X_LIST_TAIL")) : 0;          // development switch: remainder tiles the workgroup form takes
+    a.list_slots = 4 * cus; a.list_tail_max = tail_knob > 0 ? tail_knob : 2 * cus;
     // whole rounds of the chip's wave slots as persistent waves, the remainder as workgroups: both launches have a fixed size, the split is
-    // made on the device from the count (list_full_tiles)
-    if (tiles >= a.list_slots)
+    // made on the device from the count (list_plan).  Launches of fewer than two rounds of tiles (one or two frames) are the workgroup form's
+    // whatever the count: it finishes ALL 1100 tiles of a frame in 178 us where a round of waves takes ~350, and the wave launch costs 28 us
+    // of a one-frame graph even when it finds nothing to do.
+    const int grid_tail = 2 * cus;
+    if (tiles + 3 >= 2 * a.list_slots) {
         if (int rc = encode_wave_list_launch(a, a.list_slots, (hipStream_t)stream)) return rc;
-    codebook_encode_list_tail_kernel<<<tiles < a.list_tail_max ? tiles : a.list_tail_max, 512, 0, (hipStream_t)stream>>>(a);
+    } else {
+        a.list_slots = 1 << 30; a.list_tail_max = 1 << 30;
+    }
+    codebook_encode_list_tail_kernel<<<tiles < grid_tail ? tiles : grid_tail, 512, 0, (hipStream_t)stream>>>(a);
     return hip_check(hipGetLastError(), "qv2x_codebook_encode_listed_f32 launch");
 }
 

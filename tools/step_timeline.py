@@ -3,19 +3,20 @@
 The step = the last run of kernels that starts with the PFN scatter of the batch (the largest-grid pfn_scatter launch) -- `which` steps
 from the end.  Sums: kernel time, idle time between kernels, span.
 
-    python tools/step_timeline.py /tmp/prof1/.../bench_results.db [steps_from_end=2]
+    python tools/step_timeline.py /tmp/prof1/.../bench_results.db [steps_from_end=2] [big|small]
 """
 import sqlite3
 import sys
 
 
-def main(path, back=2):
+def main(path, back=2, which="big"):
     db = sqlite3.connect(path)
     tables = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
     kd = [t for t in tables if t.startswith("rocpd_kernel_dispatch")][0]
     ks = [t for t in tables if t.startswith("rocpd_info_kernel_symbol")][0]
     rows = db.execute(f"select s.kernel_name, d.start, d.end, d.grid_size_x from {kd} d join {ks} s on d.kernel_id = s.id order by d.start").fetchall()
-    big = max(r[3] for r in rows if "pfn_scatter" in r[0] and "unscatter" not in r[0])
+    pick = max if which == "big" else min                                  # "small": the one-frame graphs of the latency measurement
+    big = pick(r[3] for r in rows if "pfn_scatter" in r[0] and "unscatter" not in r[0])
     heads = [i for i, r in enumerate(rows) if "pfn_scatter" in r[0] and "unscatter" not in r[0] and r[3] == big]
     whole = [k for k in range(len(heads) - 1) if any("table_heads" in r[0] or "rows_heads" in r[0] for r in rows[heads[k]:heads[k + 1]])]   # (the stage timings after the steps repeat single stages)
     i0, i1 = heads[whole[-back]], heads[whole[-back] + 1]
@@ -34,4 +35,4 @@ def main(path, back=2):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 2)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 2, sys.argv[3] if len(sys.argv) > 3 else "big")
