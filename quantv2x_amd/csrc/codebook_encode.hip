@@ -502,6 +502,10 @@ extern "C" int qv2x_codebook_encode_listed_f32(const qv2x_encode_desc* d, const 
     } else {
         a.list_slots = 1 << 30; a.list_tail_max = 1 << 30;
     }
+    // (the remainder in tiles of SIXTEEN cells on v_mfma_f32_16x16x4_f32 -- twice the workgroups, half the chain -- was built, bit-exact, and
+    // slower: 145 against 97 us for one frame, 1164 against 940 us at the batch.  Every workgroup streams the same 2.7 MB of weights, and what
+    // the launch waits for is that stream (~3-4 TB/s over the chip whatever the prefetch depth), not the matrix pipe:
+    // tools/probes/codebook_encode_tail16_experiment.hip, profiles/r06_tail16_experiment.log)
     codebook_encode_list_tail_kernel<<<tiles < grid_tail ? tiles : grid_tail, 512, 0, (hipStream_t)stream>>>(a);
     return hip_check(hipGetLastError(), "qv2x_codebook_encode_listed_f32 launch");
 }
