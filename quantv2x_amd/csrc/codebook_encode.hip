@@ -151,7 +151,7 @@ template <int ER> constexpr int enc_smem_floats() { return 2 * ER * LDF + 4 * ER
 // LIST (round 6): the rows are the listed cells a.list[m0 .. m0 + ER) (stage 2 of the two-stage encode), not the cells m0 .. m0 + ER.
 template <int ER, bool EXT, bool LIST = false>
 __device__ __forceinline__ void encode_rows(const EncArgs& a, const int m0, float* __restrict__ smem, const unsigned* __restrict__ lst = nullptr,
-                                            const int n_listed = 0) {
+                                            const int n_listed = 0, const int start = 0) {
     constexpr int ERT = ER / 32;
     const int segs = EXT ? a.segs : 1;
     float* bufA = smem;                       // x, then q, then next x
@@ -218,6 +218,15 @@ __device__ __forceinline__ void encode_rows(const EncArgs& a, const int m0, floa
         EFINE(0);
         gemm_rows_x32(bufA, (const float2*)stage_w, head, wave, lane, acc);         // z = stage(x)
         EFINE(1);
+        // LIST: the cells' codes below level `start` are PROVEN (the candidate stage accepted them): their quantization head, |q|^2, distances
+        // and argmin are skipped, the stored code is used (as the wave form does: codebook_encode_wave.hip)
+        const bool proven = LIST && l < start;                                      // (uniform)
+        if (proven) {
+            head = gemm_head((const float2*)lhead_w, lhead_b, wave, lane);
+            store_tile(bufB, wave, lane, acc);
+            if (tid < ER) code_s[tid] = (int)a.codes[(size_t)l * a.M + lst[m0 + tid < n_listed ? m0 + tid : n_listed - 1]];
+            lds_barrier();
+        } else {
         head = gemm_head((const float2*)qhead_w, qhead_b, wave, lane);
         store_tile(bufB, wave, lane, acc);
         lds_barrier();
@@ -361,6 +370,7 @@ __device__ __forceinline__ void encode_rows(const EncArgs& a, const int m0, floa
         }
         lds_barrier();
         EFINE(9);
+        }
 
         if (l + 1 < a.levels) {      // x <- lhead(z) - C[code]
             // the chosen codewords' entries of this lane's column: 16 gathers requested ahead of the GEMM that produces the minuend
@@ -401,13 +411,13 @@ __global__ __launch_bounds__(512, ER == 32 ? 4 : 2) void codebook_encode_kernel(
 // `a.list_slots` persistent waves; what is left -- up to `a.list_tail_max` tiles of 32 cells, e.g. ALL of one frame's ~100 tiles -- runs here
 // as 8-wave workgroups, a third of a wave's latency (the same split qv2x_codebook_encode_f32 makes on the host; here both kernels derive it
 // from the DEVICE-side counts: codebook_encode.h:list_plan).
-__global__ __launch_bounds__(512, 4) void codebook_encode_list_tail_kernel(const EncArgs a) {
+__global__ __launch_bounds__(512, 2) void codebook_encode_list_tail_kernel(const EncArgs a) {      // (71 KB of LDS: two per CU whatever the registers)
     __shared__ __attribute__((aligned(16))) float smem[enc_smem_floats<32>()];
     const ListPlan plan = list_plan(a);
     for (int t = plan.full + (int)blockIdx.x; t < plan.total; t += (int)gridDim.x) {
         int cls, i0;
-        list_tile(plan, t, cls, i0);                                    // (every level of the chain for these cells, whatever their list: the same codes)
-        encode_rows<32, false, true>(a, i0, smem, a.list + (size_t)cls * a.M, plan.n[cls]);
+        list_tile(plan, t, cls, i0);                                    // list c: the cells first undecided at level c
+        encode_rows<32, false, true>(a, i0, smem, a.list + (size_t)cls * a.M, plan.n[cls], cls);
         __syncthreads();
     }
 }
