@@ -74,8 +74,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 
     const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)a.gpack, 0, a.gbytes, 0x00020000);   // past the end: zeros
-    int wo = 0;
     const int loff = lane * 16;
+    int wo = 0;
     auto gload = [&](int f) __attribute__((always_inline)) { return (v4i)__builtin_amdgcn_raw_buffer_load_b128(grs, loff, wo + f * 1024, 0); };
     v4i ring[NPF];
 #pragma unroll
