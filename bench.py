@@ -200,7 +200,7 @@ def rooflines(eng, full, frames, iters):
                                                             L.ptr(b["codes"]), L.current_stream()), "listed")
         cand_ops = 2.0 * 3 * 256 * eng.enc_levels * eng.kc * n * hw
         stage("codebook_encode_candidates_i8", stage1, "mfma-i8", cand_ops, "TOP/s", INT8_MFMA_PEAK_TOPS, 1,
-              f"stage 1: {n * hw} cells x (256 -> {eng.enc_levels * eng.kc} scores x 3 int8 limbs) = {cand_ops / 1e9:.1f} GOP on v_mfma_i32_32x32x32_i8, i32 bucket-key "
+              f"stage 1: {n * hw} cells x (256 -> {eng.enc_levels * eng.kc} scores x 3 int8 limbs) = {cand_ops / 1e9:.1f} GOP on v_mfma_i32_32x32x32_i8, fp64 packed "
               f"argmin chain; lists the cells whose top-2 gap does not exceed the proven bound")
         stage1()
         # a cell first undecided at level c runs the latent chain of every level but the quantization head + distances only from level c on

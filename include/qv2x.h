@@ -39,7 +39,7 @@ const char* qv2x_last_error(void);
 /* The ABI of this header.  A caller built against another value must not pass its structs: 5 = qv2x_encode_desc grew the trailing `segs`
  * field (round 5; a caller built before it passes garbage there unless its struct was zero-initialised -- ADVICE r5); 6 = round 6:
  * qv2x_codebook_encode_candidates_i8 / qv2x_codebook_encode_listed_f32 added, no struct changed. */
-#define QV2X_ABI_VERSION 7
+#define QV2X_ABI_VERSION 6
 int qv2x_version(void);            /* == QV2X_ABI_VERSION of the library's own build */
 
 /* Fill a padded i8 BEV tensor (border AND interior) with one byte value: the per-frame canvas clear and the
@@ -222,15 +222,13 @@ int qv2x_codebook_encode_collapsed_f32(const qv2x_encode_desc* desc /* host */, 
  * fraction of its work.
  *
  * Stage 1, qv2x_codebook_encode_candidates_i8: the collapsed scores s_l[k] = dist_l[k] - |q_l|^2 of every cell in EXACT integer arithmetic
- * (G on a fixed-point grid h as three balanced int8 limbs, v_mfma_i32_32x32x32_i8; limbs, bias and table rows combined in i32, the scores
- * compared in buckets of 65536 grid units: keys 128 floor(S / 65536) + k) -> codes [levels][n*h*w] for every cell, and the cells whose gap
- * between the two best scores at ANY level is not PROVEN (by the bucket indices) to exceed
+ * (G on a fixed-point grid h as three balanced int8 limbs, v_mfma_i32_32x32x32_i8; limbs, bias and table rows combined on integers below
+ * 2^53) -> codes [levels][n*h*w] for every cell, and the cells whose gap between the two best scores at ANY level does not exceed
  *     tau_l / h = tau[l][0] + tau[l][1] N0 + tau[l][2] N0^2 + sum |code - zx|,    N0 = in_delta * sqrt(sum (code - zx)^2)
  * appended (in no particular order) to `list`, their number in counters[0].  tau bounds twice the largest difference the fp32 chain's
  * rounding can make to a score plus this stage's own grid error: a cell NOT listed has the fp32 chain's strict minimum at every level.
  *   g_limbs  i8  [levels][kc/32][3][8][64][16]: A fragments, lane = 32 * half + score % 32, bytes = input channel 32 * step + 16 * half + 0..15
- *   bias_split i32 [levels*kc][2] = ((b >> 16) << 7) + k, b & 0xffff  with  b = rint(g / h) + (128 - zx) * rowsum(G_int), |b| < 2^38, k = the
- *            code's index in its level      (the kernel multiplies by the stored byte code - 128; 16-byte aligned)
+ *   bias_packed f64 [levels*kc] = 128 * (rint(g / h) + (128 - zx) * rowsum(G_int)) + k      (the kernel multiplies by the stored byte code - 128)
  *   tables   i32 [levels(levels-1)/2][kc][kc] = rint(T_lj / h), table (l, j) at l (l - 1) / 2 + j (>= one table's worth allocated)
  *   tau      f32 [levels][3], HOST (copied into the launch)
  *   list u32 [3][n*h*w]: list c = the cells first undecided at level c (their codes BELOW level c are proven); counters u32 [4]: [0] all
@@ -240,7 +238,7 @@ int qv2x_codebook_encode_collapsed_f32(const qv2x_encode_desc* desc /* host */, 
  * code stage 1 stored is used (the latent chain stage -> lhead -> residual runs as always: the same x at level c); `list` and `list_count`
  * are stage 1's `list` and `counters` (DEVICE), the launch is a fixed number of persistent waves + a fixed number of workgroups for the
  * remainder: both stages are capturable in a HIP graph.  seg_num 1, dict_size 32 | 64 | 96 | 128, up to three levels. */
-int qv2x_codebook_encode_candidates_i8(const qv2x_encode_desc* desc /* host */, const int8_t* in, const int8_t* g_limbs, const int32_t* bias_split,
+int qv2x_codebook_encode_candidates_i8(const qv2x_encode_desc* desc /* host */, const int8_t* in, const int8_t* g_limbs, const double* bias_packed,
                                        const int32_t* tables, const float* tau /* host */, uint8_t* codes, uint32_t* list, uint32_t* counters,
                                        void* stream);
 int qv2x_codebook_encode_listed_f32(const qv2x_encode_desc* desc /* host */, const int8_t* in, const float* const* level_weights /* host array */,

@@ -2,11 +2,8 @@
 // UMGMQuantizer.encode (opencood/models/sub_modules/codebook.py:330-337 -> :231-239 -> :106-131) with its affine heads multiplied out,
 //     dist_l[k] - |q_l|^2 = s_l[k] = G_l[k] . x_0 + g_l[k] + sum_{j<l} T_lj[code_j][k],        x_0 = delta (code - zx),
 // evaluated WITHOUT ROUNDING: G on a fixed-point grid h (24 bits as three balanced int8 limbs), the contraction with the cell's 256 stored
-// bytes on v_mfma_i32_32x32x32_i8 (exact i32 sums), the limbs, the bias and the table rows combined in i32: S = 65536 a2 + [256 a1 + a0 +
-// tables + bias] is never formed -- the wave keeps, per level and cell, the two smallest KEYS 128 P + k, P = floor(S / 65536) = a2 + bias_hi +
-// ([256 a1 + a0 + tables + bias_lo] >> 16): eight i32 instructions per candidate (a first version packed 128 S + k in fp64: two
-// conversions, two fma and three min / max at half rate per candidate -- 435 us per 32 frames, the VALU twice the MFMA time).  The bucket
-// costs the comparison at most 65535 units of the grid (2.6e-3 against bounds of 0.1-0.5).  A cell whose gap is not larger than the bound
+// bytes on v_mfma_i32_32x32x32_i8 (exact i32 sums), the limbs, the bias and the table rows combined in fp64 on integers below 2^53.  Per
+// level the wave keeps the best and the second-best packed score 128 S + k of every cell; a cell whose gap is not larger than the bound
 //     tau_l / h = t0 + t1 N0 + t2 N0^2 + sum |code - zx|,        N0 = delta sqrt(sum (code - zx)^2)
 // at ANY level is appended to the list stage 2 (codebook_encode_wave_kernel in list mode) recomputes in the reference's op order; the
 // others keep these indices, which the bound proves to be the strict minimum of the fp32 chain too.
@@ -23,7 +20,7 @@ namespace qv2x {
 namespace {
 
 struct CandArgs {
-    const int8_t* in; const int8_t* gpack; const int* bias; const int* tables;
+    const int8_t* in; const int8_t* gpack; const double* bias; const int* tables;
     uint8_t* codes; unsigned* list; unsigned* counters;
     float tau[3][3];
     int n, h, w, hw, M, levels, kc, zx, gbytes, tbytes;
@@ -34,6 +31,11 @@ constexpr int NPF = 8;                                               // A fragme
 constexpr int LIMBS = 3;
 template <int V> struct IC { static constexpr int value = V; };
 
+__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __shfl_xor((int)b, m), hi = __shfl_xor((int)(b >> 32), m);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
 
 // CT = 32-cell B tiles per wave: every A fragment feeds CT MFMAs.  4 at the batch (the 288 KB of limbs a wave streams are shared by 128 cells);
 // 2 where that launch would not reach every SIMD (one V2X-Real frame, 275 waves of 128 cells on 1024 SIMDs: 51.9 us; of 64 cells 33.2; of 32
@@ -74,8 +76,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 
     const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)a.gpack, 0, a.gbytes, 0x00020000);   // past the end: zeros
-    const int loff = lane * 16;
     int wo = 0;
+    const int loff = lane * 16;
     auto gload = [&](int f) __attribute__((always_inline)) { return (v4i)__builtin_amdgcn_raw_buffer_load_b128(grs, loff, wo + f * 1024, 0); };
     v4i ring[NPF];
 #pragma unroll
@@ -92,9 +94,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int ntile = a.kc >> 5;
     auto level = [&](auto lc) __attribute__((always_inline)) {
         constexpr int l = decltype(lc)::value;
-        int best[CT], second[CT];
+        double best[CT], second[CT];
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) best[ct] = second[ct] = 0x7fffffff;
+        for (int ct = 0; ct < CT; ++ct) best[ct] = second[ct] = 1.0e300;
         // a group's bias and table rows are requested one group AHEAD of their use (the first group's under the tile's last MFMAs): a wave is
         // alone on its SIMD, so a load issued where it is used costs its whole L2 round trip (first version: 878 us per 32 frames)
         v4i qb[2][2], qt0[2][CT], qt1[2][CT];
@@ -133,22 +135,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if (g < 3) issue(T, g + 1, (g + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
                 const int sl = g & 1;
-                // per code two dwords: (bias_hi << 7) + k and bias_lo (bias = 65536 bias_hi + bias_lo, 0 <= bias_lo < 65536)
-                const int bk[4] = {qb[sl][0][0], qb[sl][0][2], qb[sl][1][0], qb[sl][1][2]};
-                const int bl[4] = {qb[sl][0][1], qb[sl][0][3], qb[sl][1][1], qb[sl][1][3]};
+                double b[4];                                            // 128 * bias + k: the packed form
+                b[0] = __builtin_bit_cast(double, ((unsigned long long)(unsigned)qb[sl][0][1] << 32) | (unsigned)qb[sl][0][0]);
+                b[1] = __builtin_bit_cast(double, ((unsigned long long)(unsigned)qb[sl][0][3] << 32) | (unsigned)qb[sl][0][2]);
+                b[2] = __builtin_bit_cast(double, ((unsigned long long)(unsigned)qb[sl][1][1] << 32) | (unsigned)qb[sl][1][0]);
+                b[3] = __builtin_bit_cast(double, ((unsigned long long)(unsigned)qb[sl][1][3] << 32) | (unsigned)qb[sl][1][2]);
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int r = 4 * g + e;
-                        // key = 128 floor(S / 65536) + k, S = 65536 a2 + [256 a1 + a0 + tables + bias]: the bracket's low part in i32 (|a1|, |a0| <=
-                        // 2^22, table entries below 2^28, bias_lo below 2^16: encode_two_stage.py refuses larger ones), its carry into a2 + bias_hi
-                        int lo = (acc[1][ct][r] << 8) + acc[0][ct][r] + bl[e];
+                        // 128 S + k = 128 (65536 a2 + [256 a1 + a0 + tables] + bias) + k: the bracket in i32 (|a1| <= 2^22, |a0| <= 2^22, table
+                        // entries below 2^28: encode_two_stage.py refuses larger ones), the rest on integers below 2^53 in fp64 -- all exact
+                        int lo = (acc[1][ct][r] << 8) + acc[0][ct][r];
                         if (l >= 1) lo += qt0[sl][ct][e];
                         if (l >= 2) lo += qt1[sl][ct][e];
-                        const int key = ((acc[2][ct][r] + (lo >> 16)) << 7) + bk[e];
-                        second[ct] = min(second[ct], max(best[ct], key));
-                        best[ct] = min(best[ct], key);
+                        double c = __builtin_fma((double)lo, 128.0, b[e]);
+                        c = __builtin_fma((double)acc[2][ct][r], 8388608.0, c);
+                        second[ct] = fmin(second[ct], fmax(best[ct], c));
+                        best[ct] = fmin(best[ct], c);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -157,14 +162,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // ---- close the level: the two half-waves' (best, second), the index out of the packed value, the gap against the bound ---------------
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-            const int ob = __shfl_xor(best[ct], 32), os = __shfl_xor(second[ct], 32);
-            const int nb = min(best[ct], ob), ns = min(max(best[ct], ob), min(second[ct], os));
-            const int c = nb & 127;
+            const double ob = shfl_xor_f64(best[ct], 32), os = shfl_xor_f64(second[ct], 32);
+            const double nb = fmin(best[ct], ob), ns = fmin(fmax(best[ct], ob), fmin(second[ct], os));
+            const int c = (int)((long long)nb & 127);
             if (l == 0) o0[ct] = (c * a.kc + 4 * hf) * 4;
             if (l == 1) o1[ct] = (c * a.kc + 4 * hf) * 4;
             const float t = ((a.tau[l][0] + a.tau[l][1] * n0[ct]) + (a.tau[l][2] * n0[ct]) * n0[ct]) + n1[ct];
-            // accepted iff P_second - P_best >= floor(t / 65536) + 2: every other code then has S - S_best >= 65536 (P - P_best) - 65535 > t
-            const bool weak = (ns >> 7) - (nb >> 7) < (int)fminf(t * 1.52587890625e-05f, 1.0e9f) + 2;      // (fminf: a NaN bound lists the cell)
+            const bool weak = !(ns - nb > 128.0 * (double)ceilf(t) + 127.0);      // (not accepted: the gap in S is <= ceil(t))
             if (weak && first[ct] == 3) first[ct] = l;
             if (hf == 0 && m[ct] < a.M) a.codes[(size_t)l * a.M + m[ct]] = (uint8_t)c;
         }
@@ -220,20 +224,20 @@ __global__ void zero_counters_kernel(unsigned* c) { if (threadIdx.x < 4) c[threa
 }  // namespace
 }  // namespace qv2x
 
-extern "C" int qv2x_codebook_encode_candidates_i8(const qv2x_encode_desc* d, const int8_t* in, const int8_t* g_limbs, const int32_t* bias_split,
+extern "C" int qv2x_codebook_encode_candidates_i8(const qv2x_encode_desc* d, const int8_t* in, const int8_t* g_limbs, const double* bias_packed,
                                                   const int32_t* tables, const float* tau, uint8_t* codes, uint32_t* list, uint32_t* counters,
                                                   void* stream) {
     using namespace qv2x;
-    if (!d || !in || !g_limbs || !bias_split || !tau || !codes || !list || !counters) return fail(QV2X_EINVAL, "qv2x_codebook_encode_candidates_i8: null pointer");
+    if (!d || !in || !g_limbs || !bias_packed || !tau || !codes || !list || !counters) return fail(QV2X_EINVAL, "qv2x_codebook_encode_candidates_i8: null pointer");
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->levels < 1 || d->levels > 3) return fail(QV2X_EINVAL, "qv2x_codebook_encode_candidates_i8: 1..3 levels");
     if (d->segs > 1) return fail(QV2X_EINVAL, "qv2x_codebook_encode_candidates_i8: seg_num 1 only (the exact entry takes seg_num 1 | 2 | 4)");
     if (d->kc < 32 || d->kc > 128 || d->kc % 32) return fail(QV2X_EINVAL, "qv2x_codebook_encode_candidates_i8: dict_size must be 32, 64, 96 or 128 (got %d)", d->kc);
     if (d->levels > 1 && !tables) return fail(QV2X_EINVAL, "qv2x_codebook_encode_candidates_i8: the residual levels need their tables");
     if (d->in_zx < 0 || d->in_zx > 255) return fail(QV2X_EINVAL, "qv2x_codebook_encode_candidates_i8: in_zx outside 0..255");
-    if (((uintptr_t)in & 15) || ((uintptr_t)g_limbs & 15) || ((uintptr_t)tables & 15) || ((uintptr_t)bias_split & 15))
+    if (((uintptr_t)in & 15) || ((uintptr_t)g_limbs & 15) || ((uintptr_t)tables & 15) || ((uintptr_t)bias_packed & 7))
         return fail(QV2X_EALIGN, "qv2x_codebook_encode_candidates_i8: 16-byte aligned maps, limbs and tables");
     CandArgs a;
-    a.in = in; a.gpack = g_limbs; a.bias = bias_split; a.tables = tables; a.codes = codes; a.list = list; a.counters = counters;
+    a.in = in; a.gpack = g_limbs; a.bias = bias_packed; a.tables = tables; a.codes = codes; a.list = list; a.counters = counters;
     for (int l = 0; l < 3; ++l)
         for (int i = 0; i < 3; ++i) a.tau[l][i] = l < d->levels ? tau[l * 3 + i] : 0.0f;
     a.n = d->n; a.h = d->h; a.w = d->w; a.hw = d->h * d->w; a.M = d->n * a.hw; a.levels = d->levels; a.kc = d->kc; a.zx = d->in_zx;

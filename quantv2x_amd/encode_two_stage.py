@@ -140,7 +140,6 @@ def candidate_tables(state: Dict[str, np.ndarray], levels: int, in_delta: float,
       gpack  i8  [levels][kc/32][LIMBS][8][64][16]  the limbs of G on the grid ``h`` as A fragments of v_mfma_i32_32x32x32_i8
                  (lane = 32 * half + score % 32, bytes = input channel 32 * step + 16 * half + 0..15)
       bias   i64 [levels*kc]        rint(g / h) + (128 - zx) * rowsum(G_int): the kernel multiplies by the stored byte (code - 128)
-      bias_split i32 [levels*kc][2] what the kernel reads of it: ((bias >> 16) << 7) + k  and  bias & 0xffff  (k = the code's index in its level)
       tables i32 [levels(levels-1)/2][kc][kc]   rint(T_lj / h), table (l, j) at l (l - 1) / 2 + j
       tau    f32 [levels][3]        tau_l / h = tau[l][0] + tau[l][1] N0 + tau[l][2] N0^2 (+ sum |code - zx|, added by the kernel)
       h      the grid step (float64)"""
@@ -151,10 +150,10 @@ def candidate_tables(state: Dict[str, np.ndarray], levels: int, in_delta: float,
         raise ValueError("two-stage encode: dict_size 32 | 64 | 96 | 128, up to three levels, seg_num 1")
     gs = float(in_delta) * G
     # the grid: 24 bits for the largest entry of G -- coarser when a table or bias entry would leave the kernel's integer ranges (two table
-    # entries and the bias' low 16 bits are added to 256 a1 + a0 in i32: tables below 2^28 each; the packed keys 128 floor(S / 65536) + k stay
-    # in i32: bias below 2^38).  A coarser grid only costs bound (e2 = 0.5 h sum |code - zx|), never exactness.
+    # entries are added to 256 a1 + a0 in i32: below 2^28 each; the packed scores stay below 2^53: bias below 2^44).  A coarser grid only
+    # costs bound (e2 = 0.5 h sum |code - zx|), never exactness.
     tmax = max([float(np.abs(t).max()) for t in tabs.values()] + [0.0])
-    h = max(float(np.abs(gs).max()) / G_MAX_INT, tmax / (2.0 ** 28 - 2.0), float(np.abs(gb).max()) / (2.0 ** 38 - 2.0 ** 26))
+    h = max(float(np.abs(gs).max()) / G_MAX_INT, tmax / (2.0 ** 28 - 2.0), float(np.abs(gb).max()) / (2.0 ** 44 - 2.0 ** 32))
     gi = np.rint(gs / h).astype(np.int64)
     limbs, rest = [], gi.copy()
     for _ in range(LIMBS):
@@ -164,7 +163,7 @@ def candidate_tables(state: Dict[str, np.ndarray], levels: int, in_delta: float,
     assert not rest.any()
     bias = np.rint(gb / h).astype(np.int64) + (128 - int(in_zx)) * gi.sum(1)
     tables = np.stack([np.rint(tabs[(l, j)] / h) for l in range(levels) for j in range(l)]) if levels > 1 else np.zeros((1, kc, kc))
-    if np.abs(tables).max() >= 2 ** 28 or np.abs(bias).max() >= 2 ** 38:          # (the kernel adds two table entries to 256 a1 + a0 in i32)
+    if np.abs(tables).max() >= 2 ** 28 or np.abs(bias).max() >= 2 ** 44:          # (the kernel adds two table entries to 256 a1 + a0 in i32)
         raise ValueError("two-stage encode: table / bias entries leave the fixed-point range of the candidate stage")
     lane = np.arange(64)
     score = (np.arange(levels * kc // 32)[:, None, None, None] * 32 + (lane & 31)[None, None, :, None])                  # [tiles, 1, 64, 1]
@@ -177,10 +176,7 @@ def candidate_tables(state: Dict[str, np.ndarray], levels: int, in_delta: float,
     for l in range(levels):
         own = 1.0 + l + 2.0                                        # stage 1's own error, x 2: bias + tables half a unit each, + 1 unit of host slack
         tau[l] = [(ea[l] / h + own) * fp, eb[l] / h * fp, ec[l] / h * fp]
-    split = np.stack([((bias >> 16) << 7) + np.arange(levels * kc, dtype=np.int64) % kc, bias & 0xffff], axis=1)
-    assert np.abs(split).max() < 2 ** 30
     return {"gpack": np.ascontiguousarray(packed, dtype=np.int8), "bias": np.ascontiguousarray(bias, dtype=np.int64),
-            "bias_split": np.ascontiguousarray(split, dtype=np.int32),
             "tables": np.ascontiguousarray(tables, dtype=np.int32), "tau": np.ascontiguousarray(tau, dtype=np.float32), "h": h,
             "g_int": gi, "bound": (ea, eb, ec), "report": report}
 
@@ -203,20 +199,14 @@ def candidate_emulate(codes_u8: np.ndarray, tabs: Dict[str, np.ndarray], in_delt
         sc = s[:, l * kc:(l + 1) * kc].copy()
         for j in range(l):
             sc += tables[l * (l - 1) // 2 + j][out[j]].astype(np.float64)
-        si = sc.astype(np.int64)                                       # the exact integer scores S
-        assert np.array_equal(si.astype(np.float64), sc)
-        # the kernel keeps, per cell, the two smallest keys 128 P + k with P = floor(S / 65536) (i32): its candidate is the smallest key's k ...
-        key = (si >> 16) * 128 + np.arange(kc, dtype=np.int64)[None]
-        assert np.abs(key).max() < 2 ** 31
-        order = np.argsort(key, axis=1, kind="stable")
-        k1, k2 = order[:, 0], order[:, 1]
-        out[l] = k1
-        rows = np.arange(len(sc))
-        p1, p2 = key[rows, k1] >> 7, key[rows, k2] >> 7
+        order = np.argsort(sc, axis=1, kind="stable")
+        best, second = np.take_along_axis(sc, order[:, :1], 1)[:, 0], np.take_along_axis(sc, order[:, 1:2], 1)[:, 0]
+        out[l] = order[:, 0]
         t = (((tau[l, 0] + tau[l, 1] * n0) + (tau[l, 2] * n0) * n0) + n1.astype(np.float32)).astype(np.float32)     # the kernel's fp32 statement
         assert t.dtype == np.float32 and n0.dtype == np.float32
-        # ... accepted iff P_second - P_best >= floor(t / 65536) + 2: every other code then has S - S_best >= 65536 (P - P_best) - 65535 > t
-        tp = np.floor(t.astype(np.float64) / 65536.0).astype(np.int64) + 2
-        flags[l] = (p2 - p1) < tp
-        gaps[l] = (si[rows, k2] - si[rows, k1]) * h
+        t = t.astype(np.float64)
+        # the kernel compares packed values 128 S + k: accepted iff second - best > 128 T + 127  (implies S_second - S_best > T)
+        k2 = np.take_along_axis(order, np.ones((len(sc), 1), np.int64), 1)[:, 0]
+        flags[l] = (128.0 * second + k2) - (128.0 * best + out[l]) <= 128.0 * np.ceil(t) + 127.0
+        gaps[l] = (second - best) * h
     return out, flags.any(0), flags, gaps

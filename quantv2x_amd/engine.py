@@ -719,7 +719,10 @@ class DeployedModel(nn.Module):
             except ValueError as e:                                    # a codebook outside the candidate stage's fixed-point contract:
                 self.encode_mode, self.two_stage_refused = "exact", str(e)   # every cell through the chain (same indices), and say why
                 return self.encode_codes(n_agents, out=codes)
-            self._two_stage = (_dev(t["gpack"], self.dev), _dev(t["bias_split"], self.dev), _dev(t["tables"], self.dev),
+            k = np.arange(t["bias"].shape[0], dtype=np.int64) % self.kc
+            packed = (128 * t["bias"] + k).astype(np.float64)
+            assert np.array_equal(packed.astype(np.int64), 128 * t["bias"] + k)          # below 2^53: exact
+            self._two_stage = (_dev(t["gpack"], self.dev), _dev(packed, self.dev), _dev(t["tables"], self.dev),
                                (C.c_float * (3 * self.enc_levels))(*[float(v) for v in t["tau"].reshape(-1)]), t)
         gp, bias, tab, tau, _ = self._two_stage
         if "enc_list" not in b:

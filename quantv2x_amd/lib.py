@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libqv2x.so")
 MAX_GROUPS = 4
-ABI_VERSION = 7             # include/qv2x.h: QV2X_ABI_VERSION (the structs below mirror that header)
+ABI_VERSION = 6             # include/qv2x.h: QV2X_ABI_VERSION (the structs below mirror that header)
 
 SYMBOLS = [
     "qv2x_last_error", "qv2x_version", "qv2x_fill_i8", "qv2x_pfn_scatter_i8", "qv2x_pfn_unscatter_i8", "qv2x_conv3x3_i8",
