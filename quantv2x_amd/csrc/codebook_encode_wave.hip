@@ -88,8 +88,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
     float* const row = smem + j * RS;
     ListPlan plan{};
     if (LIST) plan = list_plan(a);
+    // LIST: rounds of gridDim.x tiles, every second round walked BACKWARDS -- the tiles are numbered list by list (dearest first: a tile of
+    // list 0 runs the whole chain, of list 2 seven of its eleven products), so a wave that took a dear tile in one round takes a cheap one in
+    // the next (forwards only: the first waves got list 0 + list 1, the last list 1 + list 2)
 #pragma unroll 1
-    for (int tile = (int)blockIdx.x; LIST ? tile < plan.full : tile == (int)blockIdx.x; tile += (int)gridDim.x) {
+    for (int round = 0; LIST ? round * (int)gridDim.x < plan.full : round == 0; ++round) {
+    const int tile = LIST ? round * (int)gridDim.x + ((round & 1) ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x) : (int)blockIdx.x;
+    if (LIST && tile >= plan.full) continue;
     int mrow;                                                        // this lane's cell, and whether its codes are stored
     bool owned;
     int start = 0;                                                   // LIST: the cells' codes below this level are PROVEN (the candidate stage accepted them):
