@@ -8,12 +8,13 @@
 // at ANY level is appended to the list stage 2 (codebook_encode_wave_kernel in list mode) recomputes in the reference's op order; the
 // others keep these indices, which the bound proves to be the strict minimum of the fp32 chain too.
 //
-// One wave = 64 cells (two 32-cell B tiles: every A fragment feeds two MFMAs) through all levels; the products are transposed as in
-// codebook_encode_wave.hip -- A = 32 scores x 32 input channels of one limb, streamed from L2 in fragment order by buffer loads with a
-// scalar running offset; B = the cells' bytes exactly as the padded i8 map stores them (code - 128: the offset is folded into the bias),
-// 64 registers for the whole kernel -- so a lane holds ONE cell (lane & 31) and 16 of a tile's 32 scores: the running minimum stays in the
-// lane, one exchange between the half-waves closes a level.  No LDS, no barrier.  36 fragments x 8 steps x 2 = 576 MFMAs per 64 cells
-// (0.59 MOP per cell against the chain's 43.8 MFLOP per agent-frame / 35 200 cells = 1.25 MFLOP per cell in fp32).
+// One wave = 128 cells at the batch, 64 for small launches (CT = four | two 32-cell B tiles: every A fragment feeds CT MFMAs) through all
+// levels; the products are transposed as in codebook_encode_wave.hip -- A = 32 scores x 32 input channels of one limb, streamed from L2 in
+// fragment order by buffer loads with a scalar running offset; B = the cells' bytes exactly as the padded i8 map stores them (code - 128:
+// the offset is folded into the bias), 32 CT registers for the whole kernel -- so a lane holds ONE cell per tile (lane & 31) and 16 of a
+// tile's 32 scores: the running minimum stays in the lane, one exchange between the half-waves closes a level.  No LDS and no barrier in the
+// main loop (one at the end: the workgroup reserves its list ranges together).  36 fragments x 8 steps = 288 MFMAs per 32 cells (0.59 MOP per
+// cell against the chain's 43.8 MFLOP per agent-frame / 35 200 cells = 1.25 MFLOP per cell in fp32).
 #include "common.h"
 
 namespace qv2x {
