@@ -68,3 +68,25 @@ def by_levels():
 
 if len(sys.argv) > 2 and sys.argv[2] == "levels":
     by_levels()
+
+
+def empty_list():
+    """stage 2 on an EMPTY list (counters zeroed): what the two launches cost by themselves"""
+    import ctypes as C
+    frames = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    state, eng, _, _ = bench.build_engine(min(32, os.cpu_count() or 8))
+    _, full, _, _ = bench.frame_batch(1, 0, frames, torch.device("cuda"))
+    eng(full); eng.encode_mode = "two_stage"; eng.encode_codes(frames); torch.cuda.synchronize()
+    b = eng._workspace(frames)
+    d = L.EncodeDesc()
+    d.n, d.h, d.w, d.levels, d.kc, d.segs = frames, eng.fh, eng.fw, eng.enc_levels, eng.kc, 1
+    d.in_zx, d.in_delta = int(eng.shrink1.out_q[1]), float(eng.shrink1.out_q[0])
+    s2 = lambda: L.check(eng.lib.qv2x_codebook_encode_listed_f32(C.byref(d), L.ptr(b["s1"]), eng.level_ptrs, L.ptr(b["enc_list"]), L.ptr(b["enc_counters"]),
+                                                                 L.ptr(b["codes"]), L.current_stream()), "s2")
+    print(f"frames {frames}: stage 2 on the real list {bench.event_time_us(s2, 20):.1f} us", end="")
+    b["enc_counters"].zero_(); torch.cuda.synchronize()
+    print(f", on an EMPTY list {bench.event_time_us(s2, 20):.1f} us (inside a graph {bench.event_time_us(bench._graph_of(s2), 20):.1f})")
+
+
+if len(sys.argv) > 2 and sys.argv[2] == "empty":
+    empty_list()
