@@ -500,7 +500,11 @@ extern "C" int qv2x_codebook_encode_listed_f32(const qv2x_encode_desc* d, const 
     int cus = 256, dev = 0, v = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     const int tiles = (a.M + 31) / 32;
-    static const int tail_knob = getenv("QV2X_LIST_TAIL") ? atoi(getenv("QV2X_LIST_TAIL")) : 0;          // development switch: remainder tiles the workgroup form takes
+    int tail_knob = 0;
+#ifdef QV2X_DEV_KNOBS                                                  // dev builds only: the largest remainder (tiles) the workgroup form takes
+    static const int tail_env = getenv("QV2X_LIST_TAIL") ? atoi(getenv("QV2X_LIST_TAIL")) : 0;
+    tail_knob = tail_env;
+#endif
     a.list_slots = 4 * cus; a.list_tail_max = tail_knob > 0 ? tail_knob : 2 * cus;
     // whole rounds of the chip's wave slots as persistent waves, the remainder as workgroups: both launches have a fixed size, the split is
     // made on the device from the count (list_plan).  Launches of fewer than two rounds of tiles (one or two frames) are the workgroup form's

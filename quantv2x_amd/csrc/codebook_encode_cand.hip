@@ -246,7 +246,11 @@ extern "C" int qv2x_codebook_encode_candidates_i8(const qv2x_encode_desc* d, con
     a.tbytes = (d->levels > 1 ? d->levels * (d->levels - 1) / 2 : 1) * d->kc * d->kc * 4;
     a.delta = d->in_delta;
     zero_counters_kernel<<<1, 64, 0, (hipStream_t)stream>>>(counters);
-    static const int force_ct = getenv("QV2X_CAND_CT") ? atoi(getenv("QV2X_CAND_CT")) : 0;          // development switch
+    int force_ct = 0;
+#ifdef QV2X_DEV_KNOBS                                                  // dev builds only: 32-cell tiles per wave (2 | 4)
+    static const int ct_env = getenv("QV2X_CAND_CT") ? atoi(getenv("QV2X_CAND_CT")) : 0;
+    force_ct = ct_env == 2 || ct_env == 4 ? ct_env : 0;
+#endif
     int dev = 0, cus = 256, v = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     const int ct = force_ct ? force_ct : (a.M >= 4 * cus * 128 * 2 ? 4 : 2);      // two rounds of waves of 128 cells, or the smaller tile

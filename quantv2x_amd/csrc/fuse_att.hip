@@ -109,7 +109,11 @@ extern "C" int qv2x_fuse_att_batch_f32(const qv2x_fuse_desc* d, int n_scenes, co
     // one tap per cell and are not bound by the table rows.
     // Three code planes and scenes of 2+ agents: the form with batched round trips (fuse_cell_b3; 88 against 105 us per scene of eight
     // V2X-Real agents, profiles/r05_fuse_by_agents.log).  QV2X_FUSE_MODE=0 (dev A/B switch, tools/bench_fuse.py): the round-4 walk.
-    static const int mode_env = [] { const char* e = getenv("QV2X_FUSE_MODE"); return e ? atoi(e) : -1; }();
+    int mode_env = -1;
+#ifdef QV2X_DEV_KNOBS
+    static const int mode_knob = [] { const char* e = getenv("QV2X_FUSE_MODE"); return e ? atoi(e) : -1; }();
+    mode_env = mode_knob;
+#endif
     const bool b3 = !feats && a.levels == 3 && most > 1 && mode_env != 0;   // (single-agent scenes: one tap per cell, nothing to batch)
     const dim3 grid((a.hw + 3) / 4, n_scenes);
     if (b3) {

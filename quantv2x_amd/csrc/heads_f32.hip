@@ -647,7 +647,11 @@ extern "C" int qv2x_table_heads_f32(const uint8_t* codes, int R, int hw, int lev
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     // sixteen waves per workgroup (four per SIMD: the kernel is bound by instruction issue -- 153 against 206 us per batch of 32 frames with
     // eight) once every wave has a run of 64 cells to take; below that (one frame: 550 runs) eight, whose table copy-in is over sooner
-    static const int cells_per_lane = getenv("QV2X_TABLE_HEADS_CELLS") ? atoi(getenv("QV2X_TABLE_HEADS_CELLS")) : 4;          // development switch
+    int cells_per_lane = 4;
+#ifdef QV2X_DEV_KNOBS                                                  // dev builds only: 1 = the one-cell-per-lane form at every size
+    static const int cells_env = getenv("QV2X_TABLE_HEADS_CELLS") ? atoi(getenv("QV2X_TABLE_HEADS_CELLS")) : 4;
+    cells_per_lane = cells_env;
+#endif
     if (cells_per_lane == 4 && hw % 4 == 0 && (R + 255) / 256 >= 16 * cus && !((uintptr_t)codes & 3) && !((uintptr_t)out0 & 15) && !((uintptr_t)out1 & 15)) {
         if (int rc = hip_check(hipFuncSetAttribute((const void*)table_heads4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), who)) return rc;
         table_heads4_kernel<<<cus, 1024, lds, (hipStream_t)stream>>>(codes, R, hw, levels, kc, CT, ST, c0, c1, tables, bias, da, za, out0, out1);

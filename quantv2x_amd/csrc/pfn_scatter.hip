@@ -241,15 +241,21 @@ extern "C" int qv2x_pfn_scatter_i8(const float* voxel_features, const int32_t* v
         return fail(QV2X_EINVAL, "qv2x_pfn_scatter_i8: null pointer");
     if (M < 0 || max_points <= 0 || N <= 0 || ny <= 0 || nx <= 0) return fail(QV2X_EINVAL, "qv2x_pfn_scatter_i8: bad sizes");
     if (((uintptr_t)voxel_features & 15) || ((uintptr_t)voxel_coords & 15)) return fail(QV2X_EALIGN, "qv2x_pfn_scatter_i8: inputs must be 16-byte aligned");
-    static const int form = getenv("QV2X_PFN_FORM") ? atoi(getenv("QV2X_PFN_FORM")) : 16;          // development switch: 64 = one lane per channel
+    int form = 16;
+#ifdef QV2X_DEV_KNOBS                                                  // dev builds only: 64 = the lane-per-channel form of rounds 1-5
+    static const int form_env = getenv("QV2X_PFN_FORM") ? atoi(getenv("QV2X_PFN_FORM")) : 16;
+    form = form_env;
+#endif
     if (form == 64)
         pfn_scatter_kernel<<<(M + 4 * PFN_PB - 1) / (4 * PFN_PB), 256, 0, (hipStream_t)stream>>>((const float4*)voxel_features, (const int4*)voxel_coords,
                                                                          voxel_num_points, M, max_points, *params, canvas, N, ny, nx);
     else {
         // rounds of 16 pillars per workgroup: PFN_R at the batch (the weights' trip through LDS amortised), fewer for one sweep (27 k pillars:
         // eight rounds would leave 213 workgroups on 256 CUs -- 44 us against 14)
-        int dev = 0, cus = 256, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        static const int cus = [] {                                    // (one process drives one GPU model: asked once)
+            int dev = 0, v = 0;
+            return hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0 ? v : 256;
+        }();
         int rounds = M / (16 * 8 * cus);
         rounds = rounds < 1 ? 1 : (rounds > PFN_R ? PFN_R : rounds);
         pfn_scatter16_kernel<<<(M + 16 * rounds - 1) / (16 * rounds), 256, 0, (hipStream_t)stream>>>((const float4*)voxel_features, (const int4*)voxel_coords,

@@ -1,4 +1,5 @@
-"""Dev tool: the PFN + scatter of the bench's batch (32 V2X-Real sweeps), timed by HIP events inside a graph, with a hash of the canvas it leaves.
+"""(the QV2X_PFN_FORM switch exists in builds with -DQV2X_DEV_KNOBS only: python tools/build_variant.py knobs <source>.hip -DQV2X_DEV_KNOBS, then QV2X_LIB_TAG=knobs)
+Dev tool: the PFN + scatter of the bench's batch (32 V2X-Real sweeps), timed by HIP events inside a graph, with a hash of the canvas it leaves.
     QV2X_PFN_FORM=64 python tools/bench_pfn.py     one lane per channel (rounds 1-5)
     QV2X_PFN_FORM=16 python tools/bench_pfn.py     sixteen lanes per pillar (round 6; the default)
 The two hashes must be equal (the canvases are compared bit for bit by tests/test_hip_parity.py against the oracle)."""

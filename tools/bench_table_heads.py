@@ -1,3 +1,4 @@
+# the QV2X_TABLE_HEADS_CELLS switch exists in builds with -DQV2X_DEV_KNOBS only (tools/build_variant.py ... -DQV2X_DEV_KNOBS; QV2X_LIB_TAG)
 import os, sys, time
 sys.path.insert(0, "/root/repo")
 import torch, numpy as np, ctypes as C
