@@ -197,3 +197,47 @@ def test_refusals():
     assert lib.qv2x_codebook_encode_candidates_i8(C.byref(d), L.ptr(buf), L.ptr(buf), L.ptr(buf), L.ptr(buf), tau, L.ptr(buf), L.ptr(buf), L.ptr(buf), None) != 0
     d.kc, d.segs = 128, 2
     assert lib.qv2x_codebook_encode_candidates_i8(C.byref(d), L.ptr(buf), L.ptr(buf), L.ptr(buf), L.ptr(buf), tau, L.ptr(buf), L.ptr(buf), L.ptr(buf), None) != 0
+
+
+@pytest.mark.parametrize("counts", [(31, 0, 0), (1000, 12000, 19730), (1024 * 32 - 40, 0, 33), (20000, 20000, 9152), (300, 49000, 137),
+                                    (0, 0, 1536 * 32), (0, 0, 1536 * 32 + 1), (40, 511 * 32, 1024 * 32 - 7), (70400, 0, 0), (5, 7, 70388)])
+def test_stage2_alone_on_constructed_lists(golden, counts):
+    """qv2x_codebook_encode_listed_f32 by itself on lists of chosen lengths: the device-side split (whole rounds of persistent waves, every second
+    round backwards; the remainder as workgroups; more than `list_tail_max` remainder tiles = one more round of waves) at its boundaries --
+    1 tile; 2 x 1024 tiles - 1 (+ a second list); a remainder of exactly 512 and of 513 tiles; every cell of two frames listed -- with partial
+    tiles in every list.  The listed cells' codes from their list's level on are overwritten with garbage first: stage 2 must restore the
+    every-cell kernel's indices, using the STORED codes below that level."""
+    import ctypes as C
+    from quantv2x_amd import lib as L
+    g = golden["codebook_full"]
+    codes_u8, _ = golden_rows(g)
+    st, eng = v2xreal_engine(_state(), g)
+    n = 2
+    rng = np.random.default_rng(5)
+    rows = np.concatenate([codes_u8, np.roll(codes_u8, 7, axis=0)[:, rng.permutation(256)]])
+    b = put_rows(eng, n, rows)
+    eng.encode_mode = "exact"
+    ref = eng.encode_codes(n).clone()                                   # [levels, M]
+    torch.cuda.synchronize()
+    m_cells = n * eng.fh * eng.fw
+    assert sum(counts) <= m_cells
+    eng.encode_mode = "two_stage"
+    eng.encode_codes(n)                                                 # (allocates the list buffers)
+    cells = torch.from_numpy(rng.permutation(m_cells)[:sum(counts)].astype(np.int32)).cuda()
+    work = ref.clone().reshape(eng.levels, m_cells)
+    lst, cnt, at = b["enc_list"], b["enc_counters"], 0
+    lst.fill_(-1)
+    for c, k in enumerate(counts):
+        mine = cells[at:at + k]
+        lst[c * m_cells:c * m_cells + k] = mine
+        for l in range(c, eng.levels):
+            work[l, mine.long()] = 255 - l
+        at += k
+    cnt.copy_(torch.tensor([sum(counts), *counts], dtype=torch.int32))
+    d = L.EncodeDesc()
+    d.n, d.h, d.w, d.levels, d.kc, d.segs = n, eng.fh, eng.fw, eng.enc_levels, eng.kc, 1
+    d.in_zx, d.in_delta = int(eng.shrink1.out_q[1]), float(eng.shrink1.out_q[0])
+    L.check(eng.lib.qv2x_codebook_encode_listed_f32(C.byref(d), L.ptr(b["s1"]), eng.level_ptrs, L.ptr(lst), L.ptr(cnt), L.ptr(work), L.current_stream()), "listed")
+    torch.cuda.synchronize()
+    bad = (work != ref.reshape(eng.levels, m_cells)).sum().item()
+    assert bad == 0, f"{bad} indices differ after stage 2 on lists of {counts} cells"
