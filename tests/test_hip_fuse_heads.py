@@ -142,8 +142,8 @@ def test_single_agent_shortcut_honours_a_non_identity_self_transform():
     assert eng._self_transforms_are_identity(_batch([ident])["pairwise_t_matrix"])
 
 
-@pytest.mark.parametrize("c0,c1,kc", [(72, 20, 128), (70, 21, 96), (0, 8, 32)])
-def test_table_heads_at_batch_size_four_cells_per_lane(c0, c1, kc):
+@pytest.mark.parametrize("c0,c1,kc,hw,n", [(72, 20, 128, 35200, 32), (70, 21, 96, 35200, 32), (0, 8, 32, 35200, 32), (18, 6, 128, 65536, 16), (18, 6, 128, 65536, 17)])
+def test_table_heads_at_batch_size_four_cells_per_lane(c0, c1, kc, hw, n):
     """qv2x_table_heads_f32 at the bench's batch (32 V2X-Real frames: the launch takes table_heads4_kernel -- four cells per lane, 16-byte NCHW
     stores, the output quantizer as the division-exact sandwich) against the statement of the same fp32 operations in torch: bias + the
     planes' rows in plane order, then (clamp(rint(y / d) + z, 0, 255) - z) * d on the channels that carry a quantizer.  Bit for bit."""
@@ -151,7 +151,7 @@ def test_table_heads_at_batch_size_four_cells_per_lane(c0, c1, kc):
     from quantv2x_amd import lib as L
     lib = L.load()
     g = torch.Generator(device="cuda").manual_seed(7)
-    hw, n, planes = 35200, 32, 3
+    planes = 3                                                        # (65536 x 16: exactly the smallest launch that takes the four-cell form)
     R, CT = n * hw, c0 + c1
     codes = torch.randint(0, kc, (planes, R), dtype=torch.uint8, device="cuda", generator=g)
     tab = torch.randn((planes, kc, CT), device="cuda", generator=g)
