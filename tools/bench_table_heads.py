@@ -4,6 +4,8 @@ sys.path.insert(0, "/root/repo")
 import torch, numpy as np, ctypes as C
 import bench
 from quantv2x_amd import lib as L
+if os.environ.get("QV2X_LIB_TAG"):           # a side library from tools/build_variant.py
+    L.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cache", "abl", f"libqv2x_{os.environ['QV2X_LIB_TAG']}.so")
 lib = L.load()
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
